@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/{golden.json,inputs.npz} by RUNNING the Python/Cython reference.
+
+Runs only in the build container (needs /root/reference).  Nothing from the reference is
+copied into the repo: the reference package is copied to a scratch dir under /tmp, its three
+Cython modules are compiled there with the recipe below (cython --cplus + g++, not the
+reference's setup.py), the package is imported with its absent third-party imports
+(tensorflow, h5py, progressbar, mappy, Bio) stubbed, and the reference's functions are called
+on inputs that this script also writes out.  The committed fixtures are data only: inputs
+(float32 logits / probability tables / strings) and the outputs the reference produced.
+
+    python3 tests/golden/make_golden.py
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+SCRATCH = "/tmp/po_golden_ref"
+sys.path.insert(0, REPO)
+
+
+def build_reference():
+    if os.path.isdir(SCRATCH):
+        shutil.rmtree(SCRATCH)
+    os.makedirs(SCRATCH)
+    shutil.copytree(os.path.join(REF, "poreover"), os.path.join(SCRATCH, "poreover"))
+    inc = ["-I" + sysconfig.get_paths()["include"], "-I" + np.get_include()]
+    ext = sysconfig.get_config_var("EXT_SUFFIX")
+    for rel in ("decoding/decoding_cpp", "decoding/decoding_cy", "align/align"):
+        d, base = os.path.split(rel)
+        cwd = os.path.join(SCRATCH, "poreover", d)
+        subprocess.check_call([sys.executable, "-m", "cython", "--cplus", base + ".pyx", "-o", base + ".cpp"],
+                              cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call(["g++", "-O2", "-std=c++11", "-w", "-fPIC", "-shared", *inc,
+                               "-I" + os.path.join(SCRATCH, "poreover", "decoding"), base + ".cpp", "-o", base + ext],
+                              cwd=cwd)
+
+
+def import_reference():
+    class _Any:
+        def __getattr__(self, k):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    for m in ("tensorflow", "h5py", "progressbar", "mappy", "Bio"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["progressbar"].streams = types.SimpleNamespace(wrap_stderr=lambda: None)
+    sys.modules["tensorflow"].keras = _Any()
+    sys.modules["tensorflow"].compat = _Any()
+    for sub in ("SeqIO", "pairwise2", "Seq"):
+        s = types.ModuleType("Bio." + sub)
+        sys.modules["Bio." + sub] = s
+        setattr(sys.modules["Bio"], sub, s)
+    try:
+        import pkg_resources  # noqa: F401
+    except Exception:
+        pr = types.ModuleType("pkg_resources")
+        pr.get_distribution = lambda n: types.SimpleNamespace(version="1.0.0")
+        sys.modules["pkg_resources"] = pr
+    np.product = np.prod
+    sys.path.insert(0, SCRATCH)
+    import poreover  # noqa: F401
+    import poreover.decoding as decoding
+    import poreover.align as align
+    return decoding, align
+
+
+def jf(x):
+    """float -> json (exact repr via hex so no decimal rounding is involved)"""
+    return float(x).hex()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--keep", action="store_true", help="keep the scratch build")
+    args = ap.parse_args()
+    build_reference()
+    decoding, align = import_reference()
+    from poreover.decoding import pair_decode as ref_pd, decode as ref_decode, prefix_search as ref_ps
+    from poreover.decoding import transducer as ref_tr, envelope as ref_env
+    from poreover_amd.synth import synth_pair
+
+    G = {}
+    inputs = {}
+
+    # ---- G1: toy matrices of the reference's own tests (tests/test_beam.py, test_forward.py,
+    #          test_prefix.py, test_transducer.py) with the reference's ACTUAL outputs
+    toy = {
+        "t1": [[0.8, 0.1, 0.1], [0.1, 0.3, 0.6], [0.7, 0.2, 0.1], [0.1, 0.1, 0.8]],
+        "t2": [[0.4, 0.5, 0.1], [0.4, 0.2, 0.4], [0.3, 0.5, 0.2]],
+        "t3": [[0.7, 0.2, 0.1], [0.2, 0.3, 0.5], [0.7, 0.2, 0.1], [0.05, 0.05, 0.9]],
+        "ff": [[0.8, 0.1, 0.05, 0.05], [0.1, 0.3, 0.5, 0.1], [0.7, 0.2, 0.05, 0.05], [0.1, 0.1, 0.2, 0.6]],
+    }
+    G["toy_prob"] = toy
+    t1, t2, t3 = (np.array(toy[k]) for k in ("t1", "t2", "t3"))
+    ff32 = np.array(toy["ff"], dtype=np.float32)
+    t1_32 = np.array(toy["t1"], dtype=np.float32)
+    g1 = {}
+    g1["beam1d_t1"] = decoding.cpp_beam_search(np.log(t1), alphabet_="AB")
+    g1["beam1d_t2"] = decoding.cpp_beam_search(np.log(t2), alphabet_="AB")
+    g1["beam2d_same_t1"] = decoding.cpp_beam_search_2d(np.log(t1), np.log(t1), alphabet_="AB")
+    g1["beam2d_t1_t3"] = decoding.cpp_beam_search_2d(np.log(t1), np.log(t3), alphabet_="AB")
+    g1["ff_beam1d"] = decoding.cpp_beam_search(np.log(ff32), alphabet_="AB", model_="ctc_flipflop")
+    g1["ff_beam2d_row"] = decoding.cpp_beam_search_2d(np.log(ff32), np.log(ff32), alphabet_="AB", method_="row",
+                                                      model_="ctc_flipflop")
+    labels = ["AAAA", "ABBA", "ABA", "AAA", "BBB", "AA", "BB", "A", "B"]
+    g1["forward_ctc_t1f32"] = {l: jf(decoding.cpp_forward(np.log(t1_32), l, "AB")) for l in labels}
+    g1["forward_ff_f32"] = {l: jf(decoding.cpp_forward(np.log(ff32), l, "AB", model_="ctc_flipflop")) for l in labels}
+    g1["viterbi_t1"] = ref_tr.poreover(t1, "AB").viterbi_decode()
+    G["toy"] = g1
+
+    # prefix-search toys (tests/test_prefix.py)
+    from collections import OrderedDict
+    toy_alpha = OrderedDict([("A", 0), ("B", 1)])
+    pfx = {}
+    pm = {
+        "p1": [[0.8, 0.1, 0.1], [0.1, 0.3, 0.6], [0.7, 0.2, 0.1], [0.1, 0.1, 0.8]],
+        "p2": [[0.7, 0.2, 0.1], [0.2, 0.3, 0.5], [0.7, 0.2, 0.1], [0.05, 0.05, 0.9]],
+        "p3": [[0.7, 0.1, 0.2], [0.1, 0.4, 0.5], [0.6, 0.3, 0.1]],
+    }
+    G["prefix_prob"] = pm
+    with np.errstate(divide="ignore"):
+        for k, m in pm.items():
+            y = np.log(np.array(m))
+            lab, lp = ref_ps.prefix_search_log(y, alphabet=toy_alpha)
+            lab2, lp2 = ref_ps.prefix_search_log_cy(y, alphabet=toy_alpha)
+            pfx[k] = {"py": [lab, jf(lp)], "cy": [lab2, jf(lp2)]}
+        pairs = {}
+        for a, b in (("p1", "p2"), ("p1", "p3"), ("p2", "p3")):
+            ya, yb = np.log(np.array(pm[a])), np.log(np.array(pm[b]))
+            lab, lp = ref_ps.pair_prefix_search_log(ya, yb, alphabet=toy_alpha)
+            lab2, lp2 = ref_ps.pair_prefix_search_log_cy(ya, yb, alphabet=toy_alpha)
+            g = ref_ps.pair_gamma_log(ya, yb)
+            gc = np.asarray(decoding.decoding_cy.pair_gamma_log(ya, yb))
+            pairs[a + "_" + b] = {"py": [lab, jf(lp)], "cy": [lab2, jf(lp2)], "gamma00_py": jf(g[0, 0]),
+                                  "gamma00_cy": jf(gc[0, 0]),
+                                  "beam2d": decoding.cpp_beam_search_2d(ya, yb, alphabet_="AB")}
+    G["prefix_toy"] = pfx
+    G["pair_prefix_toy"] = pairs
+
+    # ---- G2: the reference's data fixture tests/poreover.csv (500x5 probabilities) -> stored as data
+    csv = np.loadtxt(os.path.join(REF, "tests", "poreover.csv"), delimiter=",", skiprows=1)
+    inputs["poreover_csv_prob"] = csv
+    model = ref_decode.model_from_trace(os.path.join(REF, "tests", "poreover.csv"))
+    y = model.log_prob
+    g2 = {}
+    vseq, vpath = model.viterbi_decode(return_path=True)
+    g2["viterbi"] = vseq
+    g2["viterbi_path"] = [int(x) for x in vpath]
+    for W in (5, 10, 25):
+        g2["beam_w%d" % W] = decoding.cpp_beam_search(y, beam_width_=W)
+    g2["beam_merge_w10"] = decoding.cpp_beam_search(y, beam_width_=10, model_="ctc_merge_repeats")
+    g2["forward_viterbi"] = jf(decoding.cpp_forward(y, vseq))
+    T = len(y)
+    env10 = np.array([(max(0, i - 10), min(i + 10, T)) for i in range(T)])
+    g2["self2d_row_w10"] = decoding.cpp_beam_search_2d(y, y, env10.tolist(), beam_width_=10, method_="row")
+    g2["self2d_row_col_w10"] = decoding.cpp_beam_search_2d(y, y, env10.tolist(), beam_width_=10, method_="row_col")
+    g2["self2d_row_col_w5"] = decoding.cpp_beam_search_2d(y, y, env10.tolist(), beam_width_=5, method_="row_col")
+    g2["self2d_diag_w25"] = decoding.cpp_beam_search_2d(y, y, np.array([(i, i + 1) for i in range(T)]).tolist())
+    g2["acceptor_cpp"] = [int(x) for x in decoding.decoding_cpp.cpp_viterbi_acceptor(y, vseq)]
+    g2["acceptor_cy"] = [int(x) for x in decoding.decoding_cy.viterbi_acceptor(y, vseq)]
+    g2["prefix_first100_cy"] = [ref_ps.prefix_search_log_cy(y[:100])[0], jf(ref_ps.prefix_search_log_cy(y[:100])[1])]
+    g2["prefix_first100_py"] = [ref_ps.prefix_search_log(y[:100])[0], jf(ref_ps.prefix_search_log(y[:100])[1])]
+    # decode --algorithm prefix windows of 400 (decode.py:182-188)
+    seq = ""
+    i = 0
+    while i + 400 < T:
+        seq += ref_ps.prefix_search_log_cy(y[i:i + 400])[0]
+        i += 400
+    seq += ref_ps.prefix_search_log_cy(y[i:])[0]
+    g2["decode_prefix_w400"] = seq
+    G["csv"] = g2
+
+    # ---- G3: alignment (align.pyx) — fixed strings and random mutated pairs
+    rng = np.random.default_rng(1234)
+
+    def rand_seq(n):
+        return "".join("ACGT"[i] for i in rng.integers(4, size=n))
+
+    def mutate(s):
+        out = []
+        for ch in s:
+            r = rng.random()
+            if r < 0.04:
+                continue
+            if r < 0.08:
+                ch = "ACGT"[rng.integers(4)]
+            out.append(ch)
+            if rng.random() < 0.03:
+                out.append("ACGT"[rng.integers(4)])
+        return "".join(out)
+
+    nw_cases = [("ACGTACGTTT", "ACGTCGTTTA"), ("A", "A"), ("A", "C"), ("ACGT", "ACGT"), ("AAAA", "TTTTTTT"),
+                ("ACGTTGCA", "ACG"), ("AC", "ACGTACGTAC")]
+    for n in (50, 80, 120, 200, 333, 500, 640, 1200):
+        for _ in range(2):
+            a = rand_seq(n)
+            nw_cases.append((a, mutate(a)))
+    nw_cases.append((rand_seq(100), rand_seq(140)))  # unrelated, unequal
+    nw = []
+    for a, b in nw_cases:
+        f1, f2, _ = align.global_pair(a, b)
+        b1, b2 = align.global_pair_banded(a, b)
+        rec = {"s1": a, "s2": b, "full": ["".join(f1), "".join(f2)], "banded": ["".join(b1), "".join(b2)]}
+        if len(a) >= 120:
+            n1, n2 = align.global_pair_banded(a, b, 30)
+            rec["banded30"] = ["".join(n1), "".join(n2)]
+        nw.append(rec)
+    G["nw"] = nw
+
+    # ---- G4: end-to-end pair_decode_helper on synthetic pairs (real helper, Namespace args)
+    def ns(**kw):
+        d = dict(dir=".", basecaller="poreover", reverse_complement=False, out="out", threads=1,
+                 method="envelope", single="viterbi", logging="info", debug=False, algorithm="beam",
+                 alignment="banded", beam_width=5, debug_envelope=False, diagonal_envelope=False,
+                 diagonal_width=50, padding=5, skip_matches=False, skip_threshold=10,
+                 beam_search_method="row_col", window=200)
+        d.update(kw)
+        n = argparse.Namespace(**d)
+        setattr(n, "in", ["read_a.npy", "read_b.npy"])
+        return n
+
+    captured = {}
+    real_build = ref_env.build_envelope
+
+    def spy_build(*a, **k):
+        e = real_build(*a, **k)
+        captured["env"] = np.array(e)
+        return e
+
+    ref_env.build_envelope = spy_build
+    real_align_b, real_align_f = align.global_pair_banded, align.global_pair
+
+    def spy_b(*a, **k):
+        r = real_align_b(*a, **k)
+        captured["aln"] = ["".join(r[0]), "".join(r[1])]
+        return r
+
+    def spy_f(*a, **k):
+        r = real_align_f(*a, **k)
+        captured["aln"] = ["".join(r[0]), "".join(r[1])]
+        return r
+
+    ref_pd.align.global_pair_banded = spy_b
+    ref_pd.align.global_pair = spy_f
+
+    pair_recs = []
+    specs = [(i, T_, "poreover") for i, T_ in enumerate((300, 360, 420, 480, 520, 560, 600, 333, 450, 590))]
+    specs += [(20, 400, "bonito"), (21, 500, "bonito"), (30, 400, "flipflop"), (31, 480, "flipflop")]
+    for idx, T_, kind in specs:
+        y1, y2 = synth_pair(idx, T=T_, flipflop=(kind == "flipflop"))
+        inputs["pair%d_y1" % idx] = y1
+        inputs["pair%d_y2" % idx] = y2
+        cls = {"poreover": ref_tr.poreover, "bonito": ref_tr.bonito, "flipflop": ref_tr.flipflop}[kind]
+        basecaller = {"poreover": "poreover", "bonito": "bonito", "flipflop": "flappie"}[kind]
+        models = {"read_a.npy": y1, "read_b.npy": y2}
+        ref_decode.model_from_trace = lambda f, basecaller="", _m=models, _c=cls: _c(np.array(_m[os.path.basename(str(f))]))
+        rec = {"index": idx, "T": T_, "kind": kind, "runs": {}}
+        m1 = cls(np.array(y1))
+        s1, p1 = m1.viterbi_decode(return_path=True)
+        m2 = cls(np.array(y2))
+        s2, p2 = m2.viterbi_decode(return_path=True)
+        rec["viterbi1"], rec["viterbi2"] = s1, s2
+        rec["path1"], rec["path2"] = [int(x) for x in p1], [int(x) for x in p2]
+        rec["map1"] = [int(x) for x in ref_pd.get_sequence_mapping(p1, m1.kind)[0]]
+        rec["map2"] = [int(x) for x in ref_pd.get_sequence_mapping(p2, m2.kind)[0]]
+        model_name = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}[kind]
+        for W in (5, 10):
+            rec["beam1d_w%d" % W] = decoding.cpp_beam_search(y1, beam_width_=W, model_=model_name)
+        runs = [("row_col", 5, "banded"), ("row", 5, "banded")]
+        if kind == "poreover" and idx < 4:
+            runs += [("row_col", 10, "banded"), ("row_col", 5, "full")]
+        for method, W, aln in runs:
+            captured.clear()
+            out = ref_pd.pair_decode_helper(ns(beam_width=W, beam_search_method=method, alignment=aln,
+                                               basecaller=basecaller))
+            r = {"n_out": len(out)}
+            if len(out) == 3:
+                r["fasta_1d"], r["fasta_2d"] = out[0], out[1]
+                r["summary"] = {k: (jf(v) if isinstance(v, float) else v) for k, v in out[2].items()}
+                r["envelope"] = captured["env"].tolist()
+                r["alignment"] = captured["aln"]
+            else:
+                r["summary"] = {k: (jf(v) if isinstance(v, float) else v) for k, v in out[0].items()}
+            rec["runs"]["%s_w%d_%s" % (method, W, aln)] = r
+        # diagonal envelope flag (consensus header quirk, pair_decode.py:527)
+        if kind == "poreover" and idx < 2:
+            out = ref_pd.pair_decode_helper(ns(diagonal_envelope=True, diagonal_width=30))
+            rec["runs"]["diag30"] = {"n_out": len(out), "fasta_2d": out[0]}
+        pair_recs.append(rec)
+    G["pairs"] = pair_recs
+
+    # ---- G5: ingest (decode.py:34-51,67-88): logits -> log-likelihood, probabilities -> log
+    lg = np.random.default_rng(7).normal(0, 2, (3, 40, 5)).astype(np.float32)
+    inputs["ingest_logits"] = lg
+    tmpd = os.path.join(SCRATCH, "ingest")
+    os.makedirs(tmpd, exist_ok=True)
+    np.save(os.path.join(tmpd, "l.npy"), lg)
+    inputs["ingest_logits_out"] = ref_decode.load_logits(os.path.join(tmpd, "l.npy"), flatten=True)
+    pr = np.exp(inputs["ingest_logits_out"][:50]).astype(np.float64)
+    pr = pr / pr.sum(axis=1, keepdims=True)
+    inputs["ingest_prob"] = pr
+    np.save(os.path.join(tmpd, "p.npy"), pr)
+    inputs["ingest_prob_out"] = ref_decode.load_logits(os.path.join(tmpd, "p.npy"), flatten=True)
+    G["fasta_format"] = {"short": ref_decode.fasta_format("r1", "ACGT" * 10),
+                         "exact60": ref_decode.fasta_format("r2", "A" * 60),
+                         "long": ref_decode.fasta_format("r3", "ACGTT" * 31),
+                         "empty": ref_decode.fasta_format("r4", "")}
+
+    # ---- G6: prefix search on windows of a synthetic read, forward_vec_log vectors
+    y1, _ = synth_pair(40, T=400)
+    inputs["prefix_y"] = y1
+    pw = {}
+    for lo, hi in ((0, 100), (100, 250), (0, 400)):
+        a = ref_ps.prefix_search_log_cy(y1[lo:hi])
+        b = ref_ps.prefix_search_log(y1[lo:hi])
+        pw["%d_%d" % (lo, hi)] = {"cy": [a[0], jf(a[1])], "py": [b[0], jf(b[1])]}
+    G["prefix_windows"] = pw
+    fw0 = np.asarray(decoding.decoding_cy.forward_vec_log(-1, 0, y1[:100]))
+    fw1 = np.asarray(decoding.decoding_cy.forward_vec_log(2, 1, y1[:100], fw0))
+    fw2 = np.asarray(decoding.decoding_cy.forward_vec_log(1, 2, y1[:100], fw1))
+    inputs["fwvec_cy"] = np.stack([fw0, fw1, fw2])
+    fp0 = ref_ps.forward_vec_log(-1, 0, y1[:100])
+    fp1 = ref_ps.forward_vec_log(2, 1, y1[:100], fp0)
+    fp2 = ref_ps.forward_vec_log(1, 2, y1[:100], fp1)
+    inputs["fwvec_py"] = np.stack([fp0, fp1, fp2])
+    ya, yb = y1[:30], y1[40:65]
+    inputs["gamma_dense_cy"] = np.asarray(decoding.decoding_cy.pair_gamma_log(ya, yb))
+    inputs["gamma_dense_py"] = ref_ps.pair_gamma_log(ya, yb)
+    pp = ref_ps.pair_prefix_search_log_cy(ya[:20], ya[:20] * 1.0)
+    G["pair_prefix_synth"] = [pp[0], jf(pp[1])]
+
+    # ---- G7: revcomp (transducer.py:68-70,104-106)
+    m = ref_tr.poreover(np.array(y1[:50]))
+    m.reverse_complement()
+    inputs["revcomp_poreover_in"] = y1[:50]
+    inputs["revcomp_poreover_out"] = m.log_prob
+
+    # ---- G8: real-data sanity: hashes only (the data stays in the reference)
+    import hashlib
+    real = {}
+    try:
+        r1 = ref_decode.model_from_trace(os.path.join(REF, "data/reads/read1.npy"), "poreover")
+        s = r1.viterbi_decode()
+        real["read1_viterbi_len"] = len(s)
+        real["read1_viterbi_md5"] = hashlib.md5(s.encode()).hexdigest()[:12]
+    except Exception as e:  # pragma: no cover
+        real["error"] = repr(e)
+    G["real"] = real
+
+    with open(os.path.join(HERE, "golden.json"), "w") as f:
+        json.dump(G, f, indent=0, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "inputs.npz"), **inputs)
+    print("wrote golden.json (%d bytes), inputs.npz (%d bytes)" % (
+        os.path.getsize(os.path.join(HERE, "golden.json")), os.path.getsize(os.path.join(HERE, "inputs.npz"))))
+    if not args.keep:
+        shutil.rmtree(SCRATCH, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
