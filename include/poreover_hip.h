@@ -1,0 +1,170 @@
+/* poreover_hip.h — C-ABI of libporeover_hip.so, the MI355X (gfx950) decoding engine.
+ *
+ * This is the drop-in boundary for PoreOver's native decode path.  In the reference the
+ * boundary is the set of Python-callable functions that Cython exports from
+ * poreover/decoding/decoding_cpp.pyx, poreover/decoding/decoding_cy.pyx and
+ * poreover/align/align.pyx; each entry point below names the reference interface it
+ * replaces.  The reference decodes ONE read / pair per call and gets its parallelism from
+ * multiprocessing.Pool (decode.py:158-162, pair_decode.py:292-297); here every entry point is
+ * BATCHED — one launch decodes n independent reads / pairs — which is the natural shape for a
+ * GPU.  The single-item Python wrappers with the reference's exact signatures
+ * (poreover_amd/decoding/decoding_cpp.py) call these with n == 1.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in _h
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); no call allocates or frees device memory: scratch comes from `ws`
+ *   - y:       concatenated C-contiguous (T_i, C) float64 natural-log probabilities
+ *     y_off:   int64[n+1] ROW offsets into y (read i owns rows [y_off[i], y_off[i+1]))
+ *   - env:     concatenated (U_i, 2) int32 half-open column ranges, row-aligned with y1
+ *   - seq:     output characters; read/pair i writes at seq + seq_off[i], at most
+ *              seq_off[i+1]-seq_off[i] bytes (no terminator); seq_len[i] gets the length
+ *   - status:  int32[n], 0 on success or a PO_E_* code for that item (the launch itself
+ *              returns 0 unless the arguments are unusable)
+ *   - model:   PO_MODEL_CTC ('ctc'), PO_MODEL_MERGE ('ctc_merge_repeats'),
+ *              PO_MODEL_FLIPFLOP ('ctc_flipflop')       (decode.py:172, pair_decode.py:147)
+ *   - alphabet: HOST string of A <= 4 symbols (the reference's alphabet_ argument, default
+ *              "ACGT"); C == A + 1 for the CTC models (blank last), C == 2A for flip-flop
+ */
+#ifndef POREOVER_HIP_H
+#define POREOVER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PO_MODEL_CTC 0
+#define PO_MODEL_MERGE 1
+#define PO_MODEL_FLIPFLOP 2
+
+#define PO_METHOD_ROW 0
+#define PO_METHOD_ROW_COL 1
+#define PO_METHOD_GRID 2
+
+#define PO_KIND_POREOVER 0
+#define PO_KIND_BONITO 1
+#define PO_KIND_FLIPFLOP 2
+
+#define PO_OK 0
+#define PO_E_CAP (-1)        /* an output or workspace buffer is too small                    */
+#define PO_E_ARG (-2)        /* unusable argument                                             */
+#define PO_E_ENVELOPE (-3)   /* envelope on which the reference itself is undefined           */
+#define PO_E_NOMEM (-4)      /* per-item node arena / band capacity exceeded                  */
+#define PO_E_UNSUPPORTED (-6)/* valid for the reference, not yet handled by this engine       */
+#define PO_E_HIP (-7)        /* HIP runtime error (see po_last_error)                         */
+#define PO_SKIP_LENGTH (-10) /* pair skipped: |len1 - len2| > 1000   (pair_decode.py:372-375) */
+#define PO_SKIP_IDENTITY (-11)/* pair skipped: identity < 0.5        (pair_decode.py:395-398) */
+
+/* ---- library / device ----------------------------------------------------------------- */
+int po_version(void);
+int po_device_count(void);
+int po_set_device(int device);
+const char* po_last_error(void);
+/* name, compute units and clock of `device`; returns 0 on success */
+int po_device_info(int device, char* name, int name_cap, int* compute_units, int* clock_khz,
+                   size_t* total_mem);
+
+/* ---- transducer.argmax_decode / viterbi_decode ------------------------------------------
+ * replaces transducer.py:27-33 (argmax), :72-73 (poreover), :83-89 (bonito), :35-59 +
+ * :94-103 (flip-flop Viterbi) and pair_decode.get_sequence_mapping (pair_decode.py:114-142).
+ *   path    int8[total_rows]   per-frame state                          (may be NULL)
+ *   map     int32[total_rows]  frame index of each emitted base, written at map + y_off[i]
+ *                              for read i, seq_len[i] entries            (may be NULL)
+ * seq capacity per read must be >= T_i.  */
+size_t po_viterbi_workspace_bytes(int n, int64_t total_rows, int C, int kind);
+int po_viterbi_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int kind,
+                     int8_t* path,
+                     char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* map,
+                     int32_t* status, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- decoding_cpp.cpp_beam_search ---------------------------------------------------------
+ * replaces decoding_cpp.pyx:88-103 -> BeamSearch.h:400-408 beam_search(y, t_max, alphabet,
+ * beam_width, model) -> beam_search_<Tree,Beam> (BeamSearch.h:18-58).  */
+size_t po_beam1d_workspace_bytes(int n, int64_t total_rows, int64_t max_rows, int C, int beam_width,
+                                 int model);
+int po_beam1d_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int beam_width,
+                    int model, char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* ---- decoding_cpp.cpp_beam_search_2d ------------------------------------------------------
+ * replaces decoding_cpp.pyx:107-139 -> BeamSearch.h:411-458 beam_search(y1, y2, U, V, alphabet,
+ * envelope_ranges, beam_width, model, method): method row_col = :262-397 (CLI default,
+ * __main__.py:89), row = :110-172.  env rows are [lo, hi) per row of y1.  */
+size_t po_beam2d_workspace_bytes(int n, int64_t total_rows1, int64_t total_rows2, int64_t max_rows1,
+                                 int64_t max_rows2, int C, int beam_width, int model, int method);
+int po_beam2d_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
+                    const int32_t* env, int n, int C, const char* alphabet, int beam_width, int model,
+                    int method, char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---- pair_decode.pair_decode_helper stage chain -------------------------------------------
+ * replaces pair_decode.py:305-529 for the default route (--method envelope --algorithm beam
+ * --single viterbi): 1-D Viterbi of both reads (:360-362) -> length skip (:372-375) ->
+ * get_sequence_mapping (:377-382) -> align.global_pair_banded / global_pair
+ * (align.pyx:100-178 / :29-98; :385-389) -> identity skip (:391-398) ->
+ * envelope.get_alignment_columns + build_envelope (envelope.py:26-87; :500-501) ->
+ * cpp_beam_search_2d (:166-173,511).  All stages run on the device.
+ *   seq1d / seq1d_off / len1 / len2: the two 1-D basecalls (read 1 at seq1d + seq1d_off[2i],
+ *                                    read 2 at seq1d + seq1d_off[2i+1])
+ *   identity  float64[n]  matches / alignment columns
+ *   env_out   int32[2*total_rows1]  the envelope that was used (may be NULL) */
+typedef struct {
+    int beam_width;        /* --beam_width 5                     */
+    int model;             /* PO_MODEL_*                         */
+    int method;            /* --beam_search_method row_col       */
+    int padding;           /* --padding 5                        */
+    int full_alignment;    /* --alignment full (0 = banded, 500) */
+    int diagonal_envelope; /* --diagonal_envelope                */
+    int diagonal_width;    /* --diagonal_width 50                */
+} po_pair_options;
+size_t po_pair_decode_workspace_bytes(int n, int64_t total_rows1, int64_t total_rows2, int64_t max_rows1,
+                                      int64_t max_rows2, int C, const po_pair_options* opt);
+int po_pair_decode_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
+                         int n, int C, const po_pair_options* opt, char* seq1d, const int64_t* seq1d_off,
+                         int32_t* len1, int32_t* len2, double* identity, int32_t* env_out, char* seq,
+                         const int64_t* seq_off, int32_t* seq_len, int32_t* status, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* ---- host-buffer conveniences (numpy callers): allocate, copy in, launch, copy out, free ----
+ * Same semantics as the device-pointer forms with every pointer a HOST pointer; synchronous. */
+int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int kind,
+                       int8_t* path_h,
+                       char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* map_h,
+                       int32_t* status_h);
+int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
+                      int beam_width, int model,
+                      char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h);
+int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
+                      const int64_t* y2_off_h, const int32_t* env_h, int n, int C, const char* alphabet,
+                      int beam_width, int model, int method, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,
+                      int32_t* status_h);
+int po_pair_decode_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
+                           const int64_t* y2_off_h, int n, int C, const po_pair_options* opt, char* seq1d_h,
+                           const int64_t* seq1d_off_h, int32_t* len1_h, int32_t* len2_h, double* identity_h,
+                           int32_t* env_out_h, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,
+                           int32_t* status_h);
+
+/* ---- timing aid for bench.py: HIP events on the stream the kernels run on ----------------- */
+void* po_event_create(void);
+int po_event_record(void* ev, void* stream);
+int po_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+void po_event_destroy(void* ev);
+/* accumulated device time (ms) and launch count of the named kernel family since the last
+ * reset, measured with HIP events around each launch when profiling is enabled */
+#define PO_K_VITERBI 0
+#define PO_K_BEAM1D 1
+#define PO_K_BEAM2D 2
+#define PO_K_ALIGN 3
+#define PO_K_ENVELOPE 4
+#define PO_K_COUNT 5
+void po_profile_enable(int on);
+void po_profile_reset(void);
+int po_profile_get(int kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes binding of libporeover_hip.so (include/poreover_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or no GPU is visible,
+calls raise EngineUnavailable.  (The CPU restatement under oracle/ is test infrastructure and
+is never imported from here.)
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libporeover_hip.so")
+
+OK = 0
+E_CAP, E_ARG, E_ENVELOPE, E_NOMEM, E_UNSUPPORTED, E_HIP = -1, -2, -3, -4, -6, -7
+SKIP_LENGTH, SKIP_IDENTITY = -10, -11
+MODELS = {"ctc": 0, "ctc_merge_repeats": 1, "ctc_flipflop": 2}
+METHODS = {"row": 0, "row_col": 1, "grid": 2}
+KINDS = {"poreover": 0, "bonito": 1, "flipflop": 2}
+K_VITERBI, K_BEAM1D, K_BEAM2D, K_ALIGN, K_ENVELOPE = range(5)
+_CODE_NAMES = {E_CAP: "PO_E_CAP (buffer too small)", E_ARG: "PO_E_ARG (bad argument)",
+               E_ENVELOPE: "PO_E_ENVELOPE (envelope undefined for the reference)",
+               E_NOMEM: "PO_E_NOMEM (node arena / band capacity exceeded)",
+               E_UNSUPPORTED: "PO_E_UNSUPPORTED", E_HIP: "PO_E_HIP"}
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        super().__init__("%s: %s%s" % (what, _CODE_NAMES.get(code, "code %d" % code),
+                                       (" — " + detail) if detail else ""))
+        self.code = code
+
+
+class PairOptions(C.Structure):
+    _fields_ = [("beam_width", C.c_int), ("model", C.c_int), ("method", C.c_int), ("padding", C.c_int),
+                ("full_alignment", C.c_int), ("diagonal_envelope", C.c_int), ("diagonal_width", C.c_int)]
+
+
+_vp, _i64p, _i32p, _dp, _cp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+# every symbol include/poreover_hip.h declares: (restype, argtypes)
+PROTOTYPES = {
+    "po_version": (C.c_int, []),
+    "po_device_count": (C.c_int, []),
+    "po_set_device": (C.c_int, [C.c_int]),
+    "po_last_error": (C.c_char_p, []),
+    "po_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_size_t)]),
+    "po_viterbi_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "po_viterbi_batch": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _vp, _cp, _i64p, _i32p,
+                                   _i32p, _i32p, _vp, C.c_size_t, _vp]),
+    "po_beam1d_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "po_beam1d_batch": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, _cp, _i64p, _i32p,
+                                  _i32p, _vp, C.c_size_t, _vp]),
+    "po_beam2d_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                               C.c_int, C.c_int, C.c_int]),
+    "po_beam2d_batch": (C.c_int, [_dp, _i64p, _dp, _i64p, _i32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                  C.c_int, _cp, _i64p, _i32p, _i32p, _vp, C.c_size_t, _vp]),
+    "po_pair_decode_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                                    C.POINTER(PairOptions)]),
+    "po_pair_decode_batch": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.POINTER(PairOptions), _cp,
+                                       _i64p, _i32p, _i32p, _dp, _i32p, _cp, _i64p, _i32p, _i32p, _vp,
+                                       C.c_size_t, _vp]),
+    "po_viterbi_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _vp, _cp, _i64p, _i32p,
+                                     _i32p, _i32p]),
+    "po_beam1d_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, _cp, _i64p,
+                                    _i32p, _i32p]),
+    "po_beam2d_batch_h": (C.c_int, [_dp, _i64p, _dp, _i64p, _i32p, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                    C.c_int, C.c_int, _cp, _i64p, _i32p, _i32p]),
+    "po_pair_decode_batch_h": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.POINTER(PairOptions), _cp,
+                                         _i64p, _i32p, _i32p, _dp, _i32p, _cp, _i64p, _i32p, _i32p]),
+    "po_event_create": (C.c_void_p, []),
+    "po_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "po_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "po_event_destroy": (None, [C.c_void_p]),
+    "po_profile_enable": (None, [C.c_int]),
+    "po_profile_reset": (None, []),
+    "po_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load(require_gpu=True):
+    """Load the HIP library (once).  Raises EngineUnavailable instead of falling back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineUnavailable(
+                "libporeover_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError here means the .so is stale vs the header
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    if require_gpu and _lib.po_device_count() < 1:
+        raise EngineUnavailable("no HIP device visible: the decoding engine needs an MI355X (gfx950) GPU; "
+                                "there is no CPU fallback")
+    return _lib
+
+
+def check(rc, what):
+    if rc != OK:
+        detail = load(False).po_last_error()
+        raise EngineError(rc, what, detail.decode() if detail else "")

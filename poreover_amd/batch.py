@@ -1,0 +1,153 @@
+"""Batched numpy front end of the engine: lists of (T, C) arrays in, lists of strings out.
+
+These are what the drivers (decode / pair-decode) call instead of the reference's
+multiprocessing.Pool fan-out (decode.py:158-162, pair_decode.py:292-297): one launch per batch.
+Host buffers go through the *_h entry points of the C-ABI (which copy to the device, launch,
+and copy back); device-resident callers use the device-pointer forms directly (see bench.py).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+__all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows"]
+
+
+def pack_rows(arrays, C_expected=None):
+    """Concatenate (T_i, C) arrays into one float64 C-contiguous matrix + int64 row offsets."""
+    mats = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
+    for m in mats:
+        if m.ndim != 2:
+            raise ValueError("expected (T, C) matrices")
+    Cc = mats[0].shape[1] if mats else (C_expected or 5)
+    if any(m.shape[1] != Cc for m in mats):
+        raise ValueError("all matrices of a batch must have the same number of columns")
+    off = np.zeros(len(mats) + 1, dtype=np.int64)
+    np.cumsum([m.shape[0] for m in mats], out=off[1:])
+    y = np.concatenate(mats, axis=0) if mats else np.zeros((0, Cc))
+    return np.ascontiguousarray(y), off, Cc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _strings(buf, off, lens):
+    raw = buf.tobytes()
+    return [raw[off[i]:off[i] + lens[i]].decode("ascii") for i in range(len(lens))]
+
+
+def viterbi_batch(arrays, kind="poreover", alphabet="ACGT", return_path=False, return_map=False):
+    """transducer.*.viterbi_decode for a batch.  Returns a list of sequences (and paths / maps)."""
+    lib = L.load()
+    y, off, Cc = pack_rows(arrays)
+    n = len(arrays)
+    rows = int(off[-1])
+    seq = np.zeros(max(rows, 1), dtype=np.uint8)
+    lens = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    path = np.zeros(max(rows, 1), dtype=np.int8)
+    mp = np.zeros(max(rows, 1), dtype=np.int32) if return_map else None
+    L.check(lib.po_viterbi_batch_h(_ptr(y), _ptr(off), n, Cc, alphabet.encode(), L.KINDS[kind], _ptr(path),
+                                   _ptr(seq), _ptr(off), _ptr(lens), _ptr(mp), _ptr(st)), "po_viterbi_batch_h")
+    for i in range(n):
+        if st[i] != 0 and not (return_map and st[i] == L.E_ARG):
+            raise L.EngineError(int(st[i]), "viterbi decode of read %d" % i)
+    out = [_strings(seq, off, lens)]
+    if return_path:
+        out.append([path[off[i]:off[i + 1]].astype(np.int64) for i in range(n)])
+    if return_map:
+        out.append([mp[off[i]:off[i] + lens[i]].astype(np.int64) for i in range(n)])
+        out.append(st[:n].copy())
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def beam_search_batch(arrays, beam_width=25, alphabet="ACGT", model="ctc"):
+    """decoding_cpp.cpp_beam_search for a batch of reads."""
+    lib = L.load()
+    y, off, Cc = pack_rows(arrays)
+    n = len(arrays)
+    seq = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+    lens = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    L.check(lib.po_beam1d_batch_h(_ptr(y), _ptr(off), n, Cc, alphabet.encode(), int(beam_width), L.MODELS[model],
+                                  _ptr(seq), _ptr(off), _ptr(lens), _ptr(st)), "po_beam1d_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "beam search of read %d" % i)
+    return _strings(seq, off, lens)
+
+
+def beam_search_2d_batch(arrays1, arrays2, envelopes, beam_width=25, alphabet="ACGT", model="ctc",
+                         method="row", return_status=False):
+    """decoding_cpp.cpp_beam_search_2d for a batch of pairs; envelopes: list of (U_i, 2) or None."""
+    lib = L.load()
+    y1, o1, Cc = pack_rows(arrays1)
+    y2, o2, _ = pack_rows(arrays2, Cc)
+    n = len(arrays1)
+    env = None
+    if envelopes is not None:
+        es = [np.ascontiguousarray(e, dtype=np.int32) for e in envelopes]
+        for e, a in zip(es, arrays1):
+            if e.ndim != 2 or e.shape[1] != 2 or e.shape[0] < len(a):
+                raise ValueError("envelope must be (U, 2)")
+        env = np.ascontiguousarray(np.concatenate([e[:len(a)] for e, a in zip(es, arrays1)], axis=0))
+    so = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(a) + len(b) for a, b in zip(arrays1, arrays2)], out=so[1:])
+    seq = np.zeros(max(int(so[-1]), 1), dtype=np.uint8)
+    lens = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    L.check(lib.po_beam2d_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), _ptr(env), n, Cc, alphabet.encode(),
+                                  int(beam_width), L.MODELS[model], L.METHODS[method], _ptr(seq), _ptr(so),
+                                  _ptr(lens), _ptr(st)), "po_beam2d_batch_h")
+    if not return_status:
+        for i in range(n):
+            if st[i] != 0:
+                raise L.EngineError(int(st[i]), "pair beam search of pair %d" % i)
+    seqs = _strings(seq, so, lens)
+    return (seqs, st[:n].copy()) if return_status else seqs
+
+
+def pair_decode_batch(arrays1, arrays2, kind="poreover", beam_width=5, method="row_col", padding=5,
+                      alignment="banded", diagonal_envelope=False, diagonal_width=50):
+    """pair_decode_helper stage chain (pair_decode.py:305-529) for a batch of pairs, all on the GPU.
+    Returns a list of dicts: seq1, seq2, consensus (None if skipped), length1, length2,
+    sequence_identity, skipped, status, envelope."""
+    lib = L.load()
+    y1, o1, Cc = pack_rows(arrays1)
+    y2, o2, _ = pack_rows(arrays2, Cc)
+    n = len(arrays1)
+    model = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}[kind]
+    opt = L.PairOptions(int(beam_width), L.MODELS[model], L.METHODS[method], int(padding),
+                        1 if alignment == "full" else 0, 1 if diagonal_envelope else 0, int(diagonal_width))
+    s1o = np.zeros(2 * n + 1, dtype=np.int64)
+    caps = []
+    for a, b in zip(arrays1, arrays2):
+        caps += [len(a), len(b)]
+    np.cumsum(caps, out=s1o[1:])
+    so = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(a) + len(b) for a, b in zip(arrays1, arrays2)], out=so[1:])
+    seq1d = np.zeros(max(int(s1o[-1]), 1), dtype=np.uint8)
+    seq = np.zeros(max(int(so[-1]), 1), dtype=np.uint8)
+    l1, l2, lens, st = (np.zeros(max(n, 1), dtype=np.int32) for _ in range(4))
+    ident = np.zeros(max(n, 1), dtype=np.float64)
+    env = np.zeros((max(int(o1[-1]), 1), 2), dtype=np.int32)
+    L.check(lib.po_pair_decode_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), n, Cc, C.byref(opt), _ptr(seq1d),
+                                       _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(ident), _ptr(env), _ptr(seq), _ptr(so),
+                                       _ptr(lens), _ptr(st)), "po_pair_decode_batch_h")
+    raw1, raw = seq1d.tobytes(), seq.tobytes()
+    out = []
+    for i in range(n):
+        code = int(st[i])
+        if code not in (0, L.SKIP_LENGTH, L.SKIP_IDENTITY):
+            raise L.EngineError(code, "pair decode of pair %d" % i)
+        out.append({
+            "seq1": raw1[s1o[2 * i]:s1o[2 * i] + l1[i]].decode("ascii"),
+            "seq2": raw1[s1o[2 * i + 1]:s1o[2 * i + 1] + l2[i]].decode("ascii"),
+            "consensus": raw[so[i]:so[i] + lens[i]].decode("ascii") if code == 0 else None,
+            "length1": int(l1[i]), "length2": int(l2[i]),
+            "sequence_identity": float(ident[i]) if code != L.SKIP_LENGTH else None,
+            "skipped": 0 if code == 0 else 1, "status": code,
+            "envelope": env[o1[i]:o1[i + 1]].astype(np.int64) if code == 0 else None})
+    return out

@@ -1,0 +1,369 @@
+// Batched 1-D CTC beam search over a prefix tree.
+//
+// Replaces decoding_cpp.cpp_beam_search (decoding_cpp.pyx:88-103) -> beam_search
+// (BeamSearch.h:400-408) -> beam_search_<Tree,Beam> (BeamSearch.h:18-58) with the three tree
+// recurrences of PrefixTree.h: PoreOver 'ctc' (:478-488), Bonito 'ctc_merge_repeats' (:649-663),
+// flip-flop 'ctc_flipflop' (:548-574).
+//
+// What the reference does per time step t: every beam node and every child of a beam node is
+// updated from values at time t-1 ONLY (own alpha[t-1] and the parent's alpha[t-1]); a value
+// that was never stored reads as -inf (PrefixTree.h:55-61).  alpha[t-1] of a node exists iff
+// the node was in the candidate set (beam + children of beam nodes) of step t-1, or is the
+// root.  So the exact live state is the previous step's candidate table (<= 5W nodes with
+// their values), not the whole tree.  That table lives in LDS, double-buffered; the tree
+// itself is reduced to an HBM arena of packed (parent, last) words — written once per node,
+// read only for the final label walk — plus a first_child word per node that is read only
+// when a node re-enters the beam after having dropped out of the candidate table.
+//
+// Mapping: ONE WAVE PER READ (the step-to-step dependency is serial; parallelism comes from
+// the <= 5W candidates of a step and from thousands of reads in flight).  Lane s owns
+// candidate slot s (slots [0,Wc) = beam nodes in rank order, slot Wc + 4*j + c = child c of
+// beam node j), strided when 5W > 64.  Prune = dedupe by node id + rank by (score desc, id asc)
+// + keep the top W (Beam.h:93-108; tie rule: see DESIGN.md).
+#include "po_device.h"
+
+namespace {
+
+template <int MODEL>
+struct ModelTraits {
+    static constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
+    static constexpr int CMAX = (MODEL == PO_MODEL_FLIPFLOP) ? 2 * PO_A : PO_A + 1;
+};
+
+// one candidate table (struct of arrays carved from dynamic LDS)
+struct Table {
+    int* id;      // [NC]  node id
+    int* fc;      // [NC]  first child id; -1 = never expanded; -2 = unknown (ask the arena)
+    int* depth;   // [NC]
+    double* val;  // [K][NC] values at the table's time step (channel 0 = total)
+    int* par;     // [WM]  beam slots only: parent id
+    int* gpar;    // [WM]  grand-parent id (-1 if none)
+    int* plast;   // [WM]  parent's last symbol (A for the root)
+    int* last;    // [WM]  own last symbol
+};
+
+__device__ __forceinline__ char* carve(char*& p, size_t bytes) {
+    char* r = p;
+    p += (bytes + 15) & ~size_t(15);
+    return r;
+}
+
+// root values at time tm1 (tree constructors PrefixTree.h:467-476, :541-546, :641-647)
+template <int MODEL>
+__device__ __forceinline__ void root_values(int tm1, double blank_cum, double* out) {
+    if (MODEL == PO_MODEL_CTC) {
+        out[0] = (tm1 < 0) ? 0.0 : blank_cum;
+    } else if (MODEL == PO_MODEL_MERGE) {
+        out[0] = (tm1 < 0) ? 0.0 : PO_NEG_INF;
+        out[1] = (tm1 < 0) ? 0.0 : PO_NEG_INF;
+        out[2] = PO_NEG_INF;
+    } else {
+        const double h = log(0.5);
+        out[0] = (tm1 < 0) ? 0.0 : PO_NEG_INF;
+        out[1] = (tm1 < 0) ? h : PO_NEG_INF;
+        out[2] = (tm1 < 0) ? h : PO_NEG_INF;
+    }
+}
+
+}  // namespace
+
+// update_prob for one node at one time: sp = own values at t-1, pp = parent's values at t-1,
+// yr = row t of y.  first_frame_of_root_child = (parent->depth == 0 && t == 0).
+template <int MODEL>
+__device__ __forceinline__ void po_update(const double* sp, const double* pp, const double* yr, int A, int last,
+                                          int plast, bool first_frame_of_root_child, double* out) {
+    if (MODEL == PO_MODEL_CTC) {
+        out[0] = po_lae(pp[0] + yr[last], sp[0] + yr[A]);
+    } else if (MODEL == PO_MODEL_MERGE) {
+        const double gap = sp[0] + yr[A];
+        double ng;
+        if (first_frame_of_root_child) ng = yr[last];
+        else if (plast == last) ng = po_lae(pp[1] + yr[last], sp[2] + yr[last]);
+        else ng = po_lae(pp[0] + yr[last], sp[2] + yr[last]);
+        out[0] = po_lae(gap, ng);
+        out[1] = gap;
+        out[2] = ng;
+    } else {
+        const double stay_flip = sp[1] + yr[last];
+        const double stay_flop = sp[2] + yr[last + A];
+        double ef, eo;
+        if (first_frame_of_root_child) {
+            ef = yr[last];
+            eo = yr[last + A];
+        } else if (plast == last) {
+            ef = pp[2] + yr[last];
+            eo = pp[1] + yr[last + A];
+        } else {
+            ef = po_lae(pp[1], pp[2]) + yr[last];
+            eo = PO_NEG_INF;
+        }
+        const double flip = po_lae(ef, stay_flip);
+        const double flop = po_lae(eo, stay_flop);
+        out[0] = po_lae(flip, flop);
+        out[1] = flip;
+        out[2] = flop;
+    }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
+    const double* __restrict__ y, const int64_t* __restrict__ y_off, int A, uint32_t alphabet, int W,
+    int* __restrict__ arena_pl, int* __restrict__ arena_fc, char* __restrict__ seq,
+    const int64_t* __restrict__ seq_off, int32_t* __restrict__ seq_len, int32_t* __restrict__ status) {
+    constexpr int K = ModelTraits<MODEL>::K, CMAX = ModelTraits<MODEL>::CMAX;
+    const int C = (MODEL == PO_MODEL_FLIPFLOP) ? 2 * A : A + 1;  // A = |alphabet| <= PO_A
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = po_lane();
+    const int r = blockIdx.x;
+    const int64_t r0 = y_off[r];
+    const int T = (int)(y_off[r + 1] - r0);
+    const double* yr0 = y + r0 * C;
+    const int WM = max(W, PO_A), NC = WM * (PO_A + 1);  // layout uses the maximum alphabet size
+    // node arena of read r: closed-form offset, (1 + PO_A) + PO_A*WM*T entries (po_beam1d_arena_nodes)
+    const int64_t aoff = (int64_t)r * (1 + PO_A) + (int64_t)PO_A * WM * (r0 - y_off[0]);
+    const int64_t acap = (1 + PO_A) + (int64_t)PO_A * WM * T;
+    int* apl = arena_pl + aoff;
+    int* afc = arena_fc + aoff;
+
+    // two candidate tables; selected by value each step (a runtime-indexed array of structs
+    // would live in scratch memory)
+    Table T0, T1;
+    char* p = smem;
+    for (int b = 0; b < 2; ++b) {
+        Table& tb = b ? T1 : T0;
+        tb.id = (int*)carve(p, sizeof(int) * NC);
+        tb.fc = (int*)carve(p, sizeof(int) * NC);
+        tb.depth = (int*)carve(p, sizeof(int) * NC);
+        tb.val = (double*)carve(p, sizeof(double) * K * NC);
+        tb.par = (int*)carve(p, sizeof(int) * WM);
+        tb.gpar = (int*)carve(p, sizeof(int) * WM);
+        tb.plast = (int*)carve(p, sizeof(int) * WM);
+        tb.last = (int*)carve(p, sizeof(int) * WM);
+    }
+    int* sel = (int*)carve(p, sizeof(int) * WM);     // table-P slots forming the current beam
+    int* isnew = (int*)carve(p, sizeof(int) * WM);   // beam node expanded in this very step
+    int* dup = (int*)carve(p, sizeof(int) * NC);
+    int* nsel = (int*)carve(p, sizeof(int) * WM);
+
+    if (T < 1) {
+        if (lane == 0) { seq_len[r] = 0; status[r] = PO_E_ARG; }
+        return;
+    }
+    if (acap < 1 + A) {
+        if (lane == 0) { seq_len[r] = 0; status[r] = PO_E_NOMEM; }
+        return;
+    }
+
+    int cur = 0;  // cur == 0: P (previous step) = T0, Q (being built) = T1; swapped each step
+    int Pnb = 0;  // number of beam slots in P
+    int next_id = 1 + A;
+    int st = PO_OK;
+    double blank_cum = 0.0;
+
+    // ---- t = 0: the A children of the root (BeamSearch.h:25-30), no prune
+    {
+        const Table P = T0;
+        double yr[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) yr[c] = (c < C) ? yr0[c] : 0.0;
+        if (lane == 0) { apl[0] = po_pack_node(-1, A); afc[0] = 1; }
+        if (lane < A) {
+            double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, pp[3], out[3];
+            root_values<MODEL>(-1, 0.0, pp);
+            po_update<MODEL>(sp, pp, yr, A, lane, A, true, out);
+            P.id[lane] = 1 + lane;
+            P.fc[lane] = -1;
+            P.depth[lane] = 1;
+            for (int k = 0; k < K; ++k) P.val[k * NC + lane] = out[k];
+            apl[1 + lane] = po_pack_node(0, lane);
+            afc[1 + lane] = -1;
+            sel[lane] = lane;
+        }
+        if (MODEL == PO_MODEL_CTC) blank_cum = yr[A];
+    }
+    int Wc = A;  // beam size entering step 1 (all root children; the first prune is at t = 1)
+    __syncthreads();
+
+    for (int t = 1; t < T; ++t) {
+        const Table P = cur ? T1 : T0;
+        const Table Q = cur ? T0 : T1;
+        const bool first = (t == 1);
+        double yr[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) yr[c] = (c < C) ? yr0[(int64_t)t * C + c] : 0.0;
+
+        // ---- phase 1: beam slots
+        bool need = false;
+        for (int j = lane; j < Wc; j += PO_WAVE) {
+            const int s = sel[j];
+            int par, gpar, plast, last, pslot = -2;
+            if (first) {
+                par = 0; gpar = -1; plast = A; last = s; pslot = -1;
+            } else if (s >= Pnb) {  // promoted from a child slot: its parent was beam slot b
+                const int b = (s - Pnb) / A;
+                par = P.id[b]; gpar = P.par[b]; plast = P.last[b]; last = (s - Pnb) % A; pslot = b;
+            } else {
+                par = P.par[s]; gpar = P.gpar[s]; plast = P.plast[s]; last = P.last[s];
+                if (par == 0) pslot = -1;
+                else {
+                    for (int i = 0; i < Pnb; ++i) if (P.id[i] == par) pslot = i;
+                    if (pslot < 0)
+                        for (int i = 0; i < Pnb; ++i) if (P.id[i] == gpar) pslot = Pnb + A * i + plast;
+                }
+            }
+            double sp[3], pp[3], out[3];
+            for (int k = 0; k < K; ++k) sp[k] = P.val[k * NC + s];
+            if (pslot >= 0) { for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + pslot]; }
+            else if (pslot == -1) root_values<MODEL>(t - 1, blank_cum, pp);
+            else { for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF; }
+            po_update<MODEL>(sp, pp, yr, A, last, plast, false, out);
+            int fc = P.fc[s];
+            if (fc == -2) fc = afc[P.id[s]];  // re-entered the beam: the arena remembers
+            Q.id[j] = P.id[s]; Q.depth[j] = P.depth[s];
+            Q.par[j] = par; Q.gpar[j] = gpar; Q.plast[j] = plast; Q.last[j] = last;
+            for (int k = 0; k < K; ++k) Q.val[k * NC + j] = out[k];
+            Q.fc[j] = fc;
+            need = (fc == -1);
+        }
+        // ---- expansion: A fresh ids per beam node that has never had children
+        //      (PrefixTree::expand, PrefixTree.h:439-446), in beam order
+        {
+            int base = next_id;
+            for (int j0 = 0; j0 < Wc; j0 += PO_WAVE) {
+                const int j = j0 + lane;
+                const bool nd = (j < Wc) && need;  // `need` belongs to this lane's j in this chunk
+                const unsigned long long m = __ballot(nd);
+                if (nd) {
+                    const int fc = base + A * __popcll(m & ((1ull << lane) - 1ull));
+                    if ((int64_t)fc + A <= acap) {
+                        Q.fc[j] = fc;
+                        afc[Q.id[j]] = fc;
+                        for (int c = 0; c < A; ++c) { apl[fc + c] = po_pack_node(Q.id[j], c); afc[fc + c] = -1; }
+                    } else {
+                        Q.fc[j] = 0;  // points at the root: harmless, the read is flagged below
+                    }
+                }
+                if (j < Wc) isnew[j] = nd ? 1 : 0;
+                base += A * __popcll(m);
+            }
+            if ((int64_t)base > acap) st = PO_E_NOMEM;
+            next_id = base;
+        }
+        __syncthreads();
+        if (st != PO_OK) break;
+
+        // ---- phase 2: the A children of every beam node
+        const int NCc = Wc * (A + 1);
+        for (int s = Wc + lane; s < NCc; s += PO_WAVE) {
+            const int j = (s - Wc) / A, c = (s - Wc) % A;
+            const int x = Q.fc[j] + c, sj = sel[j];
+            int slot = -2, fcx = isnew[j] ? -1 : -2;
+            if (!isnew[j] && !first) {
+                for (int i = 0; i < Pnb; ++i) if (P.id[i] == x) slot = i;
+                if (slot < 0 && sj < Pnb) slot = Pnb + A * sj + c;
+            }
+            double sp[3], pp[3], out[3];
+            if (slot >= 0) { fcx = P.fc[slot]; for (int k = 0; k < K; ++k) sp[k] = P.val[k * NC + slot]; }
+            else { for (int k = 0; k < K; ++k) sp[k] = PO_NEG_INF; }
+            for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + sj];
+            po_update<MODEL>(sp, pp, yr, A, c, Q.last[j], false, out);
+            Q.id[s] = x; Q.fc[s] = fcx; Q.depth[s] = Q.depth[j] + 1;
+            for (int k = 0; k < K; ++k) Q.val[k * NC + s] = out[k];
+        }
+        __syncthreads();
+
+        // ---- phase 3: prune (Beam.h:93-108).  A child slot whose node is also a beam slot is the
+        //      same node pushed twice: std::unique removes it.
+        for (int s = lane; s < NCc; s += PO_WAVE) {
+            int d = 0;
+            if (s >= Wc) {
+                const int x = Q.id[s];
+                for (int j = 0; j < Wc; ++j) d |= (Q.id[j] == x);
+            }
+            dup[s] = d;
+        }
+        __syncthreads();
+        int kept = 0;
+        for (int s0 = 0; s0 < NCc; s0 += PO_WAVE) {
+            const int s = s0 + lane;
+            const bool valid = (s < NCc) && !dup[s];
+            if (valid) {
+                const double sc = Q.val[s];
+                const int id = Q.id[s];
+                int rank = 0;
+                for (int o = 0; o < NCc; ++o)
+                    if (!dup[o] && po_better(Q.val[o], Q.id[o], sc, id)) rank++;
+                if (rank < W) nsel[rank] = s;
+            }
+            kept += __popcll(__ballot(valid));
+        }
+        __syncthreads();
+        const int Wn = min(W, kept);
+        for (int j = lane; j < Wn; j += PO_WAVE) sel[j] = nsel[j];
+        if (MODEL == PO_MODEL_CTC) blank_cum += yr[A];
+        cur ^= 1;
+        Pnb = Wc;
+        Wc = Wn;
+        __syncthreads();
+    }
+
+    // ---- label of the top node (PrefixTree::get_label, PrefixTree.h:449-457)
+    if (lane == 0) {
+        int n = 0;
+        if (st == PO_OK) {
+            const Table P = cur ? T1 : T0;
+            int node = P.id[sel[0]];
+            n = P.depth[sel[0]];
+            char* out = seq + seq_off[r];
+            const int cap = (int)(seq_off[r + 1] - seq_off[r]);
+            if (n > cap) { st = PO_E_CAP; n = 0; }
+            else
+                for (int i = n - 1; i >= 0; --i) {
+                    const int pk = apl[node];
+                    out[i] = (char)((alphabet >> (8 * (po_node_last(pk) & 3))) & 0xffu);
+                    node = po_node_parent(pk);
+                }
+        }
+        seq_len[r] = n;
+        status[r] = st;
+    }
+}
+
+extern "C" size_t po_beam1d_lds_bytes(int W, int model) {
+    const int K = (model == PO_MODEL_CTC) ? 1 : 3;
+    const int WM = W > PO_A ? W : PO_A, NC = WM * (PO_A + 1);
+    auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
+    size_t per = 3 * al(sizeof(int) * NC) + al(sizeof(double) * K * NC) + 4 * al(sizeof(int) * WM);
+    return 2 * per + 3 * al(sizeof(int) * WM) + al(sizeof(int) * NC);
+}
+
+// node-arena entries for a batch: per read root + A children + A * max(W, A) new nodes per frame
+extern "C" int64_t po_beam1d_arena_nodes(int n, int64_t total_rows, int W) {
+    const int64_t WM = W > PO_A ? W : PO_A;
+    return (int64_t)n * (1 + PO_A) + PO_A * WM * total_rows;
+}
+
+extern "C" int po_launch_beam1d(const double* y, const int64_t* y_off, int n, int C, int A, uint32_t alphabet,
+                                int W, int model,
+                                int* arena_pl, int* arena_fc, char* seq,
+                                const int64_t* seq_off, int32_t* seq_len, int32_t* status,
+                                hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    if (W < 1 || W > 64 || A < 1 || A > PO_A) return PO_E_ARG;
+    const size_t lds = po_beam1d_lds_bytes(W, model);
+    if (lds > 160 * 1024) return PO_E_ARG;
+#define PO_LAUNCH_B1(M)                                                                                   \
+    do {                                                                                                  \
+        if (lds > 64 * 1024)                                                                              \
+            (void)hipFuncSetAttribute((const void*)beam1d_kernel<M>,                                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+        hipLaunchKernelGGL(beam1d_kernel<M>, dim3(n), dim3(PO_WAVE), lds, stream, y, y_off, A, alphabet, W, arena_pl, \
+                           arena_fc, seq, seq_off, seq_len, status);                                      \
+    } while (0)
+    if (model == PO_MODEL_CTC) { if (C != A + 1) return PO_E_ARG; PO_LAUNCH_B1(PO_MODEL_CTC); }
+    else if (model == PO_MODEL_MERGE) { if (C != A + 1) return PO_E_ARG; PO_LAUNCH_B1(PO_MODEL_MERGE); }
+    else if (model == PO_MODEL_FLIPFLOP) { if (C != 2 * A) return PO_E_ARG; PO_LAUNCH_B1(PO_MODEL_FLIPFLOP); }
+    else return PO_E_ARG;
+#undef PO_LAUNCH_B1
+    return PO_OK;
+}

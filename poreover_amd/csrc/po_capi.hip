@@ -1,0 +1,446 @@
+// C-ABI of libporeover_hip.so (include/poreover_hip.h): argument checks, workspace carving,
+// kernel launches, host-buffer conveniences and the HIP-event profiling aid used by bench.py.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/poreover_hip.h"
+
+extern "C" {
+int po_launch_viterbi(const double*, const int64_t*, int, int, int, uint32_t, int, int8_t*, char*, const int64_t*, int32_t*,
+                      int32_t*, int32_t*, int8_t*, int8_t*, hipStream_t);
+int po_launch_beam1d(const double*, const int64_t*, int, int, int, uint32_t, int, int, int*, int*, char*, const int64_t*,
+                     int32_t*, int32_t*, hipStream_t);
+int64_t po_beam1d_arena_nodes(int, int64_t, int);
+size_t po_beam2d_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, int, int, int);
+int po_launch_beam2d(const double*, const int64_t*, const double*, const int64_t*, const int32_t*, int, int,
+                     int, uint32_t, int, int, int, char*, const int64_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
+size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const po_pair_options*);
+int po_launch_pair_decode(const double*, const int64_t*, const double*, const int64_t*, int, int,
+                          const po_pair_options*, char*, const int64_t*, int32_t*, int32_t*, double*, int32_t*,
+                          char*, const int64_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
+}
+
+namespace {
+thread_local std::string g_err;
+int fail_hip(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return PO_E_HIP;
+}
+#define HIPCHK(x)                                      \
+    do {                                               \
+        hipError_t e_ = (x);                           \
+        if (e_ != hipSuccess) return fail_hip(e_, #x); \
+    } while (0)
+inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+// alphabet string -> (A, packed bytes); NULL means "ACGT"
+inline int pack_alphabet(const char* a, uint32_t* packed) {
+    if (!a) a = "ACGT";
+    const size_t n = std::strlen(a);
+    if (n < 1 || n > 4) return -1;
+    uint32_t p = 0;
+    for (size_t i = 0; i < n; ++i) p |= (uint32_t)(unsigned char)a[i] << (8 * i);
+    *packed = p;
+    return (int)n;
+}
+
+// ---- per-launch event timing (bench.py's roofline leg) ----
+struct ProfRec { hipEvent_t a, b; int kernel; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+double g_prof_ms[PO_K_COUNT];
+int64_t g_prof_n[PO_K_COUNT];
+
+struct ProfScope {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    int k;
+    bool on;
+    ProfScope(int kernel, hipStream_t stream) : s(stream), k(kernel), on(g_prof_on) {
+        if (on) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_prof.push_back({a, b, k});
+        }
+    }
+};
+void prof_drain() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) {
+        float ms = 0;
+        (void)hipEventSynchronize(r.b);
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_prof_ms[r.kernel] += ms; g_prof_n[r.kernel]++; }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+}
+}  // namespace
+
+extern "C" {
+
+int po_version(void) { return 100; }
+
+int po_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int po_set_device(int device) {
+    HIPCHK(hipSetDevice(device));
+    return PO_OK;
+}
+
+const char* po_last_error(void) { return g_err.c_str(); }
+
+int po_device_info(int device, char* name, int name_cap, int* cus, int* clock_khz, size_t* total_mem) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (name && name_cap > 0) { std::strncpy(name, p.name, name_cap - 1); name[name_cap - 1] = 0; }
+    if (cus) *cus = p.multiProcessorCount;
+    if (clock_khz) *clock_khz = p.clockRate;
+    if (total_mem) *total_mem = p.totalGlobalMem;
+    return PO_OK;
+}
+
+// -------------------------------------------------------------------------------- viterbi
+size_t po_viterbi_workspace_bytes(int n, int64_t total_rows, int C, int kind) {
+    if (kind != PO_KIND_FLIPFLOP) return 256;
+    return al256((size_t)total_rows * 8) + al256((size_t)total_rows) + 256;  // ptr[T][8] + path[T]
+}
+
+int po_viterbi_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int kind,
+                     int8_t* path, char* seq,
+                     const int64_t* seq_off, int32_t* seq_len, int32_t* map, int32_t* status, void* ws,
+                     size_t ws_bytes, void* stream) {
+    if (n < 0 || !y || !y_off || !seq || !seq_off || !seq_len || !status) { g_err = "po_viterbi_batch: null argument"; return PO_E_ARG; }
+    uint32_t ap = 0;
+    const int A = pack_alphabet(alphabet, &ap);
+    if (A < 0) { g_err = "po_viterbi_batch: alphabet must have 1..4 symbols"; return PO_E_ARG; }
+    int8_t *ff_ptr = nullptr, *ff_path = nullptr;
+    if (kind == PO_KIND_FLIPFLOP) {
+        if (!ws) { g_err = "po_viterbi_batch: flip-flop needs a workspace"; return PO_E_CAP; }
+        int64_t ends[2] = {0, 0};  // total rows, to split and bounds-check the workspace
+        HIPCHK(hipMemcpyAsync(&ends[0], y_off, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIPCHK(hipMemcpyAsync(&ends[1], y_off + n, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        const size_t rows = (size_t)(ends[1] - ends[0]);
+        if (ws_bytes < al256(rows * 8) + al256(rows)) { g_err = "po_viterbi_batch: workspace too small"; return PO_E_CAP; }
+        ff_ptr = (int8_t*)ws;
+        ff_path = ff_ptr + al256(rows * 8);
+    }
+    ProfScope ps(PO_K_VITERBI, (hipStream_t)stream);
+    int rc = po_launch_viterbi(y, y_off, n, C, A, ap, kind, path, seq, seq_off, seq_len, map, status, ff_ptr, ff_path,
+                               (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_viterbi_batch: unsupported C/kind"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
+// -------------------------------------------------------------------------------- beam 1-D
+size_t po_beam1d_workspace_bytes(int n, int64_t total_rows, int64_t max_rows, int C, int W, int model) {
+    (void)max_rows; (void)C; (void)model;
+    return 2 * al256(sizeof(int) * (size_t)po_beam1d_arena_nodes(n, total_rows, W)) + 256;
+}
+
+// The arena is sized from the rows the CALLER declared when sizing the workspace; the kernel
+// bounds-checks every allocation against its own per-read share, so a short workspace yields
+// PO_E_CAP here rather than a stray write.
+int po_beam1d_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int W, int model,
+                    char* seq,
+                    const int64_t* seq_off, int32_t* seq_len, int32_t* status, void* ws, size_t ws_bytes,
+                    void* stream) {
+    if (n < 0 || !y || !y_off || !seq || !seq_off || !seq_len || !status || !ws) { g_err = "po_beam1d_batch: null argument"; return PO_E_ARG; }
+    if (ws_bytes < 512) { g_err = "po_beam1d_batch: workspace too small"; return PO_E_CAP; }
+    uint32_t ap = 0;
+    const int A = pack_alphabet(alphabet, &ap);
+    if (A < 0) { g_err = "po_beam1d_batch: alphabet must have 1..4 symbols"; return PO_E_ARG; }
+    const size_t half = ((ws_bytes - 256) / 2) / 256 * 256;
+    int* apl = (int*)ws;
+    int* afc = (int*)((char*)ws + half);
+    // total rows, for the capacity check (one small D2H; the rest of the call stays asynchronous)
+    int64_t ends[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&ends[0], y_off, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(&ends[1], y_off + n, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (sizeof(int) * (size_t)po_beam1d_arena_nodes(n, ends[1] - ends[0], W) > half) { g_err = "po_beam1d_batch: workspace too small"; return PO_E_CAP; }
+    ProfScope ps(PO_K_BEAM1D, (hipStream_t)stream);
+    int rc = po_launch_beam1d(y, y_off, n, C, A, ap, W, model, apl, afc, seq, seq_off, seq_len, status, (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_beam1d_batch: unsupported C/model/beam_width"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
+// -------------------------------------------------------------------------------- beam 2-D
+size_t po_beam2d_workspace_bytes(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, int W,
+                                 int model, int method) {
+    return po_beam2d_ws_bytes_impl(n, tr1, tr2, mr1, mr2, C, W, model, method);
+}
+
+int po_beam2d_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
+                    const int32_t* env, int n, int C, const char* alphabet, int W, int model, int method,
+                    char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status, void* ws,
+                    size_t ws_bytes, void* stream) {
+    if (n < 0 || !y1 || !y1_off || !y2 || !y2_off || !seq || !seq_off || !seq_len || !status || !ws) { g_err = "po_beam2d_batch: null argument"; return PO_E_ARG; }
+    uint32_t ap = 0;
+    const int A = pack_alphabet(alphabet, &ap);
+    if (A < 0) { g_err = "po_beam2d_batch: alphabet must have 1..4 symbols"; return PO_E_ARG; }
+    ProfScope ps(PO_K_BEAM2D, (hipStream_t)stream);
+    int rc = po_launch_beam2d(y1, y1_off, y2, y2_off, env, n, C, A, ap, W, model, method, seq, seq_off, seq_len, status,
+                              ws, ws_bytes, (hipStream_t)stream);
+    if (rc != PO_OK) { if (g_err.empty()) g_err = "po_beam2d_batch: launch refused"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
+// -------------------------------------------------------------------------------- pair decode
+size_t po_pair_decode_workspace_bytes(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C,
+                                      const po_pair_options* opt) {
+    return po_pair_ws_bytes_impl(n, tr1, tr2, mr1, mr2, C, opt);
+}
+
+int po_pair_decode_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off, int n,
+                         int C, const po_pair_options* opt, char* seq1d, const int64_t* seq1d_off, int32_t* len1,
+                         int32_t* len2, double* identity, int32_t* env_out, char* seq, const int64_t* seq_off,
+                         int32_t* seq_len, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0 || !y1 || !y1_off || !y2 || !y2_off || !opt || !seq1d || !seq1d_off || !len1 || !len2 || !identity ||
+        !seq || !seq_off || !seq_len || !status || !ws) { g_err = "po_pair_decode_batch: null argument"; return PO_E_ARG; }
+    int rc = po_launch_pair_decode(y1, y1_off, y2, y2_off, n, C, opt, seq1d, seq1d_off, len1, len2, identity,
+                                   env_out, seq, seq_off, seq_len, status, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != PO_OK) { if (g_err.empty()) g_err = "po_pair_decode_batch: launch refused"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
+// -------------------------------------------------------------------------------- host-buffer forms
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t b) { return hipMalloc(&p, b ? b : 16) == hipSuccess ? 0 : -1; }
+};
+#define UP(buf, src, bytes)                                                                      \
+    do {                                                                                         \
+        if ((buf).alloc(bytes)) { g_err = "hipMalloc failed"; return PO_E_HIP; }                 \
+        if ((src) && (bytes)) HIPCHK(hipMemcpy((buf).p, (src), (bytes), hipMemcpyHostToDevice)); \
+    } while (0)
+#define DOWN(dst, buf, bytes)                                                                      \
+    do {                                                                                           \
+        if ((dst) && (bytes)) HIPCHK(hipMemcpy((dst), (buf).p, (bytes), hipMemcpyDeviceToHost));   \
+    } while (0)
+}  // namespace
+
+int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int kind,
+                       int8_t* path_h,
+                       char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* map_h,
+                       int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t rows = y_off_h[n] - y_off_h[0];
+    const int64_t seqb = seq_off_h[n];
+    DevBuf y, yo, so, sq, sl, st, pt, mp, ws;
+    UP(y, y_h + y_off_h[0] * C, sizeof(double) * rows * C);
+    std::vector<int64_t> off(y_off_h, y_off_h + n + 1);
+    for (auto& o : off) o -= y_off_h[0];
+    UP(yo, off.data(), sizeof(int64_t) * (n + 1));
+    UP(so, seq_off_h, sizeof(int64_t) * (n + 1));
+    UP(sq, nullptr, (size_t)seqb);
+    UP(sl, nullptr, sizeof(int32_t) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    UP(pt, nullptr, (size_t)rows);
+    UP(mp, nullptr, sizeof(int32_t) * rows);
+    const size_t wsb = po_viterbi_workspace_bytes(n, rows, C, kind);
+    UP(ws, nullptr, wsb);
+    int rc = po_viterbi_batch((const double*)y.p, (const int64_t*)yo.p, n, C, alphabet, kind, (int8_t*)pt.p, (char*)sq.p,
+                              (const int64_t*)so.p, (int32_t*)sl.p, map_h ? (int32_t*)mp.p : nullptr,
+                              (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(seq_h, sq, (size_t)seqb);
+    DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    DOWN(path_h, pt, (size_t)rows);
+    DOWN(map_h, mp, sizeof(int32_t) * rows);
+    return PO_OK;
+}
+
+int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int W,
+                      int model, char* seq_h,
+                      const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t rows = y_off_h[n] - y_off_h[0];
+    const int64_t seqb = seq_off_h[n];
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) mx = std::max<int64_t>(mx, y_off_h[i + 1] - y_off_h[i]);
+    DevBuf y, yo, so, sq, sl, st, ws;
+    UP(y, y_h + y_off_h[0] * C, sizeof(double) * rows * C);
+    std::vector<int64_t> off(y_off_h, y_off_h + n + 1);
+    for (auto& o : off) o -= y_off_h[0];
+    UP(yo, off.data(), sizeof(int64_t) * (n + 1));
+    UP(so, seq_off_h, sizeof(int64_t) * (n + 1));
+    UP(sq, nullptr, (size_t)seqb);
+    UP(sl, nullptr, sizeof(int32_t) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_beam1d_workspace_bytes(n, rows, mx, C, W, model);
+    UP(ws, nullptr, wsb);
+    int rc = po_beam1d_batch((const double*)y.p, (const int64_t*)yo.p, n, C, alphabet, W, model, (char*)sq.p,
+                             (const int64_t*)so.p, (int32_t*)sl.p, (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(seq_h, sq, (size_t)seqb);
+    DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                      const int32_t* env_h, int n, int C, const char* alphabet, int W, int model, int method,
+                      char* seq_h,
+                      const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
+    const int64_t seqb = seq_off_h[n];
+    int64_t m1 = 0, m2 = 0;
+    for (int i = 0; i < n; ++i) {
+        m1 = std::max<int64_t>(m1, y1_off_h[i + 1] - y1_off_h[i]);
+        m2 = std::max<int64_t>(m2, y2_off_h[i + 1] - y2_off_h[i]);
+    }
+    DevBuf a, ao, b, bo, ev, so, sq, sl, st, ws;
+    UP(a, y1_h + y1_off_h[0] * C, sizeof(double) * r1 * C);
+    UP(b, y2_h + y2_off_h[0] * C, sizeof(double) * r2 * C);
+    std::vector<int64_t> o1(y1_off_h, y1_off_h + n + 1), o2(y2_off_h, y2_off_h + n + 1);
+    for (auto& o : o1) o -= y1_off_h[0];
+    for (auto& o : o2) o -= y2_off_h[0];
+    UP(ao, o1.data(), sizeof(int64_t) * (n + 1));
+    UP(bo, o2.data(), sizeof(int64_t) * (n + 1));
+    if (env_h) UP(ev, env_h + 2 * y1_off_h[0], sizeof(int32_t) * 2 * r1);
+    UP(so, seq_off_h, sizeof(int64_t) * (n + 1));
+    UP(sq, nullptr, (size_t)seqb);
+    UP(sl, nullptr, sizeof(int32_t) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_beam2d_workspace_bytes(n, r1, r2, m1, m2, C, W, model, method);
+    UP(ws, nullptr, wsb);
+    int rc = po_beam2d_batch((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p,
+                             env_h ? (const int32_t*)ev.p : nullptr, n, C, alphabet, W, model, method, (char*)sq.p,
+                             (const int64_t*)so.p, (int32_t*)sl.p, (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(seq_h, sq, (size_t)seqb);
+    DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_pair_decode_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
+                           const int64_t* y2_off_h, int n, int C, const po_pair_options* opt, char* seq1d_h,
+                           const int64_t* seq1d_off_h, int32_t* len1_h, int32_t* len2_h, double* identity_h,
+                           int32_t* env_out_h, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,
+                           int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
+    const int64_t seqb = seq_off_h[n], s1b = seq1d_off_h[2 * n];
+    int64_t m1 = 0, m2 = 0;
+    for (int i = 0; i < n; ++i) {
+        m1 = std::max<int64_t>(m1, y1_off_h[i + 1] - y1_off_h[i]);
+        m2 = std::max<int64_t>(m2, y2_off_h[i + 1] - y2_off_h[i]);
+    }
+    DevBuf a, ao, b, bo, so, sq, sl, st, s1o, s1, l1, l2, idn, ev, ws;
+    UP(a, y1_h + y1_off_h[0] * C, sizeof(double) * r1 * C);
+    UP(b, y2_h + y2_off_h[0] * C, sizeof(double) * r2 * C);
+    std::vector<int64_t> o1(y1_off_h, y1_off_h + n + 1), o2(y2_off_h, y2_off_h + n + 1);
+    for (auto& o : o1) o -= y1_off_h[0];
+    for (auto& o : o2) o -= y2_off_h[0];
+    UP(ao, o1.data(), sizeof(int64_t) * (n + 1));
+    UP(bo, o2.data(), sizeof(int64_t) * (n + 1));
+    UP(so, seq_off_h, sizeof(int64_t) * (n + 1));
+    UP(sq, nullptr, (size_t)seqb);
+    UP(sl, nullptr, sizeof(int32_t) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    UP(s1o, seq1d_off_h, sizeof(int64_t) * (2 * n + 1));
+    UP(s1, nullptr, (size_t)s1b);
+    UP(l1, nullptr, sizeof(int32_t) * n);
+    UP(l2, nullptr, sizeof(int32_t) * n);
+    UP(idn, nullptr, sizeof(double) * n);
+    UP(ev, nullptr, sizeof(int32_t) * 2 * r1);
+    const size_t wsb = po_pair_decode_workspace_bytes(n, r1, r2, m1, m2, C, opt);
+    UP(ws, nullptr, wsb);
+    int rc = po_pair_decode_batch((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p,
+                                  (const int64_t*)bo.p, n, C, opt, (char*)s1.p, (const int64_t*)s1o.p,
+                                  (int32_t*)l1.p, (int32_t*)l2.p, (double*)idn.p, (int32_t*)ev.p, (char*)sq.p,
+                                  (const int64_t*)so.p, (int32_t*)sl.p, (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(seq_h, sq, (size_t)seqb);
+    DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    DOWN(seq1d_h, s1, (size_t)s1b);
+    DOWN(len1_h, l1, sizeof(int32_t) * n);
+    DOWN(len2_h, l2, sizeof(int32_t) * n);
+    DOWN(identity_h, idn, sizeof(double) * n);
+    DOWN(env_out_h, ev, sizeof(int32_t) * 2 * r1);
+    return PO_OK;
+}
+
+// -------------------------------------------------------------------------------- events / profile
+void* po_event_create(void) {
+    hipEvent_t e;
+    return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
+}
+int po_event_record(void* ev, void* stream) {
+    HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return PO_OK;
+}
+int po_event_elapsed_ms(void* start, void* stop, float* ms) {
+    HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PO_OK;
+}
+void po_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+
+void po_profile_enable(int on) { g_prof_on = on != 0; }
+void po_profile_reset(void) {
+    prof_drain();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::memset(g_prof_ms, 0, sizeof(g_prof_ms));
+    std::memset(g_prof_n, 0, sizeof(g_prof_n));
+}
+int po_profile_get(int kernel, double* total_ms, int64_t* launches) {
+    if (kernel < 0 || kernel >= PO_K_COUNT) return PO_E_ARG;
+    prof_drain();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (total_ms) *total_ms = g_prof_ms[kernel];
+    if (launches) *launches = g_prof_n[kernel];
+    return PO_OK;
+}
+// internal: lets the pair pipeline time its own stages under their kernel ids
+void po_prof_stage(int kernel, hipStream_t s, int begin, void** tok) {
+    if (!g_prof_on) return;
+    if (begin) {
+        auto* r = new ProfRec{nullptr, nullptr, kernel};
+        (void)hipEventCreate(&r->a);
+        (void)hipEventCreate(&r->b);
+        (void)hipEventRecord(r->a, s);
+        *tok = r;
+    } else if (*tok) {
+        auto* r = (ProfRec*)*tok;
+        (void)hipEventRecord(r->b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(*r);
+        delete r;
+        *tok = nullptr;
+    }
+}
+
+}  // extern "C"

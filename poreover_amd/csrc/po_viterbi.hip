@@ -1,0 +1,252 @@
+// Batched argmax / Viterbi decode of (T, C) log-probability matrices.
+//
+// Replaces transducer.argmax_decode / poreover.viterbi_decode / bonito.viterbi_decode /
+// transducer.viterbi_decode (reference transducer.py:27-59,72-73,83-89,94-103) and
+// pair_decode.get_sequence_mapping (pair_decode.py:114-142).
+//
+// This is the one kernel on the path that is a pure HBM stream: 8*T*C bytes in, about
+// T + 5*L bytes out per read (path, characters, frame map).  One workgroup per read; rows are
+// copied HBM -> LDS with fully coalesced 8-byte-per-lane loads (a wave covers 512 contiguous
+// bytes per instruction), the per-frame argmax is taken from LDS (row stride 40 B = 10 dwords:
+// conflict-free for ds_read_b64 within each 32-lane group), and the emitted bases are
+// compacted with a ballot/popcount scan per wave plus a 4-entry LDS scan across waves.
+#include "po_device.h"
+
+#define VT_THREADS 256
+#define VT_WAVES (VT_THREADS / PO_WAVE)
+
+// Exclusive prefix count of `flag` over the 256-thread block; returns this thread's offset
+// and the block total through *total.  Uses LDS wsum[VT_WAVES].
+__device__ __forceinline__ int block_exclusive_count(bool flag, int* wsum, int* total) {
+    const unsigned long long mask = __ballot(flag);
+    const int lane = po_lane(), wave = threadIdx.x >> 6;
+    const int below = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(mask);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < VT_WAVES; ++w) {
+        const int c = wsum[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + below;
+}
+
+// kind: PO_KIND_POREOVER (blanks dropped, repeats kept) or PO_KIND_BONITO (groupby collapse).
+__global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
+    const double* __restrict__ y, const int64_t* __restrict__ y_off, int C, uint32_t alphabet, int kind, int8_t* __restrict__ path,
+    char* __restrict__ seq, const int64_t* __restrict__ seq_off, int32_t* __restrict__ seq_len,
+    int32_t* __restrict__ map, int32_t* __restrict__ status) {
+    __shared__ double tile[VT_THREADS * (PO_A + 1)];
+    __shared__ int wsum[VT_WAVES];
+    __shared__ int8_t pth[VT_THREADS + 1];  // pth[0] = last state of the previous tile
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int64_t r0 = y_off[r];
+    const int T = (int)(y_off[r + 1] - r0);
+    const int blank = C - 1;
+    const double* yr = y + r0 * C;
+    char* sq = seq + seq_off[r];
+    const int cap = (int)(seq_off[r + 1] - seq_off[r]);
+    int32_t* mp = map ? map + r0 : nullptr;
+    int n_seq = 0, n_map = 0, st = PO_OK;
+
+    // get_sequence_mapping('bonito') compares frame 0 with path[-1], i.e. the LAST frame
+    int last_state = -1;
+    if (kind == PO_KIND_BONITO && T > 0) {
+        const double* row = yr + (int64_t)(T - 1) * C;
+        int b = 0;
+        double bv = row[0];
+        for (int c = 1; c < C; ++c) {
+            const double v = row[c];
+            if (v > bv) { bv = v; b = c; }
+        }
+        last_state = b;
+    }
+    if (tid == 0) pth[0] = -1;
+    __syncthreads();
+
+    for (int t0 = 0; t0 < T; t0 += VT_THREADS) {
+        const int rows = min(VT_THREADS, T - t0);
+        const double* src = yr + (int64_t)t0 * C;
+        for (int i = tid; i < rows * C; i += VT_THREADS) tile[i] = src[i];
+        __syncthreads();
+        int p = blank;
+        if (tid < rows) {  // np.argmax: first maximum wins
+            double bv = tile[tid * C];
+            p = 0;
+            for (int c = 1; c < C; ++c) {
+                const double v = tile[tid * C + c];
+                if (v > bv) { bv = v; p = c; }
+            }
+            pth[tid + 1] = (int8_t)p;
+            if (path) path[r0 + t0 + tid] = (int8_t)p;
+        }
+        __syncthreads();
+        const int prev = pth[tid];  // state of frame t-1 (-1 before frame 0)
+        const int t = t0 + tid;
+        bool emit = false, emit_map = false;
+        if (tid < rows && p != blank) {
+            if (kind == PO_KIND_POREOVER) {
+                emit = emit_map = true;
+            } else {
+                emit = (t == 0) || (p != prev);
+                emit_map = (p != ((t == 0) ? last_state : prev));
+            }
+        }
+        int tot_s, tot_m;
+        const int pos_s = n_seq + block_exclusive_count(emit, wsum, &tot_s);
+        if (emit) {
+            if (pos_s < cap) sq[pos_s] = (char)((alphabet >> (8 * p)) & 0xffu);
+            else st = PO_E_CAP;
+        }
+        n_seq += tot_s;
+        if (mp) {
+            const int pos_m = n_map + block_exclusive_count(emit_map, wsum, &tot_m);
+            if (emit_map) mp[pos_m] = t;
+            n_map += tot_m;
+        }
+        if (tid == 0) pth[0] = pth[rows];
+        __syncthreads();
+    }
+    if (__syncthreads_or(st != PO_OK)) st = PO_E_CAP;
+    // the reference asserts len(sequence_to_signal) == len(basecall) (pair_decode.py:379,382)
+    if (st == PO_OK && mp && n_map != n_seq) st = PO_E_ARG;
+    if (T < 1) st = PO_E_ARG;
+    if (tid == 0) {
+        seq_len[r] = n_seq;
+        status[r] = st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flip-flop Viterbi (transducer.py:35-59 with the 8x8 transition matrix :94-103).  The 0/1
+// "transition" is ADDED to the log-probabilities, as in the reference (:44): illegal moves cost
+// one nat less than legal ones rather than being forbidden.
+// One 8-lane group per read (lane j = state j), 8 reads per wave.  ptr is int8[T][8] per read.
+#define FF_S 8
+__global__ __launch_bounds__(PO_WAVE) void flipflop_dp_kernel(const double* __restrict__ y,
+                                                              const int64_t* __restrict__ y_off, int n, int A,
+                                                              int8_t* __restrict__ ptr,
+                                                              int8_t* __restrict__ path,
+                                                              int32_t* __restrict__ status) {
+    __shared__ int8_t chunk[8][512 * FF_S];
+    const int lane = po_lane(), g = lane >> 3, j = lane & 7;
+    const int r = blockIdx.x * 8 + g;
+    const bool live = r < n;
+    const int64_t r0 = live ? y_off[r] : 0;
+    const int T = live ? (int)(y_off[r + 1] - r0) : 0;
+    int Tmax = T;
+#pragma unroll
+    for (int o = 8; o < PO_WAVE; o <<= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
+    const int S = 2 * A;  // live states; lanes j >= S of a group idle
+    const double* yr = y + r0 * S;
+    int8_t* pr = ptr + r0 * FF_S;
+    double v = (T > 0 && j < S) ? yr[j] : PO_NEG_INF;
+    for (int t = 1; t < Tmax; ++t) {
+        const bool on = t < T;
+        const double yt = (on && j < S) ? yr[(int64_t)t * S + j] : 0.0;
+        double bv = 0;
+        int bi = 0;
+#pragma unroll
+        for (int i = 0; i < FF_S; ++i) {
+            const double vi = __shfl(v, (g << 3) | i);
+            const double tr = (j < A) ? 1.0 : (((i % A) == (j - A)) ? 1.0 : 0.0);
+            const double cand = tr + vi;
+            if (i < S && (i == 0 || cand > bv)) { bv = cand; bi = i; }
+        }
+        if (on && j < S) {
+            pr[(int64_t)t * FF_S + j] = (int8_t)bi;
+            v = yt + bv;
+        }
+    }
+    // argmax of the final column (first maximum), held by every lane of the group
+    double bv = __shfl(v, g << 3);
+    int best = 0;
+#pragma unroll
+    for (int i = 1; i < FF_S; ++i) {
+        const double vi = __shfl(v, (g << 3) | i);
+        if (i < S && vi > bv) { bv = vi; best = i; }
+    }
+    __threadfence_block();
+    // back-trace in 512-frame chunks staged through LDS (the chain of dependent reads then runs
+    // at LDS latency instead of L2 latency)
+    int cur = best;
+    for (int lo = ((Tmax + 511) / 512 - 1) * 512; lo >= 0; lo -= 512) {  // uniform trip count
+        const int hi = min(T, lo + 512), len = hi - lo;                  // len <= 0: nothing here
+        for (int i = j; i < len * FF_S; i += 8) chunk[g][i] = pr[(int64_t)lo * FF_S + i];
+        __syncthreads();
+        if (j == 0) {
+            for (int t = hi - 1; t >= lo; --t) {
+                path[r0 + t] = (int8_t)cur;
+                if (t > 0) cur = chunk[g][(t - lo) * FF_S + cur];  // path[t-1] = ptr[t][path[t]]
+            }
+        }
+        cur = __shfl(cur, g << 3);
+        __syncthreads();
+    }
+    if (live && j == 0) status[r] = (T < 1) ? PO_E_ARG : PO_OK;
+}
+
+// remove_repeated(...).upper() (transducer.py:4-9,55) and get_sequence_mapping('flipflop')
+// (pair_decode.py:124-132) from a stored flip-flop state path: a base is emitted at frame 0 and
+// wherever the state changes.
+__global__ __launch_bounds__(VT_THREADS) void flipflop_compact_kernel(
+    const int8_t* __restrict__ path, const int64_t* __restrict__ y_off, int A, uint32_t alphabet,
+    char* __restrict__ seq, const int64_t* __restrict__ seq_off, int32_t* __restrict__ seq_len,
+    int32_t* __restrict__ map, int32_t* __restrict__ status) {
+    __shared__ int wsum[VT_WAVES];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int64_t r0 = y_off[r];
+    const int T = (int)(y_off[r + 1] - r0);
+    char* sq = seq + seq_off[r];
+    const int cap = (int)(seq_off[r + 1] - seq_off[r]);
+    int n_seq = 0, st = PO_OK;
+    for (int t0 = 0; t0 < T; t0 += VT_THREADS) {
+        const int t = t0 + tid;
+        bool emit = false;
+        int p = 0;
+        if (t < T) {
+            p = path[r0 + t];
+            emit = (t == 0) || (p != path[r0 + t - 1]);
+        }
+        int tot;
+        const int pos = n_seq + block_exclusive_count(emit, wsum, &tot);
+        if (emit) {
+            if (pos < cap) {
+                sq[pos] = (char)((alphabet >> (8 * (p % A))) & 0xffu);
+                if (map) map[r0 + pos] = t;
+            } else st = PO_E_CAP;
+        }
+        n_seq += tot;
+    }
+    if (__syncthreads_or(st != PO_OK)) st = PO_E_CAP;
+    if (tid == 0) {
+        seq_len[r] = n_seq;
+        if (status[r] == PO_OK) status[r] = st;
+    }
+}
+
+extern "C" int po_launch_viterbi(const double* y, const int64_t* y_off, int n, int C, int A, uint32_t alphabet,
+                                 int kind, int8_t* path,
+                                 char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* map,
+                                 int32_t* status, int8_t* ff_ptr, int8_t* ff_path, hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    if (A < 1 || A > PO_A) return PO_E_ARG;
+    if (kind == PO_KIND_FLIPFLOP) {
+        if (C != 2 * A) return PO_E_ARG;
+        int8_t* pth = path ? path : ff_path;
+        hipLaunchKernelGGL(flipflop_dp_kernel, dim3((n + 7) / 8), dim3(PO_WAVE), 0, stream, y, y_off, n, A, ff_ptr,
+                           pth, status);
+        hipLaunchKernelGGL(flipflop_compact_kernel, dim3(n), dim3(VT_THREADS), 0, stream, pth, y_off, A, alphabet,
+                           seq, seq_off, seq_len, map, status);
+        return PO_OK;
+    }
+    if (kind != PO_KIND_POREOVER && kind != PO_KIND_BONITO) return PO_E_ARG;
+    if (C != A + 1) return PO_E_ARG;
+    hipLaunchKernelGGL(viterbi_ctc_kernel, dim3(n), dim3(VT_THREADS), 0, stream, y, y_off, C, alphabet, kind, path, seq,
+                       seq_off, seq_len, map, status);
+    return PO_OK;
+}

@@ -1,0 +1,27 @@
+"""Drop-in for poreover.decoding.decoding_cpp (reference decoding_cpp.pyx:49-188): same names,
+argument meaning and defaults; the work is done by the gfx950 engine (libporeover_hip.so)."""
+import numpy as np
+
+from .. import batch as _batch
+
+DTYPE = np.float64
+
+
+def _as2d(y_):
+    y = np.asarray(y_, dtype=DTYPE, order="C")
+    if y.ndim != 2:
+        raise ValueError("expected a (T, C) matrix of log-probabilities")
+    return y
+
+
+def cpp_beam_search(y_, beam_width_=25, alphabet_="ACGT", model_="ctc"):
+    """decoding_cpp.pyx:88-103"""
+    return _batch.beam_search_batch([_as2d(y_)], beam_width_, alphabet_, model_)[0]
+
+
+def cpp_beam_search_2d(y1_, y2_, envelope_ranges_=None, beam_width_=25, alphabet_="ACGT", model_="ctc",
+                       method_="row"):
+    """decoding_cpp.pyx:107-139; envelope_ranges_: (U, 2) half-open column range per row of y1_"""
+    env = None if envelope_ranges_ is None else [np.asarray(envelope_ranges_, dtype=np.intc)]
+    return _batch.beam_search_2d_batch([_as2d(y1_)], [_as2d(y2_)], env, beam_width_, alphabet_, model_,
+                                       method_)[0]

@@ -1,0 +1,64 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol
+include/poreover_hip.h declares (no compute calls without a GPU), and the product fails loudly
+instead of falling back when no GPU is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def _have_lib():
+    from poreover_amd import _lib
+    return os.path.exists(_lib.LIB_PATH)
+
+
+def _ensure_built():
+    if not _have_lib():
+        from poreover_amd import build
+        build.build()
+
+
+def test_header_symbols_all_exported():
+    _ensure_built()
+    from poreover_amd import _lib
+    lib = _lib.load(require_gpu=False)
+    hdr = open(os.path.join(REPO, "include", "poreover_hip.h")).read()
+    declared = set(re.findall(r"\b(po_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libporeover_hip.so does not export %s" % name
+    assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
+    assert lib.po_version() >= 100
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, "poreover_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M) or "po_oracle" in txt or "libporef" in txt:
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad
+
+
+def test_fails_loudly_without_gpu():
+    _ensure_built()
+    from poreover_amd import _lib, batch
+    if _lib.load(require_gpu=False).po_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.EngineUnavailable):
+        batch.beam_search_batch([np.zeros((4, 5))], 5)
+    with pytest.raises(_lib.EngineUnavailable):
+        batch.viterbi_batch([np.zeros((4, 5))])
+
+
+def test_pack_rows():
+    from poreover_amd.batch import pack_rows
+    y, off, C = pack_rows([np.zeros((3, 5)), np.ones((2, 5), dtype=np.float32)])
+    assert y.shape == (5, 5) and y.dtype == np.float64 and off.tolist() == [0, 3, 5] and C == 5
+    with pytest.raises(ValueError):
+        pack_rows([np.zeros((3, 5)), np.zeros((3, 8))])
