@@ -48,62 +48,7 @@ __device__ __forceinline__ char* carve(char*& p, size_t bytes) {
     return r;
 }
 
-// root values at time tm1 (tree constructors PrefixTree.h:467-476, :541-546, :641-647)
-template <int MODEL>
-__device__ __forceinline__ void root_values(int tm1, double blank_cum, double* out) {
-    if (MODEL == PO_MODEL_CTC) {
-        out[0] = (tm1 < 0) ? 0.0 : blank_cum;
-    } else if (MODEL == PO_MODEL_MERGE) {
-        out[0] = (tm1 < 0) ? 0.0 : PO_NEG_INF;
-        out[1] = (tm1 < 0) ? 0.0 : PO_NEG_INF;
-        out[2] = PO_NEG_INF;
-    } else {
-        const double h = log(0.5);
-        out[0] = (tm1 < 0) ? 0.0 : PO_NEG_INF;
-        out[1] = (tm1 < 0) ? h : PO_NEG_INF;
-        out[2] = (tm1 < 0) ? h : PO_NEG_INF;
-    }
-}
-
 }  // namespace
-
-// update_prob for one node at one time: sp = own values at t-1, pp = parent's values at t-1,
-// yr = row t of y.  first_frame_of_root_child = (parent->depth == 0 && t == 0).
-template <int MODEL>
-__device__ __forceinline__ void po_update(const double* sp, const double* pp, const double* yr, int A, int last,
-                                          int plast, bool first_frame_of_root_child, double* out) {
-    if (MODEL == PO_MODEL_CTC) {
-        out[0] = po_lae(pp[0] + yr[last], sp[0] + yr[A]);
-    } else if (MODEL == PO_MODEL_MERGE) {
-        const double gap = sp[0] + yr[A];
-        double ng;
-        if (first_frame_of_root_child) ng = yr[last];
-        else if (plast == last) ng = po_lae(pp[1] + yr[last], sp[2] + yr[last]);
-        else ng = po_lae(pp[0] + yr[last], sp[2] + yr[last]);
-        out[0] = po_lae(gap, ng);
-        out[1] = gap;
-        out[2] = ng;
-    } else {
-        const double stay_flip = sp[1] + yr[last];
-        const double stay_flop = sp[2] + yr[last + A];
-        double ef, eo;
-        if (first_frame_of_root_child) {
-            ef = yr[last];
-            eo = yr[last + A];
-        } else if (plast == last) {
-            ef = pp[2] + yr[last];
-            eo = pp[1] + yr[last + A];
-        } else {
-            ef = po_lae(pp[1], pp[2]) + yr[last];
-            eo = PO_NEG_INF;
-        }
-        const double flip = po_lae(ef, stay_flip);
-        const double flop = po_lae(eo, stay_flop);
-        out[0] = po_lae(flip, flop);
-        out[1] = flip;
-        out[2] = flop;
-    }
-}
 
 template <int MODEL>
 __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
@@ -170,7 +115,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         if (lane < A) {
             double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, pp[3], out[3];
             root_values<MODEL>(-1, 0.0, pp);
-            po_update<MODEL>(sp, pp, yr, A, lane, A, true, out);
+            po_update<MODEL>(sp, pp, yr[lane], (MODEL == PO_MODEL_FLIPFLOP) ? yr[lane + A] : yr[A], false, true, out);
             P.id[lane] = 1 + lane;
             P.fc[lane] = -1;
             P.depth[lane] = 1;
@@ -216,7 +161,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             if (pslot >= 0) { for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + pslot]; }
             else if (pslot == -1) root_values<MODEL>(t - 1, blank_cum, pp);
             else { for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF; }
-            po_update<MODEL>(sp, pp, yr, A, last, plast, false, out);
+            po_update<MODEL>(sp, pp, yr[last], (MODEL == PO_MODEL_FLIPFLOP) ? yr[last + A] : yr[A], plast == last, false, out);
             int fc = P.fc[s];
             if (fc == -2) fc = afc[P.id[s]];  // re-entered the beam: the arena remembers
             Q.id[j] = P.id[s]; Q.depth[j] = P.depth[s];
@@ -266,7 +211,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             if (slot >= 0) { fcx = P.fc[slot]; for (int k = 0; k < K; ++k) sp[k] = P.val[k * NC + slot]; }
             else { for (int k = 0; k < K; ++k) sp[k] = PO_NEG_INF; }
             for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + sj];
-            po_update<MODEL>(sp, pp, yr, A, c, Q.last[j], false, out);
+            po_update<MODEL>(sp, pp, yr[c], (MODEL == PO_MODEL_FLIPFLOP) ? yr[c + A] : yr[A], Q.last[j] == c, false, out);
             Q.id[s] = x; Q.fc[s] = fcx; Q.depth[s] = Q.depth[j] + 1;
             for (int k = 0; k < K; ++k) Q.val[k * NC + s] = out[k];
         }
