@@ -279,7 +279,7 @@ def pair_decode(y1_, y2_, kind="poreover", beam_width=5, method="row_col", paddi
     return {"seq1": s1.value.decode(), "seq2": s2.value.decode(),
             "consensus": cons.value.decode() if rc >= 0 else None, "envelope": env.astype(np.int64),
             "length1": sm.len1, "length2": sm.len2, "ncol": sm.ncol,
-            "sequence_identity": sm.identity, "skipped": sm.skipped, "status": rc}
+            "sequence_identity": sm.identity, "skipped": sm.skipped, "status": 0 if rc >= 0 else rc}
 
 
 # ------------------------------------------------------------- the reference's own C++ (_ref)

@@ -62,6 +62,7 @@ struct B2Args {
     int n, A, W, C;
     uint32_t alphabet;
     char* seq; const int64_t* seq_off; int32_t* seq_len; int32_t* status;
+    int use_pre_status;       // status[] already holds skip / error codes for some pairs: leave those alone
     // workspace (per persistent workgroup unless noted)
     int* queue;               // one counter for the launch
     char* pool; size_t pool_bytes;
@@ -142,6 +143,10 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
         const int pi = sh[0];
         if (pi >= a.n) break;
         epoch++;
+        if (a.use_pre_status && a.status[pi] != PO_OK) {  // skipped upstream (pair_decode.py:372-375,395-398)
+            if (tid == 0) a.seq_len[pi] = 0;
+            continue;
+        }
         const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
         const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
         const double* yA = a.y1 + o1 * C;
@@ -585,8 +590,8 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
 extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
                                      const int32_t* env, int n, int C, int A, uint32_t alphabet, int W, int model,
                                      int method, int64_t mr1, int64_t mr2, char* seq, const int64_t* seq_off,
-                                     int32_t* seq_len, int32_t* status, void* ws, size_t ws_bytes,
-                                     hipStream_t stream) {
+                                     int32_t* seq_len, int32_t* status, int use_pre_status, void* ws,
+                                     size_t ws_bytes, hipStream_t stream) {
     if (n <= 0) return PO_OK;
     if (A < 1 || A > PO_A || W < 1 || W > 25) return PO_E_ARG;
     if (method != PO_METHOD_ROW_COL) return PO_E_UNSUPPORTED;
@@ -599,6 +604,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
     a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
     a.n = n; a.A = A; a.W = W; a.C = C; a.alphabet = alphabet;
     a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status;
+    a.use_pre_status = use_pre_status;
     a.queue = (int*)(w + g.off_queue);
     a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
     a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
@@ -644,13 +650,6 @@ extern "C" int po_launch_beam2d(const double* y1, const int64_t* y1_off, const d
     free(h);
     if (rc != PO_OK) return rc;
     return po_launch_beam2d_geom(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, m1, m2, seq, seq_off,
-                                 seq_len, status, ws, ws_bytes, stream);
+                                 seq_len, status, 0, ws, ws_bytes, stream);
 }
 
-// pair pipeline: placeholder until the alignment / envelope kernels land
-extern "C" size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const po_pair_options*) { return 256; }
-extern "C" int po_launch_pair_decode(const double*, const int64_t*, const double*, const int64_t*, int, int,
-                                     const po_pair_options*, char*, const int64_t*, int32_t*, int32_t*, double*, int32_t*,
-                                     char*, const int64_t*, int32_t*, int32_t*, void*, size_t, hipStream_t) {
-    return PO_E_UNSUPPORTED;
-}

@@ -1,0 +1,480 @@
+// Pair pipeline between the two 1-D basecalls and the pair beam search, all on the device:
+// alignment of the two basecalls, identity / length skips, and the alignment envelope.
+//
+// Replaces, for pair_decode.pair_decode_helper's default route (pair_decode.py:305-529):
+//   align.global_pair_banded  (align/align.pyx:100-178)   band 500, match 2 / mismatch -1 / gap -1
+//   align.global_pair         (align/align.pyx:29-98)     --alignment full
+//   the identity and length skips (pair_decode.py:372-375, 391-398)
+//   envelope.get_alignment_columns + add_block + build_envelope (decoding/envelope.py:5-87)
+//   the --diagonal_envelope band (pair_decode.py:497-498)
+//
+// The banded aligner is NOT a textbook banded NW and is reproduced as written: its boundary
+// initialisation is a no-op (the sparse matrix has no rows yet), rows 0..l1-1 are filled over
+// [start, end) with `end` itself left at the default 0, reads outside a row's stored range give
+// 0, seq[i-1] / seq[j-1] wrap to the last character at index 0, and the trace-back takes EVERY
+// neighbour that equals the maximum in turn (no break), emitting up to three columns per pass.
+//
+// Mapping.  One workgroup (256 threads) per pair, persistent over an atomic queue.  A DP row is
+// produced in parallel: c(j) = max(diag + score, up + gap) per cell, then the left-neighbour
+// dependency cell(j) = max(c(j), cell(j-1) - 1) is an integer prefix-max of c(k) + k (exact,
+// order-independent), done with a block scan.  The trace-back is inherently serial (one lane,
+// three independent L2 loads per step).  The envelope is built with integer atomics on the
+// output rows; its final fix-up pass carries one scalar (prev_end) and runs from LDS.
+#include <algorithm>
+#include <cstdlib>
+
+#include "po_device.h"
+
+namespace {
+
+constexpr int PP_THREADS = 256;
+constexpr int PP_WAVES = PP_THREADS / PO_WAVE;
+constexpr int NW_MATCH = 2, NW_MISMATCH = -1, NW_GAP = -1, NW_BAND = 500;
+
+struct PPArgs {
+    const int64_t* y1_off; const int64_t* y2_off;  // U_i, V_i
+    int n;
+    const char* seq1d; const int64_t* seq1d_off;   // interleaved: read1 at [2i], read2 at [2i+1]
+    const int32_t* len1; const int32_t* len2;
+    const int32_t* map1; const int32_t* map2;       // frame of each base, at y*_off[i]
+    const int32_t* st1; const int32_t* st2;         // status of the two 1-D decodes
+    int padding, full_alignment, diagonal_envelope, diagonal_width;
+    int32_t* env; double* identity; int32_t* status;
+    // workspace
+    int* queue;
+    int* dp; long long dp_cap;          // per workgroup: DP cells
+    int* rowinfo; long long row_cap;    // per workgroup: start[row_cap], end[row_cap], off (as 2 ints) -> 4 ints/row
+    char* aln; long long aln_cap;       // per workgroup: 2 * aln_cap chars
+};
+
+__device__ __forceinline__ int py_idx(int i, int len) { return i < 0 ? i + len : i; }  // python str index
+
+}  // namespace
+
+__global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
+    __shared__ int wsum[PP_WAVES];
+    __shared__ int sh[8];
+    __shared__ int lo_s[PP_THREADS], hi_s[PP_THREADS], pm[PP_THREADS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* dp = a.dp + (size_t)blockIdx.x * a.dp_cap;
+    int* r_start = a.rowinfo + (size_t)blockIdx.x * 4 * a.row_cap;
+    int* r_end = r_start + a.row_cap;
+    long long* r_off = (long long*)(r_end + a.row_cap);
+    char* al1 = a.aln + (size_t)blockIdx.x * 2 * a.aln_cap;
+    char* al2 = al1 + a.aln_cap;
+
+    // block-wide inclusive prefix max of one int per thread
+    auto block_prefix_max = [&](int v) {
+#pragma unroll
+        for (int o = 1; o < PO_WAVE; o <<= 1) {
+            const int t = __shfl_up(v, o);
+            if (lane >= o) v = max(v, t);
+        }
+        if (lane == PO_WAVE - 1) wsum[wave] = v;
+        __syncthreads();
+        int carry = INT_MIN;
+        for (int w = 0; w < wave; ++w) carry = max(carry, wsum[w]);
+        __syncthreads();
+        return max(v, carry);
+    };
+    // block-wide sum / exclusive prefix sum of one int per thread
+    auto block_excl_sum = [&](int v, int* total) {
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < PO_WAVE; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == PO_WAVE - 1) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0, tot = 0;
+        for (int w = 0; w < PP_WAVES; ++w) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
+        __syncthreads();
+        *total = tot;
+        return base + inc - v;
+    };
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) sh[0] = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int pi = sh[0];
+        if (pi >= a.n) break;
+        const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
+        const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
+        int32_t* env = a.env + 2 * o1;
+
+        if (a.diagonal_envelope) {  // pair_decode.py:497-498, python float arithmetic u/U*V
+            for (int u = tid; u < U; u += PP_THREADS) {
+                const int c = (int)((double)u / (double)U * (double)V);
+                env[2 * u] = max(c - a.diagonal_width, 0);
+                env[2 * u + 1] = min(c + a.diagonal_width, V);
+            }
+            if (tid == 0) { a.status[pi] = (U < 1 || V < 1) ? PO_E_ARG : PO_OK; a.identity[pi] = 0.0; }
+            continue;
+        }
+
+        const int l1 = a.len1[pi], l2 = a.len2[pi];
+        const char* s1 = a.seq1d + a.seq1d_off[2 * pi];
+        const char* s2 = a.seq1d + a.seq1d_off[2 * pi + 1];
+        const int32_t* m1 = a.map1 + o1;
+        const int32_t* m2 = a.map2 + o2;
+        int st = PO_OK;
+        if (a.st1[pi] != PO_OK) st = a.st1[pi];
+        else if (a.st2[pi] != PO_OK) st = a.st2[pi];
+        else if (abs(l1 - l2) > 1000) st = PO_SKIP_LENGTH;         // pair_decode.py:372-375
+        else if (l1 < 1 || l2 < 1) st = PO_E_ARG;                  // empty basecall: IndexError upstream
+        const bool full = a.full_alignment != 0;
+        const int nrows = full ? l1 + 1 : l1;
+        if (st == PO_OK && (nrows > a.row_cap || (long long)l1 + l2 + 8 > a.aln_cap)) st = PO_E_CAP;
+        if (st != PO_OK) {
+            if (tid == 0) { a.status[pi] = st; a.identity[pi] = 0.0; }
+            continue;
+        }
+
+        // ------------------------------------------------------------------ DP row geometry
+        // banded (align.pyx:119-125): center = int(np.round(l2 / l1 * i)); computed cells [start, end)
+        // with end = min(center + band, l2 - 1); full: columns [0, l2] all computed
+        for (int i = tid; i < nrows; i += PP_THREADS) {
+            int st_, en_;
+            if (full) { st_ = 0; en_ = l2 + 1; }
+            else {
+                const int center = (int)rint((double)l2 / (double)l1 * (double)i);
+                st_ = max(center - NW_BAND, 0);
+                en_ = min(center + NW_BAND, l2 - 1);
+                if (en_ < st_) en_ = st_;
+            }
+            r_start[i] = st_; r_end[i] = en_;
+        }
+        __syncthreads();
+        if (tid == 0) {  // row offsets (serial prefix sum over <= a few thousand rows)
+            long long acc = 0;
+            for (int i = 0; i < nrows; ++i) { r_off[i] = acc; acc += r_end[i] - r_start[i]; }
+            sh[1] = (acc > a.dp_cap) ? 1 : 0;
+        }
+        __syncthreads();
+        if (sh[1]) {
+            if (tid == 0) { a.status[pi] = PO_E_CAP; a.identity[pi] = 0.0; }
+            continue;
+        }
+        // SparseMatrix<int>::get (SparseMatrix.h:51-57,108-115): default 0 outside the computed cells
+        auto get = [&](int i, int j) -> int {
+            if (i < 0 || i >= nrows) return 0;
+            if (j < r_start[i] || j >= r_end[i]) return 0;
+            return dp[r_off[i] + (j - r_start[i])];
+        };
+
+        // ------------------------------------------------------------------ DP fill, row by row
+        for (int i = 0; i < nrows; ++i) {
+            const int js = r_start[i], je = r_end[i], w = je - js;
+            int* row = dp + r_off[i];
+            if (full && i == 0) {  // dpMatrix[0, j] = gap * j (align.pyx:44-45)
+                for (int j = tid; j < w; j += PP_THREADS) row[j] = NW_GAP * j;
+                __syncthreads();
+                continue;
+            }
+            // left boundary value and the character of seq1 this row scores against
+            //   banded: cell(i, js-1) reads 0 (out of range); seq1[i-1] wraps at i == 0
+            //   full:   cell(i, 0) = gap * i, filled cells start at j = 1; seq1[i-1]
+            const int jfirst = full ? 1 : js;
+            const int left0 = full ? NW_GAP * i : 0;
+            const char c1 = s1[py_idx(i - 1, l1)];
+            if (full && tid == 0) row[0] = left0;
+            const int cnt = je - jfirst;
+            const int per = (cnt + PP_THREADS - 1) / PP_THREADS;  // consecutive columns per thread
+            if (per > 8) {  // a row wider than 2048 cells (only --alignment full on very long reads)
+                if (tid == 0) sh[1] = 1;
+                __syncthreads();
+                break;
+            }
+            // local running max of c(k) + k over this thread's columns ...
+            const int j0 = jfirst + tid * per;
+            int loc[8];
+            int m = INT_MIN;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = j0 + q;
+                int val = INT_MIN;
+                if (q < per && j < je) {
+                    const char c2 = s2[py_idx(j - 1, l2)];
+                    const int diag = get(i - 1, j - 1) + (c1 == c2 ? NW_MATCH : NW_MISMATCH);
+                    const int up = get(i - 1, j) + NW_GAP;
+                    val = max(diag, up) + j;
+                }
+                m = max(m, val);
+                loc[q] = m;
+            }
+            // ... combined across threads (exclusive = inclusive of the previous thread), seeded with
+            // the value left of the first computed cell
+            const int incl = block_prefix_max(m);
+            pm[tid] = incl;
+            __syncthreads();
+            const int excl = max(left0 + (jfirst - 1), tid > 0 ? pm[tid - 1] : INT_MIN);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = j0 + q;
+                if (q < per && j < je) row[j - js] = max(loc[q], excl) - j;
+            }
+            __syncthreads();
+        }
+        if (sh[1]) {
+            if (tid == 0) { a.status[pi] = PO_E_UNSUPPORTED; a.identity[pi] = 0.0; }
+            continue;
+        }
+
+        // ------------------------------------------------------------------ trace-back (align.pyx:56-95 == :137-174)
+        if (tid == 0) {
+            int i = l1, j = l2, n = 0;
+            const int cap = (int)a.aln_cap;
+            bool ovf = false;
+#define PP_EMIT(c1_, c2_) do { if (n < cap) { al1[n] = (c1_); al2[n] = (c2_); } else ovf = true; n++; } while (0)
+            while (i > 0 && j > 0) {
+                const int sc = (s1[py_idx(i - 1, l1)] == s2[py_idx(j - 1, l2)]) ? NW_MATCH : NW_MISMATCH;
+                const int c0 = get(i - 1, j - 1) + sc, c1v = get(i - 1, j) + NW_GAP, c2v = get(i, j - 1) + NW_GAP;
+                const int mx = max(c0, max(c1v, c2v));
+                if (c0 == mx) { i--; j--; PP_EMIT(s1[py_idx(i, l1)], s2[py_idx(j, l2)]); }
+                if (c1v == mx) { i--; PP_EMIT(s1[py_idx(i, l1)], '-'); }
+                if (c2v == mx) { j--; PP_EMIT('-', s2[py_idx(j, l2)]); }
+            }
+            while (i > 0 || j > 0) {
+                if (i > 0) { i--; PP_EMIT(s1[py_idx(i, l1)], '-'); }
+                else if (j > 0) { j--; PP_EMIT('-', s2[py_idx(j, l2)]); }
+            }
+#undef PP_EMIT
+            sh[2] = n;
+            sh[3] = ovf ? 1 : 0;
+        }
+        __syncthreads();
+        const int ncol = sh[2];
+        if (sh[3]) {
+            if (tid == 0) { a.status[pi] = PO_E_CAP; a.identity[pi] = 0.0; }
+            continue;
+        }
+        // alignment is stored reversed: column k of the forward alignment is index ncol-1-k
+        // identity = matches / columns (pair_decode.py:391-393)
+        int matches = 0;
+        for (int k = tid; k < ncol; k += PP_THREADS) matches += (al1[k] == al2[k]);
+        int tot_m;
+        (void)block_excl_sum(matches, &tot_m);
+        const double identity = (double)tot_m / (double)ncol;
+        if (identity < 0.5) {  // pair_decode.py:395-398
+            if (tid == 0) { a.status[pi] = PO_SKIP_IDENTITY; a.identity[pi] = identity; }
+            continue;
+        }
+
+        // ------------------------------------------------------------------ envelope (envelope.py:46-87)
+        for (int u = tid; u < U; u += PP_THREADS) { env[2 * u] = INT_MAX; env[2 * u + 1] = -1; }
+        __syncthreads();
+        // get_alignment_columns (:26-44): x_index / y_index = running count of non-gap characters - 1
+        int xbase = -1, ybase = -1;
+        for (int k0 = 0; k0 < ncol; k0 += PP_THREADS) {
+            const int k = k0 + tid;  // forward column index
+            const bool in = k < ncol;
+            const char ca = in ? al1[ncol - 1 - k] : '-', cb = in ? al2[ncol - 1 - k] : '-';
+            int tx, ty;
+            const int ex = block_excl_sum(ca != '-' ? 1 : 0, &tx);
+            const int ey = block_excl_sum(cb != '-' ? 1 : 0, &ty);
+            if (in) {
+                const int xi = xbase + ex + (ca != '-' ? 1 : 0);
+                const int yi = ybase + ey + (cb != '-' ? 1 : 0);
+                const int i1 = min(max(xi, 0), l1 - 1), i2 = min(max(yi, 0), l2 - 1);
+                const int sx = m1[i1], exr = (i1 + 1 < l1) ? m1[i1 + 1] : U;
+                const int sy = m2[i2], eyr = (i2 + 1 < l2) ? m2[i2 + 1] : V;
+                for (int i = sx; i < exr; ++i)  // add_block (:5-17)
+                    if (i < U) { atomicMin(&env[2 * i], sy); atomicMax(&env[2 * i + 1], eyr); }
+            }
+            xbase += tx;
+            ybase += ty;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // padding (:73-75), then the sequential fix-ups (:78-85): prev_end only moves inside the 2nd if
+        int prev_end = 0;
+        for (int u0 = 0; u0 < U; u0 += PP_THREADS) {
+            const int u = u0 + tid;
+            if (u < U) {
+                int lo = env[2 * u], hi = env[2 * u + 1];
+                if (lo == INT_MAX) lo = -1;
+                lo = max(0, lo - a.padding);
+                hi = min(V, hi + a.padding);
+                lo_s[tid] = lo; hi_s[tid] = hi;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const int cnt = min(PP_THREADS, U - u0);
+                for (int q = 0; q < cnt; ++q) {
+                    int lo = lo_s[q];
+                    const int hi = hi_s[q];
+                    if (lo > hi) lo = 0;
+                    if (lo > prev_end) { lo = prev_end; prev_end = hi; }
+                    lo_s[q] = lo;
+                }
+                sh[4] = prev_end;
+            }
+            __syncthreads();
+            prev_end = sh[4];
+            if (u < U) { env[2 * u] = lo_s[tid]; env[2 * u + 1] = hi_s[tid]; }
+            __syncthreads();
+        }
+        if (tid == 0) { a.status[pi] = PO_OK; a.identity[pi] = identity; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+int po_launch_viterbi_strided(const double*, const int64_t*, int, int, int, uint32_t, int, int8_t*, char*,
+                              const int64_t*, int, int, int32_t*, int32_t*, int32_t*, int8_t*, int8_t*, hipStream_t);
+size_t po_beam2d_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, int, int, int);
+int po_launch_beam2d_geom(const double*, const int64_t*, const double*, const int64_t*, const int32_t*, int, int, int,
+                          uint32_t, int, int, int, int64_t, int64_t, char*, const int64_t*, int32_t*, int32_t*, int,
+                          void*, size_t, hipStream_t);
+void po_prof_stage(int kernel, hipStream_t s, int begin, void** tok);
+}
+
+namespace {
+inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+
+struct PPGeom {
+    int blocks;
+    size_t dp_cap, row_cap, aln_cap;
+    size_t off_queue, off_map1, off_map2, off_st1, off_st2, off_dp, off_rows, off_aln, off_ff, off_env, off_b2, total;
+    size_t ff_bytes, b2_bytes;
+};
+
+int pp_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, const po_pair_options* opt) {
+    PPGeom g;
+    g.blocks = std::min(n > 0 ? n : 1, pp_num_cus() * 4);
+    // a basecall has at most one base per frame, so lengths are bounded by the row counts; the DP
+    // budget assumes basecalls of at most max_rows / 4 bases (nanopore basecallers emit roughly one
+    // base per 8-10 frames) — longer ones are reported per pair as PO_E_CAP, never overrun
+    const int64_t lmax1 = std::max<int64_t>(64, mr1 / 4 + 8), lmax2 = std::max<int64_t>(64, mr2 / 4 + 8);
+    g.row_cap = (size_t)(lmax1 + 1);
+    const int64_t width = opt->full_alignment ? (lmax2 + 1) : std::min<int64_t>(lmax2 + 1, 2 * NW_BAND + 1);
+    g.dp_cap = (size_t)((lmax1 + 1) * width);
+    g.aln_cap = (size_t)(lmax1 + lmax2 + 16);
+    const int kind = opt->model == PO_MODEL_FLIPFLOP ? PO_KIND_FLIPFLOP : PO_KIND_POREOVER;
+    g.ff_bytes = (kind == PO_KIND_FLIPFLOP) ? al256((size_t)std::max(tr1, tr2) * 8) + al256((size_t)std::max(tr1, tr2)) : 0;
+    g.b2_bytes = po_beam2d_ws_bytes_impl(n, tr1, tr2, mr1, mr2, C, opt->beam_width, opt->model, opt->method);
+    size_t o = 0;
+    g.off_queue = o; o += 256;
+    g.off_map1 = o; o += al256(sizeof(int32_t) * (size_t)tr1);
+    g.off_map2 = o; o += al256(sizeof(int32_t) * (size_t)tr2);
+    g.off_st1 = o; o += al256(sizeof(int32_t) * (size_t)n);
+    g.off_st2 = o; o += al256(sizeof(int32_t) * (size_t)n);
+    g.off_dp = o; o += al256(sizeof(int) * g.dp_cap * g.blocks);
+    g.off_rows = o; o += al256(sizeof(int) * 4 * g.row_cap * g.blocks);
+    g.off_aln = o; o += al256(2 * g.aln_cap * g.blocks);
+    g.off_ff = o; o += g.ff_bytes;
+    g.off_env = o; o += al256(sizeof(int32_t) * 2 * (size_t)tr1);
+    g.off_b2 = o; o += g.b2_bytes;
+    g.total = o + 256;
+    return g;
+}
+}  // namespace
+
+extern "C" size_t po_pair_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C,
+                                        const po_pair_options* opt) {
+    return pp_geometry(n, tr1, tr2, mr1, mr2, C, opt).total;
+}
+
+extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_off, const double* y2,
+                                          const int64_t* y2_off, int n, int C, const po_pair_options* opt,
+                                          int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, char* seq1d,
+                                          const int64_t* seq1d_off, int32_t* len1, int32_t* len2, double* identity,
+                                          int32_t* env_out, char* seq, const int64_t* seq_off, int32_t* seq_len,
+                                          int32_t* status, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    const int A = PO_A;
+    const uint32_t alphabet = 'A' | ('C' << 8) | ('G' << 16) | ((uint32_t)'T' << 24);
+    if (opt->model < 0 || opt->model > 2) return PO_E_ARG;
+    if ((opt->model == PO_MODEL_FLIPFLOP) ? (C != 2 * A) : (C != A + 1)) return PO_E_ARG;
+    const int kind = opt->model == PO_MODEL_CTC ? PO_KIND_POREOVER
+                                                 : (opt->model == PO_MODEL_MERGE ? PO_KIND_BONITO : PO_KIND_FLIPFLOP);
+    const PPGeom g = pp_geometry(n, tr1, tr2, mr1, mr2, C, opt);
+    if (ws_bytes < g.total) return PO_E_CAP;
+    char* w = (char*)ws;
+    int32_t* map1 = (int32_t*)(w + g.off_map1);
+    int32_t* map2 = (int32_t*)(w + g.off_map2);
+    int32_t* st1 = (int32_t*)(w + g.off_st1);
+    int32_t* st2 = (int32_t*)(w + g.off_st2);
+    int32_t* env = env_out ? env_out : (int32_t*)(w + g.off_env);
+    int8_t* ffp = g.ff_bytes ? (int8_t*)(w + g.off_ff) : nullptr;
+    int8_t* ffpath = ffp ? ffp + al256((size_t)std::max(tr1, tr2) * 8) : nullptr;
+    void* tok = nullptr;
+    int rc;
+    // (1) the two 1-D basecalls with their frame maps (pair_decode.py:360-362, 377-382)
+    if (!opt->diagonal_envelope) {
+        po_prof_stage(PO_K_VITERBI, stream, 1, &tok);
+        rc = po_launch_viterbi_strided(y1, y1_off, n, C, A, alphabet, kind, nullptr, seq1d, seq1d_off, 0, 2, len1, map1,
+                                       st1, ffp, ffpath, stream);
+        if (rc != PO_OK) return rc;
+        rc = po_launch_viterbi_strided(y2, y2_off, n, C, A, alphabet, kind, nullptr, seq1d, seq1d_off, 1, 2, len2, map2,
+                                       st2, ffp, ffpath, stream);
+        if (rc != PO_OK) return rc;
+        po_prof_stage(PO_K_VITERBI, stream, 0, &tok);
+    } else {
+        if (hipMemsetAsync(len1, 0, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
+        if (hipMemsetAsync(len2, 0, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
+    }
+    // (2) alignment, skips, envelope
+    PPArgs a;
+    a.y1_off = y1_off; a.y2_off = y2_off; a.n = n;
+    a.seq1d = seq1d; a.seq1d_off = seq1d_off; a.len1 = len1; a.len2 = len2;
+    a.map1 = map1; a.map2 = map2; a.st1 = st1; a.st2 = st2;
+    a.padding = opt->padding; a.full_alignment = opt->full_alignment;
+    a.diagonal_envelope = opt->diagonal_envelope; a.diagonal_width = opt->diagonal_width;
+    a.env = env; a.identity = identity; a.status = status;
+    a.queue = (int*)(w + g.off_queue);
+    a.dp = (int*)(w + g.off_dp); a.dp_cap = (long long)g.dp_cap;
+    a.rowinfo = (int*)(w + g.off_rows); a.row_cap = (long long)g.row_cap;
+    a.aln = w + g.off_aln; a.aln_cap = (long long)g.aln_cap;
+    if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    po_prof_stage(PO_K_ALIGN, stream, 1, &tok);
+    hipLaunchKernelGGL(pair_prep_kernel, dim3(g.blocks), dim3(PP_THREADS), 0, stream, a);
+    po_prof_stage(PO_K_ALIGN, stream, 0, &tok);
+    // (3) the pair beam search inside the envelope (pair_decode.py:166-173,511)
+    po_prof_stage(PO_K_BEAM2D, stream, 1, &tok);
+    rc = po_launch_beam2d_geom(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, opt->beam_width, opt->model, opt->method,
+                               mr1, mr2, seq, seq_off, seq_len, status, 1, w + g.off_b2, g.b2_bytes, stream);
+    po_prof_stage(PO_K_BEAM2D, stream, 0, &tok);
+    return rc;
+}
+
+extern "C" int po_launch_pair_decode(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
+                                     int n, int C, const po_pair_options* opt, char* seq1d, const int64_t* seq1d_off,
+                                     int32_t* len1, int32_t* len2, double* identity, int32_t* env_out, char* seq,
+                                     const int64_t* seq_off, int32_t* seq_len, int32_t* status, void* ws,
+                                     size_t ws_bytes, hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    int64_t* h = (int64_t*)malloc(sizeof(int64_t) * 2 * (size_t)(n + 1));
+    if (!h) return PO_E_NOMEM;
+    int rc = PO_OK;
+    if (hipMemcpyAsync(h, y1_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipMemcpyAsync(h + n + 1, y2_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        rc = PO_E_HIP;
+    int64_t m1 = 0, m2 = 0, t1 = 0, t2 = 0;
+    if (rc == PO_OK) {
+        for (int i = 0; i < n; ++i) {
+            m1 = std::max<int64_t>(m1, h[i + 1] - h[i]);
+            m2 = std::max<int64_t>(m2, h[n + 1 + i + 1] - h[n + 1 + i]);
+        }
+        t1 = h[n] - h[0];
+        t2 = h[2 * n + 1] - h[n + 1];
+    }
+    free(h);
+    if (rc != PO_OK) return rc;
+    return po_launch_pair_decode_geom(y1, y1_off, y2, y2_off, n, C, opt, t1, t2, m1, m2, seq1d, seq1d_off, len1, len2,
+                                      identity, env_out, seq, seq_off, seq_len, status, ws, ws_bytes, stream);
+}

@@ -37,9 +37,9 @@ __device__ __forceinline__ int block_exclusive_count(bool flag, int* wsum, int* 
 
 // kind: PO_KIND_POREOVER (blanks dropped, repeats kept) or PO_KIND_BONITO (groupby collapse).
 __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
-    const double* __restrict__ y, const int64_t* __restrict__ y_off, int C, uint32_t alphabet, int kind, int8_t* __restrict__ path,
-    char* __restrict__ seq, const int64_t* __restrict__ seq_off, int32_t* __restrict__ seq_len,
-    int32_t* __restrict__ map, int32_t* __restrict__ status) {
+    const double* __restrict__ y, const int64_t* __restrict__ y_off, int C, uint32_t alphabet, int kind,
+    int8_t* __restrict__ path, char* __restrict__ seq, const int64_t* __restrict__ seq_off, int so_base,
+    int so_stride, int32_t* __restrict__ seq_len, int32_t* __restrict__ map, int32_t* __restrict__ status) {
     __shared__ double tile[VT_THREADS * (PO_A + 1)];
     __shared__ int wsum[VT_WAVES];
     __shared__ int8_t pth[VT_THREADS + 1];  // pth[0] = last state of the previous tile
@@ -48,8 +48,9 @@ __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
     const int T = (int)(y_off[r + 1] - r0);
     const int blank = C - 1;
     const double* yr = y + r0 * C;
-    char* sq = seq + seq_off[r];
-    const int cap = (int)(seq_off[r + 1] - seq_off[r]);
+    const int64_t so = seq_off[so_base + (int64_t)r * so_stride];
+    char* sq = seq + so;
+    const int cap = (int)(seq_off[so_base + (int64_t)r * so_stride + 1] - so);
     int32_t* mp = map ? map + r0 : nullptr;
     int n_seq = 0, n_map = 0, st = PO_OK;
 
@@ -195,14 +196,15 @@ __global__ __launch_bounds__(PO_WAVE) void flipflop_dp_kernel(const double* __re
 // wherever the state changes.
 __global__ __launch_bounds__(VT_THREADS) void flipflop_compact_kernel(
     const int8_t* __restrict__ path, const int64_t* __restrict__ y_off, int A, uint32_t alphabet,
-    char* __restrict__ seq, const int64_t* __restrict__ seq_off, int32_t* __restrict__ seq_len,
-    int32_t* __restrict__ map, int32_t* __restrict__ status) {
+    char* __restrict__ seq, const int64_t* __restrict__ seq_off, int so_base, int so_stride,
+    int32_t* __restrict__ seq_len, int32_t* __restrict__ map, int32_t* __restrict__ status) {
     __shared__ int wsum[VT_WAVES];
     const int r = blockIdx.x, tid = threadIdx.x;
     const int64_t r0 = y_off[r];
     const int T = (int)(y_off[r + 1] - r0);
-    char* sq = seq + seq_off[r];
-    const int cap = (int)(seq_off[r + 1] - seq_off[r]);
+    const int64_t so = seq_off[so_base + (int64_t)r * so_stride];
+    char* sq = seq + so;
+    const int cap = (int)(seq_off[so_base + (int64_t)r * so_stride + 1] - so);
     int n_seq = 0, st = PO_OK;
     for (int t0 = 0; t0 < T; t0 += VT_THREADS) {
         const int t = t0 + tid;
@@ -229,10 +231,25 @@ __global__ __launch_bounds__(VT_THREADS) void flipflop_compact_kernel(
     }
 }
 
+extern "C" int po_launch_viterbi_strided(const double* y, const int64_t* y_off, int n, int C, int A,
+                                         uint32_t alphabet, int kind, int8_t* path, char* seq,
+                                         const int64_t* seq_off, int so_base, int so_stride, int32_t* seq_len,
+                                         int32_t* map, int32_t* status, int8_t* ff_ptr, int8_t* ff_path,
+                                         hipStream_t stream);
+
 extern "C" int po_launch_viterbi(const double* y, const int64_t* y_off, int n, int C, int A, uint32_t alphabet,
-                                 int kind, int8_t* path,
-                                 char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* map,
-                                 int32_t* status, int8_t* ff_ptr, int8_t* ff_path, hipStream_t stream) {
+                                 int kind, int8_t* path, char* seq, const int64_t* seq_off, int32_t* seq_len,
+                                 int32_t* map, int32_t* status, int8_t* ff_ptr, int8_t* ff_path,
+                                 hipStream_t stream) {
+    return po_launch_viterbi_strided(y, y_off, n, C, A, alphabet, kind, path, seq, seq_off, 0, 1, seq_len, map,
+                                     status, ff_ptr, ff_path, stream);
+}
+
+extern "C" int po_launch_viterbi_strided(const double* y, const int64_t* y_off, int n, int C, int A,
+                                         uint32_t alphabet, int kind, int8_t* path, char* seq,
+                                         const int64_t* seq_off, int so_base, int so_stride, int32_t* seq_len,
+                                         int32_t* map, int32_t* status, int8_t* ff_ptr, int8_t* ff_path,
+                                         hipStream_t stream) {
     if (n <= 0) return PO_OK;
     if (A < 1 || A > PO_A) return PO_E_ARG;
     if (kind == PO_KIND_FLIPFLOP) {
@@ -241,12 +258,12 @@ extern "C" int po_launch_viterbi(const double* y, const int64_t* y_off, int n, i
         hipLaunchKernelGGL(flipflop_dp_kernel, dim3((n + 7) / 8), dim3(PO_WAVE), 0, stream, y, y_off, n, A, ff_ptr,
                            pth, status);
         hipLaunchKernelGGL(flipflop_compact_kernel, dim3(n), dim3(VT_THREADS), 0, stream, pth, y_off, A, alphabet,
-                           seq, seq_off, seq_len, map, status);
+                           seq, seq_off, so_base, so_stride, seq_len, map, status);
         return PO_OK;
     }
     if (kind != PO_KIND_POREOVER && kind != PO_KIND_BONITO) return PO_E_ARG;
     if (C != A + 1) return PO_E_ARG;
     hipLaunchKernelGGL(viterbi_ctc_kernel, dim3(n), dim3(VT_THREADS), 0, stream, y, y_off, C, alphabet, kind, path, seq,
-                       seq_off, seq_len, map, status);
+                       seq_off, so_base, so_stride, seq_len, map, status);
     return PO_OK;
 }

@@ -1,0 +1,102 @@
+"""GPU parity, whole pair-decode stage chain (pair_decode.pair_decode_helper default route) run on
+the device through po_pair_decode_batch: 1-D basecalls, banded / full alignment, identity and length
+skips, envelope, consensus — vs the golden outputs of the reference and vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import hexf
+from poreover_amd.synth import synth_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from poreover_amd import _lib, batch
+    _lib.load()
+    return batch
+
+
+def _fasta_seq(txt):
+    return "".join(txt.split("\n")[1:])
+
+
+def test_pipeline_golden(eng, golden, golden_inputs):
+    for rec in golden["pairs"]:
+        y1 = golden_inputs["pair%d_y1" % rec["index"]]
+        y2 = golden_inputs["pair%d_y2" % rec["index"]]
+        for name, run in rec["runs"].items():
+            if name == "diag30":
+                out = eng.pair_decode_batch([y1], [y2], rec["kind"], 5, "row_col", diagonal_envelope=True,
+                                            diagonal_width=30)[0]
+                assert out["consensus"] == _fasta_seq(run["fasta_2d"])
+                continue
+            method, W, aln = name.rsplit("_", 2)
+            if method != "row_col":
+                continue
+            out = eng.pair_decode_batch([y1], [y2], rec["kind"], int(W[1:]), method, 5, aln)[0]
+            sm = run["summary"]
+            assert (out["seq1"], out["seq2"]) == (rec["viterbi1"], rec["viterbi2"])
+            assert out["length1"] == sm["length1"] and out["length2"] == sm["length2"]
+            assert out["skipped"] == sm["skipped"]
+            if run["n_out"] != 3:
+                continue
+            assert out["sequence_identity"] == hexf(sm["sequence_identity"])
+            assert out["envelope"].tolist() == run["envelope"], (rec["index"], name)
+            assert out["consensus"] == _fasta_seq(run["fasta_2d"]), (rec["index"], name)
+
+
+@pytest.mark.parametrize("kind", ["poreover", "bonito", "flipflop"])
+def test_pipeline_matches_oracle_batch(eng, oracle, kind):
+    y1s, y2s = [], []
+    for i in range(10):
+        y1, y2 = synth_pair(6000 + i, T=250 + 45 * i, flipflop=(kind == "flipflop"))
+        y1s.append(y1); y2s.append(y2)
+    got = eng.pair_decode_batch(y1s, y2s, kind, 5, "row_col")
+    for i, (y1, y2) in enumerate(zip(y1s, y2s)):
+        try:
+            want = oracle.pair_decode(y1, y2, kind, 5, "row_col")
+        except oracle.OracleError as e:      # e.g. the bonito frame-map assertion of the reference
+            assert got[i]["status"] == e.code
+            continue
+        assert got[i]["status"] == want["status"], i
+        assert (got[i]["seq1"], got[i]["seq2"]) == (want["seq1"], want["seq2"])
+        if want["status"] == 0:
+            assert np.array_equal(got[i]["envelope"], want["envelope"]), i
+            assert got[i]["sequence_identity"] == want["sequence_identity"]
+            assert got[i]["consensus"] == want["consensus"], i
+
+
+def test_pipeline_full_alignment_and_skips(eng, oracle):
+    y1, y2 = synth_pair(6100, T=500)
+    got = eng.pair_decode_batch([y1], [y2], "poreover", 5, "row_col", alignment="full")[0]
+    want = oracle.pair_decode(y1, y2, "poreover", 5, "row_col", alignment="full")
+    assert got["consensus"] == want["consensus"] and np.array_equal(got["envelope"], want["envelope"])
+    # reads with nothing in common -> identity < 0.5 -> skipped (pair_decode.py:395-398)
+    from poreover_amd.synth import _render
+    rng = np.random.default_rng(5)
+    a = _render(rng, np.zeros(40, dtype=np.int64), 400, False)        # AAAA...
+    b = _render(rng, np.ones(44, dtype=np.int64), 420, False)         # CCCC...
+    got = eng.pair_decode_batch([a], [b])[0]
+    want = oracle.pair_decode(a, b)
+    assert want["skipped"] == 1 and want["status"] == oracle.SKIP_IDENTITY
+    assert got["skipped"] == 1 and got["status"] == want["status"]
+    assert got["sequence_identity"] == want["sequence_identity"] and got["consensus"] is None
+    # length mismatch > 1000 bases -> skipped before alignment (pair_decode.py:372-375)
+    long_, _ = synth_pair(6103, T=12000)
+    got = eng.pair_decode_batch([long_], [a])[0]
+    want = oracle.pair_decode(long_, a)
+    assert want["status"] == oracle.SKIP_LENGTH and got["status"] == want["status"]
+    assert (got["length1"], got["length2"]) == (want["length1"], want["length2"])
+
+
+def test_pipeline_full_size(eng, oracle):
+    """BASELINE config 3/4 shape: T ~ 4000 pairs, CLI defaults (W = 5, row_col, banded, padding 5)"""
+    y1s, y2s = zip(*[synth_pair(7000 + i, T=4000) for i in range(8)])
+    got = eng.pair_decode_batch(list(y1s), list(y2s))
+    for i in range(8):
+        want = oracle.pair_decode(y1s[i], y2s[i])
+        assert got[i]["status"] == 0 and want["status"] >= 0
+        assert np.array_equal(got[i]["envelope"], want["envelope"]), i
+        assert got[i]["sequence_identity"] == want["sequence_identity"]
+        assert got[i]["consensus"] == want["consensus"], i
