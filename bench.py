@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py — pair-decode throughput of the MI355X decoding engine on synthetic read pairs.
+
+One "step" = one pass of the hot path (pair_decode_helper's stage chain: two 1-D Viterbi
+basecalls, banded alignment, envelope, pair beam search — all on the GPU, through the C-ABI of
+include/poreover_hip.h) over this rank's shard of synthetic pairs, with the log-probability
+matrices ALREADY RESIDENT IN HBM when the timed region starts.
+
+Workload (BASELINE.json configs[3]): 10 000 synthetic pairs, T ~ 4000 frames, C = 5, CLI defaults
+(beam width 5, method row_col, banded alignment, padding 5), sharded over 8 GPUs = 1250 pairs per
+GPU.  Scaling is WEAK: every rank decodes its own 1250 pairs (no data-path collective; results
+stay on the rank, as the reference's per-process outputs do), so N = 8 is the full 10k-pair job.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--T 4000]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the byte accounting).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def _cpu_pair_worker(args):
+    """Decode a few pairs on one host core: C port for the glue stages + the reference's own C++
+    (oracle/_ref) for the pair beam search when it is available."""
+    seeds, T, use_ref = args
+    from oracle import po_oracle as O
+    from poreover_amd.synth import synth_pair
+    t_total, bases = 0.0, 0
+    for sd in seeds:
+        y1, y2 = synth_pair(sd, T=T)
+        t0 = time.perf_counter()
+        s1, p1 = O.viterbi_decode(y1)                                   # pair_decode.py:360-362
+        s2, p2 = O.viterbi_decode(y2)
+        m1, m2 = O.get_sequence_mapping(p1, "poreover"), O.get_sequence_mapping(p2, "poreover")
+        a1, a2 = O.global_pair_banded(s1, s2)                            # :389
+        ident = sum(x == y for x, y in zip(a1, a2)) / len(a1)
+        if abs(len(s1) - len(s2)) <= 1000 and ident >= 0.5:
+            env = O.build_envelope(len(y1), len(y2), a1, a2, m1, m2, 5)  # :500-501
+            beam = O.ref_beam_search_2d if use_ref else O.cpp_beam_search_2d
+            bases += len(beam(y1, y2, env, 5, method_="row_col"))        # :511
+        t_total += time.perf_counter() - t0
+    return t_total, bases, len(seeds)
+
+
+def cpu_baseline(T, sample_pairs):
+    """Bounded CPU sample of the same workload on this host's cores (mirrors --threads N)."""
+    import multiprocessing as mp
+    from oracle import po_oracle as O
+    O.build()
+    use_ref = O.have_ref()
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    per = max(1, sample_pairs // cores)
+    jobs = [([900000 + c * per + i for i in range(per)], T, use_ref) for c in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_pair_worker, jobs)
+    wall = time.perf_counter() - t0
+    n = sum(r[2] for r in res)
+    busy = sum(r[0] for r in res)
+    return {
+        "value": round(n / (busy / cores), 3),     # aggregate pairs/s with all `cores` busy
+        "unit": "read-pairs/s",
+        "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "per_core": round(n / busy, 3),
+        "mbases_per_s": round(sum(r[1] for r in res) / (busy / cores) / 1e6, 6),
+        "sample": ("%d synthetic pairs (T~%d, W=5 row_col) on %d processes, %.1f s wall; pair beam search = "
+                   "%s, glue stages (Viterbi, banded NW, envelope) = C port of the reference's Python/Cython"
+                   % (n, T, cores, wall,
+                      "the reference's own C++ (oracle/_ref)" if use_ref else "C port (oracle/_ref not built)")),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1250, help="pairs per GPU (10k / 8)")
+    ap.add_argument("--T", type=int, default=4000)
+    ap.add_argument("--beam_width", type=int, default=5)
+    ap.add_argument("--cpu_sample", type=int, default=96, help="pairs decoded on the CPU for the baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from poreover_amd import _lib
+    from poreover_amd.batch import pack_rows
+    from poreover_amd.synth import synth_pair
+    lib = _lib.load()
+    _lib.check(lib.po_set_device(local_rank), "po_set_device")
+
+    # ---- synthetic shard of this rank, generated on the host then moved to HBM
+    P, T = args.pairs, args.T
+    pairs = [synth_pair(rank * P + i, T=T) for i in range(P)]
+    y1, o1, Cc = pack_rows([p[0] for p in pairs])
+    y2, o2, _ = pack_rows([p[1] for p in pairs])
+    del pairs
+    tr1, tr2 = int(o1[-1]), int(o2[-1])
+    mr1, mr2 = int(np.diff(o1).max()), int(np.diff(o2).max())
+    s1o = np.zeros(2 * P + 1, dtype=np.int64)
+    caps = np.empty(2 * P, dtype=np.int64)
+    caps[0::2], caps[1::2] = np.diff(o1), np.diff(o2)
+    np.cumsum(caps, out=s1o[1:])
+    so = np.zeros(P + 1, dtype=np.int64)
+    np.cumsum(np.diff(o1) + np.diff(o2), out=so[1:])
+
+    dev = torch.device("cuda", local_rank)
+    d_y1 = torch.from_numpy(y1).to(dev)
+    d_y2 = torch.from_numpy(y2).to(dev)
+    d_o1, d_o2 = torch.from_numpy(o1).to(dev), torch.from_numpy(o2).to(dev)
+    d_s1o, d_so = torch.from_numpy(s1o).to(dev), torch.from_numpy(so).to(dev)
+    d_seq1d = torch.empty(int(s1o[-1]), dtype=torch.uint8, device=dev)
+    d_seq = torch.empty(int(so[-1]), dtype=torch.uint8, device=dev)
+    d_l1, d_l2, d_len, d_st = (torch.zeros(P, dtype=torch.int32, device=dev) for _ in range(4))
+    d_id = torch.zeros(P, dtype=torch.float64, device=dev)
+    d_env = torch.zeros(2 * tr1, dtype=torch.int32, device=dev)
+    opt = _lib.PairOptions(args.beam_width, _lib.MODELS["ctc"], _lib.METHODS["row_col"], 5, 0, 0, 50)
+    wsb = lib.po_pair_decode_workspace_bytes(P, tr1, tr2, mr1, mr2, Cc, C.byref(opt))
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        _lib.check(lib.po_pair_decode_batch(
+            d_y1.data_ptr(), d_o1.data_ptr(), d_y2.data_ptr(), d_o2.data_ptr(), P, Cc, C.byref(opt),
+            d_seq1d.data_ptr(), d_s1o.data_ptr(), d_l1.data_ptr(), d_l2.data_ptr(), d_id.data_ptr(),
+            d_env.data_ptr(), d_seq.data_ptr(), d_so.data_ptr(), d_len.data_ptr(), d_st.data_ptr(),
+            d_ws.data_ptr(), wsb, stream), "po_pair_decode_batch")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    lib.po_profile_enable(1)
+    lib.po_profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.po_profile_enable(0)
+
+    st = d_st.cpu().numpy()
+    lens = d_len.cpu().numpy()
+    decoded = int((st == 0).sum())
+    bases = int(lens[st == 0].sum())
+    bad = int(((st != 0) & (st != _lib.SKIP_LENGTH) & (st != _lib.SKIP_IDENTITY)).sum())
+    if bad:
+        raise SystemExit("bench.py: %d pairs failed with an engine error (first code %d)" % (bad, int(st[(st != 0)][0])))
+
+    # whole-job aggregate: max time over ranks, sum of units
+    tmax, tot_pairs, tot_bases = elapsed, P * args.steps, bases * args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        u = torch.tensor([P * args.steps, bases * args.steps], dtype=torch.float64, device=dev)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        tmax, tot_pairs, tot_bases = float(t[0]), float(u[0]), float(u[1])
+
+    def kernel_ms(k):
+        ms, cnt = C.c_double(), C.c_int64()
+        lib.po_profile_get(k, C.byref(ms), C.byref(cnt))
+        return ms.value, cnt.value
+
+    if rank == 0:
+        # algorithmic bytes per launch of the dominant kernel (pair beam search), SURVEY.md §8(d):
+        # 8*C*(U+V) log-probs + 8*U envelope + L output characters, summed over the launch's pairs
+        alg_bytes = 8.0 * Cc * (tr1 + tr2) + 8.0 * tr1 + bases
+        b2_ms, b2_n = kernel_ms(_lib.K_BEAM2D)
+        vt_ms, vt_n = kernel_ms(_lib.K_VITERBI)
+        al_ms, al_n = kernel_ms(_lib.K_ALIGN)
+        b2_avg = b2_ms / max(b2_n, 1)
+        achieved = alg_bytes / (b2_avg * 1e-3) / 1e9 if b2_avg > 0 else 0.0
+        n1d = int(d_l1.sum().item() + d_l2.sum().item())
+        vt_bytes = 8.0 * Cc * (tr1 + tr2) + 5.0 * n1d  # log-probs in; per base one character + one int32 frame index out
+        vt_avg = vt_ms / max(vt_n, 1)
+        out = {
+            "metric": "decoded Mbases/s + read-pairs/s, 10k synthetic pairs T~4000, 1/2/4/8 MI355X",
+            "value": round(tot_pairs / tmax, 3),
+            "unit": "read-pairs/s",
+            "mbases_per_s": round(tot_bases / tmax / 1e6, 4),
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(tmax / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "pair-decode (Viterbi x2 + banded NW + envelope + pair beam row_col) of %d "
+                                   "synthetic pairs per GPU, T~%d, C=5, beam_width=%d, padding=5; inputs resident in "
+                                   "HBM" % (P, T, args.beam_width),
+                       "pairs_per_gpu": P, "T": T, "beam_width": args.beam_width, "method": "row_col",
+                       "decoded_pairs_rank0": decoded, "parallelism": "shard%d (no collective)" % args.gpus},
+            "roofline": {"bound": "hbm", "kernel": "beam2d_rowcol_kernel", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
+                         "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(b2_avg, 3),
+                         "launches": b2_n,
+                         "note": "f64 log-space beam search: bound by dependent exp/log chains and LDS/L2 "
+                                 "latency, not by HBM (SURVEY.md §8(d)); the streaming Viterbi kernel is the "
+                                 "HBM-bound one, see viterbi_roofline"},
+            "viterbi_roofline": {"bound": "hbm", "kernel": "viterbi_ctc_kernel (2 launches per step)",
+                                 "achieved": round(vt_bytes / (vt_avg * 1e-3) / 1e9, 3) if vt_avg > 0 else 0.0,
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": round(vt_bytes / (vt_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6) if vt_avg > 0 else 0.0,
+                                 "avg_ms_per_step": round(vt_avg, 3)},
+            "stage_ms_per_step": {"viterbi_x2": round(vt_avg, 3), "align_envelope": round(al_ms / max(al_n, 1), 3),
+                                  "pair_beam": round(b2_avg, 3)},
+        }
+        if args.gpus == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(T, args.cpu_sample)
+            out["gpu_over_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
