@@ -6,10 +6,11 @@ basecalls, banded alignment, envelope, pair beam search — all on the GPU, thro
 include/poreover_hip.h) over this rank's shard of synthetic pairs, with the log-probability
 matrices ALREADY RESIDENT IN HBM when the timed region starts.
 
-Workload (BASELINE.json configs[3]): 10 000 synthetic pairs, T ~ 4000 frames, C = 5, CLI defaults
-(beam width 5, method row_col, banded alignment, padding 5), sharded over 8 GPUs = 1250 pairs per
-GPU.  Scaling is WEAK: every rank decodes its own 1250 pairs (no data-path collective; results
-stay on the rank, as the reference's per-process outputs do), so N = 8 is the full 10k-pair job.
+Workload (the configuration BASELINE.json's metric is quoted on): 10 000 synthetic pairs, T ~ 4000
+frames, C = 5, CLI defaults (beam width 5, method row_col, banded alignment, padding 5) PER GPU.
+Scaling is WEAK: every rank decodes its own 10 000 pairs (pairs are independent: no data-path
+collective; results stay on the rank, as the reference's per-process outputs do), so N = 1 is the
+BASELINE 10k-pair job and N GPUs decode N x 10k pairs.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--T 4000]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -88,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1250, help="pairs per GPU (10k / 8)")
+    ap.add_argument("--pairs", type=int, default=10000, help="pairs per GPU")
     ap.add_argument("--T", type=int, default=4000)
     ap.add_argument("--beam_width", type=int, default=5)
     ap.add_argument("--cpu_sample", type=int, default=96, help="pairs decoded on the CPU for the baseline (0 = skip)")
@@ -111,6 +112,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from poreover_amd import _lib
+    from poreover_amd import dist as podist
     from poreover_amd.batch import pack_rows
     from poreover_amd.synth import synth_pair
     lib = _lib.load()
@@ -118,7 +120,14 @@ def main():
 
     # ---- synthetic shard of this rank, generated on the host then moved to HBM
     P, T = args.pairs, args.T
-    pairs = [synth_pair(rank * P + i, T=T) for i in range(P)]
+    seeds = list(podist.shard_seeds(P, rank))
+    nproc = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    if nproc > 1 and P >= 256:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nproc) as pool:
+            pairs = pool.starmap(synth_pair, [(sd, T) for sd in seeds], chunksize=32)
+    else:
+        pairs = [synth_pair(sd, T=T) for sd in seeds]
     y1, o1, Cc = pack_rows([p[0] for p in pairs])
     y2, o2, _ = pack_rows([p[1] for p in pairs])
     del pairs
@@ -180,13 +189,7 @@ def main():
         raise SystemExit("bench.py: %d pairs failed with an engine error (first code %d)" % (bad, int(st[(st != 0)][0])))
 
     # whole-job aggregate: max time over ranks, sum of units
-    tmax, tot_pairs, tot_bases = elapsed, P * args.steps, bases * args.steps
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        u = torch.tensor([P * args.steps, bases * args.steps], dtype=torch.float64, device=dev)
-        dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        tmax, tot_pairs, tot_bases = float(t[0]), float(u[0]), float(u[1])
+    tmax, (tot_pairs, tot_bases) = podist.job_aggregate(dist, elapsed, [P * args.steps, bases * args.steps], dev)
 
     def kernel_ms(k):
         ms, cnt = C.c_double(), C.c_int64()

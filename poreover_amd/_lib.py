@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libporeover_hip.so")
+# POREOVER_HIP_LIB selects an alternative build of the same library (A/B timing builds)
+LIB_PATH = os.environ.get("POREOVER_HIP_LIB") or os.path.join(HERE, "libporeover_hip.so")
 
 OK = 0
 E_CAP, E_ARG, E_ENVELOPE, E_NOMEM, E_UNSUPPORTED, E_HIP = -1, -2, -3, -4, -6, -7

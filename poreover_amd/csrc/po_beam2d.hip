@@ -35,6 +35,7 @@
 //     pairs from an atomic queue, so a launch fills the 256 CUs for any batch size and the
 //     per-workgroup store (a few MB) is reused pair after pair.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "po_device.h"
@@ -42,7 +43,7 @@
 namespace {
 
 constexpr int B2_CH = 32;    // staging chunk: iterations per refill of the frozen-parent buffer
-constexpr int B2_NGL = 512;  // row groups tracked per pair (LDS bookkeeping)
+constexpr int B2_NGL = 256;  // row groups tracked per pair (LDS bookkeeping)
 
 template <int K>
 struct alignas(K == 1 ? 16 : 32) Entry {
@@ -69,6 +70,7 @@ struct B2Args {
     int* arena; long long arena_cap;   // 3 arrays of arena_cap ints: packed(parent,last), first_child, row group
     double* cum; long long tcap;       // 2 arrays of tcap doubles: blank prefix sums of each read
     int* envt; long long vcap;         // 2 * vcap ints: transposed envelope
+    long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
 };
 
 __device__ __forceinline__ char* carve(char*& p, size_t bytes) {
@@ -134,6 +136,16 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
     double* cum1 = cum0 + a.tcap;
     int* envt = a.envt + (size_t)blockIdx.x * 2 * a.vcap;
     unsigned epoch = 0;
+#ifdef PO_B2_TIMING
+    long long tk[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tlast = 0;
+#define TK_START() do { tlast = wall_clock64(); } while (0)
+#define TK(i) do { const long long n_ = wall_clock64(); tk[i] += n_ - tlast; tlast = n_; } while (0)
+#define TKC(i) do { tk[i]++; } while (0)
+#else
+#define TK_START() do {} while (0)
+#define TK(i) do {} while (0)
+#define TKC(i) do {} while (0)
+#endif
 
     for (;;) {
         // ---------------------------------------------------------------- next pair from the queue
@@ -143,6 +155,7 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
         const int pi = sh[0];
         if (pi >= a.n) break;
         epoch++;
+        TK_START();
         if (a.use_pre_status && a.status[pi] != PO_OK) {  // skipped upstream (pair_decode.py:372-375,395-398)
             if (tid == 0) a.seq_len[pi] = 0;
             continue;
@@ -200,7 +213,6 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
             continue;
         }
         const int Rm = R - 1;
-
         // blank prefix sums of both reads = the CTC root's alpha (PrefixTree.h:509-515); serial
         // in t so the rounding is the reference's
         if (MODEL == PO_MODEL_CTC && s == 0) {
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
         int nb = A;  // beam size
         int u = 0, v = 0, step = 0;
         __syncthreads();
+        TK(0);  // pre-pass + init
 
         // one scan = every participating element advances over its window, parent values flowing
         // through the LDS exchange buffer.  main: all elements of both reads; catch-up: beam
@@ -298,6 +311,7 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                 for (int k = 0; k < K; ++k) xch[((1 * 2 + r) * NCP + s) * K + k] = self[k];
             }
             const int64_t ycol_a = sym, ycol_b = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
+            TK(is_main ? 3 : 7);  // scan: self read
             for (int k0 = 0; k0 < Lmax; k0 += B2_CH) {
                 // ---- stage the parents that are not moving in this scan (frozen / root): times
                 //      t0-1+k0 .. for B2_CH iterations, both reads, every beam slot that needs it
@@ -316,7 +330,8 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) stg[((j * 2 + rr) * B2_CH + kk) * K + k] = out[k];
                 }
-                __syncthreads();
+                po_lds_barrier();
+                TK(is_main ? 4 : 8);  // scan: staging
                 const int kend = min(Lmax, k0 + B2_CH);
                 for (int k = k0; k < kend; ++k) {
                     const bool act = part && (k < len);
@@ -331,6 +346,8 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
 #pragma unroll
                             for (int q = 0; q < K; ++q) pp[q] = stg[((s * 2 + r) * B2_CH + (k - k0)) * K + q];
                         }
+                        // y[t][.] does not depend on the chain: the loads issue ahead and hit L1 (the
+                        // windows of consecutive steps overlap); an LDS ring for y measured no faster
                         const double ya = yr_[(int64_t)t * C + ycol_a], yb = yr_[(int64_t)t * C + ycol_b];
                         po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out);
                         st_write(row, r, t, node, out);
@@ -338,8 +355,9 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                         for (int q = 0; q < K; ++q) { self[q] = out[q]; xch[(((k & 1) * 2 + r) * NCP + s) * K + q] = out[q]; }
                         if (out[0] > mx) mx = out[0];
                     }
-                    __syncthreads();
+                    po_lds_barrier();  // only xch crosses iterations; the stores stay in flight
                 }
+                TK(is_main ? 5 : 9);  // scan: iterations
             }
             if (s < nelem) mxs[r * NCP + s] = mx;
         };
@@ -361,9 +379,12 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                     e_pslot[tid] = ps; b_stage[tid] = mode;
                     atomicMax(&g_hi1[B.row[tid] / PO_A], v + 1);
                 }
-                __syncthreads();
+                po_lds_barrier();
+                __syncthreads();  // store writes of earlier steps -> visible to this scan's reads
+                TK(6);  // catch-up: setup
                 scan(false, nbe, 0, 0, v, 1);
-                __syncthreads();
+                po_lds_barrier();
+                TKC(11);
                 v++;
                 continue;
             }
@@ -380,9 +401,12 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                     e_pslot[tid] = ps; b_stage[tid] = mode;
                     atomicMax(&g_hi0[B.row[tid] / PO_A], u + 1);
                 }
+                po_lds_barrier();
                 __syncthreads();
+                TK(6);
                 scan(false, nbe, u, 1, 0, 0);
-                __syncthreads();
+                po_lds_barrier();
+                TKC(11);
                 u++;
                 continue;
             }
@@ -426,7 +450,7 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                 sh[2] = next_id; sh[3] = cur;
                 if (err != PO_OK) sh[4] = err;
             }
-            __syncthreads();
+            po_lds_barrier();
             if (sh[4] != PO_OK) { st = sh[4]; break; }
             // (2) element table: beam slots [0, nb), child c of beam node j at nb + A*j + c
             const int NCc = nb * (A + 1);
@@ -450,10 +474,12 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                     e_pslot[tid] = j;
                 }
             }
-            __syncthreads();
+            po_lds_barrier();
+            __syncthreads();  // arena + store writes -> visible to the reads below
+            TK(2);  // main: expansion + element table
             // (3) the two look-ahead windows (BeamSearch.h:342-375)
             scan(true, NCc, u, ece - u, v, ere - v);
-            __syncthreads();
+            po_lds_barrier();
             // (4) prune by max0 + max1 (node_greater_max_sym); a child that is also a beam node is
             //     the same node pushed twice (std::unique)
             if (tid < NCc) {
@@ -466,7 +492,7 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                 dup[tid] = d;
             }
             if (tid == 0) sh[5] = 0;
-            __syncthreads();
+            po_lds_barrier();
             if (tid < NCc && !dup[tid]) {
                 const double sc = score[tid];
                 const int id = e_id[tid];
@@ -476,7 +502,7 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                 if (rank < W) sel[rank] = tid;
                 atomicAdd(&sh[5], 1);
             }
-            __syncthreads();
+            po_lds_barrier();
             const int nbn = min(W, sh[5]);
             // (5) next beam table; a promoted child learns from the arena whether it was ever expanded
             if (tid < nbn) {
@@ -493,14 +519,15 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                     Bn.fc[tid] = afc[id]; Bn.crow[tid] = acrow[id];
                 }
             }
-            __syncthreads();
+            po_lds_barrier();
             if (tid < nbn) {
                 B.id[tid] = Bn.id[tid]; B.row[tid] = Bn.row[tid]; B.prow[tid] = Bn.prow[tid]; B.par[tid] = Bn.par[tid];
                 B.gpar[tid] = Bn.gpar[tid]; B.plast[tid] = Bn.plast[tid]; B.last[tid] = Bn.last[tid];
                 B.depth[tid] = Bn.depth[tid]; B.fc[tid] = Bn.fc[tid]; B.crow[tid] = Bn.crow[tid];
             }
             nb = nbn;
-            __syncthreads();
+            po_lds_barrier();
+            TK(1);  // main: prune + next beam
             u++;
             v++;
         }
@@ -525,7 +552,12 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
             a.seq_len[pi] = nout;
             a.status[pi] = st;
         }
+        TK(10);  // label walk
     }
+#ifdef PO_B2_TIMING
+    if (tid == 0 && a.dbg && blockIdx.x == 0)
+        for (int i = 0; i < 12; ++i) a.dbg[i] = tk[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -557,7 +589,7 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model) {
     while (ncp < NC) ncp <<= 1;
     g.threads = 2 * ncp;
     const int waves = g.threads / PO_WAVE;
-    const int per_cu = waves <= 1 ? 8 : (waves == 2 ? 4 : 2);
+    const int per_cu = waves <= 1 ? 12 : (waves == 2 ? 6 : 3);  // 3 waves per SIMD (<= 168 VGPRs)
     g.blocks = b2_num_cus() * per_cu;
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
     auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
@@ -610,6 +642,12 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
     a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
     a.cum = (double*)(w + g.off_cum); a.tcap = (long long)g.tcap;
     a.envt = (int*)(w + g.off_envt); a.vcap = (long long)g.vcap;
+    a.dbg = nullptr;
+#ifdef PO_B2_TIMING
+    static long long* dbg_buf = nullptr;
+    if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 12 * sizeof(long long));
+    a.dbg = dbg_buf;
+#endif
     // queue counter and the store's tags start from zero on every launch
     if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
     if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
@@ -625,6 +663,18 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
     else if (model == PO_MODEL_FLIPFLOP) PO_LAUNCH_B2(PO_MODEL_FLIPFLOP);
     else return PO_E_ARG;
 #undef PO_LAUNCH_B2
+#ifdef PO_B2_TIMING
+    {
+        long long h[12];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const char* nm[12] = {"prepass+init", "main:prune+nextbeam", "main:expand+table", "main:scan selfread", "main:scan staging",
+                              "main:scan iterations", "catchup:setup", "catchup:selfread", "catchup:staging", "catchup:iterations",
+                              "label walk", "#catchup steps"};
+        fprintf(stderr, "[po_b2_timing] block 0, wall_clock64 ticks (100 MHz => 10 ns each):\n");
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-24s %12lld\n", nm[i], h[i]);
+    }
+#endif
     return PO_OK;
 }
 

@@ -24,6 +24,14 @@ __device__ __forceinline__ double po_lae(double x1, double x2) {
 
 __device__ __forceinline__ int po_lane() { return threadIdx.x & (PO_WAVE - 1); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global access (s_waitcnt vmcnt(0)); inside a dependent loop that turns each
+// fire-and-forget global store into a full round trip.  Use this one when only LDS data is
+// exchanged across the barrier and global visibility is established later by __syncthreads().
+__device__ __forceinline__ void po_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Candidate ordering used by every prune: higher score first; exact ties by node creation
 // order (ascending id).  The reference's tie order is heap-address order (Beam.h:96-107).
 __device__ __forceinline__ bool po_better(double sa, int ia, double sb, int ib) {

@@ -7,9 +7,9 @@
 // This is the one kernel on the path that is a pure HBM stream: 8*T*C bytes in, about
 // T + 5*L bytes out per read (path, characters, frame map).  One workgroup per read; rows are
 // copied HBM -> LDS with fully coalesced 8-byte-per-lane loads (a wave covers 512 contiguous
-// bytes per instruction), the per-frame argmax is taken from LDS (row stride 40 B = 10 dwords:
-// conflict-free for ds_read_b64 within each 32-lane group), and the emitted bases are
-// compacted with a ballot/popcount scan per wave plus a 4-entry LDS scan across waves.
+// bytes per instruction; all loads of a 512-frame tile are issued before the first use), the
+// per-frame argmax is taken from LDS, and the emitted bases are compacted with a wave scan plus a
+// 4-entry LDS scan across waves.
 #include "po_device.h"
 
 #define VT_THREADS 256
@@ -36,13 +36,22 @@ __device__ __forceinline__ int block_exclusive_count(bool flag, int* wsum, int* 
 }
 
 // kind: PO_KIND_POREOVER (blanks dropped, repeats kept) or PO_KIND_BONITO (groupby collapse).
+//
+// Streaming structure: a tile is VT_TILE = 512 frames (20 KB of log-probs at C = 5).  Each thread
+// issues its VT_LD = 10 coalesced 8-byte loads of the tile back to back BEFORE the first use, so a
+// workgroup keeps 20 KB in flight and a CU (6 resident workgroups) ~120 KB — enough to cover HBM
+// latency.  Every thread then decodes VT_FPT = 2 consecutive frames from LDS.
+#define VT_FPT 2
+#define VT_TILE (VT_THREADS * VT_FPT)
+#define VT_CMAX (PO_A + 1)
+#define VT_LD ((VT_TILE * VT_CMAX) / VT_THREADS)
 __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
     const double* __restrict__ y, const int64_t* __restrict__ y_off, int C, uint32_t alphabet, int kind,
     int8_t* __restrict__ path, char* __restrict__ seq, const int64_t* __restrict__ seq_off, int so_base,
     int so_stride, int32_t* __restrict__ seq_len, int32_t* __restrict__ map, int32_t* __restrict__ status) {
-    __shared__ double tile[VT_THREADS * (PO_A + 1)];
+    __shared__ double tile[VT_TILE * VT_CMAX];
     __shared__ int wsum[VT_WAVES];
-    __shared__ int8_t pth[VT_THREADS + 1];  // pth[0] = last state of the previous tile
+    __shared__ int8_t pth[VT_TILE + 1];  // pth[0] = last state of the previous tile
     const int r = blockIdx.x, tid = threadIdx.x;
     const int64_t r0 = y_off[r];
     const int T = (int)(y_off[r + 1] - r0);
@@ -69,44 +78,95 @@ __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
     if (tid == 0) pth[0] = -1;
     __syncthreads();
 
-    for (int t0 = 0; t0 < T; t0 += VT_THREADS) {
-        const int rows = min(VT_THREADS, T - t0);
+    for (int t0 = 0; t0 < T; t0 += VT_TILE) {
+        const int rows = min(VT_TILE, T - t0);
+        const int nval = rows * C;
         const double* src = yr + (int64_t)t0 * C;
-        for (int i = tid; i < rows * C; i += VT_THREADS) tile[i] = src[i];
-        __syncthreads();
-        int p = blank;
-        if (tid < rows) {  // np.argmax: first maximum wins
-            double bv = tile[tid * C];
-            p = 0;
-            for (int c = 1; c < C; ++c) {
-                const double v = tile[tid * C + c];
-                if (v > bv) { bv = v; p = c; }
-            }
-            pth[tid + 1] = (int8_t)p;
-            if (path) path[r0 + t0 + tid] = (int8_t)p;
+        double reg[VT_LD];
+#pragma unroll
+        for (int q = 0; q < VT_LD; ++q) {  // all loads issued before any use
+            const int i = tid + q * VT_THREADS;
+            reg[q] = (i < nval) ? src[i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < VT_LD; ++q) {
+            const int i = tid + q * VT_THREADS;
+            if (i < nval) tile[i] = reg[q];
         }
         __syncthreads();
-        const int prev = pth[tid];  // state of frame t-1 (-1 before frame 0)
-        const int t = t0 + tid;
-        bool emit = false, emit_map = false;
-        if (tid < rows && p != blank) {
-            if (kind == PO_KIND_POREOVER) {
-                emit = emit_map = true;
-            } else {
-                emit = (t == 0) || (p != prev);
-                emit_map = (p != ((t == 0) ? last_state : prev));
+        int p[VT_FPT];
+#pragma unroll
+        for (int f = 0; f < VT_FPT; ++f) {  // np.argmax: first maximum wins
+            const int fr = tid * VT_FPT + f;
+            p[f] = blank;
+            if (fr < rows) {
+                double bv = tile[fr * C];
+                int b = 0;
+                for (int c = 1; c < C; ++c) {
+                    const double v = tile[fr * C + c];
+                    if (v > bv) { bv = v; b = c; }
+                }
+                p[f] = b;
+                pth[fr + 1] = (int8_t)b;
+                if (path) path[r0 + t0 + fr] = (int8_t)b;
             }
         }
+        __syncthreads();
+        bool emit[VT_FPT], emit_map[VT_FPT];
+        int ne = 0, nm = 0;
+#pragma unroll
+        for (int f = 0; f < VT_FPT; ++f) {
+            const int fr = tid * VT_FPT + f, t = t0 + fr;
+            const int prev = pth[fr];  // state of frame t-1 (-1 before frame 0)
+            emit[f] = emit_map[f] = false;
+            if (fr < rows && p[f] != blank) {
+                if (kind == PO_KIND_POREOVER) {
+                    emit[f] = emit_map[f] = true;
+                } else {
+                    emit[f] = (t == 0) || (p[f] != prev);
+                    emit_map[f] = (p[f] != ((t == 0) ? last_state : prev));
+                }
+            }
+            ne += emit[f];
+            nm += emit_map[f];
+        }
+        // exclusive prefix of per-thread counts: wave scan + 4-entry cross-wave scan
+        auto block_excl = [&](int v, int* total) {
+            const int lane = po_lane(), wave = tid >> 6;
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < PO_WAVE; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (lane == PO_WAVE - 1) wsum[wave] = inc;
+            __syncthreads();
+            int base = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < VT_WAVES; ++w) {
+                const int c = wsum[w];
+                if (w < wave) base += c;
+                tot += c;
+            }
+            __syncthreads();
+            *total = tot;
+            return base + inc - v;
+        };
         int tot_s, tot_m;
-        const int pos_s = n_seq + block_exclusive_count(emit, wsum, &tot_s);
-        if (emit) {
-            if (pos_s < cap) sq[pos_s] = (char)((alphabet >> (8 * p)) & 0xffu);
-            else st = PO_E_CAP;
-        }
+        int pos_s = n_seq + block_excl(ne, &tot_s);
+#pragma unroll
+        for (int f = 0; f < VT_FPT; ++f)
+            if (emit[f]) {
+                if (pos_s < cap) sq[pos_s] = (char)((alphabet >> (8 * p[f])) & 0xffu);
+                else st = PO_E_CAP;
+                pos_s++;
+            }
         n_seq += tot_s;
         if (mp) {
-            const int pos_m = n_map + block_exclusive_count(emit_map, wsum, &tot_m);
-            if (emit_map) mp[pos_m] = t;
+            int pos_m = n_map + block_excl(nm, &tot_m);
+#pragma unroll
+            for (int f = 0; f < VT_FPT; ++f)
+                if (emit_map[f]) mp[pos_m++] = t0 + tid * VT_FPT + f;
             n_map += tot_m;
         }
         if (tid == 0) pth[0] = pth[rows];
