@@ -1,39 +1,44 @@
-// Batched pair (2-D) CTC beam search restricted to an alignment envelope: method "row_col".
+// Batched pair (2-D) CTC beam search: methods "row_col" and "row", with or without an envelope.
 //
-// Replaces decoding_cpp.cpp_beam_search_2d (decoding_cpp.pyx:107-139) -> beam_search(...,
-// envelope_ranges, ..., method="row_col") (BeamSearch.h:411-427) -> beam_search_2d_by_row_col
-// (BeamSearch.h:262-397) over the 2-D prefix trees of PrefixTree.h (:492-533 ctc, :578-633
-// flip-flop, :667-706 merge-repeats), with Beam<..., node_greater_max_sym> (Beam.h:30-38,93-108).
+// Replaces decoding_cpp.cpp_beam_search_2d (decoding_cpp.pyx:107-139) -> beam_search(...)
+// (BeamSearch.h:411-458) ->
+//   method "row_col": beam_search_2d_by_row_col          (BeamSearch.h:262-397)   pair-decode CLI default
+//   method "row":     beam_search_2d_by_row, envelope    (BeamSearch.h:110-172)   API default
+//                     beam_search_2d_by_row, no envelope (BeamSearch.h:175-260)
+// over the 2-D prefix trees of PrefixTree.h (:492-533 ctc, :578-633 flip-flop, :667-706 merge
+// repeats) with Beam<..., node_greater_max_sym / node_greater_max> (Beam.h:20-38,93-108).
 //
-// What the reference does.  It walks the envelope along a diagonal (u, v).  A MAIN step updates
-// every element (the <= W beam nodes and their 4 children) on read 0 over the look-ahead window
+// What the reference does.  row_col walks the envelope along a diagonal (u, v): a MAIN step updates
+// every element (the <= W beam nodes and their children) on read 0 over the look-ahead window
 // [u, ce) and on read 1 over [v, re), then keeps the W elements with the largest
-// max_t alpha0[t] + max_t alpha1[t].  A CATCH-UP step advances only one of u, v and updates only
-// the beam nodes at that single time.  Every update reads alpha of the node and of its parent at
-// time t-1 from per-node std::unordered_map<int,double>s that are never erased; an absent
-// entry reads as -inf.  Values written in one step are read again in later steps — by the same
-// node (t = start-1), by beam nodes whose parent has left the beam (the parent's old look-ahead
-// values, "frozen"), and by children that become elements again when their parent re-enters the
-// beam — so the maps ARE the algorithm's state and have to be reproduced exactly.
+// max_t alpha0[t] + max_t alpha1[t]; a CATCH-UP step advances only u or v and updates only the beam
+// nodes at that one time.  row visits every row u: beam nodes and children are updated on read 0 at
+// time u only, every element is updated on read 1 over the whole row band [rs, re), and the score is
+// alpha0[u] + max_t alpha1[t].  (Its `for b < beam_width` loop runs over a vector that GROWS while it
+// is iterated, so while the beam is smaller than W, children pushed in the same row are expanded
+// too — reproduced here, see "growing".)  Every update reads alpha of the node and of its parent at
+// time t-1 from per-node std::unordered_map<int,double>s that are never erased; an absent entry
+// reads as -inf.  Values written in one step are read again in later steps — by the same node
+// (t = start-1), by beam nodes whose parent has left the beam (the parent's old values, "frozen"),
+// and by children that become elements again when their parent re-enters the beam — so the maps
+// ARE the algorithm's state and are reproduced exactly.
 //
 // Data layout on MI355X.
-//   * The maps become a VALUE STORE in HBM (L2-resident in practice): each node owns a ring
-//     row of R entries per read, entry = {64-bit tag(epoch, node, t), K doubles}; a read hits iff
-//     the tag matches, so absent == -inf falls out with no bookkeeping and rows can be recycled
-//     without clearing.  R = pow2 >= widest window + 2 (every time a step can still read lies in
-//     [u-1, u-1+R)).  Rows are handed out per parent in groups of 4 (one per child symbol) and
-//     recycled as soon as every time written into them lies below u-1 / v-1 (nothing reads it).
-//   * The tree shrinks to an arena of packed (parent,last) words for the final label walk, plus
-//     first-child / row-group words that are read only when a node (re-)enters the beam.
-//   * Within a step the recurrence alpha[t] = lae(alpha_parent[t-1] + y[t][c], alpha[t-1] +
-//     y[t][blank]) is a wavefront over (depth, t): every element advances one t per iteration
-//     and takes its parent's value of the previous iteration from an LDS exchange buffer
-//     (double-buffered, one barrier per iteration).  Parents that are not elements ("frozen")
-//     and the root are staged from the store / the blank prefix sums into LDS in chunks of 32
-//     iterations, so the dependent chain never waits on HBM.
-//   * One workgroup per pair, thread = (read, element slot); workgroups are persistent and pull
-//     pairs from an atomic queue, so a launch fills the 256 CUs for any batch size and the
-//     per-workgroup store (a few MB) is reused pair after pair.
+//   * VALUE STORE in HBM (L2-resident in practice): each node owns a ring row of R entries per read,
+//     entry = {64-bit tag(epoch, node, t), K doubles}; a read hits iff the tag matches, so
+//     "absent == -inf" needs no bookkeeping and rows are recycled without clearing.  R = pow2 >=
+//     widest window + 2.  Rows are handed out per parent in groups of 4 (one per child symbol) and
+//     recycled as soon as every time written into them lies below what any later step can read.
+//   * The tree is an arena of packed (parent,last) words for the final label walk, plus first-child /
+//     row-group words read only when a node (re-)enters the beam.
+//   * Within a step the recurrence alpha[t] = lae(alpha_parent[t-1] + y[t][c], alpha[t-1] + y[t][blank])
+//     is a wavefront over (depth, t): every element advances one t per iteration and takes its
+//     parent's value of the previous iteration from an LDS exchange buffer (double-buffered, one
+//     LDS-only barrier per iteration).  Parents that do not move in the step (frozen, or the root's
+//     blank prefix sums) are staged from the store into LDS 32 iterations at a time.
+//   * One workgroup per pair, thread = (read, element slot); the LDS layout is a compile-time struct
+//     per beam-width class (W <= 6 / 12 / 25 -> 64 / 128 / 256 threads).  Workgroups are persistent
+//     and pull pairs from an atomic queue.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -59,79 +64,69 @@ __device__ __forceinline__ unsigned long long make_tag(unsigned epoch, int node,
 struct B2Args {
     const double* y1; const int64_t* y1_off;
     const double* y2; const int64_t* y2_off;
-    const int32_t* env;
-    int n, A, W, C;
+    const int32_t* env;       // NULL: no envelope (method row only)
+    int n, A, W, C, method;
     uint32_t alphabet;
     char* seq; const int64_t* seq_off; int32_t* seq_len; int32_t* status;
     int use_pre_status;       // status[] already holds skip / error codes for some pairs: leave those alone
     // workspace (per persistent workgroup unless noted)
     int* queue;               // one counter for the launch
     char* pool; size_t pool_bytes;
-    int* arena; long long arena_cap;   // 3 arrays of arena_cap ints: packed(parent,last), first_child, row group
+    int* arena; long long arena_cap;   // 3 int arrays (packed(parent,last), first_child, row group) + 1 double array
     double* cum; long long tcap;       // 2 arrays of tcap doubles: blank prefix sums of each read
     int* envt; long long vcap;         // 2 * vcap ints: transposed envelope
     long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
 };
 
-__device__ __forceinline__ char* carve(char*& p, size_t bytes) {
-    char* r = p;
-    p += (bytes + 15) & ~size_t(15);
-    return r;
-}
+// element-table field indices
+enum { F_ID, F_ROW, F_PSLOT, F_SYM, F_FC, F_CROW, F_PAR, F_GPAR, F_PROW, F_DEPTH, F_COUNT };
+// F_SYM packs: own symbol (bits 0-2) | parent's symbol (bits 4-6) | parent-is-root (bit 9)
+__device__ __forceinline__ int sym_pack(int last, int plast, bool rootpar) { return last | (plast << 4) | (rootpar ? 512 : 0); }
+__device__ __forceinline__ int sym_last(int s) { return s & 7; }
+__device__ __forceinline__ int sym_plast(int s) { return (s >> 4) & 7; }
 
-// beam table: one entry per beam node, carried from step to step
-struct BeamTab {
-    int *id, *row, *prow, *par, *gpar, *plast, *last, *depth, *fc, *crow;
+template <int MODEL, int WMAX>
+struct B2Smem {
+    static constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
+    static constexpr int NCM = WMAX * (PO_A + 1);                      // element slots
+    static constexpr int NCP = (NCM <= 32) ? 32 : (NCM <= 64 ? 64 : 128);  // threads per read
+    int e[F_COUNT][NCM];    // element table: slots [0, nb) are the beam nodes in rank order
+    int nx[F_COUNT][WMAX];  // next beam under construction
+    int sel[WMAX];
+    int dup[NCM];
+    int stage[NCM];         // 0: parent moves in this scan; 1: parent staged from the store; 2: root
+    int g_owner[B2_NGL], g_hi0[B2_NGL], g_hi1[B2_NGL];
+    int sh[16];
+    double score[NCM];
+    double mxs[2][NCP];
+    double xch[2][2][NCP][K];
+    double stg[WMAX][2][B2_CH][K];
 };
-__device__ __forceinline__ void carve_beam(BeamTab& b, char*& p, int WM) {
-    const size_t n = sizeof(int) * WM;  // spelled out: a loop over member pointers would go to scratch
-    b.id = (int*)carve(p, n); b.row = (int*)carve(p, n); b.prow = (int*)carve(p, n); b.par = (int*)carve(p, n);
-    b.gpar = (int*)carve(p, n); b.plast = (int*)carve(p, n); b.last = (int*)carve(p, n);
-    b.depth = (int*)carve(p, n); b.fc = (int*)carve(p, n); b.crow = (int*)carve(p, n);
-}
 
 }  // namespace
 
-template <int MODEL>
-__global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
-    constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
+// threads per workgroup for a beam-width class: 2 reads x (element slots padded to 32 / 64 / 128)
+#define B2_THREADS(WM) ((WM) * (PO_A + 1) <= 32 ? 64 : ((WM) * (PO_A + 1) <= 64 ? 128 : 256))
+
+template <int MODEL, int WMAX>
+__global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
+    using SM = B2Smem<MODEL, WMAX>;
+    constexpr int K = SM::K, NCM = SM::NCM, NCP = SM::NCP, nthr = 2 * NCP;
     using Ent = Entry<K>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int NCP = nthr >> 1;         // element slots per read (padded)
+    __shared__ SM sm;
+    const int tid = threadIdx.x;
     const int r = tid / NCP;           // read handled by this thread
     const int s = tid - r * NCP;       // element slot handled by this thread
     const int A = a.A, W = a.W, C = a.C;
-    const int WM = max(W, PO_A);
-    const int NCmax = WM * (A + 1);
-
-    // ---- LDS carve
-    char* p = smem;
-    BeamTab B, Bn;
-    carve_beam(B, p, WM);
-    carve_beam(Bn, p, WM);
-    int* e_id = (int*)carve(p, sizeof(int) * NCmax);
-    int* e_row = (int*)carve(p, sizeof(int) * NCmax);
-    int* e_pslot = (int*)carve(p, sizeof(int) * NCmax);  // >=0: element slot of the parent; -1: staged
-    int* e_sym = (int*)carve(p, sizeof(int) * NCmax);    // own symbol | same-as-parent << 8 | parent-is-root << 9
-    int* sel = (int*)carve(p, sizeof(int) * WM);
-    int* dup = (int*)carve(p, sizeof(int) * NCmax);
-    int* b_stage = (int*)carve(p, sizeof(int) * WM);     // beam slot needs its parent staged (1) / root (2)
-    int* g_owner = (int*)carve(p, sizeof(int) * B2_NGL);
-    int* g_hi0 = (int*)carve(p, sizeof(int) * B2_NGL);    // one past the latest time written, read 0
-    int* g_hi1 = (int*)carve(p, sizeof(int) * B2_NGL);    // ... read 1
-    int* sh = (int*)carve(p, sizeof(int) * 16);
-    double* score = (double*)carve(p, sizeof(double) * NCmax);
-    double* mxs = (double*)carve(p, sizeof(double) * 2 * NCP);
-    double* xch = (double*)carve(p, sizeof(double) * 2 * 2 * NCP * K);
-    double* stg = (double*)carve(p, sizeof(double) * WM * 2 * B2_CH * K);
+    const bool is_row = (a.method == PO_METHOD_ROW);
 
     // ---- per-workgroup workspace
     Ent* pool = (Ent*)(a.pool + (size_t)blockIdx.x * a.pool_bytes);
     const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
-    int* apl = a.arena + (size_t)blockIdx.x * 3 * a.arena_cap;
+    int* apl = a.arena + (size_t)blockIdx.x * 5 * a.arena_cap;
     int* afc = apl + a.arena_cap;
     int* acrow = afc + a.arena_cap;
+    double* amax = (double*)(acrow + a.arena_cap);  // row method: a node's max over its last non-empty row band
     double* cum0 = a.cum + (size_t)blockIdx.x * 2 * a.tcap;
     double* cum1 = cum0 + a.tcap;
     int* envt = a.envt + (size_t)blockIdx.x * 2 * a.vcap;
@@ -150,9 +145,9 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
     for (;;) {
         // ---------------------------------------------------------------- next pair from the queue
         __syncthreads();
-        if (tid == 0) sh[0] = atomicAdd(a.queue, 1);
+        if (tid == 0) sm.sh[0] = atomicAdd(a.queue, 1);
         __syncthreads();
-        const int pi = sh[0];
+        const int pi = sm.sh[0];
         if (pi >= a.n) break;
         epoch++;
         TK_START();
@@ -165,56 +160,68 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
         const double* yA = a.y1 + o1 * C;
         const double* yB = a.y2 + o2 * C;
         const double* yr_ = r ? yB : yA;
-        const int32_t* env = a.env + 2 * o1;
-        const double* cum = r ? cum1 : cum0;
+        const int32_t* env = a.env ? a.env + 2 * o1 : nullptr;
         int st = PO_OK;
         if (U < 1 || V < 1 || U > a.tcap || V > a.vcap || V > a.tcap || U >= (1 << 24) || V >= (1 << 24)) st = PO_E_ARG;
+        if (!env && !is_row) st = PO_E_UNSUPPORTED;
 
         // ---------------------------------------------------------------- envelope pre-pass
-        // bounds, widest row, transposed envelope (BeamSearch.h:270-284), widest column
+        // bounds, widest row, and for row_col the transposed envelope (BeamSearch.h:270-284)
         int R = 32, NG = 0;
         if (st == PO_OK) {
-            int bad = 0, wmax = 0;
-            for (int u = tid; u < U; u += nthr) {
-                const int lo = env[2 * u], hi = env[2 * u + 1];
-                if (lo < hi && (lo < 0 || hi > V)) bad = 1;
-                wmax = max(wmax, hi - lo);
-            }
-            for (int x = tid; x < V; x += nthr) { envt[2 * x] = -1; envt[2 * x + 1] = -1; }
-            if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
-            if (st == PO_OK) {
-                // each column x is always visited by thread x % nthr, rows in order: race-free
-                for (int u = 0; u < U; ++u) {
+            int bad = 0, wmax = env ? 0 : V;
+            int unsup = 0;
+            if (env)
+                for (int u = tid; u < U; u += nthr) {
                     const int lo = env[2 * u], hi = env[2 * u + 1];
-                    int x = lo + ((tid - lo) % nthr + nthr) % nthr;
-                    for (; x < hi; x += nthr) {
-                        if (envt[2 * x] < 0) { envt[2 * x] = u; envt[2 * x + 1] = u + 1; }
-                        else envt[2 * x + 1]++;
-                    }
+                    if (lo < hi && (lo < 0 || hi > V)) bad = 1;
+                    // row method: a later row reads time rs-1, so row starts must not move backwards
+                    // for the ring store to still hold it (every envelope the pipeline builds complies)
+                    if (is_row && u > 0 && lo < env[2 * u - 2]) unsup = 1;
+                    wmax = max(wmax, hi - lo);
                 }
+            if (!is_row)
+                for (int x = tid; x < V; x += nthr) { envt[2 * x] = -1; envt[2 * x + 1] = -1; }
+            if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
+            if (__syncthreads_or(unsup) && st == PO_OK) st = PO_E_UNSUPPORTED;
+            if (st == PO_OK) {
+                if (!is_row) {
+                    // each column x is always visited by thread x % nthr, rows in order: race-free
+                    for (int u = 0; u < U; ++u) {
+                        const int lo = env[2 * u], hi = env[2 * u + 1];
+                        int x = lo + ((tid - lo) % nthr + nthr) % nthr;
+                        for (; x < hi; x += nthr) {
+                            if (envt[2 * x] < 0) { envt[2 * x] = u; envt[2 * x + 1] = u + 1; }
+                            else envt[2 * x + 1]++;
+                        }
+                    }
+                    __syncthreads();
+                    for (int x = tid; x < V; x += nthr) wmax = max(wmax, envt[2 * x + 1] - envt[2 * x]);
+                }
+                if (tid == 0) sm.sh[1] = 0;
                 __syncthreads();
-                for (int x = tid; x < V; x += nthr) wmax = max(wmax, envt[2 * x + 1] - envt[2 * x]);
-                // block max through LDS
-                if (tid == 0) sh[1] = 0;
+                atomicMax(&sm.sh[1], wmax);
                 __syncthreads();
-                atomicMax(&sh[1], wmax);
-                __syncthreads();
-                wmax = sh[1];
+                wmax = sm.sh[1];
                 while (R < wmax + 2) R <<= 1;
                 const long long ng = pool_entries / ((long long)PO_A * 2 * R);
                 NG = (int)min((long long)B2_NGL, ng);
-                if (NG < 2 * WM + 4) st = PO_E_NOMEM;  // envelope too wide for the per-pair store
+                if (NG < 2 * max(W, PO_A) + 4) st = PO_E_NOMEM;  // band too wide for the per-pair value store
             }
         }
-        const long long arena_need = 1 + A + (long long)A * WM * (min(U, V) + 1);
-        if (st == PO_OK && (arena_need > a.arena_cap || arena_need >= (1 << 24))) st = PO_E_NOMEM;
+        {   // node budget: every processed element creates at most A nodes per step
+            const long long steps = is_row ? U : min(U, V);
+            const long long need = 1 + A + (long long)A * max(W, A) * (steps + 1);
+            if (st == PO_OK && (need > a.arena_cap || need >= (1 << 24))) st = PO_E_NOMEM;
+        }
         if (st != PO_OK) {
             if (tid == 0) { a.status[pi] = st; a.seq_len[pi] = 0; }
             continue;
         }
         const int Rm = R - 1;
-        // blank prefix sums of both reads = the CTC root's alpha (PrefixTree.h:509-515); serial
-        // in t so the rounding is the reference's
+
+        // blank prefix sums of both reads = the CTC root's alpha (PrefixTree.h:509-515); serial in t so
+        // the rounding is the reference's
         if (MODEL == PO_MODEL_CTC && s == 0) {
             double* cw = r ? cum1 : cum0;
             const int Tn = r ? V : U;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                     if (t0 + q < Tn) { acc += b[q]; cw[t0 + q] = acc; }
             }
         }
-        for (int g = tid; g < B2_NGL; g += nthr) { g_owner[g] = -1; g_hi0[g] = 0; g_hi1[g] = 0; }
+        for (int g = tid; g < B2_NGL; g += nthr) { sm.g_owner[g] = -1; sm.g_hi0[g] = 0; sm.g_hi1[g] = 0; }
         __syncthreads();
 
         // ---------------------------------------------------------------- store access helpers
@@ -265,20 +272,48 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                 for (int k = 0; k < K; ++k) out[k] = tmp[k];
             }
         };
+        // a free row group: nothing a later step can read is stored in it.  lo0 / lo1 = smallest
+        // time a later step can still read on read 0 / 1.  Without an envelope (row method) the read-1
+        // band restarts at 0 in every row, so time never retires read-1 values; there a value can
+        // only be read again as a frozen parent's, i.e. through a beam node's own row, its parent's
+        // row or its children's group, and a group nobody in the beam points to is free.
+        auto alloc_group = [&](int owner, int lo0, int lo1, int nbeam) -> int {
+            int cur = sm.sh[3];
+            int g = -1;
+            for (int tries = 0; tries < NG; ++tries) {
+                const int c = cur;
+                cur = (cur + 1 == NG) ? 0 : cur + 1;
+                bool free_ = sm.g_owner[c] < 0 || (sm.g_hi0[c] <= lo0 && sm.g_hi1[c] <= lo1);
+                if (!free_ && !env && sm.g_hi0[c] <= lo0) {
+                    bool ref = false;
+                    for (int j = 0; j < nbeam; ++j)
+                        ref |= (sm.e[F_ROW][j] / PO_A == c) || (sm.e[F_PROW][j] >= 0 && sm.e[F_PROW][j] / PO_A == c) ||
+                               (sm.e[F_CROW][j] == c);
+                    free_ = !ref;
+                }
+                if (free_) { g = c; break; }
+            }
+            sm.sh[3] = cur;
+            if (g < 0) { sm.sh[4] = PO_E_NOMEM; g = 0; }
+            sm.g_owner[g] = owner;
+            sm.g_hi0[g] = 0; sm.g_hi1[g] = 0;
+            return g;
+        };
 
         // ---------------------------------------------------------------- tree + beam initialisation
-        // root = node 0; its A children = nodes 1..A in row group 0 (BeamSearch.h:286-293)
+        // root = node 0; its A children = nodes 1..A in row group 0 (BeamSearch.h:119-127,286-293)
         if (tid == 0) {
             apl[0] = po_pack_node(-1, A); afc[0] = 1; acrow[0] = 0;
-            g_owner[0] = 0; g_hi0[0] = 1; g_hi1[0] = 1;  // the root's children hold values at t = 0
-            sh[2] = 1 + A;  // next node id
-            sh[3] = 1;      // group allocation cursor
-            sh[4] = PO_OK;
+            sm.g_owner[0] = 0; sm.g_hi0[0] = 1; sm.g_hi1[0] = 1;  // the root's children hold values at t = 0
+            sm.sh[2] = 1 + A;  // next node id
+            sm.sh[3] = 1;      // group allocation cursor
+            sm.sh[4] = PO_OK;
         }
         if (tid < A) {
             apl[1 + tid] = po_pack_node(0, tid); afc[1 + tid] = -1; acrow[1 + tid] = -1;
-            B.id[tid] = 1 + tid; B.row[tid] = tid; B.prow[tid] = -1; B.par[tid] = 0; B.gpar[tid] = -1;
-            B.plast[tid] = A; B.last[tid] = tid; B.depth[tid] = 1; B.fc[tid] = -1; B.crow[tid] = -1;
+            sm.e[F_ID][tid] = 1 + tid; sm.e[F_ROW][tid] = tid; sm.e[F_PROW][tid] = -1; sm.e[F_PAR][tid] = 0;
+            sm.e[F_GPAR][tid] = -1; sm.e[F_SYM][tid] = sym_pack(tid, A, true); sm.e[F_DEPTH][tid] = 1;
+            sm.e[F_FC][tid] = -1; sm.e[F_CROW][tid] = -1;
         }
         if (s < A) {  // update_prob(n, r, 0) for both reads
             double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, pp[3], out[3];
@@ -286,49 +321,49 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
             const double ya = yr_[s], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr_[s + A] : yr_[A];
             po_update<MODEL>(sp, pp, ya, yb, false, true, out);
             st_write(s, r, 0, 1 + s, out);
+            if (r == 1) amax[1 + s] = out[0];
         }
         int nb = A;  // beam size
-        int u = 0, v = 0, step = 0;
         __syncthreads();
         TK(0);  // pre-pass + init
 
-        // one scan = every participating element advances over its window, parent values flowing
-        // through the LDS exchange buffer.  main: all elements of both reads; catch-up: beam
-        // nodes of one read at one time (len == 1).
-        // t0x / lenx: window start / length for read x (len 0 = read not touched).
-        auto scan = [&](bool is_main, int nelem, int t00, int len0, int t01, int len1) {
+        // ---------------------------------------------------------------- one scan
+        // Every participating element advances over its window, parent values flowing through the
+        // LDS exchange buffer.  t0x / lenx: window start / length on read x (len 0 = read untouched);
+        // slots [skip_lo, skip_hi) do not move on read 0 (row method: beam nodes beyond the first W).
+        auto scan = [&](bool is_main, int nelem, int skip_lo, int skip_hi, int t00, int len0, int t01, int len1) {
             const int t0 = r ? t01 : t00, len = r ? len1 : len0;
-            const bool part = (s < nelem) && (len > 0);
+            const bool part = (s < nelem) && (len > 0) && !(r == 0 && s >= skip_lo && s < skip_hi);
             const int Lmax = max(len0, len1);
             int node = 0, row = -1, pslot = -1, sym = 0;
             bool same = false, rootpar = false;
             double self[K], mx = PO_NEG_INF;
             if (part) {
-                node = e_id[s]; row = e_row[s]; pslot = e_pslot[s];
-                sym = e_sym[s] & 0xff; same = (e_sym[s] >> 8) & 1; rootpar = (e_sym[s] >> 9) & 1;
+                node = sm.e[F_ID][s]; row = sm.e[F_ROW][s]; pslot = sm.e[F_PSLOT][s];
+                const int sy = sm.e[F_SYM][s];
+                sym = sym_last(sy); same = (sym_plast(sy) == sym); rootpar = (sy >> 9) & 1;
                 st_read(row, r, t0 - 1, node, self);
 #pragma unroll
-                for (int k = 0; k < K; ++k) xch[((1 * 2 + r) * NCP + s) * K + k] = self[k];
+                for (int k = 0; k < K; ++k) sm.xch[1][r][s][k] = self[k];
             }
             const int64_t ycol_a = sym, ycol_b = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
             TK(is_main ? 3 : 7);  // scan: self read
             for (int k0 = 0; k0 < Lmax; k0 += B2_CH) {
-                // ---- stage the parents that are not moving in this scan (frozen / root): times
-                //      t0-1+k0 .. for B2_CH iterations, both reads, every beam slot that needs it
-                const int nbs = min(nelem, nb);
-                for (int idx = tid; idx < nbs * 2 * B2_CH; idx += nthr) {
+                // ---- stage the parents that do not move in this scan (frozen / root)
+                const int nst = min(nelem, WMAX);
+                for (int idx = tid; idx < nst * 2 * B2_CH; idx += nthr) {
                     const int j = idx / (2 * B2_CH), rem = idx - j * 2 * B2_CH;
                     const int rr = rem / B2_CH, kk = rem - rr * B2_CH;
                     const int lr = rr ? len1 : len0, tr0 = rr ? t01 : t00;
-                    const int mode = b_stage[j];
+                    const int mode = sm.stage[j];
                     if (mode == 0) continue;  // parent moves in this scan: its values come through xch
                     if (k0 + kk >= lr) continue;
                     double out[K];
                     const int tt = tr0 - 1 + k0 + kk;
                     if (mode == 2) root_at(rr, tt, out);
-                    else st_read(B.prow[j], rr, tt, B.par[j], out);
+                    else st_read(sm.e[F_PROW][j], rr, tt, sm.e[F_PAR][j], out);
 #pragma unroll
-                    for (int k = 0; k < K; ++k) stg[((j * 2 + rr) * B2_CH + kk) * K + k] = out[k];
+                    for (int k = 0; k < K; ++k) sm.stg[j][rr][kk][k] = out[k];
                 }
                 po_lds_barrier();
                 TK(is_main ? 4 : 8);  // scan: staging
@@ -341,10 +376,10 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                         double pp[K];
                         if (pslot >= 0) {
 #pragma unroll
-                            for (int q = 0; q < K; ++q) pp[q] = xch[((((k + 1) & 1) * 2 + r) * NCP + pslot) * K + q];
+                            for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][pslot][q];
                         } else {
 #pragma unroll
-                            for (int q = 0; q < K; ++q) pp[q] = stg[((s * 2 + r) * B2_CH + (k - k0)) * K + q];
+                            for (int q = 0; q < K; ++q) pp[q] = sm.stg[s][r][k - k0][q];
                         }
                         // y[t][.] does not depend on the chain: the loads issue ahead and hit L1 (the
                         // windows of consecutive steps overlap); an LDS ring for y measured no faster
@@ -352,184 +387,262 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
                         po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out);
                         st_write(row, r, t, node, out);
 #pragma unroll
-                        for (int q = 0; q < K; ++q) { self[q] = out[q]; xch[(((k & 1) * 2 + r) * NCP + s) * K + q] = out[q]; }
+                        for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }
                         if (out[0] > mx) mx = out[0];
                     }
                     po_lds_barrier();  // only xch crosses iterations; the stores stay in flight
                 }
                 TK(is_main ? 5 : 9);  // scan: iterations
             }
-            if (s < nelem) mxs[r * NCP + s] = mx;
+            if (s < nelem) sm.mxs[r][s] = mx;
         };
 
-        // ================================================================ the diagonal walk
-        while (u <= U - 1 && v <= V - 1) {
-            const int ers = env[2 * u], ere = env[2 * u + 1];
-            const int ecs = envt[2 * v], ece = envt[2 * v + 1];
-            const bool row_ok = (v >= ers && v < ere);
-            if (!row_ok && v < ers) {  // catch-up along read 1 (BeamSearch.h:314-322)
-                const int nbe = min(W, nb);
-                if (tid < nbe) {  // element table = beam nodes only
-                    e_id[tid] = B.id[tid]; e_row[tid] = B.row[tid];
-                    e_sym[tid] = B.last[tid] | ((B.plast[tid] == B.last[tid]) << 8) | ((B.par[tid] == 0) << 9);
-                    int ps = -1, mode = 1;
-                    if (B.par[tid] == 0) mode = 2;
-                    else
-                        for (int i = 0; i < nbe; ++i) if (B.id[i] == B.par[tid]) { ps = i; mode = 0; }
-                    e_pslot[tid] = ps; b_stage[tid] = mode;
-                    atomicMax(&g_hi1[B.row[tid] / PO_A], v + 1);
-                }
-                po_lds_barrier();
-                __syncthreads();  // store writes of earlier steps -> visible to this scan's reads
-                TK(6);  // catch-up: setup
-                scan(false, nbe, 0, 0, v, 1);
-                po_lds_barrier();
-                TKC(11);
-                v++;
-                continue;
+        // parent slot of beam slot j: the parent is an element if it is a beam node or a child of a
+        // beam node (grand-parent in the beam); otherwise it is staged (frozen) or the root
+        auto beam_parent = [&](int j, int nbm, bool with_children, int* mode) -> int {
+            const int par = sm.e[F_PAR][j];
+            if (par == 0) { *mode = 2; return -1; }
+            int ps = -1;
+            for (int i = 0; i < nbm; ++i) if (sm.e[F_ID][i] == par) ps = i;
+            if (ps < 0 && with_children) {
+                const int gp = sm.e[F_GPAR][j];
+                for (int i = 0; i < nbm; ++i) if (sm.e[F_ID][i] == gp) ps = nbm + A * i + sym_plast(sm.e[F_SYM][j]);
             }
-            const bool col_ok = (u >= ecs && u < ece);
-            if (!col_ok && u < ecs) {  // catch-up along read 0 (BeamSearch.h:328-336)
-                const int nbe = min(W, nb);
-                if (tid < nbe) {
-                    e_id[tid] = B.id[tid]; e_row[tid] = B.row[tid];
-                    e_sym[tid] = B.last[tid] | ((B.plast[tid] == B.last[tid]) << 8) | ((B.par[tid] == 0) << 9);
-                    int ps = -1, mode = 1;
-                    if (B.par[tid] == 0) mode = 2;
-                    else
-                        for (int i = 0; i < nbe; ++i) if (B.id[i] == B.par[tid]) { ps = i; mode = 0; }
-                    e_pslot[tid] = ps; b_stage[tid] = mode;
-                    atomicMax(&g_hi0[B.row[tid] / PO_A], u + 1);
-                }
-                po_lds_barrier();
-                __syncthreads();
-                TK(6);
-                scan(false, nbe, u, 1, 0, 0);
-                po_lds_barrier();
-                TKC(11);
-                u++;
-                continue;
-            }
-            if (!row_ok || !col_ok) { st = PO_E_ENVELOPE; break; }  // uninitialised bounds upstream (:309)
+            *mode = (ps >= 0) ? 0 : 1;
+            return ps;
+        };
 
-            // ------------------------------------------------------------ MAIN step at (u, v)
-            step++;
-            // (1) expansion: fresh ids + a row group for beam nodes that never had children;
-            //     nodes that re-entered keep their children (and the group, if it is still theirs)
+        // expansion of the processed elements + children slots.  Regular shape: every beam node is
+        // processed, child c of beam node j sits at nb + A*j + c.  lo0/lo1: see alloc_group.
+        auto build_regular = [&](int lo0, int lo1, int hi0, int hi1) -> int {
             if (tid == 0) {
-                int next_id = sh[2], cur = sh[3], err = PO_OK;
+                int next_id = sm.sh[2];
                 for (int j = 0; j < nb; ++j) {
                     bool need_group = false;
-                    if (B.fc[j] < 0) {
-                        B.fc[j] = next_id;
-                        afc[B.id[j]] = next_id;
-                        for (int c = 0; c < A; ++c) { apl[next_id + c] = po_pack_node(B.id[j], c); afc[next_id + c] = -1; acrow[next_id + c] = -1; }
+                    const int id = sm.e[F_ID][j];
+                    if (sm.e[F_FC][j] < 0) {
+                        sm.e[F_FC][j] = next_id;
+                        afc[id] = next_id;
+                        for (int c = 0; c < A; ++c) {
+                            apl[next_id + c] = po_pack_node(id, c); afc[next_id + c] = -1; acrow[next_id + c] = -1;
+                            if (is_row) amax[next_id + c] = PO_NEG_INF;
+                        }
                         next_id += A;
                         need_group = true;
-                    } else if (B.crow[j] < 0 || g_owner[B.crow[j]] != B.id[j]) {
+                    } else if (sm.e[F_CROW][j] < 0 || sm.e[F_CROW][j] >= NG || sm.g_owner[sm.e[F_CROW][j]] != id) {
                         need_group = true;  // its old rows were recycled: every value in them was dead
                     }
                     if (need_group) {
-                        int g = -1;
-                        for (int tries = 0; tries < NG; ++tries) {
-                            const int c = cur;
-                            cur = (cur + 1 == NG) ? 0 : cur + 1;
-                            // every stored time is < hi; a step only reads times >= u-1 / v-1
-                            if (g_owner[c] < 0 || (g_hi0[c] <= u - 1 && g_hi1[c] <= v - 1)) { g = c; break; }
-                        }
-                        if (g < 0) { err = PO_E_NOMEM; g = 0; }
-                        g_owner[g] = B.id[j];
-                        B.crow[j] = g;
-                        acrow[B.id[j]] = g;
+                        const int g = alloc_group(id, lo0, lo1, nb);
+                        sm.e[F_CROW][j] = g;
+                        acrow[id] = g;
                     }
-                    // this step writes [u, ece) x [v, ere) into the children's rows and the node's own
-                    const int gc = B.crow[j], go = B.row[j] / PO_A;
-                    g_hi0[gc] = max(g_hi0[gc], ece); g_hi1[gc] = max(g_hi1[gc], ere);
-                    g_hi0[go] = max(g_hi0[go], ece); g_hi1[go] = max(g_hi1[go], ere);
+                    // this step writes up to (hi0, hi1) into the children's rows and the node's own
+                    const int gc = sm.e[F_CROW][j], go = sm.e[F_ROW][j] / PO_A;
+                    sm.g_hi0[gc] = max(sm.g_hi0[gc], hi0); sm.g_hi1[gc] = max(sm.g_hi1[gc], hi1);
+                    sm.g_hi0[go] = max(sm.g_hi0[go], hi0); sm.g_hi1[go] = max(sm.g_hi1[go], hi1);
                 }
-                sh[2] = next_id; sh[3] = cur;
-                if (err != PO_OK) sh[4] = err;
+                sm.sh[2] = next_id;
             }
             po_lds_barrier();
-            if (sh[4] != PO_OK) { st = sh[4]; break; }
-            // (2) element table: beam slots [0, nb), child c of beam node j at nb + A*j + c
-            const int NCc = nb * (A + 1);
-            if (tid < NCc) {
+            const int ne = nb * (A + 1);
+            if (tid < ne) {
                 if (tid < nb) {
-                    const int j = tid;
-                    e_id[j] = B.id[j]; e_row[j] = B.row[j];
-                    e_sym[j] = B.last[j] | ((B.plast[j] == B.last[j]) << 8) | ((B.par[j] == 0) << 9);
-                    int ps = -1, mode = 1;
-                    if (B.par[j] == 0) mode = 2;
-                    else {
-                        for (int i = 0; i < nb; ++i) if (B.id[i] == B.par[j]) { ps = i; mode = 0; }
-                        if (ps < 0)
-                            for (int i = 0; i < nb; ++i) if (B.id[i] == B.gpar[j]) { ps = nb + A * i + B.plast[j]; mode = 0; }
-                    }
-                    e_pslot[j] = ps; b_stage[j] = mode;
+                    int mode;
+                    sm.e[F_PSLOT][tid] = beam_parent(tid, nb, true, &mode);
+                    sm.stage[tid] = mode;
                 } else {
                     const int j = (tid - nb) / A, c = (tid - nb) - j * A;
-                    e_id[tid] = B.fc[j] + c; e_row[tid] = B.crow[j] * PO_A + c;
-                    e_sym[tid] = c | ((B.last[j] == c) << 8);
-                    e_pslot[tid] = j;
+                    sm.e[F_ID][tid] = sm.e[F_FC][j] + c; sm.e[F_ROW][tid] = sm.e[F_CROW][j] * PO_A + c;
+                    sm.e[F_SYM][tid] = sym_pack(c, sym_last(sm.e[F_SYM][j]), false);
+                    sm.e[F_PSLOT][tid] = j; sm.e[F_FC][tid] = -2; sm.e[F_CROW][tid] = -2;
+                    if (tid < WMAX) sm.stage[tid] = 0;
                 }
             }
+            return ne;
+        };
+        // growing shape (row method while the beam is smaller than W, BeamSearch.h:132-144): the loop
+        // `for b < beam_width` runs over the vector it is appending to, so children pushed earlier
+        // in the same row are processed (updated on read 0, expanded) as well.  Serial; first row only.
+        auto build_growing = [&](int lo0, int lo1, int hi0, int hi1, int* nproc) -> int {
+            if (tid == 0) {
+                int next_id = sm.sh[2], ne = nb, np = 0;
+                for (int b = 0; b < W && b < ne; ++b) {
+                    np = b + 1;
+                    const int id = sm.e[F_ID][b];
+                    if (sm.e[F_FC][b] == -2) { sm.e[F_FC][b] = afc[id]; sm.e[F_CROW][b] = acrow[id]; }
+                    bool need_group = false;
+                    if (sm.e[F_FC][b] < 0) {
+                        sm.e[F_FC][b] = next_id;
+                        afc[id] = next_id;
+                        for (int c = 0; c < A; ++c) {
+                            apl[next_id + c] = po_pack_node(id, c); afc[next_id + c] = -1; acrow[next_id + c] = -1;
+                            amax[next_id + c] = PO_NEG_INF;
+                        }
+                        next_id += A;
+                        need_group = true;
+                    } else if (sm.e[F_CROW][b] < 0 || sm.e[F_CROW][b] >= NG || sm.g_owner[sm.e[F_CROW][b]] != id) {
+                        need_group = true;
+                    }
+                    if (need_group) {
+                        const int g = alloc_group(id, lo0, lo1, ne);
+                        sm.e[F_CROW][b] = g;
+                        acrow[id] = g;
+                    }
+                    const int gc = sm.e[F_CROW][b], go = sm.e[F_ROW][b] / PO_A;
+                    sm.g_hi0[gc] = max(sm.g_hi0[gc], hi0); sm.g_hi1[gc] = max(sm.g_hi1[gc], hi1);
+                    sm.g_hi0[go] = max(sm.g_hi0[go], hi0); sm.g_hi1[go] = max(sm.g_hi1[go], hi1);
+                    for (int c = 0; c < A && ne < NCM; ++c, ++ne) {
+                        sm.e[F_ID][ne] = sm.e[F_FC][b] + c; sm.e[F_ROW][ne] = gc * PO_A + c;
+                        sm.e[F_SYM][ne] = sym_pack(c, sym_last(sm.e[F_SYM][b]), false);
+                        sm.e[F_PSLOT][ne] = b; sm.e[F_FC][ne] = -2; sm.e[F_CROW][ne] = -2;
+                        sm.e[F_PAR][ne] = id; sm.e[F_GPAR][ne] = sm.e[F_PAR][b]; sm.e[F_PROW][ne] = sm.e[F_ROW][b];
+                        sm.e[F_DEPTH][ne] = sm.e[F_DEPTH][b] + 1;
+                        if (ne < WMAX) sm.stage[ne] = 0;
+                    }
+                }
+                for (int j = 0; j < nb; ++j) {  // beam slots: parent among the elements, else staged
+                    int mode = 1, ps = -1;
+                    if (sm.e[F_PAR][j] == 0) mode = 2;
+                    else
+                        for (int i = 0; i < ne; ++i) if (sm.e[F_ID][i] == sm.e[F_PAR][j]) { ps = i; mode = 0; }
+                    sm.e[F_PSLOT][j] = ps; sm.stage[j] = mode;
+                }
+                sm.sh[2] = next_id; sm.sh[6] = ne; sm.sh[7] = np;
+            }
             po_lds_barrier();
-            __syncthreads();  // arena + store writes -> visible to the reads below
-            TK(2);  // main: expansion + element table
-            // (3) the two look-ahead windows (BeamSearch.h:342-375)
-            scan(true, NCc, u, ece - u, v, ere - v);
-            po_lds_barrier();
-            // (4) prune by max0 + max1 (node_greater_max_sym); a child that is also a beam node is
-            //     the same node pushed twice (std::unique)
-            if (tid < NCc) {
-                score[tid] = mxs[tid] + mxs[NCP + tid];
+            *nproc = sm.sh[7];
+            return sm.sh[6];
+        };
+
+        // prune (Beam.h:93-108) + next beam table.  A slot whose node also sits in an earlier slot is
+        // the same node pushed twice (std::unique).
+        auto prune_and_advance = [&](int ne, bool regular) {
+            if (tid < ne) {
                 int d = 0;
-                if (tid >= nb) {
-                    const int x = e_id[tid];
-                    for (int j = 0; j < nb; ++j) d |= (e_id[j] == x);
-                }
-                dup[tid] = d;
-            }
-            if (tid == 0) sh[5] = 0;
-            po_lds_barrier();
-            if (tid < NCc && !dup[tid]) {
-                const double sc = score[tid];
-                const int id = e_id[tid];
-                int rank = 0;
-                for (int o = 0; o < NCc; ++o)
-                    if (!dup[o] && po_better(score[o], e_id[o], sc, id)) rank++;
-                if (rank < W) sel[rank] = tid;
-                atomicAdd(&sh[5], 1);
-            }
-            po_lds_barrier();
-            const int nbn = min(W, sh[5]);
-            // (5) next beam table; a promoted child learns from the arena whether it was ever expanded
-            if (tid < nbn) {
-                const int e = sel[tid];
-                if (e < nb) {
-                    Bn.id[tid] = B.id[e]; Bn.row[tid] = B.row[e]; Bn.prow[tid] = B.prow[e]; Bn.par[tid] = B.par[e];
-                    Bn.gpar[tid] = B.gpar[e]; Bn.plast[tid] = B.plast[e]; Bn.last[tid] = B.last[e];
-                    Bn.depth[tid] = B.depth[e]; Bn.fc[tid] = B.fc[e]; Bn.crow[tid] = B.crow[e];
+                const int x = sm.e[F_ID][tid];
+                if (regular) {
+                    if (tid >= nb)
+                        for (int j = 0; j < nb; ++j) d |= (sm.e[F_ID][j] == x);
                 } else {
-                    const int j = (e - nb) / A, c = (e - nb) - j * A;
-                    const int id = B.fc[j] + c;
-                    Bn.id[tid] = id; Bn.row[tid] = B.crow[j] * PO_A + c; Bn.prow[tid] = B.row[j]; Bn.par[tid] = B.id[j];
-                    Bn.gpar[tid] = B.par[j]; Bn.plast[tid] = B.last[j]; Bn.last[tid] = c; Bn.depth[tid] = B.depth[j] + 1;
-                    Bn.fc[tid] = afc[id]; Bn.crow[tid] = acrow[id];
+                    for (int j = 0; j < tid; ++j) d |= (sm.e[F_ID][j] == x);
+                }
+                sm.dup[tid] = d;
+            }
+            if (tid == 0) sm.sh[5] = 0;
+            po_lds_barrier();
+            if (tid < ne && !sm.dup[tid]) {
+                const double sc = sm.score[tid];
+                const int id = sm.e[F_ID][tid];
+                int rank = 0;
+                for (int o = 0; o < ne; ++o)
+                    if (!sm.dup[o] && po_better(sm.score[o], sm.e[F_ID][o], sc, id)) rank++;
+                if (rank < W) sm.sel[rank] = tid;
+                atomicAdd(&sm.sh[5], 1);
+            }
+            po_lds_barrier();
+            const int nbn = min(W, sm.sh[5]);
+            if (tid < nbn) {
+                const int e = sm.sel[tid];
+                if (e < nb) {
+#pragma unroll
+                    for (int f = 0; f < F_COUNT; ++f) sm.nx[f][tid] = sm.e[f][e];
+                } else {  // a child enters the beam; the arena knows whether it was ever expanded
+                    const int p = sm.e[F_PSLOT][e];
+                    const int id = sm.e[F_ID][e];
+                    sm.nx[F_ID][tid] = id; sm.nx[F_ROW][tid] = sm.e[F_ROW][e]; sm.nx[F_PSLOT][tid] = -1;
+                    sm.nx[F_SYM][tid] = sym_pack(sym_last(sm.e[F_SYM][e]), sym_last(sm.e[F_SYM][p]), false);
+                    sm.nx[F_PAR][tid] = sm.e[F_ID][p]; sm.nx[F_GPAR][tid] = sm.e[F_PAR][p];
+                    sm.nx[F_PROW][tid] = sm.e[F_ROW][p]; sm.nx[F_DEPTH][tid] = sm.e[F_DEPTH][p] + 1;
+                    int fc = sm.e[F_FC][e], cr = sm.e[F_CROW][e];
+                    if (fc == -2) { fc = afc[id]; cr = acrow[id]; }
+                    sm.nx[F_FC][tid] = fc; sm.nx[F_CROW][tid] = cr;
                 }
             }
             po_lds_barrier();
             if (tid < nbn) {
-                B.id[tid] = Bn.id[tid]; B.row[tid] = Bn.row[tid]; B.prow[tid] = Bn.prow[tid]; B.par[tid] = Bn.par[tid];
-                B.gpar[tid] = Bn.gpar[tid]; B.plast[tid] = Bn.plast[tid]; B.last[tid] = Bn.last[tid];
-                B.depth[tid] = Bn.depth[tid]; B.fc[tid] = Bn.fc[tid]; B.crow[tid] = Bn.crow[tid];
+#pragma unroll
+                for (int f = 0; f < F_COUNT; ++f) sm.e[f][tid] = sm.nx[f][tid];
             }
             nb = nbn;
             po_lds_barrier();
-            TK(1);  // main: prune + next beam
-            u++;
-            v++;
+        };
+
+        if (!is_row) {
+            // ============================================================ row_col: the diagonal walk
+            int u = 0, v = 0;
+            while (u <= U - 1 && v <= V - 1) {
+                const int ers = env[2 * u], ere = env[2 * u + 1];
+                const int ecs = envt[2 * v], ece = envt[2 * v + 1];
+                const bool row_ok = (v >= ers && v < ere);
+                const bool col_ok = (u >= ecs && u < ece);
+                const bool cu_v = (!row_ok && v < ers);                 // catch-up on read 1 (:314-322)
+                const bool cu_u = !cu_v && (!col_ok && u < ecs);        // catch-up on read 0 (:328-336)
+                if (cu_v || cu_u) {
+                    const int nbe = min(W, nb);  // the reference indexes b < beam_width
+                    if (tid < nbe) {
+                        int mode;
+                        sm.e[F_PSLOT][tid] = beam_parent(tid, nbe, false, &mode);
+                        sm.stage[tid] = mode;
+                        if (cu_v) atomicMax(&sm.g_hi1[sm.e[F_ROW][tid] / PO_A], v + 1);
+                        else atomicMax(&sm.g_hi0[sm.e[F_ROW][tid] / PO_A], u + 1);
+                    }
+                    __syncthreads();  // store writes of earlier steps -> visible to this scan's reads
+                    TK(6);
+                    if (cu_v) scan(false, nbe, 0, 0, 0, 0, v, 1);
+                    else scan(false, nbe, 0, 0, u, 1, 0, 0);
+                    po_lds_barrier();
+                    TKC(11);
+                    if (cu_v) v++; else u++;
+                    continue;
+                }
+                if (!row_ok || !col_ok) { st = PO_E_ENVELOPE; break; }  // uninitialised bounds upstream (:309)
+                // ---- MAIN step at (u, v): windows [u, ece) x [v, ere)  (:342-375)
+                const int ne = build_regular(u - 1, v - 1, ece, ere);
+                __syncthreads();  // arena + store writes -> visible to the reads below
+                if (sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
+                TK(2);
+                scan(true, ne, 0, 0, u, ece - u, v, ere - v);
+                po_lds_barrier();
+                if (tid < ne) sm.score[tid] = sm.mxs[0][tid] + sm.mxs[1][tid];  // node_greater_max_sym
+                prune_and_advance(ne, true);
+                TK(1);
+                u++;
+                v++;
+            }
+        } else {
+            // ============================================================ row: every row of read 0
+            for (int u = env ? 0 : 1; u < U; ++u) {
+                const int rs = env ? env[2 * u] : 0, re = env ? env[2 * u + 1] : V;
+                const int wlen = max(0, re - rs);
+                int ne, nproc;
+                const bool regular = (nb == W);
+                if (regular) { ne = build_regular(u - 1, rs - 1, u + 1, re); nproc = nb; }
+                else ne = build_growing(u - 1, rs - 1, u + 1, re, &nproc);
+                __syncthreads();
+                if (sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
+                TK(2);
+                // every element is updated on read 0 at time u except beam nodes beyond the first W
+                // (possible only in the first row, when W < |alphabet|): `for b < beam_width` (:132)
+                const int skip_lo = min(nproc, nb), skip_hi = nb;
+                scan(true, ne, skip_lo, skip_hi, u, 1, rs, wlen);
+                po_lds_barrier();
+                if (tid < ne) {  // node_greater_max: last_prob[0] + max_prob[1]
+                    const int id = sm.e[F_ID][tid];
+                    double m0 = sm.mxs[0][tid], m1 = sm.mxs[1][tid];
+                    if (tid >= skip_lo && tid < skip_hi) {  // last_prob[0] is still the seed value at t = 0
+                        double tmp[K];
+                        st_read(sm.e[F_ROW][tid], 0, 0, id, tmp);
+                        m0 = tmp[0];
+                    }
+                    if (wlen > 0) amax[id] = m1;  // reset_max happened at v == rs
+                    else m1 = amax[id];           // empty band: max_prob[1] keeps its last value
+                    sm.score[tid] = m0 + m1;
+                }
+                __syncthreads();
+                prune_and_advance(ne, regular);
+                TK(1);
+            }
         }
 
         // ---------------------------------------------------------------- label of the top node
@@ -537,8 +650,8 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
         if (tid == 0) {
             int nout = 0;
             if (st == PO_OK) {
-                int node = B.id[0];
-                nout = B.depth[0];
+                int node = sm.e[F_ID][0];
+                nout = sm.e[F_DEPTH][0];
                 char* out = a.seq + a.seq_off[pi];
                 const int cap = (int)(a.seq_off[pi + 1] - a.seq_off[pi]);
                 if (nout > cap) { st = PO_E_CAP; nout = 0; }
@@ -564,8 +677,8 @@ __global__ __launch_bounds__(256) void beam2d_rowcol_kernel(B2Args a) {
 // host side: geometry, workspace layout, launch
 namespace {
 struct B2Geom {
-    int threads, blocks;
-    size_t lds, pool_bytes, arena_cap, tcap, vcap;
+    int threads, blocks, wclass;
+    size_t pool_bytes, arena_cap, tcap, vcap;
     size_t off_queue, off_pool, off_arena, off_cum, off_envt, total;
 };
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
@@ -581,42 +694,47 @@ int b2_num_cus() {
     return cus;
 }
 
-B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model) {
+B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method) {
     B2Geom g;
     const int K = (model == PO_MODEL_CTC) ? 1 : 3;
-    const int WM = W > PO_A ? W : PO_A, NC = WM * (PO_A + 1);
-    int ncp = 32;
-    while (ncp < NC) ncp <<= 1;
-    g.threads = 2 * ncp;
+    g.wclass = W <= 6 ? 6 : (W <= 12 ? 12 : 25);
+    g.threads = g.wclass == 6 ? 64 : (g.wclass == 12 ? 128 : 256);
     const int waves = g.threads / PO_WAVE;
-    const int per_cu = waves <= 1 ? 12 : (waves == 2 ? 6 : 3);  // 3 waves per SIMD (<= 168 VGPRs)
+    const int per_cu = waves <= 1 ? 12 : (waves == 2 ? 6 : 3);  // 3 waves per SIMD
     g.blocks = b2_num_cus() * per_cu;
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
-    auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
-    g.lds = 20 * al(sizeof(int) * WM) + 4 * al(sizeof(int) * NC) + al(sizeof(int) * WM) + al(sizeof(int) * NC) +
-            al(sizeof(int) * WM) + 3 * al(sizeof(int) * B2_NGL) + al(sizeof(int) * 16) + al(sizeof(double) * NC) +
-            al(sizeof(double) * 2 * ncp) + al(sizeof(double) * 4 * ncp * K) + al(sizeof(double) * WM * 2 * B2_CH * K);
-    g.pool_bytes = (K == 1 ? (size_t)4 : (size_t)8) << 20;  // value store per workgroup
-    const int64_t mn = mr1 < mr2 ? mr1 : mr2;
-    g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (mn + 1));
-    g.tcap = (size_t)(mr1 > mr2 ? mr1 : mr2);
+    g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << 20);  // value store per workgroup
+    const int64_t WM = W > PO_A ? W : PO_A;
+    const int64_t steps = (method == PO_METHOD_ROW) ? mr1 : std::min(mr1, mr2);
+    g.arena_cap = ((size_t)(1 + PO_A + (int64_t)PO_A * WM * (steps + 1)) + 1) & ~size_t(1);  // even: a double array follows
+    g.tcap = (size_t)std::max(mr1, mr2);
     g.vcap = (size_t)mr2;
     size_t o = 0;
     g.off_queue = o; o += 256;
-    g.off_pool = o; o += al256(g.pool_bytes) * g.blocks;
-    g.pool_bytes = al256(g.pool_bytes);
-    g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * g.blocks);
+    g.off_pool = o; o += g.pool_bytes * g.blocks;
+    g.off_arena = o; o += al256(sizeof(int) * 5 * g.arena_cap * g.blocks);  // 3 int arrays + 1 double array
     g.off_cum = o; o += al256(sizeof(double) * 2 * g.tcap * g.blocks);
     g.off_envt = o; o += al256(sizeof(int) * 2 * g.vcap * g.blocks);
     g.total = o + 256;
     return g;
 }
+
+template <int MODEL, int WMAX>
+void b2_launch(const B2Geom& g, const B2Args& a, hipStream_t stream) {
+    hipLaunchKernelGGL((beam2d_kernel<MODEL, WMAX>), dim3(g.blocks), dim3(g.threads), 0, stream, a);
+}
+template <int MODEL>
+void b2_launch_w(const B2Geom& g, const B2Args& a, hipStream_t stream) {
+    if (g.wclass == 6) b2_launch<MODEL, 6>(g, a, stream);
+    else if (g.wclass == 12) b2_launch<MODEL, 12>(g, a, stream);
+    else b2_launch<MODEL, 25>(g, a, stream);
+}
 }  // namespace
 
 extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, int W,
                                           int model, int method) {
-    (void)tr1; (void)tr2; (void)C; (void)method;
-    return b2_geometry(n, mr1, mr2, W, model).total;
+    (void)tr1; (void)tr2; (void)C;
+    return b2_geometry(n, mr1, mr2, W, model, method).total;
 }
 
 extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
@@ -626,15 +744,15 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
                                      size_t ws_bytes, hipStream_t stream) {
     if (n <= 0) return PO_OK;
     if (A < 1 || A > PO_A || W < 1 || W > 25) return PO_E_ARG;
-    if (method != PO_METHOD_ROW_COL) return PO_E_UNSUPPORTED;
-    if (!env) return PO_E_UNSUPPORTED;
+    if (method != PO_METHOD_ROW_COL && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // grid: not on the GPU yet
+    if (!env && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // the reference routes these to grid
     if ((model == PO_MODEL_FLIPFLOP) ? (C != 2 * A) : (C != A + 1)) return PO_E_ARG;
-    const B2Geom g = b2_geometry(n, mr1, mr2, W, model);
+    const B2Geom g = b2_geometry(n, mr1, mr2, W, model, method);
     if (ws_bytes < g.total) return PO_E_CAP;
     char* w = (char*)ws;
     B2Args a;
     a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
-    a.n = n; a.A = A; a.W = W; a.C = C; a.alphabet = alphabet;
+    a.n = n; a.A = A; a.W = W; a.C = C; a.method = method; a.alphabet = alphabet;
     a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status;
     a.use_pre_status = use_pre_status;
     a.queue = (int*)(w + g.off_queue);
@@ -651,18 +769,10 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
     // queue counter and the store's tags start from zero on every launch
     if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
     if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
-#define PO_LAUNCH_B2(M)                                                                                        \
-    do {                                                                                                       \
-        if (g.lds > 64 * 1024)                                                                                 \
-            (void)hipFuncSetAttribute((const void*)beam2d_rowcol_kernel<M>,                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);                 \
-        hipLaunchKernelGGL(beam2d_rowcol_kernel<M>, dim3(g.blocks), dim3(g.threads), g.lds, stream, a);        \
-    } while (0)
-    if (model == PO_MODEL_CTC) PO_LAUNCH_B2(PO_MODEL_CTC);
-    else if (model == PO_MODEL_MERGE) PO_LAUNCH_B2(PO_MODEL_MERGE);
-    else if (model == PO_MODEL_FLIPFLOP) PO_LAUNCH_B2(PO_MODEL_FLIPFLOP);
+    if (model == PO_MODEL_CTC) b2_launch_w<PO_MODEL_CTC>(g, a, stream);
+    else if (model == PO_MODEL_MERGE) b2_launch_w<PO_MODEL_MERGE>(g, a, stream);
+    else if (model == PO_MODEL_FLIPFLOP) b2_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
     else return PO_E_ARG;
-#undef PO_LAUNCH_B2
 #ifdef PO_B2_TIMING
     {
         long long h[12];
@@ -702,4 +812,3 @@ extern "C" int po_launch_beam2d(const double* y1, const int64_t* y1_off, const d
     return po_launch_beam2d_geom(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, m1, m2, seq, seq_off,
                                  seq_len, status, 0, ws, ws_bytes, stream);
 }
-

@@ -97,3 +97,80 @@ def test_rowcol_errors(eng, oracle):
                                         return_status=True)
     assert st.tolist() == [0, _lib.E_ENVELOPE, 0]
     assert seqs[0] == seqs[2] == oracle.cpp_beam_search_2d(y1, y2, good, 5, method_="row_col")
+
+
+# ------------------------------------------------------------------------------------------------
+# method "row" (the API default) and the no-envelope overload
+def test_row_golden_toys_and_csv(eng, golden, golden_inputs):
+    """the reference's own 2-D tests (tests/test_beam.py:25-105), with its actual outputs"""
+    from poreover_amd.decoding import cpp_beam_search_2d
+    toy, g = golden["toy_prob"], golden["toy"]
+    t1, t3 = np.log(np.array(toy["t1"])), np.log(np.array(toy["t3"]))
+    ff = np.log(np.array(toy["ff"], dtype=np.float32))
+    assert cpp_beam_search_2d(t1, t1, alphabet_="AB") == g["beam2d_same_t1"]          # no envelope, W = 25
+    assert cpp_beam_search_2d(t1, t3, alphabet_="AB") == g["beam2d_t1_t3"]
+    assert cpp_beam_search_2d(ff, ff, alphabet_="AB", method_="row", model_="ctc_flipflop") == g["ff_beam2d_row"]
+    pm = golden["prefix_prob"]
+    with np.errstate(divide="ignore"):
+        for k, rec in golden["pair_prefix_toy"].items():
+            a, b = k.split("_")
+            assert cpp_beam_search_2d(np.log(np.array(pm[a])), np.log(np.array(pm[b])), alphabet_="AB") == rec["beam2d"]
+    y = np.log(golden_inputs["poreover_csv_prob"])
+    T = len(y)
+    env10 = np.array([(max(0, i - 10), min(i + 10, T)) for i in range(T)])
+    assert cpp_beam_search_2d(y, y, env10.tolist(), beam_width_=10, method_="row") == golden["csv"]["self2d_row_w10"]
+    diag = np.array([(i, i + 1) for i in range(T)])
+    assert cpp_beam_search_2d(y, y, diag.tolist()) == golden["csv"]["self2d_diag_w25"]  # W = 25, 1-cell band
+
+
+def test_row_golden_pairs(eng, golden, golden_inputs):
+    for rec in golden["pairs"]:
+        y1 = golden_inputs["pair%d_y1" % rec["index"]]
+        y2 = golden_inputs["pair%d_y2" % rec["index"]]
+        run = rec["runs"].get("row_w5_banded")
+        if not run or run["n_out"] != 3:
+            continue
+        got = eng.beam_search_2d_batch([y1], [y2], [np.array(run["envelope"])], 5,
+                                       model=MODEL_OF_KIND[rec["kind"]], method="row")[0]
+        assert got == _fasta_seq(run["fasta_2d"]), rec["index"]
+
+
+@pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
+@pytest.mark.parametrize("W", [1, 3, 5, 10, 25])
+def test_row_matches_oracle_batch(eng, oracle, model, ff, W):
+    kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
+    y1s, y2s, envs, want = [], [], [], []
+    for i in range(4):
+        y1, y2 = synth_pair(8000 + i, T=260 + 50 * i, flipflop=ff)
+        env = (oracle.pair_decode(y1, y2, kind, 5, "row")["envelope"] if i % 2 == 0
+               else oracle.diagonal_envelope(len(y1), len(y2), 10 + i))
+        y1s.append(y1); y2s.append(y2); envs.append(env)
+        want.append(oracle.cpp_beam_search_2d(y1, y2, env, W, model_=model, method_="row"))
+    assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row") == want
+
+
+@pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
+@pytest.mark.parametrize("W", [2, 5, 25])
+def test_row_no_envelope_matches_oracle(eng, oracle, model, ff, W):
+    y1s, y2s, want = [], [], []
+    for i in range(3):
+        y1, y2 = synth_pair(8100 + i, T=70 + 25 * i, flipflop=ff)
+        y1, y2 = y1[:60 + 20 * i], y2[:50 + 15 * i]
+        y1s.append(y1); y2s.append(y2)
+        want.append(oracle.cpp_beam_search_2d(y1, y2, None, W, model_=model, method_="row"))
+    assert eng.beam_search_2d_batch(y1s, y2s, None, W, model=model, method="row") == want
+
+
+def test_row_full_size_and_limits(eng, oracle):
+    from poreover_amd import _lib
+    y1, y2 = synth_pair(8200, T=4000)
+    env = oracle.pair_decode(y1, y2, "poreover", 5, "row")["envelope"]
+    assert eng.beam_search_2d_batch([y1], [y2], [env], 5, method="row")[0] == \
+        oracle.cpp_beam_search_2d(y1, y2, env, 5, method_="row")
+    # methods this engine does not run on the GPU yet are refused, not approximated
+    with pytest.raises(_lib.EngineError) as ei:
+        eng.beam_search_2d_batch([y1[:50]], [y2[:50]], [env[:50]], 5, method="grid")
+    assert ei.value.code == _lib.E_UNSUPPORTED
+    # row without an envelope keeps V+2 times per node: refused when that exceeds the per-pair store
+    seqs, st = eng.beam_search_2d_batch([y1], [y2], None, 5, method="row", return_status=True)
+    assert st[0] == _lib.E_NOMEM
