@@ -1,0 +1,123 @@
+"""GPU: the decode / pair-decode DRIVERS end to end (files in, FASTA / log files out), compared with
+what the reference's drivers produced for the same inputs (golden fixtures)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from poreover_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _pair_args(**kw):
+    d = dict(dir=".", basecaller="poreover", reverse_complement=False, out="out", threads=1, method="envelope",
+             single="viterbi", logging="info", debug=False, algorithm="beam", alignment="banded", beam_width=5,
+             debug_envelope=False, diagonal_envelope=False, diagonal_width=50, padding=5, skip_matches=False,
+             skip_threshold=10, beam_search_method="row_col", window=200)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_decode_driver_files(eng, tmp_path, golden, golden_inputs):
+    from poreover_amd.decoding import decode
+    prob = golden_inputs["poreover_csv_prob"]
+    csv = tmp_path / "poreover.csv"
+    with open(csv, "w") as f:
+        f.write("A,C,G,T,\n")
+        np.savetxt(f, prob, delimiter=",", fmt="%.18e")
+    g = golden["csv"]
+    for algo, want in (("viterbi", g["viterbi"]), ("beam", g["beam_w25"])):
+        a = argparse.Namespace(out=str(tmp_path / algo), basecaller=None, algorithm=algo, window=400, beam_width=25,
+                               threads=1)
+        setattr(a, "in", [str(csv)])
+        decode.decode(a)
+        txt = open(str(tmp_path / algo) + ".fasta").read()
+        assert txt == decode.fasta_format("poreover", want) + "\n"      # print() adds the blank line
+    # several files -> one batched call, records in input order
+    for i in range(3):
+        np.save(tmp_path / ("r%d.npy" % i), np.exp(golden_inputs["pair%d_y1" % i]))
+    a = argparse.Namespace(out=str(tmp_path / "multi"), basecaller="poreover", algorithm="viterbi", window=400,
+                           beam_width=25, threads=4)
+    setattr(a, "in", [str(tmp_path / ("r%d.npy" % i)) for i in range(3)])
+    decode.decode(a)
+    recs = open(str(tmp_path / "multi") + ".fasta").read().split(">")[1:]
+    assert [r.split("\n")[0] for r in recs] == ["r0", "r1", "r2"]
+    with pytest.raises(eng.EngineError):
+        a.algorithm = "prefix"
+        decode.decode(a)
+
+
+def test_pair_decode_driver_matches_reference_outputs(eng, tmp_path, monkeypatch, golden, golden_inputs):
+    """pairs file -> {out}.1d.fasta / .2d.fasta / .log, byte-for-byte what the reference's callback writes
+    (the golden run injected the same float64 matrices the loader is patched to return here)"""
+    from poreover_amd.decoding import decode, pair_decode, transducer
+    recs = [r for r in golden["pairs"] if r["kind"] == "poreover"][:6]
+    mats = {}
+    lines = []
+    for r in recs:
+        a, b = "p%d_a.npy" % r["index"], "p%d_b.npy" % r["index"]
+        mats[a], mats[b] = golden_inputs["pair%d_y1" % r["index"]], golden_inputs["pair%d_y2" % r["index"]]
+        lines.append(a + " " + b)
+    pairs_file = tmp_path / "pairs.txt"
+    pairs_file.write_text("\n".join(lines) + "\n")
+    monkeypatch.setattr(decode, "model_from_trace",
+                        lambda f, basecaller="": transducer.poreover(mats[os.path.basename(str(f))]))
+    args = _pair_args(out=str(tmp_path / "run"))
+    setattr(args, "in", [str(pairs_file)])
+    pair_decode.pair_decode(args)
+    want_1d, want_2d, want_log = "", "", []
+    for r in recs:
+        run = r["runs"]["row_col_w5_banded"]
+        a, b = "p%d_a.npy" % r["index"], "p%d_b.npy" % r["index"]
+        want_1d += run["fasta_1d"].replace("read_a.npy", a).replace("read_b.npy", b) + "\n"
+        want_2d += run["fasta_2d"].replace("consensus;read_a;read_b", "consensus;%s;%s" % (a[:-4], b[:-4])) + "\n"
+        sm = run["summary"]
+        want_log.append("\t".join(map(str, [a, b, sm["length1"], sm["length2"],
+                                            float.fromhex(sm["sequence_identity"]), sm["skipped"]])))
+    assert open(str(tmp_path / "run") + ".1d.fasta").read() == want_1d
+    assert open(str(tmp_path / "run") + ".2d.fasta").read() == want_2d
+    log = open(str(tmp_path / "run") + ".log").read().splitlines()
+    assert log[0] == "# PoreOver pair-decode" and log[2].split("\t")[-1] == "skipped"
+    assert log[3:] == want_log
+    # two positionals -> one pair -> {out}.fasta, same consensus
+    a0 = lines[0].split()
+    args2 = _pair_args(out=str(tmp_path / "single"))
+    setattr(args2, "in", a0)
+    res = pair_decode.pair_decode_helper(args2)
+    assert len(res) == 3 and res[1].split("\n", 1)[1] == recs[0]["runs"]["row_col_w5_banded"]["fasta_2d"].split("\n", 1)[1]
+    pair_decode.pair_decode(args2)
+    assert open(str(tmp_path / "single") + ".fasta").read() == res[1] + "\n"
+    # --diagonal_envelope: 2-tuple with the reference's header quirk (pair_decode.py:527)
+    args3 = _pair_args(diagonal_envelope=True, diagonal_width=30)
+    setattr(args3, "in", a0)
+    out = pair_decode.pair_decode_helper(args3)
+    assert len(out) == 2 and out[0].startswith(">consensus;envelope;p%d_a\n" % recs[0]["index"])
+    assert out[0].split("\n", 1)[1] == recs[0]["runs"]["diag30"]["fasta_2d"].split("\n", 1)[1]
+    # unsupported routes are refused loudly
+    for kw in (dict(method="split"), dict(algorithm="prefix"), dict(single="beam"), dict(skip_matches=True)):
+        bad = _pair_args(**kw)
+        setattr(bad, "in", a0)
+        with pytest.raises(eng.EngineError):
+            pair_decode.pair_decode_helper(bad)
+
+
+def test_transducer_classes(eng, golden, golden_inputs):
+    from poreover_amd.decoding import transducer
+    m = transducer.poreover(np.log(golden_inputs["poreover_csv_prob"]))
+    seq, path = m.viterbi_decode(return_path=True)
+    assert seq == golden["csv"]["viterbi"] and path.tolist() == golden["csv"]["viterbi_path"]
+    assert m.argmax_decode() == seq
+    assert transducer.poreover(np.array(golden["toy_prob"]["t1"]), "AB").viterbi_decode() == golden["toy"]["viterbi_t1"]
+    for rec in golden["pairs"]:
+        if rec["kind"] == "poreover":
+            continue
+        cls = {"bonito": transducer.bonito, "flipflop": transducer.flipflop}[rec["kind"]]
+        s, p = cls(golden_inputs["pair%d_y1" % rec["index"]]).viterbi_decode(return_path=True)
+        assert s == rec["viterbi1"] and p.tolist() == rec["path1"]
