@@ -53,6 +53,7 @@ extern "C" {
 #define PO_E_ARG (-2)        /* unusable argument                                             */
 #define PO_E_ENVELOPE (-3)   /* envelope on which the reference itself is undefined           */
 #define PO_E_NOMEM (-4)      /* per-item node arena / band capacity exceeded                  */
+#define PO_E_DIVERGE (-5)    /* input on which the reference never terminates                 */
 #define PO_E_UNSUPPORTED (-6)/* valid for the reference, not yet handled by this engine       */
 #define PO_E_HIP (-7)        /* HIP runtime error (see po_last_error)                         */
 #define PO_SKIP_LENGTH (-10) /* pair skipped: |len1 - len2| > 1000   (pair_decode.py:372-375) */
@@ -100,6 +101,23 @@ int po_beam2d_batch(const double* y1, const int64_t* y1_off, const double* y2, c
                     int method, char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* ---- decoding_cpp.cpp_forward ---------------------------------------------------------------
+ * replaces decoding_cpp.pyx:49-65 -> forward(y, t_max, label, alphabet, model) (PrefixTree.h:751-759):
+ * log P(label | y) under the model's tree recurrence.  labels: concatenated characters (device),
+ * label_off int64[n+1]; characters outside the alphabet count as its first symbol, as upstream. */
+size_t po_forward_workspace_bytes(int n, int64_t max_rows, int model);
+int po_forward_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int model,
+                     const char* labels, const int64_t* label_off, double* logp, int32_t* status, void* ws,
+                     size_t ws_bytes, void* stream);
+
+/* ---- decoding_cpp.cpp_viterbi_acceptor -------------------------------------------------------
+ * replaces decoding_cpp.pyx:69-84 -> viterbi_acceptor_poreover (Forward.h:14-121): best alignment
+ * path of a known label, band +-band_size around the diagonal.  path int32[total_rows] (blank = A). */
+size_t po_viterbi_acceptor_workspace_bytes(int n, int64_t max_rows, int64_t max_label);
+int po_viterbi_acceptor_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet,
+                              int band_size, const char* labels, const int64_t* label_off, int32_t* path,
+                              int32_t* status, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- pair_decode.pair_decode_helper stage chain -------------------------------------------
  * replaces pair_decode.py:305-529 for the default route (--method envelope --algorithm beam
  * --single viterbi): 1-D Viterbi of both reads (:360-362) -> length skip (:372-375) ->
@@ -137,6 +155,11 @@ int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, 
 int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
                       int beam_width, int model,
                       char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h);
+int po_forward_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int model,
+                       const char* labels_h, const int64_t* label_off_h, double* logp_h, int32_t* status_h);
+int po_viterbi_acceptor_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
+                                int band_size, const char* labels_h, const int64_t* label_off_h, int32_t* path_h,
+                                int32_t* status_h);
 int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
                       const int64_t* y2_off_h, const int32_t* env_h, int n, int C, const char* alphabet,
                       int beam_width, int model, int method, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("POREOVER_HIP_LIB") or os.path.join(HERE, "libporeover_hip.so")
 
 OK = 0
-E_CAP, E_ARG, E_ENVELOPE, E_NOMEM, E_UNSUPPORTED, E_HIP = -1, -2, -3, -4, -6, -7
+E_CAP, E_ARG, E_ENVELOPE, E_NOMEM, E_DIVERGE, E_UNSUPPORTED, E_HIP = -1, -2, -3, -4, -5, -6, -7
 SKIP_LENGTH, SKIP_IDENTITY = -10, -11
 MODELS = {"ctc": 0, "ctc_merge_repeats": 1, "ctc_flipflop": 2}
 METHODS = {"row": 0, "row_col": 1, "grid": 2}
@@ -21,6 +21,7 @@ K_VITERBI, K_BEAM1D, K_BEAM2D, K_ALIGN, K_ENVELOPE = range(5)
 _CODE_NAMES = {E_CAP: "PO_E_CAP (buffer too small)", E_ARG: "PO_E_ARG (bad argument)",
                E_ENVELOPE: "PO_E_ENVELOPE (envelope undefined for the reference)",
                E_NOMEM: "PO_E_NOMEM (node arena / band capacity exceeded)",
+               E_DIVERGE: "PO_E_DIVERGE (the reference never terminates on this input)",
                E_UNSUPPORTED: "PO_E_UNSUPPORTED", E_HIP: "PO_E_HIP"}
 
 
@@ -59,6 +60,15 @@ PROTOTYPES = {
                                                C.c_int, C.c_int, C.c_int]),
     "po_beam2d_batch": (C.c_int, [_dp, _i64p, _dp, _i64p, _i32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                   C.c_int, _cp, _i64p, _i32p, _i32p, _vp, C.c_size_t, _vp]),
+    "po_forward_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
+    "po_forward_batch": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _dp, _i32p, _vp,
+                                   C.c_size_t, _vp]),
+    "po_viterbi_acceptor_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64]),
+    "po_viterbi_acceptor_batch": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _i32p,
+                                            _i32p, _vp, C.c_size_t, _vp]),
+    "po_forward_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _dp, _i32p]),
+    "po_viterbi_acceptor_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _i32p,
+                                              _i32p]),
     "po_pair_decode_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                                     C.POINTER(PairOptions)]),
     "po_pair_decode_batch": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.POINTER(PairOptions), _cp,

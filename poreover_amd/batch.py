@@ -11,7 +11,8 @@ import numpy as np
 
 from . import _lib as L
 
-__all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows"]
+__all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows",
+           "forward_batch", "viterbi_acceptor_batch"]
 
 
 def pack_rows(arrays, C_expected=None):
@@ -151,3 +152,43 @@ def pair_decode_batch(arrays1, arrays2, kind="poreover", beam_width=5, method="r
             "skipped": 0 if code == 0 else 1, "status": code,
             "envelope": env[o1[i]:o1[i + 1]].astype(np.int64) if code == 0 else None})
     return out
+
+
+def _pack_labels(labels):
+    enc = [l.encode("ascii") for l in labels]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in enc], out=off[1:])
+    buf = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy()
+    return buf, off
+
+
+def forward_batch(arrays, labels, alphabet="ACGT", model="ctc"):
+    """decoding_cpp.cpp_forward for a batch: log P(label_i | y_i)."""
+    lib = L.load()
+    y, off, Cc = pack_rows(arrays)
+    n = len(arrays)
+    lb, lo = _pack_labels(labels)
+    out = np.zeros(max(n, 1), dtype=np.float64)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    L.check(lib.po_forward_batch_h(_ptr(y), _ptr(off), n, Cc, alphabet.encode(), L.MODELS[model], _ptr(lb), _ptr(lo),
+                                   _ptr(out), _ptr(st)), "po_forward_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "forward of item %d" % i)
+    return out[:n].copy()
+
+
+def viterbi_acceptor_batch(arrays, labels, band_size=1000, alphabet="ACGT"):
+    """decoding_cpp.cpp_viterbi_acceptor for a batch: per-frame state paths (blank = len(alphabet))."""
+    lib = L.load()
+    y, off, Cc = pack_rows(arrays)
+    n = len(arrays)
+    lb, lo = _pack_labels(labels)
+    path = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    L.check(lib.po_viterbi_acceptor_batch_h(_ptr(y), _ptr(off), n, Cc, alphabet.encode(), int(band_size), _ptr(lb),
+                                            _ptr(lo), _ptr(path), _ptr(st)), "po_viterbi_acceptor_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "viterbi acceptor of item %d" % i)
+    return [path[off[i]:off[i + 1]].astype(np.int64) for i in range(n)]

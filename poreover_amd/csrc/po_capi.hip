@@ -20,6 +20,11 @@ size_t po_beam2d_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, int
 int po_launch_beam2d(const double*, const int64_t*, const double*, const int64_t*, const int32_t*, int, int,
                      int, uint32_t, int, int, int, char*, const int64_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
 size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const po_pair_options*);
+size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
+int po_launch_forward(const double*, const int64_t*, int, int, int, uint32_t, int, const char*, const int64_t*, int64_t,
+                      double*, int32_t*, void*, size_t, hipStream_t);
+int po_launch_acceptor(const double*, const int64_t*, int, int, int, uint32_t, int, const char*, const int64_t*, int64_t,
+                       int64_t, int32_t*, int32_t*, void*, size_t, hipStream_t);
 int po_launch_pair_decode(const double*, const int64_t*, const double*, const int64_t*, int, int,
                           const po_pair_options*, char*, const int64_t*, int32_t*, int32_t*, double*, int32_t*,
                           char*, const int64_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
@@ -206,6 +211,64 @@ int po_beam2d_batch(const double* y1, const int64_t* y1_off, const double* y2, c
     return PO_OK;
 }
 
+// -------------------------------------------------------------------------------- forward / acceptor
+namespace {
+// max rows / max label length of a batch, read back from the device offset tables
+int batch_maxima(const int64_t* y_off, const int64_t* label_off, int n, hipStream_t s, int64_t* mr, int64_t* ml) {
+    std::vector<int64_t> h(2 * (size_t)(n + 1));
+    HIPCHK(hipMemcpyAsync(h.data(), y_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h.data() + n + 1, label_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *mr = 0; *ml = 0;
+    for (int i = 0; i < n; ++i) {
+        *mr = std::max<int64_t>(*mr, h[i + 1] - h[i]);
+        *ml = std::max<int64_t>(*ml, h[n + 1 + i + 1] - h[n + 1 + i]);
+    }
+    return PO_OK;
+}
+}  // namespace
+
+size_t po_forward_workspace_bytes(int n, int64_t max_rows, int model) { return po_lattice_ws_bytes(n, max_rows, 0, model, 0); }
+
+int po_forward_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int model,
+                     const char* labels, const int64_t* label_off, double* logp, int32_t* status, void* ws,
+                     size_t ws_bytes, void* stream) {
+    if (n < 0 || !y || !y_off || !labels || !label_off || !logp || !status || !ws) { g_err = "po_forward_batch: null argument"; return PO_E_ARG; }
+    uint32_t ap = 0;
+    const int A = pack_alphabet(alphabet, &ap);
+    if (A < 0) { g_err = "po_forward_batch: alphabet must have 1..4 symbols"; return PO_E_ARG; }
+    if (n == 0) return PO_OK;
+    int64_t mr = 0, ml = 0;
+    int rc = batch_maxima(y_off, label_off, n, (hipStream_t)stream, &mr, &ml);
+    if (rc != PO_OK) return rc;
+    rc = po_launch_forward(y, y_off, n, C, A, ap, model, labels, label_off, mr, logp, status, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_forward_batch: unsupported C/model or workspace too small"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
+size_t po_viterbi_acceptor_workspace_bytes(int n, int64_t max_rows, int64_t max_label) {
+    return po_lattice_ws_bytes(n, max_rows, max_label, PO_MODEL_CTC, 1);
+}
+
+int po_viterbi_acceptor_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int band_size,
+                              const char* labels, const int64_t* label_off, int32_t* path, int32_t* status, void* ws,
+                              size_t ws_bytes, void* stream) {
+    if (n < 0 || !y || !y_off || !labels || !label_off || !path || !status || !ws) { g_err = "po_viterbi_acceptor_batch: null argument"; return PO_E_ARG; }
+    uint32_t ap = 0;
+    const int A = pack_alphabet(alphabet, &ap);
+    if (A < 0) { g_err = "po_viterbi_acceptor_batch: alphabet must have 1..4 symbols"; return PO_E_ARG; }
+    if (n == 0) return PO_OK;
+    int64_t mr = 0, ml = 0;
+    int rc = batch_maxima(y_off, label_off, n, (hipStream_t)stream, &mr, &ml);
+    if (rc != PO_OK) return rc;
+    rc = po_launch_acceptor(y, y_off, n, C, A, ap, band_size, labels, label_off, mr, ml, path, status, ws, ws_bytes,
+                            (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_viterbi_acceptor_batch: unsupported C or workspace too small"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
 // -------------------------------------------------------------------------------- pair decode
 size_t po_pair_decode_workspace_bytes(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C,
                                       const po_pair_options* opt) {
@@ -301,6 +364,65 @@ int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, c
     HIPCHK(hipDeviceSynchronize());
     DOWN(seq_h, sq, (size_t)seqb);
     DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_forward_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int model,
+                       const char* labels_h, const int64_t* label_off_h, double* logp_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t rows = y_off_h[n] - y_off_h[0], nl = label_off_h[n] - label_off_h[0];
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) mx = std::max<int64_t>(mx, y_off_h[i + 1] - y_off_h[i]);
+    DevBuf y, yo, lb, lo, out, st, ws;
+    UP(y, y_h + y_off_h[0] * C, sizeof(double) * rows * C);
+    std::vector<int64_t> off(y_off_h, y_off_h + n + 1), lof(label_off_h, label_off_h + n + 1);
+    for (auto& o : off) o -= y_off_h[0];
+    for (auto& o : lof) o -= label_off_h[0];
+    UP(yo, off.data(), sizeof(int64_t) * (n + 1));
+    UP(lb, labels_h + label_off_h[0], (size_t)nl);
+    UP(lo, lof.data(), sizeof(int64_t) * (n + 1));
+    UP(out, nullptr, sizeof(double) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_forward_workspace_bytes(n, mx, model);
+    UP(ws, nullptr, wsb);
+    int rc = po_forward_batch((const double*)y.p, (const int64_t*)yo.p, n, C, alphabet, model, (const char*)lb.p,
+                              (const int64_t*)lo.p, (double*)out.p, (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(logp_h, out, sizeof(double) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_viterbi_acceptor_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
+                                int band_size, const char* labels_h, const int64_t* label_off_h, int32_t* path_h,
+                                int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t rows = y_off_h[n] - y_off_h[0], nl = label_off_h[n] - label_off_h[0];
+    int64_t mx = 0, ml = 0;
+    for (int i = 0; i < n; ++i) {
+        mx = std::max<int64_t>(mx, y_off_h[i + 1] - y_off_h[i]);
+        ml = std::max<int64_t>(ml, label_off_h[i + 1] - label_off_h[i]);
+    }
+    DevBuf y, yo, lb, lo, pt, st, ws;
+    UP(y, y_h + y_off_h[0] * C, sizeof(double) * rows * C);
+    std::vector<int64_t> off(y_off_h, y_off_h + n + 1), lof(label_off_h, label_off_h + n + 1);
+    for (auto& o : off) o -= y_off_h[0];
+    for (auto& o : lof) o -= label_off_h[0];
+    UP(yo, off.data(), sizeof(int64_t) * (n + 1));
+    UP(lb, labels_h + label_off_h[0], (size_t)nl);
+    UP(lo, lof.data(), sizeof(int64_t) * (n + 1));
+    UP(pt, nullptr, sizeof(int32_t) * rows);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_viterbi_acceptor_workspace_bytes(n, mx, ml);
+    UP(ws, nullptr, wsb);
+    int rc = po_viterbi_acceptor_batch((const double*)y.p, (const int64_t*)yo.p, n, C, alphabet, band_size,
+                                       (const char*)lb.p, (const int64_t*)lo.p, (int32_t*)pt.p, (int32_t*)st.p, ws.p,
+                                       wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(path_h, pt, sizeof(int32_t) * rows);
     DOWN(status_h, st, sizeof(int32_t) * n);
     return PO_OK;
 }

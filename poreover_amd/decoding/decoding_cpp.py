@@ -25,3 +25,13 @@ def cpp_beam_search_2d(y1_, y2_, envelope_ranges_=None, beam_width_=25, alphabet
     env = None if envelope_ranges_ is None else [np.asarray(envelope_ranges_, dtype=np.intc)]
     return _batch.beam_search_2d_batch([_as2d(y1_)], [_as2d(y2_)], env, beam_width_, alphabet_, model_,
                                        method_)[0]
+
+
+def cpp_forward(y_, label_, alphabet_="ACGT", model_="ctc"):
+    """decoding_cpp.pyx:49-65"""
+    return float(_batch.forward_batch([_as2d(y_)], [label_], alphabet_, model_)[0])
+
+
+def cpp_viterbi_acceptor(y_, label_, band_size=1000, alphabet_="ACGT"):
+    """decoding_cpp.pyx:69-84 (the reference also prints "Mapping label" to stdout, Forward.h:20)"""
+    return _batch.viterbi_acceptor_batch([_as2d(y_)], [label_], band_size, alphabet_)[0]
