@@ -59,6 +59,11 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     const int C = (MODEL == PO_MODEL_FLIPFLOP) ? 2 * A : A + 1;  // A = |alphabet| <= PO_A
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = po_lane();
+    // specialised logaddexp (po_device.h): its tables sit at the front of the dynamic LDS block
+    PoLaeTables* lae_t = (PoLaeTables*)smem;
+    po_lae_tables_load(lae_t, lane, PO_WAVE);
+    __syncthreads();
+    const PoLaeFast lae{lae_t};
     const int r = blockIdx.x;
     const int64_t r0 = y_off[r];
     const int T = (int)(y_off[r + 1] - r0);
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     // two candidate tables; selected by value each step (a runtime-indexed array of structs
     // would live in scratch memory)
     Table T0, T1;
-    char* p = smem;
+    char* p = smem + ((sizeof(PoLaeTables) + 15) & ~size_t(15));
     for (int b = 0; b < 2; ++b) {
         Table& tb = b ? T1 : T0;
         tb.id = (int*)carve(p, sizeof(int) * NC);
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         if (lane < A) {
             double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, pp[3], out[3];
             root_values<MODEL>(-1, 0.0, pp);
-            po_update<MODEL>(sp, pp, yr[lane], (MODEL == PO_MODEL_FLIPFLOP) ? yr[lane + A] : yr[A], false, true, out);
+            po_update<MODEL>(sp, pp, yr[lane], (MODEL == PO_MODEL_FLIPFLOP) ? yr[lane + A] : yr[A], false, true, out, lae);
             P.id[lane] = 1 + lane;
             P.fc[lane] = -1;
             P.depth[lane] = 1;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             if (pslot >= 0) { for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + pslot]; }
             else if (pslot == -1) root_values<MODEL>(t - 1, blank_cum, pp);
             else { for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF; }
-            po_update<MODEL>(sp, pp, yr[last], (MODEL == PO_MODEL_FLIPFLOP) ? yr[last + A] : yr[A], plast == last, false, out);
+            po_update<MODEL>(sp, pp, yr[last], (MODEL == PO_MODEL_FLIPFLOP) ? yr[last + A] : yr[A], plast == last, false, out, lae);
             int fc = P.fc[s];
             if (fc == -2) fc = afc[P.id[s]];  // re-entered the beam: the arena remembers
             Q.id[j] = P.id[s]; Q.depth[j] = P.depth[s];
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             if (slot >= 0) { fcx = P.fc[slot]; for (int k = 0; k < K; ++k) sp[k] = P.val[k * NC + slot]; }
             else { for (int k = 0; k < K; ++k) sp[k] = PO_NEG_INF; }
             for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + sj];
-            po_update<MODEL>(sp, pp, yr[c], (MODEL == PO_MODEL_FLIPFLOP) ? yr[c + A] : yr[A], Q.last[j] == c, false, out);
+            po_update<MODEL>(sp, pp, yr[c], (MODEL == PO_MODEL_FLIPFLOP) ? yr[c + A] : yr[A], Q.last[j] == c, false, out, lae);
             Q.id[s] = x; Q.fc[s] = fcx; Q.depth[s] = Q.depth[j] + 1;
             for (int k = 0; k < K; ++k) Q.val[k * NC + s] = out[k];
         }
@@ -279,7 +284,7 @@ extern "C" size_t po_beam1d_lds_bytes(int W, int model) {
     const int WM = W > PO_A ? W : PO_A, NC = WM * (PO_A + 1);
     auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
     size_t per = 3 * al(sizeof(int) * NC) + al(sizeof(double) * K * NC) + 4 * al(sizeof(int) * WM);
-    return 2 * per + 3 * al(sizeof(int) * WM) + al(sizeof(int) * NC);
+    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + al(sizeof(int) * NC);
 }
 
 // node-arena entries for a batch: per read root + A children + A * max(W, A) new nodes per frame

@@ -101,6 +101,7 @@ struct B2Smem {
     double mxs[2][NCP];
     double xch[2][2][NCP][K];
     double stg[WMAX][2][B2_CH][K];
+    PoLaeTables lae;        // tables of the specialised logaddexp (po_device.h)
 };
 
 }  // namespace
@@ -131,6 +132,12 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
     double* cum1 = cum0 + a.tcap;
     int* envt = a.envt + (size_t)blockIdx.x * 2 * a.vcap;
     unsigned epoch = 0;
+#ifdef PO_LAE_OCML
+    const PoLaeOcml lae;
+#else
+    po_lae_tables_load(&sm.lae, tid, nthr);
+    const PoLaeFast lae{&sm.lae};
+#endif
 #ifdef PO_B2_TIMING
     long long tk[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tlast = 0;
 #define TK_START() do { tlast = wall_clock64(); } while (0)
@@ -255,6 +262,10 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             }
         };
         auto st_write = [&](int row, int rr, int t, int node, const double* v) {
+#ifdef PO_ABL_NOSTORE   // timing ablation only (results are wrong): keeps the value live, skips the store
+            if (v[0] == 12345.678) pool[0].tag = 1;
+            return;
+#endif
             Ent e;
             e.tag = make_tag(epoch, node, t);
 #pragma unroll
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, pp[3], out[3];
             root_at(r, -1, pp);
             const double ya = yr_[s], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr_[s + A] : yr_[A];
-            po_update<MODEL>(sp, pp, ya, yb, false, true, out);
+            po_update<MODEL>(sp, pp, ya, yb, false, true, out, lae);
             st_write(s, r, 0, 1 + s, out);
             if (r == 1) amax[1 + s] = out[0];
         }
@@ -384,7 +395,10 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                         // y[t][.] does not depend on the chain: the loads issue ahead and hit L1 (the
                         // windows of consecutive steps overlap); an LDS ring for y measured no faster
                         const double ya = yr_[(int64_t)t * C + ycol_a], yb = yr_[(int64_t)t * C + ycol_b];
-                        po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out);
+                        po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
+                        // direct 16-byte store per lane.  (Tried: buffering 8 iterations in LDS and flushing
+                        // row-contiguous 128-byte bursts to cut L2 requests — the flush's extra instructions
+                        // and LDS cost more than the coalescing saved: 22k vs 29k pairs/s.  DESIGN.md §3.3.)
                         st_write(row, r, t, node, out);
 #pragma unroll
                         for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }

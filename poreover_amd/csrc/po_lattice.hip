@@ -46,7 +46,11 @@ template <int MODEL>
 __global__ __launch_bounds__(LT_THREADS) void forward_kernel(LTArgs a) {
     constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
     __shared__ double xch[2][LT_THREADS][K];
+    __shared__ PoLaeTables lae_t;
     const int tid = threadIdx.x, pi = blockIdx.x;
+    po_lae_tables_load(&lae_t, tid, LT_THREADS);
+    const PoLaeFast lae{&lae_t};
+    __syncthreads();
     const int A = a.A, C = a.C;
     const int64_t r0 = a.y_off[pi];
     const int T = (int)(a.y_off[pi + 1] - r0);
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(LT_THREADS) void forward_kernel(LTArgs a) {
                 }
                 const double ya = y[(int64_t)t * C + sym];
                 const double yb = (MODEL == PO_MODEL_FLIPFLOP) ? y[(int64_t)t * C + sym + A] : y[(int64_t)t * C + A];
-                po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out);
+                po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
 #pragma unroll
                 for (int k = 0; k < K; ++k) { self[k] = out[k]; xch[t & 1][tid][k] = out[k]; }
                 if (tid == nl - 1) {
