@@ -118,6 +118,16 @@ int po_viterbi_acceptor_batch(const double* y, const int64_t* y_off, int n, int 
                               int band_size, const char* labels, const int64_t* label_off, int32_t* path,
                               int32_t* status, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- prefix_search.prefix_search_log_cy -----------------------------------------------------
+ * replaces prefix_search.py:176-238 (with decoding_cy.forward_vec_log, decoding_cy.pyx:127-156):
+ * Graves prefix search of each item; an item is any row range [y_off[i], y_off[i+1]) of y, so the
+ * windows of `decode --algorithm prefix` (decode.py:182-188) are just finer offsets into one matrix.
+ * logp: log-probability of the returned label.  CTC model ('poreover') only, as upstream. */
+size_t po_prefix_search_workspace_bytes(int n, int64_t max_rows);
+int po_prefix_search_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, char* seq,
+                           const int64_t* seq_off, int32_t* seq_len, double* logp, int32_t* status, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* ---- pair_decode.pair_decode_helper stage chain -------------------------------------------
  * replaces pair_decode.py:305-529 for the default route (--method envelope --algorithm beam
  * --single viterbi): 1-D Viterbi of both reads (:360-362) -> length skip (:372-375) ->
@@ -160,6 +170,9 @@ int po_forward_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, 
 int po_viterbi_acceptor_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
                                 int band_size, const char* labels_h, const int64_t* label_off_h, int32_t* path_h,
                                 int32_t* status_h);
+int po_prefix_search_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
+                             char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, double* logp_h,
+                             int32_t* status_h);
 int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
                       const int64_t* y2_off_h, const int32_t* env_h, int n, int C, const char* alphabet,
                       int beam_width, int model, int method, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib as L
 
 __all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows",
-           "forward_batch", "viterbi_acceptor_batch"]
+           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch"]
 
 
 def pack_rows(arrays, C_expected=None):
@@ -192,3 +192,23 @@ def viterbi_acceptor_batch(arrays, labels, band_size=1000, alphabet="ACGT"):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "viterbi acceptor of item %d" % i)
     return [path[off[i]:off[i + 1]].astype(np.int64) for i in range(n)]
+
+
+def prefix_search_batch(y, offsets, alphabet="ACGT"):
+    """prefix_search.prefix_search_log_cy on every row range [offsets[i], offsets[i+1]) of ONE (T, C)
+    matrix (so consecutive windows of a read need no copies).  Returns [(label, logp), ...]."""
+    lib = L.load()
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(off) - 1
+    so = off - off[0]
+    seq = np.zeros(max(int(so[-1]), 1), dtype=np.uint8)
+    lens = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    lp = np.zeros(max(n, 1), dtype=np.float64)
+    L.check(lib.po_prefix_search_batch_h(_ptr(y), _ptr(off), n, y.shape[1], alphabet.encode(), _ptr(seq), _ptr(so),
+                                         _ptr(lens), _ptr(lp), _ptr(st)), "po_prefix_search_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "prefix search of window %d" % i)
+    return list(zip(_strings(seq, so, lens), [float(x) for x in lp[:n]]))

@@ -21,6 +21,9 @@ int po_launch_beam2d(const double*, const int64_t*, const double*, const int64_t
                      int, uint32_t, int, int, int, char*, const int64_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
 size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const po_pair_options*);
 size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
+size_t po_prefix_ws_bytes(int, int64_t);
+int po_launch_prefix_search(const double*, const int64_t*, int, int, int, uint32_t, int64_t, char*, const int64_t*, int32_t*,
+                            double*, int32_t*, void*, size_t, hipStream_t);
 int po_launch_forward(const double*, const int64_t*, int, int, int, uint32_t, int, const char*, const int64_t*, int64_t,
                       double*, int32_t*, void*, size_t, hipStream_t);
 int po_launch_acceptor(const double*, const int64_t*, int, int, int, uint32_t, int, const char*, const int64_t*, int64_t,
@@ -269,6 +272,29 @@ int po_viterbi_acceptor_batch(const double* y, const int64_t* y_off, int n, int 
     return PO_OK;
 }
 
+// -------------------------------------------------------------------------------- prefix search
+size_t po_prefix_search_workspace_bytes(int n, int64_t max_rows) { return po_prefix_ws_bytes(n, max_rows); }
+
+int po_prefix_search_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, char* seq,
+                           const int64_t* seq_off, int32_t* seq_len, double* logp, int32_t* status, void* ws,
+                           size_t ws_bytes, void* stream) {
+    if (n < 0 || !y || !y_off || !seq || !seq_off || !seq_len || !logp || !status || !ws) { g_err = "po_prefix_search_batch: null argument"; return PO_E_ARG; }
+    uint32_t ap = 0;
+    const int A = pack_alphabet(alphabet, &ap);
+    if (A < 0) { g_err = "po_prefix_search_batch: alphabet must have 1..4 symbols"; return PO_E_ARG; }
+    if (n == 0) return PO_OK;
+    std::vector<int64_t> h((size_t)n + 1);
+    HIPCHK(hipMemcpyAsync(h.data(), y_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int64_t mr = 0;
+    for (int i = 0; i < n; ++i) mr = std::max<int64_t>(mr, h[i + 1] - h[i]);
+    int rc = po_launch_prefix_search(y, y_off, n, C, A, ap, mr, seq, seq_off, seq_len, logp, status, ws, ws_bytes,
+                                     (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_prefix_search_batch: unsupported C / window longer than the LDS rows / workspace too small"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
 // -------------------------------------------------------------------------------- pair decode
 size_t po_pair_decode_workspace_bytes(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C,
                                       const po_pair_options* opt) {
@@ -364,6 +390,36 @@ int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, c
     HIPCHK(hipDeviceSynchronize());
     DOWN(seq_h, sq, (size_t)seqb);
     DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_prefix_search_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, char* seq_h,
+                             const int64_t* seq_off_h, int32_t* seq_len_h, double* logp_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t rows = y_off_h[n] - y_off_h[0];
+    const int64_t seqb = seq_off_h[n];
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) mx = std::max<int64_t>(mx, y_off_h[i + 1] - y_off_h[i]);
+    DevBuf y, yo, so, sq, sl, lp, st, ws;
+    UP(y, y_h + y_off_h[0] * C, sizeof(double) * rows * C);
+    std::vector<int64_t> off(y_off_h, y_off_h + n + 1);
+    for (auto& o : off) o -= y_off_h[0];
+    UP(yo, off.data(), sizeof(int64_t) * (n + 1));
+    UP(so, seq_off_h, sizeof(int64_t) * (n + 1));
+    UP(sq, nullptr, (size_t)seqb);
+    UP(sl, nullptr, sizeof(int32_t) * n);
+    UP(lp, nullptr, sizeof(double) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_prefix_search_workspace_bytes(n, mx);
+    UP(ws, nullptr, wsb);
+    int rc = po_prefix_search_batch((const double*)y.p, (const int64_t*)yo.p, n, C, alphabet, (char*)sq.p,
+                                    (const int64_t*)so.p, (int32_t*)sl.p, (double*)lp.p, (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(seq_h, sq, (size_t)seqb);
+    DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(logp_h, lp, sizeof(double) * n);
     DOWN(status_h, st, sizeof(int32_t) * n);
     return PO_OK;
 }

@@ -1,0 +1,196 @@
+// Batched 1-D prefix search (Graves) over windows of a (T, C) log-probability matrix.
+//
+// Replaces prefix_search.prefix_search_log_cy (reference prefix_search.py:176-238) with its helpers
+// decoding_cy.forward_vec_log (decoding_cy.pyx:127-156: LOG_0 = -9999, log(exp(a) + exp(b))) and
+// prefix_search.forward_vec_no_gap_log (prefix_search.py:67-79), as used by `decode --algorithm
+// prefix` on consecutive windows of --window frames (decode.py:179-188).
+//
+// Per search level (one more symbol on the current prefix), for each symbol c:
+//   alpha_ast[t] = (t == 0 ? (level == 1 ? 0 : -inf) : alpha_prev[t-1]) + y[t][c]
+//   prefix_prob[c] = logsumexp_t alpha_ast[t]                       (scipy: max-shifted)
+//   alpha_c[t]   = log(exp(y[t][blank] + alpha_c[t-1]) + exp(y[t][c] + alpha_prev[t-1])), alpha_c[0] special
+//   label_prob[c] = alpha_c[T-1]
+// then the best label / best prefix bookkeeping of the reference, in its order, and the stop test
+// prefix_prob[best_prefix] < label_prob[top_label].
+//
+// Mapping: one workgroup (256 threads) per window; the alpha rows live in LDS.  The four alpha_c
+// recurrences are serial in t and run on four lanes side by side; the reductions use all threads.
+// The serial chain uses the reference's arithmetic step for step; the reductions sum in a different
+// order than numpy (pairwise) does, so prefix_prob / the blank-only probability agree to rounding
+// (tests compare with np.isclose, like the reference's own tests).
+#include <algorithm>
+#include <cstdlib>
+
+#include "po_device.h"
+
+namespace {
+constexpr int PS_THREADS = 256;
+constexpr int PS_WAVES = PS_THREADS / PO_WAVE;
+
+struct PSArgs {
+    const double* y; const int64_t* y_off; int n, C, A;
+    uint32_t alphabet;
+    char* seq; const int64_t* seq_off; int32_t* seq_len; double* logp; int32_t* status;
+    char* curr; long long curr_cap;  // per workgroup: the current prefix
+    int tcap;                        // LDS rows hold tcap doubles
+};
+}  // namespace
+
+__global__ __launch_bounds__(PS_THREADS) void prefix_search_kernel(PSArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[PS_WAVES];
+    __shared__ double shd[16];
+    __shared__ int shi[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pi = blockIdx.x;
+    const int A = a.A, C = a.C, blank = a.A;
+    const int64_t r0 = a.y_off[pi];
+    const int T = (int)(a.y_off[pi + 1] - r0);
+    const double* y = a.y + r0 * C;
+    double* alpha_prev = (double*)smem;                 // [tcap]
+    double* alpha = alpha_prev + a.tcap;                // [PO_A][tcap]
+    char* curr = a.curr + (size_t)blockIdx.x * a.curr_cap;
+    const double LOG0 = -9999.0;                        // decoding_cy.pyx:18
+    if (T < 1 || T > a.tcap || T + 2 > a.curr_cap) {
+        if (tid == 0) { a.seq_len[pi] = 0; a.logp[pi] = 0.0; a.status[pi] = (T < 1) ? PO_E_ARG : PO_E_CAP; }
+        return;
+    }
+    auto block_max = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        double r = red[0];
+        for (int w = 1; w < PS_WAVES; ++w) r = fmax(r, red[w]);
+        __syncthreads();
+        return r;
+    };
+    auto block_sum = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        double r = 0;
+        for (int w = 0; w < PS_WAVES; ++w) r += red[w];
+        __syncthreads();
+        return r;
+    };
+    // gap_prob = np.sum(y[:, -1]); alpha_prev = forward_vec_log(-1, 0, y) = running sum of blanks
+    {
+        double part = 0;
+        for (int t = tid; t < T; t += PS_THREADS) part += y[(int64_t)t * C + blank];
+        const double gp = block_sum(part);
+        if (tid == 0) {
+            shd[0] = gp;  // label_prob[top_label]
+            double acc = 0;
+            for (int t = 0; t < T; ++t) {
+                acc = (t == 0) ? y[blank] : y[(int64_t)t * C + blank] + acc;
+                alpha_prev[t] = acc;
+            }
+            shi[0] = 0;   // len(curr_label)
+            shi[1] = 0;   // level at which top_label was set (0: the empty label)
+            shi[2] = 0;   // its last symbol
+            shi[3] = 0;   // stop flag
+        }
+        __syncthreads();
+    }
+    int st = PO_OK;
+    for (int level = 1;; ++level) {
+        if (level > T) { st = PO_E_DIVERGE; break; }   // prefix_forward[.., level-1] index error upstream
+        const int curr_len = shi[0];
+        // ---- prefix probabilities: logsumexp over t of alpha_ast, for each symbol
+        for (int c = 0; c < A; ++c) {
+            double m = PO_NEG_INF;
+            for (int t = tid; t < T; t += PS_THREADS) {
+                const double prev = (t == 0) ? (curr_len + 1 == 1 ? 0.0 : PO_NEG_INF) : alpha_prev[t - 1];
+                m = fmax(m, prev + y[(int64_t)t * C + c]);
+            }
+            m = block_max(m);
+            const double ms = (m > PO_NEG_INF && m < __builtin_inf()) ? m : 0.0;  // scipy: non-finite max -> 0
+            double sacc = 0;
+            for (int t = tid; t < T; t += PS_THREADS) {
+                const double prev = (t == 0) ? (curr_len + 1 == 1 ? 0.0 : PO_NEG_INF) : alpha_prev[t - 1];
+                sacc += exp(prev + y[(int64_t)t * C + c] - ms);
+            }
+            sacc = block_sum(sacc);
+            if (tid == 0) shd[4 + c] = log(sacc) + ms;  // prefix_prob[curr + c]
+        }
+        // ---- label probabilities: the serial forward recurrences, one lane per symbol
+        if (tid < A) {
+            const int c = tid;
+            double* al = alpha + (size_t)c * a.tcap;
+            double fw = (level == 1) ? y[c] : LOG0;     // t == 0: i == 1 -> y[0, s], else stays LOG_0
+            al[0] = fw;
+            for (int t = 1; t < T; ++t) {
+                fw = log(exp(y[(int64_t)t * C + blank] + fw) + exp(y[(int64_t)t * C + c] + alpha_prev[t - 1]));
+                al[t] = fw;
+            }
+            shd[8 + c] = fw;  // label_prob[curr + c] = alpha[-1]
+        }
+        __syncthreads();
+        // ---- bookkeeping in the reference's order (prefix_search.py:203-233)
+        if (tid == 0) {
+            int best = 0;
+            double top = shd[0];
+            for (int c = 0; c < A; ++c) {
+                if (shd[8 + c] > top) { top = shd[8 + c]; shi[1] = level; shi[2] = c; }
+                if (c > 0 && shd[4 + c] > shd[4 + best]) best = c;
+            }
+            shd[0] = top;
+            if (shd[4 + best] < top) shi[3] = 1;
+            else {
+                curr[curr_len] = (char)((a.alphabet >> (8 * best)) & 0xffu);
+                shi[0] = curr_len + 1;
+                shi[4] = best;
+            }
+        }
+        __syncthreads();
+        if (shi[3]) break;
+        const double* src = alpha + (size_t)shi[4] * a.tcap;
+        for (int t = tid; t < T; t += PS_THREADS) alpha_prev[t] = src[t];
+        __syncthreads();
+    }
+    __syncthreads();
+    // top_label = curr[:top_level - 1] + top_symbol (curr only ever grows by appending)
+    if (tid == 0) {
+        int n = 0;
+        if (st == PO_OK) {
+            const int tl = shi[1];
+            n = tl;  // 0 for the empty label
+            char* out = a.seq + a.seq_off[pi];
+            const int cap = (int)(a.seq_off[pi + 1] - a.seq_off[pi]);
+            if (n > cap) { st = PO_E_CAP; n = 0; }
+            else if (n > 0) {
+                for (int i = 0; i < n - 1; ++i) out[i] = curr[i];
+                out[n - 1] = (char)((a.alphabet >> (8 * shi[2])) & 0xffu);
+            }
+        }
+        a.seq_len[pi] = n;
+        a.logp[pi] = shd[0];
+        a.status[pi] = st;
+    }
+}
+
+namespace {
+inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+}
+
+extern "C" size_t po_prefix_ws_bytes(int n, int64_t max_rows) { return al256((size_t)max_rows + 8) * (size_t)(n > 0 ? n : 1) + 256; }
+
+extern "C" int po_launch_prefix_search(const double* y, const int64_t* y_off, int n, int C, int A, uint32_t alphabet,
+                                       int64_t max_rows, char* seq, const int64_t* seq_off, int32_t* seq_len,
+                                       double* logp, int32_t* status, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    if (A < 1 || A > PO_A || C != A + 1) return PO_E_ARG;
+    const size_t lds = sizeof(double) * (size_t)(PO_A + 1) * (size_t)max_rows;
+    if (lds > 150 * 1024) return PO_E_UNSUPPORTED;  // windows longer than ~3800 frames do not fit the LDS rows
+    const size_t per = al256((size_t)max_rows + 8);
+    if (ws_bytes < per * n) return PO_E_CAP;
+    PSArgs a;
+    a.y = y; a.y_off = y_off; a.n = n; a.C = C; a.A = A; a.alphabet = alphabet;
+    a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.logp = logp; a.status = status;
+    a.curr = (char*)ws; a.curr_cap = (long long)per; a.tcap = (int)max_rows;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)prefix_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(prefix_search_kernel, dim3(n), dim3(PS_THREADS), lds, stream, a);
+    return PO_OK;
+}

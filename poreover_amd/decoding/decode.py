@@ -114,8 +114,16 @@ def decode_models(models, args):
             seqs = _batch.beam_search_batch(ys, args.beam_width, "ACGT", MODEL_TYPE[kind])
         elif args.algorithm == 'prefix':
             assert kind == "poreover"
-            raise _lib.EngineError(_lib.E_UNSUPPORTED, "decode --algorithm prefix",
-                                   "prefix search is not on the GPU yet")
+            seqs = []
+            for yy in ys:   # consecutive windows of args.window frames (decode.py:182-188): offsets, no copies
+                window, t_max = args.window, len(yy)
+                # the reference: while i + window < t_max: [i, i+window); then the rest [i, t_max)
+                offs, i = [0], 0
+                while i + window < t_max:
+                    i += window
+                    offs.append(i)
+                offs.append(t_max)
+                seqs.append("".join(lab for lab, _ in _batch.prefix_search_batch(yy, offs)))
         else:
             raise ValueError("unknown algorithm %r" % args.algorithm)
         for i, s in zip(idx, seqs):

@@ -1,0 +1,66 @@
+"""GPU parity of the 1-D prefix search (prefix_search_log_cy) and of `decode --algorithm prefix`
+vs the reference's golden values and the oracle."""
+import argparse
+
+import numpy as np
+import pytest
+
+from conftest import hexf
+from poreover_amd.synth import synth_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ps():
+    from poreover_amd import _lib
+    from poreover_amd.decoding import prefix_search
+    _lib.load()
+    return prefix_search
+
+
+def test_prefix_golden_toys(ps, golden):
+    from collections import OrderedDict
+    toy_alpha = OrderedDict([("A", 0), ("B", 1)])
+    with np.errstate(divide="ignore"):
+        for k, rec in golden["prefix_toy"].items():
+            y = np.log(np.array(golden["prefix_prob"][k]))
+            lab, lp = ps.prefix_search_log_cy(y, alphabet=toy_alpha)
+            assert lab == rec["cy"][0]
+            assert np.isclose(lp, hexf(rec["cy"][1]), rtol=1e-10, atol=0)
+
+
+def test_prefix_golden_windows_and_decode(ps, tmp_path, golden, golden_inputs):
+    y = golden_inputs["prefix_y"]
+    for k, rec in golden["prefix_windows"].items():
+        lo, hi = map(int, k.split("_"))
+        lab, lp = ps.prefix_search_log_cy(y[lo:hi])
+        assert lab == rec["cy"][0], k
+        assert np.isclose(lp, hexf(rec["cy"][1]), rtol=1e-10, atol=0)
+    yc = np.log(golden_inputs["poreover_csv_prob"])
+    lab, lp = ps.prefix_search_log_cy(yc[:100])
+    assert lab == golden["csv"]["prefix_first100_cy"][0]
+    assert np.isclose(lp, hexf(golden["csv"]["prefix_first100_cy"][1]), rtol=1e-10)
+    # decode --algorithm prefix --window 400 on the reference's csv fixture (decode.py:179-188)
+    from poreover_amd.decoding import decode
+    csv = tmp_path / "poreover.csv"
+    with open(csv, "w") as f:
+        f.write("A,C,G,T,\n")
+        np.savetxt(f, golden_inputs["poreover_csv_prob"], delimiter=",", fmt="%.18e")
+    a = argparse.Namespace(out=str(tmp_path / "pfx"), basecaller=None, algorithm="prefix", window=400, beam_width=25,
+                           threads=1)
+    setattr(a, "in", [str(csv)])
+    decode.decode(a)
+    assert open(str(tmp_path / "pfx") + ".fasta").read() == decode.fasta_format("poreover", golden["csv"]["decode_prefix_w400"]) + "\n"
+
+
+def test_prefix_matches_oracle_batch(ps, oracle):
+    from poreover_amd import batch
+    y = synth_pair(9500, T=2000)[0]
+    offs = [0, 400, 800, 1200, 1601, 1999, 2000]     # ragged windows incl. a single-frame one
+    got = batch.prefix_search_batch(y, offs)
+    for (lab, lp), lo, hi in zip(got, offs[:-1], offs[1:]):
+        wl, wp = oracle.prefix_search_log(y[lo:hi], "cy")
+        assert lab == wl, (lo, hi)
+        assert np.isclose(lp, wp, rtol=1e-10, atol=0)
+    assert ps.greedy_search(y[:300]) == oracle.viterbi_decode(y[:300])[0]
