@@ -128,6 +128,25 @@ int po_prefix_search_batch(const double* y, const int64_t* y_off, int n, int C, 
                            const int64_t* seq_off, int32_t* seq_len, double* logp, int32_t* status, void* ws,
                            size_t ws_bytes, void* stream);
 
+/* ---- align.global_pair / align.global_pair_banded -------------------------------------------
+ * replaces align/align.pyx:29-98 (band_width <= 0: full Needleman-Wunsch) and :100-178 (banded, as
+ * written upstream), match 2 / mismatch -1 / gap -1.  seqs: concatenated characters, pair i =
+ * [seq_off[2i], seq_off[2i+1]) and [seq_off[2i+1], seq_off[2i+2]).  Outputs: the two alignment rows
+ * (same length ncol[i], '-' for gaps) at aln1/aln2 + aln_off[i]; capacity len1 + len2 + 8 suffices. */
+size_t po_align_workspace_bytes(int n, int64_t max_len1, int64_t max_len2, int band_width);
+int po_align_batch(const char* seqs, const int64_t* seq_off, int n, int band_width, char* aln1, char* aln2,
+                   const int64_t* aln_off, int32_t* ncol, int32_t* status, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- envelope.get_alignment_columns + build_envelope -----------------------------------------
+ * replaces decoding/envelope.py:26-87: alignment rows + the frame index of every base of both reads
+ * (map*, get_sequence_mapping) + signal lengths U, V -> per-row column range [lo, hi) of read 2,
+ * padded and fixed up as upstream.  env rows of pair i at env + 2 * env_off[i] (U[i] rows). */
+size_t po_envelope_workspace_bytes(int n, int64_t max_ncol);
+int po_envelope_batch(const char* aln1, const char* aln2, const int64_t* aln_off, const int32_t* ncol, int n,
+                      const int32_t* map1, const int64_t* map1_off, const int32_t* map2, const int64_t* map2_off,
+                      const int32_t* U, const int32_t* V, int padding, int32_t* env, const int64_t* env_off,
+                      int32_t* status, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- pair_decode.pair_decode_helper stage chain -------------------------------------------
  * replaces pair_decode.py:305-529 for the default route (--method envelope --algorithm beam
  * --single viterbi): 1-D Viterbi of both reads (:360-362) -> length skip (:372-375) ->
@@ -173,6 +192,12 @@ int po_viterbi_acceptor_batch_h(const double* y_h, const int64_t* y_off_h, int n
 int po_prefix_search_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
                              char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, double* logp_h,
                              int32_t* status_h);
+int po_align_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, char* aln1_h, char* aln2_h,
+                     const int64_t* aln_off_h, int32_t* ncol_h, int32_t* status_h);
+int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* aln_off_h, const int32_t* ncol_h, int n,
+                        const int32_t* map1_h, const int64_t* map1_off_h, const int32_t* map2_h,
+                        const int64_t* map2_off_h, const int32_t* U_h, const int32_t* V_h, int padding,
+                        int32_t* env_h, const int64_t* env_off_h, int32_t* status_h);
 int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
                       const int64_t* y2_off_h, const int32_t* env_h, int n, int C, const char* alphabet,
                       int beam_width, int model, int method, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,

@@ -73,6 +73,14 @@ PROTOTYPES = {
     "po_prefix_search_batch": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, _cp, _i64p, _i32p, _dp, _i32p, _vp,
                                          C.c_size_t, _vp]),
     "po_prefix_search_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, _cp, _i64p, _i32p, _dp, _i32p]),
+    "po_align_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int]),
+    "po_align_batch": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, _cp, _cp, _i64p, _i32p, _i32p, _vp, C.c_size_t, _vp]),
+    "po_align_batch_h": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, _cp, _cp, _i64p, _i32p, _i32p]),
+    "po_envelope_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
+    "po_envelope_batch": (C.c_int, [_cp, _cp, _i64p, _i32p, C.c_int, _i32p, _i64p, _i32p, _i64p, _i32p, _i32p, C.c_int,
+                                    _i32p, _i64p, _i32p, _vp, C.c_size_t, _vp]),
+    "po_envelope_batch_h": (C.c_int, [_cp, _cp, _i64p, _i32p, C.c_int, _i32p, _i64p, _i32p, _i64p, _i32p, _i32p, C.c_int,
+                                      _i32p, _i64p, _i32p]),
     "po_pair_decode_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                                     C.POINTER(PairOptions)]),
     "po_pair_decode_batch": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.POINTER(PairOptions), _cp,

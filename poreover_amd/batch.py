@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib as L
 
 __all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows",
-           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch"]
+           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "align_batch", "envelope_batch"]
 
 
 def pack_rows(arrays, C_expected=None):
@@ -212,3 +212,55 @@ def prefix_search_batch(y, offsets, alphabet="ACGT"):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "prefix search of window %d" % i)
     return list(zip(_strings(seq, so, lens), [float(x) for x in lp[:n]]))
+
+
+def align_batch(pairs, band_width=500):
+    """align.global_pair_banded (band_width > 0) / align.global_pair (band_width <= 0) for a batch of
+    (seq1, seq2) string pairs.  Returns [(align1, align2), ...] as strings of equal length."""
+    lib = L.load()
+    n = len(pairs)
+    enc = []
+    for a, b in pairs:
+        enc += [a.encode("ascii"), b.encode("ascii")]
+    so = np.zeros(2 * n + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in enc], out=so[1:])
+    buf = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy()
+    ao = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(a) + len(b) + 8 for a, b in pairs], out=ao[1:])
+    a1 = np.zeros(max(int(ao[-1]), 1), dtype=np.uint8)
+    a2 = np.zeros(max(int(ao[-1]), 1), dtype=np.uint8)
+    nc = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    L.check(lib.po_align_batch_h(_ptr(buf), _ptr(so), n, int(band_width), _ptr(a1), _ptr(a2), _ptr(ao), _ptr(nc),
+                                 _ptr(st)), "po_align_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "alignment of pair %d" % i)
+    return list(zip(_strings(a1, ao, nc), _strings(a2, ao, nc)))
+
+
+def envelope_batch(alignments, maps1, maps2, Us, Vs, padding=150):
+    """envelope.build_envelope for a batch: alignments = [(row1, row2) strings], maps = frame index of every
+    base (get_sequence_mapping), Us / Vs = signal lengths.  Returns a list of (U_i, 2) int arrays."""
+    lib = L.load()
+    n = len(alignments)
+    ao = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(a) for a, _ in alignments], out=ao[1:])
+    a1 = np.frombuffer(("".join(a for a, _ in alignments)).encode("ascii") + b"\0", dtype=np.uint8).copy()
+    a2 = np.frombuffer(("".join(b for _, b in alignments)).encode("ascii") + b"\0", dtype=np.uint8).copy()
+    nc = np.array([len(a) for a, _ in alignments] or [0], dtype=np.int32)
+    m1o = np.zeros(n + 1, dtype=np.int64); np.cumsum([len(m) for m in maps1], out=m1o[1:])
+    m2o = np.zeros(n + 1, dtype=np.int64); np.cumsum([len(m) for m in maps2], out=m2o[1:])
+    m1 = np.ascontiguousarray(np.concatenate([np.asarray(m, dtype=np.int32) for m in maps1] + [np.zeros(1, np.int32)]))
+    m2 = np.ascontiguousarray(np.concatenate([np.asarray(m, dtype=np.int32) for m in maps2] + [np.zeros(1, np.int32)]))
+    U = np.array(list(Us) or [0], dtype=np.int32)
+    V = np.array(list(Vs) or [0], dtype=np.int32)
+    eo = np.zeros(n + 1, dtype=np.int64); np.cumsum(list(Us), out=eo[1:])
+    env = np.zeros((max(int(eo[-1]), 1), 2), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    L.check(lib.po_envelope_batch_h(_ptr(a1), _ptr(a2), _ptr(ao), _ptr(nc), n, _ptr(m1), _ptr(m1o), _ptr(m2), _ptr(m2o),
+                                    _ptr(U), _ptr(V), int(padding), _ptr(env), _ptr(eo), _ptr(st)), "po_envelope_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "envelope of pair %d" % i)
+    return [env[eo[i]:eo[i + 1]].astype(np.int64) for i in range(n)]

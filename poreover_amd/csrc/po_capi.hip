@@ -22,6 +22,13 @@ int po_launch_beam2d(const double*, const int64_t*, const double*, const int64_t
 size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const po_pair_options*);
 size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
 size_t po_prefix_ws_bytes(int, int64_t);
+size_t po_align_ws_bytes(int, int64_t, int64_t, int);
+int po_launch_align(const char*, const int64_t*, int, int, int64_t, int64_t, char*, char*, const int64_t*, int32_t*, int32_t*,
+                    void*, size_t, hipStream_t);
+size_t po_envelope_ws_bytes(int, int64_t);
+int po_launch_envelope(const char*, const char*, const int64_t*, const int32_t*, int, const int32_t*, const int64_t*,
+                       const int32_t*, const int64_t*, const int32_t*, const int32_t*, int, int64_t, int32_t*,
+                       const int64_t*, int32_t*, void*, size_t, hipStream_t);
 int po_launch_prefix_search(const double*, const int64_t*, int, int, int, uint32_t, int64_t, char*, const int64_t*, int32_t*,
                             double*, int32_t*, void*, size_t, hipStream_t);
 int po_launch_forward(const double*, const int64_t*, int, int, int, uint32_t, int, const char*, const int64_t*, int64_t,
@@ -295,6 +302,45 @@ int po_prefix_search_batch(const double* y, const int64_t* y_off, int n, int C, 
     return PO_OK;
 }
 
+// -------------------------------------------------------------------------------- align / envelope
+size_t po_align_workspace_bytes(int n, int64_t ml1, int64_t ml2, int band) { return po_align_ws_bytes(n, ml1, ml2, band); }
+
+int po_align_batch(const char* seqs, const int64_t* seq_off, int n, int band_width, char* aln1, char* aln2,
+                   const int64_t* aln_off, int32_t* ncol, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0 || !seqs || !seq_off || !aln1 || !aln2 || !aln_off || !ncol || !status || !ws) { g_err = "po_align_batch: null argument"; return PO_E_ARG; }
+    if (n == 0) return PO_OK;
+    std::vector<int64_t> h(2 * (size_t)n + 1);
+    HIPCHK(hipMemcpyAsync(h.data(), seq_off, sizeof(int64_t) * (2 * n + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int64_t m1 = 0, m2 = 0;
+    for (int i = 0; i < n; ++i) { m1 = std::max<int64_t>(m1, h[2 * i + 1] - h[2 * i]); m2 = std::max<int64_t>(m2, h[2 * i + 2] - h[2 * i + 1]); }
+    int rc = po_launch_align(seqs, seq_off, n, band_width, m1, m2, aln1, aln2, aln_off, ncol, status, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_align_batch: workspace too small"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
+size_t po_envelope_workspace_bytes(int n, int64_t max_ncol) { return po_envelope_ws_bytes(n, max_ncol); }
+
+int po_envelope_batch(const char* aln1, const char* aln2, const int64_t* aln_off, const int32_t* ncol, int n,
+                      const int32_t* map1, const int64_t* map1_off, const int32_t* map2, const int64_t* map2_off,
+                      const int32_t* U, const int32_t* V, int padding, int32_t* env, const int64_t* env_off,
+                      int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0 || !aln1 || !aln2 || !aln_off || !ncol || !map1 || !map1_off || !map2 || !map2_off || !U || !V || !env ||
+        !env_off || !status || !ws) { g_err = "po_envelope_batch: null argument"; return PO_E_ARG; }
+    if (n == 0) return PO_OK;
+    std::vector<int32_t> h((size_t)n);
+    HIPCHK(hipMemcpyAsync(h.data(), ncol, sizeof(int32_t) * n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int64_t mc = 0;
+    for (int i = 0; i < n; ++i) mc = std::max<int64_t>(mc, h[i]);
+    int rc = po_launch_envelope(aln1, aln2, aln_off, ncol, n, map1, map1_off, map2, map2_off, U, V, padding, mc, env,
+                                env_off, status, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_envelope_batch: workspace too small"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
 // -------------------------------------------------------------------------------- pair decode
 size_t po_pair_decode_workspace_bytes(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C,
                                       const po_pair_options* opt) {
@@ -390,6 +436,69 @@ int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, c
     HIPCHK(hipDeviceSynchronize());
     DOWN(seq_h, sq, (size_t)seqb);
     DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_align_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, char* aln1_h, char* aln2_h,
+                     const int64_t* aln_off_h, int32_t* ncol_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    int64_t m1 = 0, m2 = 0;
+    for (int i = 0; i < n; ++i) {
+        m1 = std::max<int64_t>(m1, seq_off_h[2 * i + 1] - seq_off_h[2 * i]);
+        m2 = std::max<int64_t>(m2, seq_off_h[2 * i + 2] - seq_off_h[2 * i + 1]);
+    }
+    DevBuf sq, so, a1, a2, ao, nc, st, ws;
+    UP(sq, seqs_h, (size_t)seq_off_h[2 * n]);
+    UP(so, seq_off_h, sizeof(int64_t) * (2 * n + 1));
+    UP(a1, nullptr, (size_t)aln_off_h[n]);
+    UP(a2, nullptr, (size_t)aln_off_h[n]);
+    UP(ao, aln_off_h, sizeof(int64_t) * (n + 1));
+    UP(nc, nullptr, sizeof(int32_t) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_align_workspace_bytes(n, m1, m2, band_width);
+    UP(ws, nullptr, wsb);
+    int rc = po_align_batch((const char*)sq.p, (const int64_t*)so.p, n, band_width, (char*)a1.p, (char*)a2.p,
+                            (const int64_t*)ao.p, (int32_t*)nc.p, (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(aln1_h, a1, (size_t)aln_off_h[n]);
+    DOWN(aln2_h, a2, (size_t)aln_off_h[n]);
+    DOWN(ncol_h, nc, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* aln_off_h, const int32_t* ncol_h, int n,
+                        const int32_t* map1_h, const int64_t* map1_off_h, const int32_t* map2_h,
+                        const int64_t* map2_off_h, const int32_t* U_h, const int32_t* V_h, int padding, int32_t* env_h,
+                        const int64_t* env_off_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    int64_t mc = 0;
+    for (int i = 0; i < n; ++i) mc = std::max<int64_t>(mc, ncol_h[i]);
+    DevBuf a1, a2, ao, nc, m1, m1o, m2, m2o, u, v, ev, eo, st, ws;
+    UP(a1, aln1_h, (size_t)aln_off_h[n]);
+    UP(a2, aln2_h, (size_t)aln_off_h[n]);
+    UP(ao, aln_off_h, sizeof(int64_t) * (n + 1));
+    UP(nc, ncol_h, sizeof(int32_t) * n);
+    UP(m1, map1_h, sizeof(int32_t) * (size_t)map1_off_h[n]);
+    UP(m1o, map1_off_h, sizeof(int64_t) * (n + 1));
+    UP(m2, map2_h, sizeof(int32_t) * (size_t)map2_off_h[n]);
+    UP(m2o, map2_off_h, sizeof(int64_t) * (n + 1));
+    UP(u, U_h, sizeof(int32_t) * n);
+    UP(v, V_h, sizeof(int32_t) * n);
+    UP(ev, nullptr, sizeof(int32_t) * 2 * (size_t)env_off_h[n]);
+    UP(eo, env_off_h, sizeof(int64_t) * (n + 1));
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_envelope_workspace_bytes(n, mc);
+    UP(ws, nullptr, wsb);
+    int rc = po_envelope_batch((const char*)a1.p, (const char*)a2.p, (const int64_t*)ao.p, (const int32_t*)nc.p, n,
+                               (const int32_t*)m1.p, (const int64_t*)m1o.p, (const int32_t*)m2.p, (const int64_t*)m2o.p,
+                               (const int32_t*)u.p, (const int32_t*)v.p, padding, (int32_t*)ev.p, (const int64_t*)eo.p,
+                               (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(env_h, ev, sizeof(int32_t) * 2 * (size_t)env_off_h[n]);
     DOWN(status_h, st, sizeof(int32_t) * n);
     return PO_OK;
 }

@@ -39,6 +39,12 @@ struct PPArgs {
     const int32_t* map1; const int32_t* map2;       // frame of each base, at y*_off[i]
     const int32_t* st1; const int32_t* st2;         // status of the two 1-D decodes
     int padding, full_alignment, diagonal_envelope, diagonal_width;
+    int band;                                       // banded alignment half-width (align.pyx:13: 500)
+    int mode;                                       // 0: align + skips + envelope; 1: align only; 2: envelope from a given alignment
+    const int32_t* lenU; const int32_t* lenV;       // mode 2: U_i, V_i given explicitly (y*_off unused)
+    const int64_t* map1_off; const int64_t* map2_off;  // mode 2: offsets of the frame maps
+    char* aln_out1; char* aln_out2; const int64_t* aln_off; int32_t* ncol_out;  // mode 1 out / mode 2 in (forward order)
+    const int64_t* env_off;                         // mode 2: row offsets of env
     int32_t* env; double* identity; int32_t* status;
     // workspace
     int* queue;
@@ -100,11 +106,13 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
         __syncthreads();
         const int pi = sh[0];
         if (pi >= a.n) break;
-        const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
-        const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
-        int32_t* env = a.env + 2 * o1;
+        const int64_t o1 = (a.mode == 2) ? a.map1_off[pi] : (a.mode == 1 ? 0 : a.y1_off[pi]);
+        const int64_t o2 = (a.mode == 2) ? a.map2_off[pi] : (a.mode == 1 ? 0 : a.y2_off[pi]);
+        const int U = (a.mode == 2) ? a.lenU[pi] : (a.mode == 1 ? 0 : (int)(a.y1_off[pi + 1] - o1));
+        const int V = (a.mode == 2) ? a.lenV[pi] : (a.mode == 1 ? 0 : (int)(a.y2_off[pi + 1] - o2));
+        int32_t* env = (a.mode == 1) ? nullptr : a.env + 2 * ((a.mode == 2) ? a.env_off[pi] : o1);
 
-        if (a.diagonal_envelope) {  // pair_decode.py:497-498, python float arithmetic u/U*V
+        if (a.mode == 0 && a.diagonal_envelope) {  // pair_decode.py:497-498, python float arithmetic u/U*V
             for (int u = tid; u < U; u += PP_THREADS) {
                 const int c = (int)((double)u / (double)U * (double)V);
                 env[2 * u] = max(c - a.diagonal_width, 0);
@@ -114,23 +122,41 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             continue;
         }
 
-        const int l1 = a.len1[pi], l2 = a.len2[pi];
-        const char* s1 = a.seq1d + a.seq1d_off[2 * pi];
-        const char* s2 = a.seq1d + a.seq1d_off[2 * pi + 1];
-        const int32_t* m1 = a.map1 + o1;
-        const int32_t* m2 = a.map2 + o2;
+        int l1, l2;
+        const char *s1 = nullptr, *s2 = nullptr;
+        if (a.mode == 2) {   // lengths = number of mapped bases; the strings themselves are not needed
+            l1 = (int)(a.map1_off[pi + 1] - o1); l2 = (int)(a.map2_off[pi + 1] - o2);
+        } else if (a.mode == 1) {
+            l1 = (int)(a.seq1d_off[2 * pi + 1] - a.seq1d_off[2 * pi]);
+            l2 = (int)(a.seq1d_off[2 * pi + 2] - a.seq1d_off[2 * pi + 1]);
+        } else { l1 = a.len1[pi]; l2 = a.len2[pi]; }
+        if (a.mode != 2) { s1 = a.seq1d + a.seq1d_off[2 * pi]; s2 = a.seq1d + a.seq1d_off[2 * pi + 1]; }
+        const int32_t* m1 = (a.mode == 1) ? nullptr : a.map1 + o1;
+        const int32_t* m2 = (a.mode == 1) ? nullptr : a.map2 + o2;
         int st = PO_OK;
-        if (a.st1[pi] != PO_OK) st = a.st1[pi];
-        else if (a.st2[pi] != PO_OK) st = a.st2[pi];
-        else if (abs(l1 - l2) > 1000) st = PO_SKIP_LENGTH;         // pair_decode.py:372-375
-        else if (l1 < 1 || l2 < 1) st = PO_E_ARG;                  // empty basecall: IndexError upstream
+        if (a.mode == 0 && a.st1[pi] != PO_OK) st = a.st1[pi];
+        else if (a.mode == 0 && a.st2[pi] != PO_OK) st = a.st2[pi];
+        else if (a.mode == 0 && abs(l1 - l2) > 1000) st = PO_SKIP_LENGTH;   // pair_decode.py:372-375
+        else if (a.mode != 1 && (l1 < 1 || l2 < 1)) st = PO_E_ARG;           // empty basecall: IndexError upstream
         const bool full = a.full_alignment != 0;
         const int nrows = full ? l1 + 1 : l1;
-        if (st == PO_OK && (nrows > a.row_cap || (long long)l1 + l2 + 8 > a.aln_cap)) st = PO_E_CAP;
+        if (st == PO_OK && a.mode != 2 && (nrows > a.row_cap || (long long)l1 + l2 + 8 > a.aln_cap)) st = PO_E_CAP;
         if (st != PO_OK) {
-            if (tid == 0) { a.status[pi] = st; a.identity[pi] = 0.0; }
+            if (tid == 0) { a.status[pi] = st; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
             continue;
         }
+        int ncol = 0;
+        if (a.mode == 2) {  // the alignment is given (forward order): store it reversed like the trace-back does
+            ncol = a.ncol_out[pi];
+            if (ncol > a.aln_cap || ncol < 1) {
+                if (tid == 0) a.status[pi] = (ncol < 1) ? PO_E_ARG : PO_E_CAP;
+                continue;
+            }
+            const char* g1 = a.aln_out1 + a.aln_off[pi];
+            const char* g2 = a.aln_out2 + a.aln_off[pi];
+            for (int k = tid; k < ncol; k += PP_THREADS) { al1[ncol - 1 - k] = g1[k]; al2[ncol - 1 - k] = g2[k]; }
+            __syncthreads();
+        } else {
 
         // ------------------------------------------------------------------ DP row geometry
         // banded (align.pyx:119-125): center = int(np.round(l2 / l1 * i)); computed cells [start, end)
@@ -140,8 +166,8 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             if (full) { st_ = 0; en_ = l2 + 1; }
             else {
                 const int center = (int)rint((double)l2 / (double)l1 * (double)i);
-                st_ = max(center - NW_BAND, 0);
-                en_ = min(center + NW_BAND, l2 - 1);
+                st_ = max(center - a.band, 0);
+                en_ = min(center + a.band, l2 - 1);
                 if (en_ < st_) en_ = st_;
             }
             r_start[i] = st_; r_end[i] = en_;
@@ -154,7 +180,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
         }
         __syncthreads();
         if (sh[1]) {
-            if (tid == 0) { a.status[pi] = PO_E_CAP; a.identity[pi] = 0.0; }
+            if (tid == 0) { a.status[pi] = PO_E_CAP; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
             continue;
         }
         // SparseMatrix<int>::get (SparseMatrix.h:51-57,108-115): default 0 outside the computed cells
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             __syncthreads();
         }
         if (sh[1]) {
-            if (tid == 0) { a.status[pi] = PO_E_UNSUPPORTED; a.identity[pi] = 0.0; }
+            if (tid == 0) { a.status[pi] = PO_E_UNSUPPORTED; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
             continue;
         }
 
@@ -245,9 +271,18 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             sh[3] = ovf ? 1 : 0;
         }
         __syncthreads();
-        const int ncol = sh[2];
+        ncol = sh[2];
         if (sh[3]) {
-            if (tid == 0) { a.status[pi] = PO_E_CAP; a.identity[pi] = 0.0; }
+            if (tid == 0) { a.status[pi] = PO_E_CAP; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
+            continue;
+        }
+        }  // mode != 2
+        if (a.mode == 1) {  // alignment only: forward order out
+            const int64_t ao = a.aln_off[pi];
+            const int capo = (int)(a.aln_off[pi + 1] - ao);
+            if (ncol > capo) { if (tid == 0) { a.status[pi] = PO_E_CAP; a.ncol_out[pi] = 0; } continue; }
+            for (int k = tid; k < ncol; k += PP_THREADS) { a.aln_out1[ao + k] = al1[ncol - 1 - k]; a.aln_out2[ao + k] = al2[ncol - 1 - k]; }
+            if (tid == 0) { a.ncol_out[pi] = ncol; a.status[pi] = PO_OK; }
             continue;
         }
         // alignment is stored reversed: column k of the forward alignment is index ncol-1-k
@@ -257,7 +292,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
         int tot_m;
         (void)block_excl_sum(matches, &tot_m);
         const double identity = (double)tot_m / (double)ncol;
-        if (identity < 0.5) {  // pair_decode.py:395-398
+        if (a.mode == 0 && identity < 0.5) {  // pair_decode.py:395-398
             if (tid == 0) { a.status[pi] = PO_SKIP_IDENTITY; a.identity[pi] = identity; }
             continue;
         }
@@ -316,7 +351,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             if (u < U) { env[2 * u] = lo_s[tid]; env[2 * u + 1] = hi_s[tid]; }
             __syncthreads();
         }
-        if (tid == 0) { a.status[pi] = PO_OK; a.identity[pi] = identity; }
+        if (tid == 0) { a.status[pi] = PO_OK; if (a.identity) a.identity[pi] = identity; }
     }
 }
 
@@ -434,6 +469,9 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     a.map1 = map1; a.map2 = map2; a.st1 = st1; a.st2 = st2;
     a.padding = opt->padding; a.full_alignment = opt->full_alignment;
     a.diagonal_envelope = opt->diagonal_envelope; a.diagonal_width = opt->diagonal_width;
+    a.band = NW_BAND; a.mode = 0;
+    a.lenU = a.lenV = nullptr; a.map1_off = a.map2_off = nullptr; a.aln_out1 = a.aln_out2 = nullptr;
+    a.aln_off = nullptr; a.ncol_out = nullptr; a.env_off = nullptr;
     a.env = env; a.identity = identity; a.status = status;
     a.queue = (int*)(w + g.off_queue);
     a.dp = (int*)(w + g.off_dp); a.dp_cap = (long long)g.dp_cap;
@@ -477,4 +515,63 @@ extern "C" int po_launch_pair_decode(const double* y1, const int64_t* y1_off, co
     if (rc != PO_OK) return rc;
     return po_launch_pair_decode_geom(y1, y1_off, y2, y2_off, n, C, opt, t1, t2, m1, m2, seq1d, seq1d_off, len1, len2,
                                       identity, env_out, seq, seq_off, seq_len, status, ws, ws_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone entry points of the two stages (align.global_pair / global_pair_banded; envelope.build_envelope)
+extern "C" size_t po_align_ws_bytes(int n, int64_t max_len1, int64_t max_len2, int band) {
+    const int blocks = std::min(n > 0 ? n : 1, pp_num_cus() * 4);
+    const int64_t width = band > 0 ? std::min<int64_t>(max_len2 + 1, 2 * (int64_t)band + 1) : max_len2 + 1;
+    return 256 + al256(sizeof(int) * (size_t)((max_len1 + 1) * width) * blocks) + al256(sizeof(int) * 4 * (size_t)(max_len1 + 2) * blocks) +
+           al256(2 * (size_t)(max_len1 + max_len2 + 16) * blocks) + 256;
+}
+
+extern "C" int po_launch_align(const char* seqs, const int64_t* seq_off, int n, int band, int64_t max_len1,
+                               int64_t max_len2, char* aln1, char* aln2, const int64_t* aln_off, int32_t* ncol,
+                               int32_t* status, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    if (ws_bytes < po_align_ws_bytes(n, max_len1, max_len2, band)) return PO_E_CAP;
+    const int blocks = std::min(n, pp_num_cus() * 4);
+    const int64_t width = band > 0 ? std::min<int64_t>(max_len2 + 1, 2 * (int64_t)band + 1) : max_len2 + 1;
+    char* w = (char*)ws;
+    PPArgs a = {};
+    a.n = n; a.seq1d = seqs; a.seq1d_off = seq_off; a.mode = 1;
+    a.full_alignment = band > 0 ? 0 : 1; a.band = band > 0 ? band : 0;
+    a.aln_out1 = aln1; a.aln_out2 = aln2; a.aln_off = aln_off; a.ncol_out = ncol; a.status = status;
+    size_t o = 0;
+    a.queue = (int*)(w + o); o += 256;
+    a.dp_cap = (long long)((max_len1 + 1) * width); a.dp = (int*)(w + o); o += al256(sizeof(int) * (size_t)a.dp_cap * blocks);
+    a.row_cap = (long long)(max_len1 + 2); a.rowinfo = (int*)(w + o); o += al256(sizeof(int) * 4 * (size_t)a.row_cap * blocks);
+    a.aln_cap = (long long)(max_len1 + max_len2 + 16); a.aln = w + o;
+    if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    hipLaunchKernelGGL(pair_prep_kernel, dim3(blocks), dim3(PP_THREADS), 0, stream, a);
+    return PO_OK;
+}
+
+extern "C" size_t po_envelope_ws_bytes(int n, int64_t max_ncol) {
+    const int blocks = std::min(n > 0 ? n : 1, pp_num_cus() * 4);
+    return 256 + al256(2 * (size_t)(max_ncol + 16) * blocks) + 256;
+}
+
+extern "C" int po_launch_envelope(const char* aln1, const char* aln2, const int64_t* aln_off, const int32_t* ncol, int n,
+                                  const int32_t* map1, const int64_t* map1_off, const int32_t* map2,
+                                  const int64_t* map2_off, const int32_t* U, const int32_t* V, int padding,
+                                  int64_t max_ncol, int32_t* env, const int64_t* env_off, int32_t* status, void* ws,
+                                  size_t ws_bytes, hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    if (ws_bytes < po_envelope_ws_bytes(n, max_ncol)) return PO_E_CAP;
+    const int blocks = std::min(n, pp_num_cus() * 4);
+    char* w = (char*)ws;
+    PPArgs a = {};
+    a.n = n; a.mode = 2; a.padding = padding;
+    a.aln_out1 = const_cast<char*>(aln1); a.aln_out2 = const_cast<char*>(aln2); a.aln_off = aln_off;
+    a.ncol_out = const_cast<int32_t*>(ncol);
+    a.map1 = map1; a.map1_off = map1_off; a.map2 = map2; a.map2_off = map2_off; a.lenU = U; a.lenV = V;
+    a.env = env; a.env_off = env_off; a.status = status;
+    a.queue = (int*)w;
+    a.aln_cap = (long long)(max_ncol + 16); a.aln = w + 256;
+    a.dp = nullptr; a.dp_cap = 0; a.rowinfo = (int*)w; a.row_cap = 0;
+    if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    hipLaunchKernelGGL(pair_prep_kernel, dim3(blocks), dim3(PP_THREADS), 0, stream, a);
+    return PO_OK;
 }

@@ -1,0 +1,61 @@
+"""GPU parity of the stand-alone alignment and envelope entry points (poreover.align, envelope.py)
+vs the reference's golden alignments / envelopes and the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from poreover_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def test_alignments_golden(eng, golden):
+    from poreover_amd import align, batch
+    recs = golden["nw"]
+    full = batch.align_batch([(r["s1"], r["s2"]) for r in recs], band_width=0)
+    banded = batch.align_batch([(r["s1"], r["s2"]) for r in recs], band_width=500)
+    for r, f, b in zip(recs, full, banded):
+        assert list(f) == r["full"], (r["s1"][:20], "full")
+        assert list(b) == r["banded"], (r["s1"][:20], "banded")
+    narrow = [r for r in recs if "banded30" in r]
+    got = batch.align_batch([(r["s1"], r["s2"]) for r in narrow], band_width=30)
+    for r, g in zip(narrow, got):
+        assert list(g) == r["banded30"]
+    a1, a2, mat = align.global_pair("ACGTACGTTT", "ACGTCGTTTA")
+    assert ("".join(a1), "".join(a2)) == ("ACGTACGTTT-", "ACGT-CGTTTA") and mat is None
+    b1, b2 = align.global_pair_banded("ACGTACGTTT", "ACGTCGTTTA")
+    assert ("".join(b1), "".join(b2)) == ("-ACGTACG-T-TT", "AACGT-CGTTT-A")     # the reference's banded quirk
+    with pytest.raises(NotImplementedError):
+        align.global_pair("AC", "AC", match=5)
+
+
+def test_envelope_golden(eng, golden, golden_inputs):
+    from poreover_amd.decoding import envelope
+    for rec in golden["pairs"]:
+        run = rec["runs"].get("row_col_w5_banded")
+        if not run or run["n_out"] != 3:
+            continue
+        y1, y2 = golden_inputs["pair%d_y1" % rec["index"]], golden_inputs["pair%d_y2" % rec["index"]]
+        aln = np.array([list(run["alignment"][0]), list(run["alignment"][1])])
+        cols = envelope.get_alignment_columns(aln)
+        env = envelope.build_envelope(y1, y2, cols, rec["map1"], rec["map2"], padding=5)
+        assert env.tolist() == run["envelope"], rec["index"]
+
+
+def test_envelope_helpers_and_padding(eng, oracle, golden, golden_inputs):
+    from poreover_amd.decoding import envelope
+    rec = golden["pairs"][0]
+    run = rec["runs"]["row_col_w5_banded"]
+    y1, y2 = golden_inputs["pair%d_y1" % rec["index"]], golden_inputs["pair%d_y2" % rec["index"]]
+    cols = envelope.get_alignment_columns(np.array([list(run["alignment"][0]), list(run["alignment"][1])]))
+    for pad in (0, 5, 150):
+        want = oracle.build_envelope(len(y1), len(y2), run["alignment"][0], run["alignment"][1], rec["map1"], rec["map2"], pad)
+        assert np.array_equal(envelope.build_envelope(y1, y2, cols, rec["map1"], rec["map2"], padding=pad), want)
+    e = np.full((6, 2), -1)
+    envelope.add_block((1, 3, 4, 9), e)
+    assert e.tolist() == [[-1, -1], [3, 9], [3, 9], [3, 9], [-1, -1], [-1, -1]]
+    assert envelope.offset_envelope(np.array([[0, 4], [2, 6], [5, 9]]), (1, 3, 2, 9)).tolist() == [[0, 4], [3, 7]]
