@@ -68,6 +68,20 @@ const char* po_last_error(void);
 int po_device_info(int device, char* name, int name_cap, int* compute_units, int* clock_khz,
                    size_t* total_mem);
 
+/* ---- trace ingest ------------------------------------------------------------------------------
+ * replaces decode.logit_to_log_likelihood (decode.py:34-39), the uint8 trace scaling of
+ * model_from_trace (decode.py:89-93,99-103), the Bonito column order (decode.py:79) and
+ * transducer.reverse_complement (transducer.py:68-70,104-106) — one streaming pass on the device.
+ *   mode PO_INGEST_LOGITS_F32: src float32 (rows, C) logits -> x - logsumexp(x), in float32 like the
+ *        reference, widened to float64;  PO_INGEST_TRACE_U8: src uint8 -> log((x+1e-7)/(255+1e-7));
+ *        PO_INGEST_F64: src float64, copied.   perm (host, C ints or NULL): out[:, c] = value[:, perm[c]].
+ *   reverse != 0: every item [row_off[i], row_off[i+1]) is time-reversed.   out: float64 (rows, C). */
+#define PO_INGEST_LOGITS_F32 0
+#define PO_INGEST_TRACE_U8 1
+#define PO_INGEST_F64 2
+int po_ingest_batch(const void* src, const int64_t* row_off, int n, int C, int mode, const int* perm_h,
+                    int reverse, double* out, void* stream);
+
 /* ---- transducer.argmax_decode / viterbi_decode ------------------------------------------
  * replaces transducer.py:27-33 (argmax), :72-73 (poreover), :83-89 (bonito), :35-59 +
  * :94-103 (flip-flop Viterbi) and pair_decode.get_sequence_mapping (pair_decode.py:114-142).
@@ -177,6 +191,8 @@ int po_pair_decode_batch(const double* y1, const int64_t* y1_off, const double* 
 
 /* ---- host-buffer conveniences (numpy callers): allocate, copy in, launch, copy out, free ----
  * Same semantics as the device-pointer forms with every pointer a HOST pointer; synchronous. */
+int po_ingest_batch_h(const void* src_h, const int64_t* row_off_h, int n, int C, int mode, const int* perm_h,
+                      int reverse, double* out_h);
 int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int kind,
                        int8_t* path_h,
                        char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* map_h,

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "po_last_error": (C.c_char_p, []),
     "po_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_size_t)]),
+    "po_ingest_batch": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _dp, _vp]),
+    "po_ingest_batch_h": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _dp]),
     "po_viterbi_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int]),
     "po_viterbi_batch": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _vp, _cp, _i64p, _i32p,
                                    _i32p, _i32p, _vp, C.c_size_t, _vp]),

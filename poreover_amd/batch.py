@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib as L
 
 __all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows",
-           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "align_batch", "envelope_batch"]
+           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "align_batch", "envelope_batch", "ingest_batch"]
 
 
 def pack_rows(arrays, C_expected=None):
@@ -264,3 +264,26 @@ def envelope_batch(alignments, maps1, maps2, Us, Vs, padding=150):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "envelope of pair %d" % i)
     return [env[eo[i]:eo[i + 1]].astype(np.int64) for i in range(n)]
+
+
+def ingest_batch(arrays, perm=None, reverse=False):
+    """Device ingest of basecaller outputs -> list of (T, C) float64 log-probability matrices.
+    float32 (T, C) logits -> log-softmax (decode.py:34-39); uint8 traces -> log((x+1e-7)/(255+1e-7))
+    (decode.py:92); float64 -> copied.  perm: column order (Bonito: [1,2,3,4,0]); reverse: time-reverse
+    every item (reverse_complement = reverse + perm [3,2,1,0,4])."""
+    lib = L.load()
+    if not arrays:
+        return []
+    dt = arrays[0].dtype
+    mode = {np.dtype(np.float32): 0, np.dtype(np.uint8): 1, np.dtype(np.float64): 2}.get(np.dtype(dt))
+    if mode is None or any(a.dtype != dt or a.ndim != 2 for a in arrays):
+        raise ValueError("ingest_batch takes 2-D float32 logits, uint8 traces or float64 matrices of one dtype")
+    Cc = arrays[0].shape[1]
+    off = np.zeros(len(arrays) + 1, dtype=np.int64)
+    np.cumsum([len(a) for a in arrays], out=off[1:])
+    src = np.ascontiguousarray(np.concatenate(arrays, axis=0))
+    out = np.zeros((int(off[-1]), Cc), dtype=np.float64)
+    p = (C.c_int * Cc)(*perm) if perm is not None else None
+    L.check(lib.po_ingest_batch_h(_ptr(src), _ptr(off), len(arrays), Cc, mode, p, 1 if reverse else 0, _ptr(out)),
+            "po_ingest_batch_h")
+    return [out[off[i]:off[i + 1]] for i in range(len(arrays))]

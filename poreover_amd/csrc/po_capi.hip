@@ -22,6 +22,7 @@ int po_launch_beam2d(const double*, const int64_t*, const double*, const int64_t
 size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const po_pair_options*);
 size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
 size_t po_prefix_ws_bytes(int, int64_t);
+int po_launch_ingest(const void*, const int64_t*, int, int, int, const int*, int, int64_t, double*, hipStream_t);
 size_t po_align_ws_bytes(int, int64_t, int64_t, int);
 int po_launch_align(const char*, const int64_t*, int, int, int64_t, int64_t, char*, char*, const int64_t*, int32_t*, int32_t*,
                     void*, size_t, hipStream_t);
@@ -128,6 +129,22 @@ int po_device_info(int device, char* name, int name_cap, int* cus, int* clock_kh
     if (cus) *cus = p.multiProcessorCount;
     if (clock_khz) *clock_khz = p.clockRate;
     if (total_mem) *total_mem = p.totalGlobalMem;
+    return PO_OK;
+}
+
+// -------------------------------------------------------------------------------- ingest
+int po_ingest_batch(const void* src, const int64_t* row_off, int n, int C, int mode, const int* perm_h, int reverse,
+                    double* out, void* stream) {
+    if (n < 0 || !src || !row_off || !out) { g_err = "po_ingest_batch: null argument"; return PO_E_ARG; }
+    if (n == 0) return PO_OK;
+    int64_t ends[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&ends[0], row_off, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(&ends[1], row_off + n, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (ends[0] != 0) { g_err = "po_ingest_batch: row_off[0] must be 0"; return PO_E_ARG; }
+    int rc = po_launch_ingest(src, row_off, n, C, mode, perm_h, reverse, ends[1], out, (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_ingest_batch: bad C / mode / permutation"; return rc; }
+    HIPCHK(hipGetLastError());
     return PO_OK;
 }
 
@@ -377,6 +394,22 @@ struct DevBuf {
         if ((dst) && (bytes)) HIPCHK(hipMemcpy((dst), (buf).p, (bytes), hipMemcpyDeviceToHost));   \
     } while (0)
 }  // namespace
+
+int po_ingest_batch_h(const void* src_h, const int64_t* row_off_h, int n, int C, int mode, const int* perm_h, int reverse,
+                      double* out_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t rows = row_off_h[n];
+    const size_t esz = mode == PO_INGEST_LOGITS_F32 ? 4 : (mode == PO_INGEST_TRACE_U8 ? 1 : 8);
+    DevBuf s, ro, o;
+    UP(s, src_h, esz * (size_t)rows * C);
+    UP(ro, row_off_h, sizeof(int64_t) * (n + 1));
+    UP(o, nullptr, sizeof(double) * (size_t)rows * C);
+    int rc = po_ingest_batch(s.p, (const int64_t*)ro.p, n, C, mode, perm_h, reverse, (double*)o.p, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(out_h, o, sizeof(double) * (size_t)rows * C);
+    return PO_OK;
+}
 
 int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int kind,
                        int8_t* path_h,
