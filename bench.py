@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=10000, help="pairs per GPU")
     ap.add_argument("--T", type=int, default=4000)
     ap.add_argument("--beam_width", type=int, default=5)
+    ap.add_argument("--gen_procs", type=int, default=0, help="processes generating the synthetic inputs (0 = auto; use 1 under "
+                    "rocprofv3, whose preloaded library initialises the GPU before Python starts, which makes fork unsafe)")
     ap.add_argument("--cpu_sample", type=int, default=96, help="pairs decoded on the CPU for the baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -100,6 +102,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+
+    # ---- everything that forks worker processes happens BEFORE the GPU runtime is initialised
+    # (forking a process that holds a HIP context is unsafe, in particular under rocprofv3)
+    from poreover_amd import dist as podist
+    from poreover_amd.batch import pack_rows
+    from poreover_amd.synth import synth_pair
+    P, T = args.pairs, args.T
+    seeds = list(podist.shard_seeds(P, rank))
+    nproc = args.gen_procs if args.gen_procs > 0 else max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    if nproc > 1 and P >= 256:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nproc) as pool:
+            pairs = pool.starmap(synth_pair, [(sd, T) for sd in seeds], chunksize=32)
+    else:
+        pairs = [synth_pair(sd, T=T) for sd in seeds]
+    y1, o1, Cc = pack_rows([p[0] for p in pairs])
+    y2, o2, _ = pack_rows([p[1] for p in pairs])
+    del pairs
+    cpu_base = None
+    if rank == 0 and args.gpus == 1 and world == 1 and args.cpu_sample > 0:
+        cpu_base = cpu_baseline(T, args.cpu_sample)
 
     import torch
     if not torch.cuda.is_available():
@@ -112,25 +135,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from poreover_amd import _lib
-    from poreover_amd import dist as podist
-    from poreover_amd.batch import pack_rows
-    from poreover_amd.synth import synth_pair
     lib = _lib.load()
     _lib.check(lib.po_set_device(local_rank), "po_set_device")
 
-    # ---- synthetic shard of this rank, generated on the host then moved to HBM
-    P, T = args.pairs, args.T
-    seeds = list(podist.shard_seeds(P, rank))
-    nproc = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
-    if nproc > 1 and P >= 256:
-        import multiprocessing as mp
-        with mp.get_context("fork").Pool(nproc) as pool:
-            pairs = pool.starmap(synth_pair, [(sd, T) for sd in seeds], chunksize=32)
-    else:
-        pairs = [synth_pair(sd, T=T) for sd in seeds]
-    y1, o1, Cc = pack_rows([p[0] for p in pairs])
-    y2, o2, _ = pack_rows([p[1] for p in pairs])
-    del pairs
     tr1, tr2 = int(o1[-1]), int(o2[-1])
     mr1, mr2 = int(np.diff(o1).max()), int(np.diff(o2).max())
     s1o = np.zeros(2 * P + 1, dtype=np.int64)
@@ -237,9 +244,9 @@ def main():
             "stage_ms_per_step": {"viterbi_x2": round(vt_avg, 3), "align_envelope": round(al_ms / max(al_n, 1), 3),
                                   "pair_beam": round(b2_avg, 3)},
         }
-        if args.gpus == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(T, args.cpu_sample)
-            out["gpu_over_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+            out["gpu_over_cpu_all_cores"] = round(out["value"] / cpu_base["value"], 1)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
