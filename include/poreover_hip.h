@@ -161,6 +161,20 @@ int po_envelope_batch(const char* aln1, const char* aln2, const int64_t* aln_off
                       const int32_t* U, const int32_t* V, int padding, int32_t* env, const int64_t* env_off,
                       int32_t* status, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- decoding_cpp.cpp_pair_gamma_log_envelope / decoding_cy.pair_gamma_log -------------------
+ * replaces decoding_cpp.pyx:168-188 -> pair_gamma_log_envelope (Gamma.h:15-98) and the dense
+ * decoding_cy.pair_gamma_log (decoding_cy.pyx:177-220): gamma(0,0) = log P(both reads emit the same
+ * label).  env: (U_i + 1) rows per pair with INCLUSIVE column ends (Gamma.h:26-30), rows of pair i at
+ * env + 2 * env_off[i]; env == NULL: dense.  flavor 0 = Gamma.h arithmetic (logaddexp, -inf),
+ * 1 = decoding_cy arithmetic (log(exp+exp), LOG_0 = -9999).  dense_out (optional, dense only): the full
+ * (U+1) x (V+1) gamma matrices at dense_out + dense_off[i].  max_cells = largest per-pair number of
+ * stored cells (sum over rows of end - start + 1), as used to size the workspace. */
+size_t po_pair_gamma_workspace_bytes(int n, int64_t max_cells, int64_t max_rows1, int64_t max_rows2);
+int po_pair_gamma_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
+                        const int32_t* env, const int64_t* env_off, int n, int C, int flavor, int64_t max_cells,
+                        double* gamma00, double* dense_out, const int64_t* dense_off, int32_t* status, void* ws,
+                        size_t ws_bytes, void* stream);
+
 /* ---- pair_decode.pair_decode_helper stage chain -------------------------------------------
  * replaces pair_decode.py:305-529 for the default route (--method envelope --algorithm beam
  * --single viterbi): 1-D Viterbi of both reads (:360-362) -> length skip (:372-375) ->
@@ -214,6 +228,9 @@ int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* a
                         const int32_t* map1_h, const int64_t* map1_off_h, const int32_t* map2_h,
                         const int64_t* map2_off_h, const int32_t* U_h, const int32_t* V_h, int padding,
                         int32_t* env_h, const int64_t* env_off_h, int32_t* status_h);
+int po_pair_gamma_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                          const int32_t* env_h, const int64_t* env_off_h, int n, int C, int flavor, double* gamma00_h,
+                          double* dense_out_h, const int64_t* dense_off_h, int32_t* status_h);
 int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
                       const int64_t* y2_off_h, const int32_t* env_h, int n, int C, const char* alphabet,
                       int beam_width, int model, int method, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,

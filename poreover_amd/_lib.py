@@ -83,6 +83,11 @@ PROTOTYPES = {
                                     _i32p, _i64p, _i32p, _vp, C.c_size_t, _vp]),
     "po_envelope_batch_h": (C.c_int, [_cp, _cp, _i64p, _i32p, C.c_int, _i32p, _i64p, _i32p, _i64p, _i32p, _i32p, C.c_int,
                                       _i32p, _i64p, _i32p]),
+    "po_pair_gamma_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "po_pair_gamma_batch": (C.c_int, [_dp, _i64p, _dp, _i64p, _i32p, _i64p, C.c_int, C.c_int, C.c_int, C.c_int64, _dp, _dp,
+                                      _i64p, _i32p, _vp, C.c_size_t, _vp]),
+    "po_pair_gamma_batch_h": (C.c_int, [_dp, _i64p, _dp, _i64p, _i32p, _i64p, C.c_int, C.c_int, C.c_int, _dp, _dp, _i64p,
+                                        _i32p]),
     "po_pair_decode_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                                     C.POINTER(PairOptions)]),
     "po_pair_decode_batch": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.POINTER(PairOptions), _cp,

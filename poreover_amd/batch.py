@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib as L
 
 __all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows",
-           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "align_batch", "envelope_batch", "ingest_batch"]
+           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "align_batch", "envelope_batch", "ingest_batch", "pair_gamma_batch"]
 
 
 def pack_rows(arrays, C_expected=None):
@@ -287,3 +287,41 @@ def ingest_batch(arrays, perm=None, reverse=False):
     L.check(lib.po_ingest_batch_h(_ptr(src), _ptr(off), len(arrays), Cc, mode, p, 1 if reverse else 0, _ptr(out)),
             "po_ingest_batch_h")
     return [out[off[i]:off[i + 1]] for i in range(len(arrays))]
+
+
+def pair_gamma_batch(arrays1, arrays2, envelopes=None, flavor="cpp", return_matrix=False):
+    """gamma(0,0) = log P(both reads emit the same label) for a batch of pairs.
+    envelopes: list of (U_i + 1, 2) arrays with INCLUSIVE ends (Gamma.h), or None for the dense DP.
+    flavor "cpp" = Gamma.h arithmetic, "cy" = decoding_cy.pair_gamma_log arithmetic.
+    return_matrix (dense only): also return the (U+1, V+1) gamma matrices."""
+    lib = L.load()
+    y1, o1, Cc = pack_rows(arrays1)
+    y2, o2, _ = pack_rows(arrays2, Cc)
+    n = len(arrays1)
+    env = eo = None
+    if envelopes is not None:
+        es = [np.ascontiguousarray(e, dtype=np.int32) for e in envelopes]
+        for e, a in zip(es, arrays1):
+            if e.ndim != 2 or e.shape[1] != 2 or e.shape[0] < len(a) + 1:
+                raise ValueError("gamma envelopes need U + 1 rows")
+        env = np.ascontiguousarray(np.concatenate([e[:len(a) + 1] for e, a in zip(es, arrays1)], axis=0))
+        eo = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(a) + 1 for a in arrays1], out=eo[1:])
+    g0 = np.zeros(max(n, 1), dtype=np.float64)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    dn = dof = None
+    if return_matrix:
+        if envelopes is not None:
+            raise ValueError("return_matrix needs the dense DP")
+        dof = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([(len(a) + 1) * (len(b) + 1) for a, b in zip(arrays1, arrays2)], out=dof[1:])
+        dn = np.zeros(max(int(dof[-1]), 1), dtype=np.float64)
+    L.check(lib.po_pair_gamma_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), _ptr(env), _ptr(eo), n, Cc,
+                                      0 if flavor == "cpp" else 1, _ptr(g0), _ptr(dn), _ptr(dof), _ptr(st)),
+            "po_pair_gamma_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "pair gamma of pair %d" % i)
+    if return_matrix:
+        return [dn[dof[i]:dof[i + 1]].reshape(len(arrays1[i]) + 1, len(arrays2[i]) + 1) for i in range(n)]
+    return g0[:n].copy()

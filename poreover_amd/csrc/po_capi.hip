@@ -22,6 +22,9 @@ int po_launch_beam2d(const double*, const int64_t*, const double*, const int64_t
 size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const po_pair_options*);
 size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
 size_t po_prefix_ws_bytes(int, int64_t);
+size_t po_gamma_ws_bytes(int, int64_t, int64_t, int64_t);
+int po_launch_gamma(const double*, const int64_t*, const double*, const int64_t*, const int32_t*, const int64_t*, int, int, int,
+                    int64_t, int64_t, int64_t, double*, double*, const int64_t*, int32_t*, void*, size_t, hipStream_t);
 int po_launch_ingest(const void*, const int64_t*, int, int, int, const int*, int, int64_t, double*, hipStream_t);
 size_t po_align_ws_bytes(int, int64_t, int64_t, int);
 int po_launch_align(const char*, const int64_t*, int, int, int64_t, int64_t, char*, char*, const int64_t*, int32_t*, int32_t*,
@@ -358,6 +361,29 @@ int po_envelope_batch(const char* aln1, const char* aln2, const int64_t* aln_off
     return PO_OK;
 }
 
+// -------------------------------------------------------------------------------- pair gamma
+size_t po_pair_gamma_workspace_bytes(int n, int64_t max_cells, int64_t mr1, int64_t mr2) { return po_gamma_ws_bytes(n, max_cells, mr1, mr2); }
+
+int po_pair_gamma_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
+                        const int32_t* env, const int64_t* env_off, int n, int C, int flavor, int64_t max_cells,
+                        double* gamma00, double* dense_out, const int64_t* dense_off, int32_t* status, void* ws,
+                        size_t ws_bytes, void* stream) {
+    if (n < 0 || !y1 || !y1_off || !y2 || !y2_off || !gamma00 || !status || !ws || (env && !env_off) ||
+        (dense_out && !dense_off)) { g_err = "po_pair_gamma_batch: null argument"; return PO_E_ARG; }
+    if (n == 0) return PO_OK;
+    std::vector<int64_t> h(2 * (size_t)(n + 1));
+    HIPCHK(hipMemcpyAsync(h.data(), y1_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(h.data() + n + 1, y2_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int64_t m1 = 0, m2 = 0;
+    for (int i = 0; i < n; ++i) { m1 = std::max<int64_t>(m1, h[i + 1] - h[i]); m2 = std::max<int64_t>(m2, h[n + 1 + i + 1] - h[n + 1 + i]); }
+    int rc = po_launch_gamma(y1, y1_off, y2, y2_off, env, env_off, n, C, flavor, max_cells, m1, m2, gamma00, dense_out,
+                             dense_off, status, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != PO_OK) { g_err = "po_pair_gamma_batch: bad C or workspace too small"; return rc; }
+    HIPCHK(hipGetLastError());
+    return PO_OK;
+}
+
 // -------------------------------------------------------------------------------- pair decode
 size_t po_pair_decode_workspace_bytes(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C,
                                       const po_pair_options* opt) {
@@ -469,6 +495,46 @@ int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, c
     HIPCHK(hipDeviceSynchronize());
     DOWN(seq_h, sq, (size_t)seqb);
     DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_pair_gamma_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                          const int32_t* env_h, const int64_t* env_off_h, int n, int C, int flavor, double* gamma00_h,
+                          double* dense_out_h, const int64_t* dense_off_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
+    int64_t m1 = 0, m2 = 0, mc = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t U = y1_off_h[i + 1] - y1_off_h[i], V = y2_off_h[i + 1] - y2_off_h[i];
+        m1 = std::max(m1, U); m2 = std::max(m2, V);
+        int64_t cells = 0;
+        if (env_h) for (int64_t u = 0; u <= U; ++u) { const int64_t w = env_h[2 * (env_off_h[i] + u) + 1] - env_h[2 * (env_off_h[i] + u)] + 1; cells += w > 0 ? w : 0; }
+        else cells = (U + 1) * (V + 1);
+        mc = std::max(mc, cells);
+    }
+    DevBuf a, ao, b, bo, ev, eo, g0, dn, dof, st, ws;
+    UP(a, y1_h + y1_off_h[0] * C, sizeof(double) * r1 * C);
+    UP(b, y2_h + y2_off_h[0] * C, sizeof(double) * r2 * C);
+    std::vector<int64_t> o1(y1_off_h, y1_off_h + n + 1), o2(y2_off_h, y2_off_h + n + 1);
+    for (auto& o : o1) o -= y1_off_h[0];
+    for (auto& o : o2) o -= y2_off_h[0];
+    UP(ao, o1.data(), sizeof(int64_t) * (n + 1));
+    UP(bo, o2.data(), sizeof(int64_t) * (n + 1));
+    if (env_h) { UP(ev, env_h, sizeof(int32_t) * 2 * (size_t)env_off_h[n]); UP(eo, env_off_h, sizeof(int64_t) * (n + 1)); }
+    UP(g0, nullptr, sizeof(double) * n);
+    if (dense_out_h) { UP(dn, nullptr, sizeof(double) * (size_t)dense_off_h[n]); UP(dof, dense_off_h, sizeof(int64_t) * (n + 1)); }
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_pair_gamma_workspace_bytes(n, mc, m1, m2);
+    UP(ws, nullptr, wsb);
+    int rc = po_pair_gamma_batch((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p,
+                                 env_h ? (const int32_t*)ev.p : nullptr, env_h ? (const int64_t*)eo.p : nullptr, n, C, flavor,
+                                 mc, (double*)g0.p, dense_out_h ? (double*)dn.p : nullptr,
+                                 dense_out_h ? (const int64_t*)dof.p : nullptr, (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(gamma00_h, g0, sizeof(double) * n);
+    if (dense_out_h) DOWN(dense_out_h, dn, sizeof(double) * (size_t)dense_off_h[n]);
     DOWN(status_h, st, sizeof(int32_t) * n);
     return PO_OK;
 }

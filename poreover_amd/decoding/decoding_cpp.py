@@ -35,3 +35,9 @@ def cpp_forward(y_, label_, alphabet_="ACGT", model_="ctc"):
 def cpp_viterbi_acceptor(y_, label_, band_size=1000, alphabet_="ACGT"):
     """decoding_cpp.pyx:69-84 (the reference also prints "Mapping label" to stdout, Forward.h:20)"""
     return _batch.viterbi_acceptor_batch([_as2d(y_)], [label_], band_size, alphabet_)[0]
+
+
+def cpp_pair_gamma_log_envelope(y1_, y2_, envelope_ranges_):
+    """decoding_cpp.pyx:168-188: prints gamma(0,0) and returns None, as upstream.  envelope_ranges_: (U + 1, 2)
+    with INCLUSIVE column ends (Gamma.h:26-30).  (batch.pair_gamma_batch returns the values.)"""
+    print(float(_batch.pair_gamma_batch([_as2d(y1_)], [_as2d(y2_)], [np.asarray(envelope_ranges_, dtype=np.intc)])[0]))

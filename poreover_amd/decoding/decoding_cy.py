@@ -1,0 +1,20 @@
+"""Mirror of the parts of poreover.decoding.decoding_cy (reference decoding_cy.pyx) that have a GPU
+implementation: the dense pair gamma DP and the banded-envelope helper."""
+import numpy as np
+
+from .. import batch as _batch
+
+
+def pair_gamma_log(y1, y2):
+    """decoding_cy.pyx:177-220: the dense (U+1, V+1) gamma matrix (LOG_0 = -9999 arithmetic)"""
+    return _batch.pair_gamma_batch([np.asarray(y1, dtype=np.float64)], [np.asarray(y2, dtype=np.float64)], None, "cy",
+                                   return_matrix=True)[0]
+
+
+def diagonal_band_envelope(U, V, width):
+    """decoding_cy.pyx:41-56: inclusive (start, end) per row around the main diagonal -> (U, 2) array"""
+    out = []
+    for u in range(U):
+        center = int(np.round(V / U * u))
+        out.append((max(center - width, 0), min(center + width, V - 1)))
+    return np.array(out)

@@ -100,3 +100,17 @@ def test_pipeline_full_size(eng, oracle):
         assert np.array_equal(got[i]["envelope"], want["envelope"]), i
         assert got[i]["sequence_identity"] == want["sequence_identity"]
         assert got[i]["consensus"] == want["consensus"], i
+
+
+def test_pipeline_long_reads(eng, oracle):
+    """'maximum sizes': one pair of T ~ 60 000 frame reads (the size of the reference's real read1/2.npy,
+    6 000+ bases each), so banded NW really is banded (|band| 500 < length), the label walk is long and the
+    value-store ring has to grow with the wider look-ahead windows."""
+    y1, y2 = synth_pair(9900, T=60000)
+    got = eng.pair_decode_batch([y1], [y2])[0]
+    want = oracle.pair_decode(y1, y2)
+    assert want["status"] == 0 and got["status"] == 0
+    assert got["length1"] > 6000 and (got["seq1"], got["seq2"]) == (want["seq1"], want["seq2"])
+    assert got["sequence_identity"] == want["sequence_identity"]
+    assert np.array_equal(got["envelope"], want["envelope"])
+    assert got["consensus"] == want["consensus"]
