@@ -235,6 +235,15 @@ int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double*
                       const int64_t* y2_off_h, const int32_t* env_h, int n, int C, const char* alphabet,
                       int beam_width, int model, int method, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,
                       int32_t* status_h);
+/* pair decode with the 1-D stage supplied by the caller (pair-decode --single beam, pair_decode.py:363-370:
+ * cpp_beam_search + cpp_viterbi_acceptor): seq1d / len1 / len2 and the frame maps are INPUTS.
+ * map1_h / map2_h: int32, frame index of every base, read i at map + y*_off[i]. */
+int po_pair_decode_from_1d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
+                                   const int64_t* y2_off_h, int n, int C, const po_pair_options* opt,
+                                   const char* seq1d_h, const int64_t* seq1d_off_h, const int32_t* len1_h,
+                                   const int32_t* len2_h, const int32_t* map1_h, const int32_t* map2_h,
+                                   double* identity_h, int32_t* env_out_h, char* seq_h, const int64_t* seq_off_h,
+                                   int32_t* seq_len_h, int32_t* status_h);
 int po_pair_decode_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h,
                            const int64_t* y2_off_h, int n, int C, const po_pair_options* opt, char* seq1d_h,
                            const int64_t* seq1d_off_h, int32_t* len1_h, int32_t* len2_h, double* identity_h,

@@ -101,6 +101,8 @@ PROTOTYPES = {
                                     C.c_int, C.c_int, _cp, _i64p, _i32p, _i32p]),
     "po_pair_decode_batch_h": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.POINTER(PairOptions), _cp,
                                          _i64p, _i32p, _i32p, _dp, _i32p, _cp, _i64p, _i32p, _i32p]),
+    "po_pair_decode_from_1d_batch_h": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.POINTER(PairOptions), _cp,
+                                                 _i64p, _i32p, _i32p, _i32p, _i32p, _dp, _i32p, _cp, _i64p, _i32p, _i32p]),
     "po_event_create": (C.c_void_p, []),
     "po_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "po_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

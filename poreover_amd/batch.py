@@ -111,8 +111,10 @@ def beam_search_2d_batch(arrays1, arrays2, envelopes, beam_width=25, alphabet="A
 
 
 def pair_decode_batch(arrays1, arrays2, kind="poreover", beam_width=5, method="row_col", padding=5,
-                      alignment="banded", diagonal_envelope=False, diagonal_width=50):
+                      alignment="banded", diagonal_envelope=False, diagonal_width=50, single="viterbi"):
     """pair_decode_helper stage chain (pair_decode.py:305-529) for a batch of pairs, all on the GPU.
+    single="viterbi" (default): 1-D basecalls by argmax; single="beam": by cpp_beam_search (W = 25) with
+    frame maps from cpp_viterbi_acceptor (band 1000), as pair_decode.py:363-370.
     Returns a list of dicts: seq1, seq2, consensus (None if skipped), length1, length2,
     sequence_identity, skipped, status, envelope."""
     lib = L.load()
@@ -134,9 +136,34 @@ def pair_decode_batch(arrays1, arrays2, kind="poreover", beam_width=5, method="r
     l1, l2, lens, st = (np.zeros(max(n, 1), dtype=np.int32) for _ in range(4))
     ident = np.zeros(max(n, 1), dtype=np.float64)
     env = np.zeros((max(int(o1[-1]), 1), 2), dtype=np.int32)
-    L.check(lib.po_pair_decode_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), n, Cc, C.byref(opt), _ptr(seq1d),
-                                       _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(ident), _ptr(env), _ptr(seq), _ptr(so),
-                                       _ptr(lens), _ptr(st)), "po_pair_decode_batch_h")
+    if single == "beam" and not diagonal_envelope:
+        if kind != "poreover":
+            raise L.EngineError(L.E_UNSUPPORTED, "pair decode --single beam", "only for the poreover (ctc) kind, as the "
+                                "reference's acceptor is")
+        # pair_decode.py:363-370 calls cpp_beam_search / cpp_viterbi_acceptor with their defaults
+        b1, b2 = beam_search_batch(arrays1, 25), beam_search_batch(arrays2, 25)
+        p1, p2 = viterbi_acceptor_batch(arrays1, b1, 1000), viterbi_acceptor_batch(arrays2, b2, 1000)
+        map1 = np.zeros(max(int(o1[-1]), 1), dtype=np.int32)
+        map2 = np.zeros(max(int(o2[-1]), 1), dtype=np.int32)
+        for i in range(n):   # get_sequence_mapping('poreover'): frames whose state is a base
+            for mp, off, path, bs, ln, slot in ((map1, o1, p1[i], b1[i], l1, 2 * i), (map2, o2, p2[i], b2[i], l2, 2 * i + 1)):
+                fr = np.nonzero(path < 4)[0]
+                if len(fr) != len(bs):
+                    raise L.EngineError(L.E_ARG, "pair decode --single beam", "frame map and basecall lengths differ "
+                                        "(the reference asserts here, pair_decode.py:379)")
+                mp[off[i]:off[i] + len(fr)] = fr
+                ln[i] = len(bs)
+                seq1d[s1o[slot]:s1o[slot] + len(bs)] = np.frombuffer(bs.encode("ascii"), dtype=np.uint8)
+        L.check(lib.po_pair_decode_from_1d_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), n, Cc, C.byref(opt), _ptr(seq1d),
+                                                   _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(map1), _ptr(map2), _ptr(ident),
+                                                   _ptr(env), _ptr(seq), _ptr(so), _ptr(lens), _ptr(st)),
+                "po_pair_decode_from_1d_batch_h")
+    elif single not in ("viterbi", "beam"):
+        raise ValueError("single must be 'viterbi' or 'beam'")
+    else:
+        L.check(lib.po_pair_decode_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), n, Cc, C.byref(opt), _ptr(seq1d),
+                                           _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(ident), _ptr(env), _ptr(seq), _ptr(so),
+                                           _ptr(lens), _ptr(st)), "po_pair_decode_batch_h")
     raw1, raw = seq1d.tobytes(), seq.tobytes()
     out = []
     for i in range(n):

@@ -23,6 +23,10 @@ size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const
 size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
 size_t po_prefix_ws_bytes(int, int64_t);
 size_t po_gamma_ws_bytes(int, int64_t, int64_t, int64_t);
+int po_launch_pair_decode_from_1d(const double*, const int64_t*, const double*, const int64_t*, int, int, const po_pair_options*,
+                                  int64_t, int64_t, int64_t, int64_t, const int32_t*, const int32_t*, char*, const int64_t*,
+                                  int32_t*, int32_t*, double*, int32_t*, char*, const int64_t*, int32_t*, int32_t*, void*, size_t,
+                                  hipStream_t);
 int po_launch_gamma(const double*, const int64_t*, const double*, const int64_t*, const int32_t*, const int64_t*, int, int, int,
                     int64_t, int64_t, int64_t, double*, double*, const int64_t*, int32_t*, void*, size_t, hipStream_t);
 int po_launch_ingest(const void*, const int64_t*, int, int, int, const int*, int, int64_t, double*, hipStream_t);
@@ -726,6 +730,57 @@ int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double*
     DOWN(seq_h, sq, (size_t)seqb);
     DOWN(seq_len_h, sl, sizeof(int32_t) * n);
     DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_pair_decode_from_1d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                                   int n, int C, const po_pair_options* opt, const char* seq1d_h,
+                                   const int64_t* seq1d_off_h, const int32_t* len1_h, const int32_t* len2_h,
+                                   const int32_t* map1_h, const int32_t* map2_h, double* identity_h, int32_t* env_out_h,
+                                   char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
+    const int64_t seqb = seq_off_h[n], s1b = seq1d_off_h[2 * n];
+    int64_t m1 = 0, m2 = 0;
+    for (int i = 0; i < n; ++i) {
+        m1 = std::max<int64_t>(m1, y1_off_h[i + 1] - y1_off_h[i]);
+        m2 = std::max<int64_t>(m2, y2_off_h[i + 1] - y2_off_h[i]);
+    }
+    DevBuf a, ao, b, bo, so, sq, sl, st, s1o, s1, l1, l2, idn, ev, mp1, mp2, ws;
+    UP(a, y1_h + y1_off_h[0] * C, sizeof(double) * r1 * C);
+    UP(b, y2_h + y2_off_h[0] * C, sizeof(double) * r2 * C);
+    std::vector<int64_t> o1(y1_off_h, y1_off_h + n + 1), o2(y2_off_h, y2_off_h + n + 1);
+    for (auto& o : o1) o -= y1_off_h[0];
+    for (auto& o : o2) o -= y2_off_h[0];
+    UP(ao, o1.data(), sizeof(int64_t) * (n + 1));
+    UP(bo, o2.data(), sizeof(int64_t) * (n + 1));
+    UP(so, seq_off_h, sizeof(int64_t) * (n + 1));
+    UP(sq, nullptr, (size_t)seqb);
+    UP(sl, nullptr, sizeof(int32_t) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    UP(s1o, seq1d_off_h, sizeof(int64_t) * (2 * n + 1));
+    UP(s1, seq1d_h, (size_t)s1b);
+    UP(l1, len1_h, sizeof(int32_t) * n);
+    UP(l2, len2_h, sizeof(int32_t) * n);
+    UP(mp1, map1_h + y1_off_h[0], sizeof(int32_t) * r1);
+    UP(mp2, map2_h + y2_off_h[0], sizeof(int32_t) * r2);
+    UP(idn, nullptr, sizeof(double) * n);
+    UP(ev, nullptr, sizeof(int32_t) * 2 * r1);
+    const size_t wsb = po_pair_decode_workspace_bytes(n, r1, r2, m1, m2, C, opt);
+    UP(ws, nullptr, wsb);
+    int rc = po_launch_pair_decode_from_1d((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p, n,
+                                           C, opt, r1, r2, m1, m2, (const int32_t*)mp1.p, (const int32_t*)mp2.p, (char*)s1.p,
+                                           (const int64_t*)s1o.p, (int32_t*)l1.p, (int32_t*)l2.p, (double*)idn.p,
+                                           (int32_t*)ev.p, (char*)sq.p, (const int64_t*)so.p, (int32_t*)sl.p, (int32_t*)st.p,
+                                           ws.p, wsb, nullptr);
+    if (rc != PO_OK) { g_err = "po_pair_decode_from_1d_batch_h: launch refused"; return rc; }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(seq_h, sq, (size_t)seqb);
+    DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    DOWN(identity_h, idn, sizeof(double) * n);
+    DOWN(env_out_h, ev, sizeof(int32_t) * 2 * r1);
     return PO_OK;
 }
 

@@ -425,7 +425,8 @@ extern "C" size_t po_pair_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64_t
 
 extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_off, const double* y2,
                                           const int64_t* y2_off, int n, int C, const po_pair_options* opt,
-                                          int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, char* seq1d,
+                                          int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2,
+                                          const int32_t* ext_map1, const int32_t* ext_map2, char* seq1d,
                                           const int64_t* seq1d_off, int32_t* len1, int32_t* len2, double* identity,
                                           int32_t* env_out, char* seq, const int64_t* seq_off, int32_t* seq_len,
                                           int32_t* status, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -448,8 +449,14 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     int8_t* ffpath = ffp ? ffp + al256((size_t)std::max(tr1, tr2) * 8) : nullptr;
     void* tok = nullptr;
     int rc;
-    // (1) the two 1-D basecalls with their frame maps (pair_decode.py:360-362, 377-382)
-    if (!opt->diagonal_envelope) {
+    // (1) the two 1-D basecalls with their frame maps (pair_decode.py:360-362, 377-382); with
+    //     --single beam the caller supplies them (beam search + Viterbi acceptor, :363-370)
+    if (ext_map1 && ext_map2) {
+        map1 = const_cast<int32_t*>(ext_map1);
+        map2 = const_cast<int32_t*>(ext_map2);
+        if (hipMemsetAsync(st1, 0, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
+        if (hipMemsetAsync(st2, 0, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
+    } else if (!opt->diagonal_envelope) {
         po_prof_stage(PO_K_VITERBI, stream, 1, &tok);
         rc = po_launch_viterbi_strided(y1, y1_off, n, C, A, alphabet, kind, nullptr, seq1d, seq1d_off, 0, 2, len1, map1,
                                        st1, ffp, ffpath, stream);
@@ -513,7 +520,7 @@ extern "C" int po_launch_pair_decode(const double* y1, const int64_t* y1_off, co
     }
     free(h);
     if (rc != PO_OK) return rc;
-    return po_launch_pair_decode_geom(y1, y1_off, y2, y2_off, n, C, opt, t1, t2, m1, m2, seq1d, seq1d_off, len1, len2,
+    return po_launch_pair_decode_geom(y1, y1_off, y2, y2_off, n, C, opt, t1, t2, m1, m2, nullptr, nullptr, seq1d, seq1d_off, len1, len2,
                                       identity, env_out, seq, seq_off, seq_len, status, ws, ws_bytes, stream);
 }
 
@@ -574,4 +581,18 @@ extern "C" int po_launch_envelope(const char* aln1, const char* aln2, const int6
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
     hipLaunchKernelGGL(pair_prep_kernel, dim3(blocks), dim3(PP_THREADS), 0, stream, a);
     return PO_OK;
+}
+
+// pair decode with an externally supplied 1-D stage (pair_decode.py --single beam, :363-370): seq1d / len1 /
+// len2 / map1 / map2 are INPUTS (maps: frame of every base, int32 at map + y*_off[i])
+extern "C" int po_launch_pair_decode_from_1d(const double* y1, const int64_t* y1_off, const double* y2,
+                                             const int64_t* y2_off, int n, int C, const po_pair_options* opt,
+                                             int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, const int32_t* map1,
+                                             const int32_t* map2, char* seq1d, const int64_t* seq1d_off, int32_t* len1,
+                                             int32_t* len2, double* identity, int32_t* env_out, char* seq,
+                                             const int64_t* seq_off, int32_t* seq_len, int32_t* status, void* ws,
+                                             size_t ws_bytes, hipStream_t stream) {
+    if (!map1 || !map2) return PO_E_ARG;
+    return po_launch_pair_decode_geom(y1, y1_off, y2, y2_off, n, C, opt, tr1, tr2, mr1, mr2, map1, map2, seq1d, seq1d_off,
+                                      len1, len2, identity, env_out, seq, seq_off, seq_len, status, ws, ws_bytes, stream);
 }

@@ -20,8 +20,6 @@ def _check_supported(args):
                                "only the envelope method (the reference's default) is built")
     if getattr(args, 'algorithm', 'beam') != 'beam':
         raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --algorithm %s" % args.algorithm)
-    if getattr(args, 'single', 'viterbi') != 'viterbi':
-        raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --single %s" % args.single)
     if getattr(args, 'skip_matches', False):
         raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --skip_matches")
 
@@ -54,7 +52,7 @@ def decode_pairs(in_paths, args):
                                        kind=kind, beam_width=args.beam_width, method=args.beam_search_method,
                                        padding=args.padding, alignment=args.alignment,
                                        diagonal_envelope=args.diagonal_envelope,
-                                       diagonal_width=args.diagonal_width)
+                                       diagonal_width=args.diagonal_width, single=getattr(args, 'single', 'viterbi'))
         for i, r in zip(idx, res):
             in_path = in_paths[i]
             path1, path2 = loaded[i][0], loaded[i][1]

@@ -101,7 +101,7 @@ def test_pair_decode_driver_matches_reference_outputs(eng, tmp_path, monkeypatch
     assert len(out) == 2 and out[0].startswith(">consensus;envelope;p%d_a\n" % recs[0]["index"])
     assert out[0].split("\n", 1)[1] == recs[0]["runs"]["diag30"]["fasta_2d"].split("\n", 1)[1]
     # unsupported routes are refused loudly
-    for kw in (dict(method="split"), dict(algorithm="prefix"), dict(single="beam"), dict(skip_matches=True)):
+    for kw in (dict(method="split"), dict(algorithm="prefix"), dict(skip_matches=True)):
         bad = _pair_args(**kw)
         setattr(bad, "in", a0)
         with pytest.raises(eng.EngineError):
@@ -121,3 +121,21 @@ def test_transducer_classes(eng, golden, golden_inputs):
         cls = {"bonito": transducer.bonito, "flipflop": transducer.flipflop}[rec["kind"]]
         s, p = cls(golden_inputs["pair%d_y1" % rec["index"]]).viterbi_decode(return_path=True)
         assert s == rec["viterbi1"] and p.tolist() == rec["path1"]
+
+
+def test_pair_decode_single_beam(eng, monkeypatch, golden_inputs):
+    """--single beam (pair_decode.py:363-370): 1-D basecalls by beam search W = 25, frame maps by the Viterbi
+    acceptor (band 1000); checked stage by stage against the oracle"""
+    from oracle import po_oracle as O
+    from poreover_amd import batch
+    y1, y2 = golden_inputs["pair3_y1"], golden_inputs["pair3_y2"]
+    got = batch.pair_decode_batch([y1], [y2], single="beam")[0]
+    b1, b2 = O.cpp_beam_search(y1, 25), O.cpp_beam_search(y2, 25)
+    assert (got["seq1"], got["seq2"]) == (b1, b2)
+    m1 = np.nonzero(O.cpp_viterbi_acceptor(y1, b1, 1000) < 4)[0]
+    m2 = np.nonzero(O.cpp_viterbi_acceptor(y2, b2, 1000) < 4)[0]
+    a1, a2 = O.global_pair_banded(b1, b2)
+    env = O.build_envelope(len(y1), len(y2), a1, a2, m1, m2, 5)
+    assert np.array_equal(got["envelope"], env)
+    assert got["sequence_identity"] == sum(x == y for x, y in zip(a1, a2)) / len(a1)
+    assert got["consensus"] == O.cpp_beam_search_2d(y1, y2, env, 5, method_="row_col")
