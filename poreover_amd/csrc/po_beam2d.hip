@@ -34,8 +34,8 @@
 //   * Within a step the recurrence alpha[t] = lae(alpha_parent[t-1] + y[t][c], alpha[t-1] + y[t][blank])
 //     is a wavefront over (depth, t): every element advances one t per iteration and takes its
 //     parent's value of the previous iteration from an LDS exchange buffer (double-buffered, one
-//     LDS-only barrier per iteration).  Parents that do not move in the step (frozen, or the root's
-//     blank prefix sums) are staged from the store into LDS 32 iterations at a time.
+//     LDS hand-over per iteration).  Parents that do not move in the step (frozen, or the root's
+//     blank prefix sums) are read straight from the store, one iteration ahead like the y rows.
 //   * One workgroup per pair, thread = (read, element slot); the LDS layout is a compile-time struct
 //     per beam-width class (W <= 6 / 12 / 25 -> 64 / 128 / 256 threads).  Workgroups are persistent
 //     and pull pairs from an atomic queue.
@@ -47,7 +47,6 @@
 
 namespace {
 
-constexpr int B2_CH = 32;    // staging chunk: iterations per refill of the frozen-parent buffer
 constexpr int B2_NGL = 256;  // row groups tracked per pair (LDS bookkeeping)
 
 template <int K>
@@ -78,6 +77,23 @@ struct B2Args {
     long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
 };
 
+// F_PSLOT of an element whose parent does not move in the scan: a frozen parent (its values are read from
+// its ring row in the store), or the root (closed form / blank prefix sums)
+constexpr int PS_FROZEN = -1, PS_ROOT = -2;
+
+// LDS hand-over between iterations.  One wave per workgroup: a wave's LDS operations execute in order,
+// only the compiler needs fencing.  More waves: LDS-only barrier (outstanding stores are not waited for).
+template <int NTHR>
+__device__ __forceinline__ void b2_sync_lds() {
+    if constexpr (NTHR == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        po_lds_barrier();
+    }
+}
+
 // element-table field indices
 enum { F_ID, F_ROW, F_PSLOT, F_SYM, F_FC, F_CROW, F_PAR, F_GPAR, F_PROW, F_DEPTH, F_COUNT };
 // F_SYM packs: own symbol (bits 0-2) | parent's symbol (bits 4-6) | parent-is-root (bit 9)
@@ -94,13 +110,11 @@ struct B2Smem {
     int nx[F_COUNT][WMAX];  // next beam under construction
     int sel[WMAX];
     int dup[NCM];
-    int stage[NCM];         // 0: parent moves in this scan; 1: parent staged from the store; 2: root
     int g_owner[B2_NGL], g_hi0[B2_NGL], g_hi1[B2_NGL];
     int sh[16];
     double score[NCM];
     double mxs[2][NCP];
     double xch[2][2][NCP][K];
-    double stg[WMAX][2][B2_CH][K];
     PoLaeTables lae;        // tables of the specialised logaddexp (po_device.h)
 };
 
@@ -346,83 +360,108 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             const int t0 = r ? t01 : t00, len = r ? len1 : len0;
             const bool part = (s < nelem) && (len > 0) && !(r == 0 && s >= skip_lo && s < skip_hi);
             const int Lmax = max(len0, len1);
-            int node = 0, row = -1, pslot = -1, sym = 0;
+            int pslot = PS_ROOT, sym = 0;
             bool same = false, rootpar = false;
             double self[K], mx = PO_NEG_INF;
+            Ent* myrow = pool;          // this element's ring row on read r
+            const Ent* prow = pool;     // a frozen parent's ring row
+            unsigned long long tag0 = 0, ptag0 = 0;
             if (part) {
-                node = sm.e[F_ID][s]; row = sm.e[F_ROW][s]; pslot = sm.e[F_PSLOT][s];
+                const int node = sm.e[F_ID][s];
+                pslot = sm.e[F_PSLOT][s];
                 const int sy = sm.e[F_SYM][s];
                 sym = sym_last(sy); same = (sym_plast(sy) == sym); rootpar = (sy >> 9) & 1;
-                st_read(row, r, t0 - 1, node, self);
+                myrow = pool + ((size_t)sm.e[F_ROW][s] * 2 + r) * R;
+                tag0 = make_tag(epoch, node, 0);
+                bool hit = false;
+                if (t0 >= 1) {
+                    const Ent e = myrow[(t0 - 1) & Rm];
+                    hit = (e.tag == tag0 + (unsigned)(t0 - 1));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) self[k] = e.v[k];
+                }
+                if (!hit) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) self[k] = PO_NEG_INF;
+                }
 #pragma unroll
                 for (int k = 0; k < K; ++k) sm.xch[1][r][s][k] = self[k];
+                if (pslot == PS_FROZEN) {
+                    prow = pool + ((size_t)sm.e[F_PROW][s] * 2 + r) * R;
+                    ptag0 = make_tag(epoch, sm.e[F_PAR][s], 0);
+                }
             }
-            const int64_t ycol_a = sym, ycol_b = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
+            const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
+            const double* yp = yr_ + (int64_t)t0 * C;  // y row of the next fetch
+            // Loads of iteration k that do not depend on the chain — the y row, and the value at t-1 of a
+            // parent that does not move in this scan (frozen: from its ring row; root: its closed form)
+            // — are issued one iteration ahead.
+            double ya_n = 0.0, yb_n = 0.0, pr_n[K];
+            Ent pe_n;
+            pe_n.tag = 0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) { pr_n[q] = PO_NEG_INF; pe_n.v[q] = PO_NEG_INF; }
+            auto fetch = [&](int k) {
+                ya_n = yp[ca]; yb_n = yp[cb];
+                yp += C;
+                const int tp = t0 + k - 1;
+                if (pslot == PS_FROZEN) { if (tp >= 0) pe_n = prow[tp & Rm]; }
+                else if (pslot == PS_ROOT) root_at(r, tp, pr_n);
+            };
+            if (part) fetch(0);
+            b2_sync_lds<nthr>();  // the seeds in xch[1] -> visible to the first iteration
             TK(is_main ? 3 : 7);  // scan: self read
-            for (int k0 = 0; k0 < Lmax; k0 += B2_CH) {
-                // ---- stage the parents that do not move in this scan (frozen / root)
-                const int nst = min(nelem, WMAX);
-                for (int idx = tid; idx < nst * 2 * B2_CH; idx += nthr) {
-                    const int j = idx / (2 * B2_CH), rem = idx - j * 2 * B2_CH;
-                    const int rr = rem / B2_CH, kk = rem - rr * B2_CH;
-                    const int lr = rr ? len1 : len0, tr0 = rr ? t01 : t00;
-                    const int mode = sm.stage[j];
-                    if (mode == 0) continue;  // parent moves in this scan: its values come through xch
-                    if (k0 + kk >= lr) continue;
-                    double out[K];
-                    const int tt = tr0 - 1 + k0 + kk;
-                    if (mode == 2) root_at(rr, tt, out);
-                    else st_read(sm.e[F_PROW][j], rr, tt, sm.e[F_PAR][j], out);
+            for (int k = 0; k < Lmax; ++k) {
+                if (part && k < len) {
+                    const int t = t0 + k;
+                    const double ya = ya_n, yb = yb_n;
+                    double pp[K], out[K];
+                    if (pslot >= 0) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) sm.stg[j][rr][kk][k] = out[k];
-                }
-                po_lds_barrier();
-                TK(is_main ? 4 : 8);  // scan: staging
-                const int kend = min(Lmax, k0 + B2_CH);
-                for (int k = k0; k < kend; ++k) {
-                    const bool act = part && (k < len);
-                    double out[K];
-                    if (act) {
-                        const int t = t0 + k;
-                        double pp[K];
-                        if (pslot >= 0) {
+                        for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][pslot][q];
+                    } else if (pslot == PS_FROZEN) {
+                        const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
 #pragma unroll
-                            for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][pslot][q];
-                        } else {
+                        for (int q = 0; q < K; ++q) pp[q] = hit ? pe_n.v[q] : PO_NEG_INF;
+                    } else {
 #pragma unroll
-                            for (int q = 0; q < K; ++q) pp[q] = sm.stg[s][r][k - k0][q];
-                        }
-                        // y[t][.] does not depend on the chain: the loads issue ahead and hit L1 (the
-                        // windows of consecutive steps overlap); an LDS ring for y measured no faster
-                        const double ya = yr_[(int64_t)t * C + ycol_a], yb = yr_[(int64_t)t * C + ycol_b];
-                        po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
-                        // direct 16-byte store per lane.  (Tried: buffering 8 iterations in LDS and flushing
-                        // row-contiguous 128-byte bursts to cut L2 requests — the flush's extra instructions
-                        // and LDS cost more than the coalescing saved: 22k vs 29k pairs/s.  DESIGN.md §3.3.)
-                        st_write(row, r, t, node, out);
-#pragma unroll
-                        for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }
-                        if (out[0] > mx) mx = out[0];
+                        for (int q = 0; q < K; ++q) pp[q] = pr_n[q];
                     }
-                    po_lds_barrier();  // only xch crosses iterations; the stores stay in flight
+                    if (k + 1 < len) fetch(k + 1);
+                    po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
+                    // direct 16-byte store per lane.  (Tried: buffering 8 iterations in LDS and flushing
+                    // row-contiguous 128-byte bursts to cut L2 requests — the flush's extra instructions
+                    // and LDS cost more than the coalescing saved: 22k vs 29k pairs/s.  DESIGN.md §3.3.)
+#ifdef PO_ABL_NOSTORE   // timing ablation only (results are wrong): keeps the value live, skips the store
+                    if (out[0] == 12345.678) pool[0].tag = 1;
+#else
+                    Ent e;
+                    e.tag = tag0 + (unsigned)t;
+#pragma unroll
+                    for (int q = 0; q < K; ++q) e.v[q] = out[q];
+                    myrow[t & Rm] = e;
+#endif
+#pragma unroll
+                    for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }
+                    if (out[0] > mx) mx = out[0];
                 }
-                TK(is_main ? 5 : 9);  // scan: iterations
+                b2_sync_lds<nthr>();  // only xch crosses iterations; the stores stay in flight
             }
+            TK(is_main ? 5 : 9);  // scan: iterations
             if (s < nelem) sm.mxs[r][s] = mx;
         };
 
         // parent slot of beam slot j: the parent is an element if it is a beam node or a child of a
-        // beam node (grand-parent in the beam); otherwise it is staged (frozen) or the root
-        auto beam_parent = [&](int j, int nbm, bool with_children, int* mode) -> int {
+        // beam node (grand-parent in the beam); otherwise it does not move (PS_FROZEN) or is the root
+        auto beam_parent = [&](int j, int nbm, bool with_children) -> int {
             const int par = sm.e[F_PAR][j];
-            if (par == 0) { *mode = 2; return -1; }
-            int ps = -1;
+            if (par == 0) return PS_ROOT;
+            int ps = PS_FROZEN;
             for (int i = 0; i < nbm; ++i) if (sm.e[F_ID][i] == par) ps = i;
             if (ps < 0 && with_children) {
                 const int gp = sm.e[F_GPAR][j];
                 for (int i = 0; i < nbm; ++i) if (sm.e[F_ID][i] == gp) ps = nbm + A * i + sym_plast(sm.e[F_SYM][j]);
             }
-            *mode = (ps >= 0) ? 0 : 1;
             return ps;
         };
 
@@ -462,15 +501,12 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             const int ne = nb * (A + 1);
             if (tid < ne) {
                 if (tid < nb) {
-                    int mode;
-                    sm.e[F_PSLOT][tid] = beam_parent(tid, nb, true, &mode);
-                    sm.stage[tid] = mode;
+                    sm.e[F_PSLOT][tid] = beam_parent(tid, nb, true);
                 } else {
                     const int j = (tid - nb) / A, c = (tid - nb) - j * A;
                     sm.e[F_ID][tid] = sm.e[F_FC][j] + c; sm.e[F_ROW][tid] = sm.e[F_CROW][j] * PO_A + c;
                     sm.e[F_SYM][tid] = sym_pack(c, sym_last(sm.e[F_SYM][j]), false);
                     sm.e[F_PSLOT][tid] = j; sm.e[F_FC][tid] = -2; sm.e[F_CROW][tid] = -2;
-                    if (tid < WMAX) sm.stage[tid] = 0;
                 }
             }
             return ne;
@@ -512,15 +548,14 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                         sm.e[F_PSLOT][ne] = b; sm.e[F_FC][ne] = -2; sm.e[F_CROW][ne] = -2;
                         sm.e[F_PAR][ne] = id; sm.e[F_GPAR][ne] = sm.e[F_PAR][b]; sm.e[F_PROW][ne] = sm.e[F_ROW][b];
                         sm.e[F_DEPTH][ne] = sm.e[F_DEPTH][b] + 1;
-                        if (ne < WMAX) sm.stage[ne] = 0;
                     }
                 }
                 for (int j = 0; j < nb; ++j) {  // beam slots: parent among the elements, else staged
-                    int mode = 1, ps = -1;
-                    if (sm.e[F_PAR][j] == 0) mode = 2;
+                    int ps = PS_FROZEN;
+                    if (sm.e[F_PAR][j] == 0) ps = PS_ROOT;
                     else
-                        for (int i = 0; i < ne; ++i) if (sm.e[F_ID][i] == sm.e[F_PAR][j]) { ps = i; mode = 0; }
-                    sm.e[F_PSLOT][j] = ps; sm.stage[j] = mode;
+                        for (int i = 0; i < ne; ++i) if (sm.e[F_ID][i] == sm.e[F_PAR][j]) ps = i;
+                    sm.e[F_PSLOT][j] = ps;
                 }
                 sm.sh[2] = next_id; sm.sh[6] = ne; sm.sh[7] = np;
             }
@@ -564,7 +599,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 } else {  // a child enters the beam; the arena knows whether it was ever expanded
                     const int p = sm.e[F_PSLOT][e];
                     const int id = sm.e[F_ID][e];
-                    sm.nx[F_ID][tid] = id; sm.nx[F_ROW][tid] = sm.e[F_ROW][e]; sm.nx[F_PSLOT][tid] = -1;
+                    sm.nx[F_ID][tid] = id; sm.nx[F_ROW][tid] = sm.e[F_ROW][e]; sm.nx[F_PSLOT][tid] = PS_FROZEN;
                     sm.nx[F_SYM][tid] = sym_pack(sym_last(sm.e[F_SYM][e]), sym_last(sm.e[F_SYM][p]), false);
                     sm.nx[F_PAR][tid] = sm.e[F_ID][p]; sm.nx[F_GPAR][tid] = sm.e[F_PAR][p];
                     sm.nx[F_PROW][tid] = sm.e[F_ROW][p]; sm.nx[F_DEPTH][tid] = sm.e[F_DEPTH][p] + 1;
@@ -595,9 +630,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 if (cu_v || cu_u) {
                     const int nbe = min(W, nb);  // the reference indexes b < beam_width
                     if (tid < nbe) {
-                        int mode;
-                        sm.e[F_PSLOT][tid] = beam_parent(tid, nbe, false, &mode);
-                        sm.stage[tid] = mode;
+                        sm.e[F_PSLOT][tid] = beam_parent(tid, nbe, false);
                         if (cu_v) atomicMax(&sm.g_hi1[sm.e[F_ROW][tid] / PO_A], v + 1);
                         else atomicMax(&sm.g_hi0[sm.e[F_ROW][tid] / PO_A], u + 1);
                     }
