@@ -356,7 +356,10 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
         // Every participating element advances over its window, parent values flowing through the
         // LDS exchange buffer.  t0x / lenx: window start / length on read x (len 0 = read untouched);
         // slots [skip_lo, skip_hi) do not move on read 0 (row method: beam nodes beyond the first W).
-        auto scan = [&](bool is_main, int nelem, int skip_lo, int skip_hi, int t00, int len0, int t01, int len1) {
+        auto scan = [&](bool is_main, int nelem, int skip_lo, int skip_hi, int t00, int len0_, int t01, int len1_) {
+            // the window bounds come from (wave-uniform) vector loads: pin them to SGPRs so the iteration
+            // loop is a scalar loop
+            const int len0 = __builtin_amdgcn_readfirstlane(len0_), len1 = __builtin_amdgcn_readfirstlane(len1_);
             const int t0 = r ? t01 : t00, len = r ? len1 : len0;
             const bool part = (s < nelem) && (len > 0) && !(r == 0 && s >= skip_lo && s < skip_hi);
             const int Lmax = max(len0, len1);
@@ -404,28 +407,27 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             auto fetch = [&](int k) {
                 ya_n = yp[ca]; yb_n = yp[cb];
                 yp += C;
-                const int tp = t0 + k - 1;
-                if (pslot == PS_FROZEN) { if (tp >= 0) pe_n = prow[tp & Rm]; }
-                else if (pslot == PS_ROOT) root_at(r, tp, pr_n);
+                if (pslot < 0) {
+                    const int tp = t0 + k - 1;
+                    if (pslot == PS_ROOT) root_at(r, tp, pr_n);
+                    else if (tp >= 0) pe_n = prow[tp & Rm];
+                }
             };
             if (part) fetch(0);
             b2_sync_lds<nthr>();  // the seeds in xch[1] -> visible to the first iteration
             TK(is_main ? 3 : 7);  // scan: self read
-            for (int k = 0; k < Lmax; ++k) {
+            for (int kv = 0; kv < Lmax; ++kv) {
+                const int k = __builtin_amdgcn_readfirstlane(kv);  // keeps the loop counter and branch scalar
                 if (part && k < len) {
                     const int t = t0 + k;
                     const double ya = ya_n, yb = yb_n;
                     double pp[K], out[K];
-                    if (pslot >= 0) {
 #pragma unroll
-                        for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][pslot][q];
-                    } else if (pslot == PS_FROZEN) {
+                    for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][pslot >= 0 ? pslot : s][q];
+                    if (pslot < 0) {  // rare: the parent does not move in this scan
                         const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
 #pragma unroll
-                        for (int q = 0; q < K; ++q) pp[q] = hit ? pe_n.v[q] : PO_NEG_INF;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < K; ++q) pp[q] = pr_n[q];
+                        for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
                     }
                     if (k + 1 < len) fetch(k + 1);
                     po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
@@ -747,7 +749,9 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     g.wclass = W <= 6 ? 6 : (W <= 12 ? 12 : 25);
     g.threads = g.wclass == 6 ? 64 : (g.wclass == 12 ? 128 : 256);
     const int waves = g.threads / PO_WAVE;
-    const int per_cu = waves <= 1 ? 12 : (waves == 2 ? 6 : 3);  // 3 waves per SIMD
+    // waves per SIMD the register budget allows: 4 for the one-value model (<= 128 VGPRs), 3 for the others
+    const int wps = (K == 1) ? 4 : 3;
+    const int per_cu = 4 * wps / waves;
     g.blocks = b2_num_cus() * per_cu;
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
     g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << 20);  // value store per workgroup
