@@ -722,6 +722,546 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
 #endif
 }
 
+// =================================================================================================
+// row_col with an envelope, W <= 6: TWO PAIRS PER WAVE (beam2d_x2_kernel).
+//
+// With one pair per wave and lane = (read, slot), a step costs max(len0, len1) iterations and at most
+// 25 + 25 of 64 lanes work; the per-step bookkeeping (expansion, prune) uses <= 30 lanes.  Here a
+// half-wave (32 lanes, lane = element slot) owns a pair and walks its two windows one after the
+// other (len0 + len1 iterations, the second seeded through the same LDS exchange slot); the two
+// halves run different pairs through the same instruction stream, so the bookkeeping is shared by
+// two pairs, catch-up steps of one pair overlap the other's, and the iteration count per step is
+// max over the two pairs of len0 + len1 — for two pairs.  Every per-pair quantity is half-uniform
+// (a VGPR); halves pull pairs from the queue independently.  The per-pair pre-pass (envelope check
+// and transpose, widest window, blank prefix sums) is a separate, fully parallel kernel.
+// Results are identical to beam2d_kernel's (same arithmetic, same order within every chain).
+namespace {
+constexpr int X2_NGL = 256;   // row groups tracked per pair
+
+struct X2Args {
+    const double* y1; const int64_t* y1_off;
+    const double* y2; const int64_t* y2_off;
+    const int32_t* env;
+    int n, A, W, C;
+    uint32_t alphabet;
+    char* seq; const int64_t* seq_off; int32_t* seq_len; int32_t* status;
+    int use_pre_status;
+    int* queue;
+    int2* meta;                    // per pair: {status, R}; R < 0: skipped upstream, leave status alone
+    int* envt;                     // transposed envelope: 2 ints per read-1 row of the batch
+    double* cum1; double* cum2;    // blank prefix sums at the batch row offsets (CTC root)
+    char* pool; size_t pool_bytes; // value store per half-wave
+    int* arena; long long arena_cap;  // per half-wave: 3 int arrays
+    long long* dbg;
+};
+
+template <int K>
+struct X2Half {
+    int e[F_COUNT][32];
+    int nx[F_COUNT][8];
+    int bps[8];              // beam slot -> slot of its parent in the beam, or -1
+    int sel[8];
+    int newfc[8];
+    int dup[32];
+    int g_owner[X2_NGL], g_hi0[X2_NGL], g_hi1[X2_NGL];
+    int sh[8];
+    double score[32];
+    double xch[2][32][K];
+};
+template <int K>
+struct X2Smem {
+    X2Half<K> h[2];
+    PoLaeTables lae;
+};
+__device__ __forceinline__ void x2_sync() { b2_sync_lds<64>(); }
+}  // namespace
+
+// ---- per-pair pre-pass: envelope bounds, transposed envelope, widest window -> R, node budget, blank
+// prefix sums (BeamSearch.h:270-284; PrefixTree.h:509-515)
+template <int MODEL>
+__global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
+    constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
+    constexpr int nthr = 256;
+    __shared__ int shw;
+    const int pi = blockIdx.x, tid = threadIdx.x;
+    if (a.use_pre_status && a.status[pi] != PO_OK) {
+        if (tid == 0) a.meta[pi] = make_int2(a.status[pi], -1);
+        return;
+    }
+    const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
+    const int64_t b1 = a.y1_off[0], b2 = a.y2_off[0];
+    const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
+    const int32_t* env = a.env + 2 * o1;
+    int* envt = a.envt + 2 * (o2 - b2);
+    const int C = a.C, A = a.A, W = a.W;
+    int st = PO_OK, R = 32;
+    if (U < 1 || V < 1 || U >= (1 << 24) || V >= (1 << 24)) st = PO_E_ARG;
+    if (st == PO_OK) {
+        int bad = 0, wmax = 0;
+        for (int u = tid; u < U; u += nthr) {
+            const int lo = env[2 * u], hi = env[2 * u + 1];
+            if (lo < hi && (lo < 0 || hi > V)) bad = 1;
+            wmax = max(wmax, hi - lo);
+        }
+        for (int x = tid; x < V; x += nthr) { envt[2 * x] = -1; envt[2 * x + 1] = -1; }
+        if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
+        if (st == PO_OK) {
+            for (int u = 0; u < U; ++u) {  // column x is always visited by thread x % nthr, rows in order
+                const int lo = env[2 * u], hi = env[2 * u + 1];
+                int x = lo + ((tid - lo) % nthr + nthr) % nthr;
+                for (; x < hi; x += nthr) {
+                    if (envt[2 * x] < 0) { envt[2 * x] = u; envt[2 * x + 1] = u + 1; }
+                    else envt[2 * x + 1]++;
+                }
+            }
+            __syncthreads();
+            for (int x = tid; x < V; x += nthr) wmax = max(wmax, envt[2 * x + 1] - envt[2 * x]);
+            if (tid == 0) shw = 0;
+            __syncthreads();
+            atomicMax(&shw, wmax);
+            __syncthreads();
+            wmax = shw;
+            while (R < wmax + 2) R <<= 1;
+            const long long pool_entries = (long long)(a.pool_bytes / sizeof(Entry<K>));
+            const long long ng = pool_entries / ((long long)PO_A * 2 * R);
+            if (min((long long)X2_NGL, ng) < 2 * max(W, PO_A) + 4) st = PO_E_NOMEM;
+            const long long need = 1 + A + (long long)A * max(W, A) * ((long long)min(U, V) + 1);
+            if (st == PO_OK && (need > a.arena_cap || need >= (1 << 24))) st = PO_E_NOMEM;
+        }
+    }
+    if (st == PO_OK && MODEL == PO_MODEL_CTC && (tid == 0 || tid == 64)) {  // serial: the reference's rounding
+        const int rr = tid ? 1 : 0;
+        const double* yr = rr ? a.y2 + o2 * C : a.y1 + o1 * C;
+        double* cw = rr ? a.cum2 + (o2 - b2) : a.cum1 + (o1 - b1);
+        const int Tn = rr ? V : U;
+        double acc = 0.0;
+        for (int t0 = 0; t0 < Tn; t0 += 8) {
+            double b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b[q] = (t0 + q < Tn) ? yr[(int64_t)(t0 + q) * C + A] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (t0 + q < Tn) { acc += b[q]; cw[t0 + q] = acc; }
+        }
+    }
+    if (tid == 0) a.meta[pi] = make_int2(st, R);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
+    constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
+    using Ent = Entry<K>;
+    __shared__ X2Smem<K> sm;
+    const int lane = threadIdx.x, g = lane >> 5, s = lane & 31;
+    X2Half<K>& h = sm.h[g];
+    const int A = a.A, W = a.W, C = a.C;
+    const int hid = blockIdx.x * 2 + g;
+    Ent* const pool = (Ent*)(a.pool + (size_t)hid * a.pool_bytes);
+    const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
+    int* const apl = a.arena + (size_t)hid * 3 * a.arena_cap;
+    int* const afc = apl + a.arena_cap;
+    int* const acrow = afc + a.arena_cap;
+    po_lae_tables_load(&sm.lae, lane, 64);
+    const PoLaeFast lae{&sm.lae};
+    x2_sync();
+
+    // ---- half-uniform state of the pair in flight
+    bool have = false, done = false;
+    int pi = 0, U = 1, V = 1, u = 0, v = 0, nb = 0, R = 32, Rm = 31, NG = 0, st = PO_OK;
+    unsigned epoch = 0;
+    const double *yA = a.y1, *yB = a.y2, *cumA = a.cum1, *cumB = a.cum2;
+    const int2 *env2 = (const int2*)a.env, *envt2 = (const int2*)a.envt;
+    int2 er = make_int2(0, 0), ec = make_int2(0, 0), er_n = er, ec_n = ec;  // envelope row u / column v, and the next ones
+
+    auto root_at = [&](const double* cump, int t, double* out) {
+        if (MODEL == PO_MODEL_CTC) {
+            out[0] = (t < 0) ? 0.0 : cump[t];
+        } else {
+            double tmp[3];
+            root_values<MODEL>(t, 0.0, tmp);
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[k] = tmp[k];
+        }
+    };
+    auto st_read = [&](const Ent* rowp, int t, unsigned long long tagbase, double* out) {
+        bool hit = false;
+        if (t >= 0) {
+            const Ent e = rowp[t & Rm];
+            hit = (e.tag == tagbase + (unsigned)t);
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[k] = e.v[k];
+        }
+        if (!hit) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[k] = PO_NEG_INF;
+        }
+    };
+    auto alloc_group = [&](int owner, int lo0, int lo1) -> int {
+        int cur = h.sh[3];
+        int gg = -1;
+        for (int tries = 0; tries < NG; ++tries) {
+            const int c = cur;
+            cur = (cur + 1 == NG) ? 0 : cur + 1;
+            if (h.g_owner[c] < 0 || (h.g_hi0[c] <= lo0 && h.g_hi1[c] <= lo1)) { gg = c; break; }
+        }
+        h.sh[3] = cur;
+        if (gg < 0) { h.sh[4] = PO_E_NOMEM; gg = 0; }
+        h.g_owner[gg] = owner;
+        h.g_hi0[gg] = 0; h.g_hi1[gg] = 0;
+        return gg;
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------ a half without a pair pulls one
+        if (!have && !done) {
+            int p = 0;
+            if (s == 0) p = atomicAdd(a.queue, 1);
+            p = __shfl(p, lane & 32);
+            if (p >= a.n) {
+                done = true;
+            } else {
+                pi = p;
+                epoch++;
+                const int2 m = a.meta[pi];
+                if (m.x != PO_OK || m.y < 0) {  // refused by the pre-pass, or skipped upstream
+                    if (s == 0) {
+                        a.seq_len[pi] = 0;
+                        if (m.y >= 0) a.status[pi] = m.x;
+                    }
+                } else {
+                    const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
+                    U = (int)(a.y1_off[pi + 1] - o1); V = (int)(a.y2_off[pi + 1] - o2);
+                    yA = a.y1 + o1 * C; yB = a.y2 + o2 * C;
+                    cumA = a.cum1 + (o1 - a.y1_off[0]); cumB = a.cum2 + (o2 - a.y2_off[0]);
+                    env2 = (const int2*)(a.env + 2 * o1);
+                    envt2 = (const int2*)(a.envt + 2 * (o2 - a.y2_off[0]));
+                    R = m.y; Rm = R - 1;
+                    NG = (int)min((long long)X2_NGL, pool_entries / ((long long)PO_A * 2 * R));
+                    st = PO_OK; u = 0; v = 0;
+                    er = env2[0]; ec = envt2[0];
+                    er_n = env2[min(1, U - 1)]; ec_n = envt2[min(1, V - 1)];
+                    for (int q = s; q < X2_NGL; q += 32) { h.g_owner[q] = -1; h.g_hi0[q] = 0; h.g_hi1[q] = 0; }
+                    x2_sync();
+                    // root = node 0; its A children = nodes 1..A in row group 0 (BeamSearch.h:286-293)
+                    if (s == 0) {
+                        apl[0] = po_pack_node(-1, A); afc[0] = 1; acrow[0] = 0;
+                        h.g_owner[0] = 0; h.g_hi0[0] = 1; h.g_hi1[0] = 1;
+                        h.sh[2] = 1 + A;  // next node id
+                        h.sh[3] = 1;      // group allocation cursor
+                        h.sh[4] = PO_OK;
+                    }
+                    if (s < A) {
+                        apl[1 + s] = po_pack_node(0, s); afc[1 + s] = -1; acrow[1 + s] = -1;
+                        h.e[F_ID][s] = 1 + s; h.e[F_ROW][s] = s; h.e[F_PROW][s] = -1; h.e[F_PAR][s] = 0;
+                        h.e[F_GPAR][s] = -1; h.e[F_SYM][s] = sym_pack(s, A, true); h.e[F_DEPTH][s] = 1;
+                        h.e[F_FC][s] = -1; h.e[F_CROW][s] = -1;
+                        h.bps[s] = -1;
+                        const double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
+                        const unsigned long long tg = make_tag(epoch, 1 + s, 0);
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {  // update_prob(n, rr, 0)
+                            const double* yr = rr ? yB : yA;
+                            double pp[3], out[3];
+                            root_at(rr ? cumB : cumA, -1, pp);
+                            const double ya = yr[s], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr[s + A] : yr[A];
+                            po_update<MODEL>(sp, pp, ya, yb, false, true, out, lae);
+                            Ent e;
+                            e.tag = tg;
+#pragma unroll
+                            for (int k = 0; k < K; ++k) e.v[k] = out[k];
+                            pool[((size_t)s * 2 + rr) * R] = e;
+                        }
+                    }
+                    nb = A;
+                    have = true;
+                    x2_sync();
+                }
+            }
+        }
+        if (__ballot(have) == 0) {
+            if (__ballot(!done) == 0) break;
+            continue;
+        }
+
+        // ------------------------------------------------------------ catch-up steps (BeamSearch.h:314-336)
+        // only one of u, v advances and only the beam nodes are updated, at that one time; every
+        // value read is a t-1 value already in the store, so the lanes are independent
+        bool fin = !have;
+        while (!fin) {
+            if (u > U - 1 || v > V - 1) { fin = true; break; }
+            const bool row_ok = (v >= er.x && v < er.y), col_ok = (u >= ec.x && u < ec.y);
+            const bool cu_v = (!row_ok && v < er.x);
+            const bool cu_u = !cu_v && (!col_ok && u < ec.x);
+            if (!(cu_v || cu_u)) {
+                if (!row_ok || !col_ok) { st = PO_E_ENVELOPE; fin = true; }  // uninitialised bounds upstream (:309)
+                break;
+            }
+            const int rr = cu_v ? 1 : 0, t = cu_v ? v : u;
+            if (s < min(W, nb)) {  // the reference indexes b < beam_width
+                const int node = h.e[F_ID][s], row = h.e[F_ROW][s], sy = h.e[F_SYM][s], par = h.e[F_PAR][s];
+                const int bp = h.bps[s];
+                const int prow = (bp >= 0) ? h.e[F_ROW][bp] : h.e[F_PROW][s];
+                const int sym = sym_last(sy);
+                const bool same = (sym_plast(sy) == sym), rootpar = (sy >> 9) & 1;
+                Ent* myrow = pool + ((size_t)row * 2 + rr) * R;
+                const double* yr = (rr ? yB : yA) + (int64_t)t * C;
+                const double ya = yr[sym], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr[sym + A] : yr[A];
+                double self[K], pp[K], out[K];
+                const unsigned long long tg = make_tag(epoch, node, 0);
+                st_read(myrow, t - 1, tg, self);
+                if (par == 0) root_at(rr ? cumB : cumA, t - 1, pp);
+                else st_read(pool + ((size_t)prow * 2 + rr) * R, t - 1, make_tag(epoch, par, 0), pp);
+                po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
+                Ent e;
+                e.tag = tg + (unsigned)t;
+#pragma unroll
+                for (int k = 0; k < K; ++k) e.v[k] = out[k];
+                myrow[t & Rm] = e;
+                if (rr) atomicMax(&h.g_hi1[row / PO_A], t + 1);
+                else atomicMax(&h.g_hi0[row / PO_A], t + 1);
+            }
+            if (cu_v) { v++; ec = ec_n; ec_n = envt2[min(v + 1, V - 1)]; }
+            else { u++; er = er_n; er_n = env2[min(u + 1, U - 1)]; }
+        }
+        x2_sync();
+
+        // ------------------------------------------------------------ MAIN step at (u, v)  (:342-375)
+        // windows [u, ece) on read 0 and [v, ere) on read 1; every lane flows through, predicated
+        const bool dm = have && !fin;
+        const int ece = ec.y, ere = er.y;
+        // ---- expansion: children ids and row groups of the beam nodes (serial per half)
+        if (dm && s == 0) {
+            int next_id = h.sh[2];
+            const int lo0 = u - 1, lo1 = v - 1;
+            for (int j = 0; j < nb; ++j) {
+                bool need_group = false;
+                const int id = h.e[F_ID][j];
+                int isnew = 0;
+                if (h.e[F_FC][j] < 0) {
+                    h.e[F_FC][j] = next_id;
+                    afc[id] = next_id;
+                    for (int c = 0; c < A; ++c) { apl[next_id + c] = po_pack_node(id, c); afc[next_id + c] = -1; acrow[next_id + c] = -1; }
+                    next_id += A;
+                    need_group = true;
+                    isnew = 1;
+                } else if (h.e[F_CROW][j] < 0 || h.e[F_CROW][j] >= NG || h.g_owner[h.e[F_CROW][j]] != id) {
+                    need_group = true;  // its old rows were recycled: every value in them was dead
+                }
+                h.newfc[j] = isnew;
+                if (need_group) {
+                    const int gg = alloc_group(id, lo0, lo1);
+                    h.e[F_CROW][j] = gg;
+                    acrow[id] = gg;
+                }
+                const int gc = h.e[F_CROW][j], go = h.e[F_ROW][j] / PO_A;
+                h.g_hi0[gc] = max(h.g_hi0[gc], ece); h.g_hi1[gc] = max(h.g_hi1[gc], ere);
+                h.g_hi0[go] = max(h.g_hi0[go], ece); h.g_hi1[go] = max(h.g_hi1[go], ere);
+            }
+            h.sh[2] = next_id;
+        }
+        x2_sync();
+        if (dm && h.sh[4] != PO_OK) { st = h.sh[4]; fin = true; }
+        const bool dmm = dm && !fin;
+        const int ne = dmm ? nb * (A + 1) : 0;
+        int my_fc = -1, my_cr = -1;  // a child's own expansion state (arena), loaded behind the scan
+        if (s < ne) {
+            if (s < nb) {
+                int ps = h.bps[s];
+                if (h.e[F_PAR][s] == 0) ps = PS_ROOT;
+                else if (ps < 0) {
+                    ps = PS_FROZEN;
+                    const int gp = h.e[F_GPAR][s];
+                    for (int i = 0; i < nb; ++i) if (h.e[F_ID][i] == gp) ps = nb + A * i + sym_plast(h.e[F_SYM][s]);
+                }
+                h.e[F_PSLOT][s] = ps;
+            } else {
+                const int j = (s - nb) / A, c = (s - nb) - j * A;
+                const int id = h.e[F_FC][j] + c;
+                h.e[F_ID][s] = id; h.e[F_ROW][s] = h.e[F_CROW][j] * PO_A + c;
+                h.e[F_SYM][s] = sym_pack(c, sym_last(h.e[F_SYM][j]), false);
+                h.e[F_PSLOT][s] = j;
+                if (!h.newfc[j]) { my_fc = afc[id]; my_cr = acrow[id]; }
+            }
+        }
+        x2_sync();
+        if (s < nb && s < ne && h.e[F_PSLOT][s] >= nb) h.e[F_PROW][s] = h.e[F_ROW][h.e[F_PSLOT][s]];  // parent's current row
+
+        // ---- the scan: read 0's window, then read 1's, one t per iteration
+        {
+            const int len0 = dmm ? ece - u : 0, len1 = dmm ? ere - v : 0;
+            const int tot = len0 + len1;
+            const int Ltot = max(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 32));
+            const bool part = s < ne;
+            int pslot = PS_ROOT, sym = 0;
+            bool same = false, rootpar = false;
+            double self[K], self1[K], mx0 = PO_NEG_INF, mx = PO_NEG_INF;
+            Ent *myrow = pool, *row1 = pool;
+            const Ent *prow = pool, *prow1 = pool;
+            unsigned long long tag0 = 0, ptag0 = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { self[k] = PO_NEG_INF; self1[k] = PO_NEG_INF; }
+            if (part) {
+                pslot = h.e[F_PSLOT][s];
+                const int sy = h.e[F_SYM][s];
+                sym = sym_last(sy); same = (sym_plast(sy) == sym); rootpar = (sy >> 9) & 1;
+                myrow = pool + (size_t)h.e[F_ROW][s] * 2 * R;
+                row1 = myrow + R;
+                tag0 = make_tag(epoch, h.e[F_ID][s], 0);
+                st_read(myrow, u - 1, tag0, self);
+                st_read(row1, v - 1, tag0, self1);
+                if (pslot == PS_FROZEN) {
+                    prow = pool + (size_t)h.e[F_PROW][s] * 2 * R;
+                    prow1 = prow + R;
+                    ptag0 = make_tag(epoch, h.e[F_PAR][s], 0);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) h.xch[1][s][k] = self[k];
+            }
+            const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
+            int t = u;                                  // time of the current iteration
+            const double* yp = yA + (int64_t)u * C;     // fetch context: y row, root sums, time of the next fetch
+            const double* cump = cumA;
+            int tf = u;
+            double ya_n = 0.0, yb_n = 0.0, pr_n[K];
+            Ent pe_n;
+            pe_n.tag = 0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) { pr_n[q] = PO_NEG_INF; pe_n.v[q] = PO_NEG_INF; }
+            auto fetch = [&]() {
+                ya_n = yp[ca]; yb_n = yp[cb];
+                yp += C;
+                if (pslot < 0) {
+                    const int tp = tf - 1;
+                    if (pslot == PS_ROOT) root_at(cump, tp, pr_n);
+                    else if (tp >= 0) pe_n = prow[tp & Rm];
+                }
+                tf++;
+            };
+            if (part) fetch();
+            x2_sync();
+            for (int kv = 0; kv < Ltot; ++kv) {
+                const int k = __builtin_amdgcn_readfirstlane(kv);
+                if (part && k < tot) {
+                    if (k == len0) {  // read 0's window is done: continue on read 1 from its seed
+                        mx0 = mx; mx = PO_NEG_INF; t = v; myrow = row1;
+#pragma unroll
+                        for (int q = 0; q < K; ++q) self[q] = self1[q];
+                    }
+                    const double ya = ya_n, yb = yb_n;
+                    double pp[K], out[K];
+#pragma unroll
+                    for (int q = 0; q < K; ++q) pp[q] = h.xch[(k + 1) & 1][pslot >= 0 ? pslot : s][q];
+                    if (pslot < 0) {  // rare: the parent does not move in this scan
+                        const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
+#pragma unroll
+                        for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
+                    }
+                    if (k + 1 < tot) {
+                        if (k + 1 == len0) { yp = yB + (int64_t)v * C; cump = cumB; prow = prow1; tf = v; }
+                        fetch();
+                    }
+                    po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
+                    Ent e;
+                    e.tag = tag0 + (unsigned)t;
+#pragma unroll
+                    for (int q = 0; q < K; ++q) e.v[q] = out[q];
+                    myrow[t & Rm] = e;
+                    const bool sw = (k + 1 == len0);  // the next iteration starts read 1: hand its seed over
+#pragma unroll
+                    for (int q = 0; q < K; ++q) { self[q] = out[q]; h.xch[k & 1][s][q] = sw ? self1[q] : out[q]; }
+                    mx = fmax(mx, out[0]);
+                    t++;
+                }
+                x2_sync();
+            }
+            if (part) h.score[s] = mx0 + mx;  // node_greater_max_sym: max over read 0 + max over read 1
+            if (part && s >= nb) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
+        }
+        x2_sync();
+
+        // ---- prune (Beam.h:93-108) + next beam table
+        {
+            int d = 0;
+            if (s < ne && s >= nb) {
+                const int x = h.e[F_ID][s];
+                for (int j = 0; j < nb; ++j) d |= (h.e[F_ID][j] == x);
+            }
+            if (s < 32) h.dup[s] = (s < ne) ? d : 1;
+            x2_sync();
+            int rank = 0;
+            if (s < ne && !d) {
+                const double sc = h.score[s];
+                const int id = h.e[F_ID][s];
+                for (int o = 0; o < ne; ++o)
+                    if (!h.dup[o] && po_better(h.score[o], h.e[F_ID][o], sc, id)) rank++;
+                if (rank < W) h.sel[rank] = s;
+            }
+            const unsigned long long cand = __ballot(s < ne && !d);
+            const int ncand = __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
+            x2_sync();
+            const int nbn = dmm ? min(W, ncand) : 0;
+            if (s < nbn) {
+                const int e = h.sel[s];
+                if (e < nb) {
+#pragma unroll
+                    for (int f = 0; f < F_COUNT; ++f) h.nx[f][s] = h.e[f][e];
+                } else {  // a child enters the beam
+                    const int p = h.e[F_PSLOT][e];
+                    h.nx[F_ID][s] = h.e[F_ID][e]; h.nx[F_ROW][s] = h.e[F_ROW][e]; h.nx[F_PSLOT][s] = PS_FROZEN;
+                    h.nx[F_SYM][s] = sym_pack(sym_last(h.e[F_SYM][e]), sym_last(h.e[F_SYM][p]), false);
+                    h.nx[F_PAR][s] = h.e[F_ID][p]; h.nx[F_GPAR][s] = h.e[F_PAR][p];
+                    h.nx[F_PROW][s] = h.e[F_ROW][p]; h.nx[F_DEPTH][s] = h.e[F_DEPTH][p] + 1;
+                    h.nx[F_FC][s] = h.e[F_FC][e]; h.nx[F_CROW][s] = h.e[F_CROW][e];
+                }
+            }
+            x2_sync();
+            if (s < nbn) {
+#pragma unroll
+                for (int f = 0; f < F_COUNT; ++f) h.e[f][s] = h.nx[f][s];
+            }
+            x2_sync();
+            if (s < nbn) {  // parent's slot in the new beam; its row is where its values are written from now on
+                const int par = h.e[F_PAR][s];
+                int bp = -1;
+                for (int i = 0; i < nbn; ++i) if (h.e[F_ID][i] == par) bp = i;
+                h.bps[s] = bp;
+                if (bp >= 0) h.e[F_PROW][s] = h.e[F_ROW][bp];
+            }
+            if (dmm) {
+                nb = nbn;
+                u++; v++;
+                er = er_n; er_n = env2[min(u + 1, U - 1)];
+                ec = ec_n; ec_n = envt2[min(v + 1, V - 1)];
+                if (u > U - 1 || v > V - 1) fin = true;
+            }
+            x2_sync();
+        }
+
+        // ------------------------------------------------------------ label of the top node
+        if (have && fin) {
+            if (s == 0) {
+                int nout = 0;
+                if (st == PO_OK) {
+                    int node = h.e[F_ID][0];
+                    nout = h.e[F_DEPTH][0];
+                    char* out = a.seq + a.seq_off[pi];
+                    const int cap = (int)(a.seq_off[pi + 1] - a.seq_off[pi]);
+                    if (nout > cap) { st = PO_E_CAP; nout = 0; }
+                    else
+                        for (int i = nout - 1; i >= 0; --i) {
+                            const int pk = apl[node];
+                            out[i] = (char)((a.alphabet >> (8 * (po_node_last(pk) & 3))) & 0xffu);
+                            node = po_node_parent(pk);
+                        }
+                }
+                a.seq_len[pi] = nout;
+                a.status[pi] = st;
+            }
+            have = false;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side: geometry, workspace layout, launch
 namespace {
@@ -770,6 +1310,46 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     return g;
 }
 
+// ---- two-pairs-per-wave path (row_col, envelope, W <= 6, one-value model)
+struct X2Geom {
+    int blocks;
+    size_t pool_bytes, arena_cap;
+    size_t off_queue, off_meta, off_envt, off_cum1, off_cum2, off_pool, off_arena, total;
+};
+bool x2_eligible(int W, int model, int method) {
+    static const bool legacy = getenv("PO_B2_LEGACY") != nullptr;  // A/B switch: always use beam2d_kernel
+    return !legacy && method == PO_METHOD_ROW_COL && W <= 6 && model == PO_MODEL_CTC;
+}
+int x2_blocks_per_cu() {
+    static int per_cu = 0;
+    if (!per_cu) {
+        int nblk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_x2_kernel<PO_MODEL_CTC>, 64, 0) != hipSuccess ||
+            nblk <= 0)
+            nblk = 8;
+        per_cu = nblk;
+    }
+    return per_cu;
+}
+X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W) {
+    X2Geom g;
+    g.blocks = b2_num_cus() * x2_blocks_per_cu();
+    if (g.blocks > (n + 1) / 2) g.blocks = n > 1 ? (n + 1) / 2 : 1;
+    g.pool_bytes = al256((size_t)4 << 20);
+    const int64_t WM = W > PO_A ? W : PO_A;
+    g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 1));
+    size_t o = 0;
+    g.off_queue = o; o += 256;
+    g.off_meta = o; o += al256(sizeof(int2) * (size_t)(n > 0 ? n : 1));
+    g.off_envt = o; o += al256(sizeof(int) * 2 * (size_t)tr2);
+    g.off_cum1 = o; o += al256(sizeof(double) * (size_t)tr1);
+    g.off_cum2 = o; o += al256(sizeof(double) * (size_t)tr2);
+    g.off_pool = o; o += g.pool_bytes * 2 * g.blocks;
+    g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * 2 * g.blocks);
+    g.total = o + 256;
+    return g;
+}
+
 template <int MODEL, int WMAX>
 void b2_launch(const B2Geom& g, const B2Args& a, hipStream_t stream) {
     hipLaunchKernelGGL((beam2d_kernel<MODEL, WMAX>), dim3(g.blocks), dim3(g.threads), 0, stream, a);
@@ -784,20 +1364,42 @@ void b2_launch_w(const B2Geom& g, const B2Args& a, hipStream_t stream) {
 
 extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, int W,
                                           int model, int method) {
-    (void)tr1; (void)tr2; (void)C;
+    (void)C;
+    if (x2_eligible(W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total;
 }
 
 extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
                                      const int32_t* env, int n, int C, int A, uint32_t alphabet, int W, int model,
-                                     int method, int64_t mr1, int64_t mr2, char* seq, const int64_t* seq_off,
-                                     int32_t* seq_len, int32_t* status, int use_pre_status, void* ws,
-                                     size_t ws_bytes, hipStream_t stream) {
+                                     int method, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, char* seq,
+                                     const int64_t* seq_off, int32_t* seq_len, int32_t* status, int use_pre_status,
+                                     void* ws, size_t ws_bytes, hipStream_t stream) {
     if (n <= 0) return PO_OK;
     if (A < 1 || A > PO_A || W < 1 || W > 25) return PO_E_ARG;
     if (method != PO_METHOD_ROW_COL && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // grid: not on the GPU yet
     if (!env && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // the reference routes these to grid
     if ((model == PO_MODEL_FLIPFLOP) ? (C != 2 * A) : (C != A + 1)) return PO_E_ARG;
+    if (x2_eligible(W, model, method)) {
+        const X2Geom g = x2_geometry(n, tr1, tr2, mr1, mr2, W);
+        if (ws_bytes < g.total) return PO_E_CAP;
+        char* w = (char*)ws;
+        X2Args a;
+        a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
+        a.n = n; a.A = A; a.W = W; a.C = C; a.alphabet = alphabet;
+        a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status; a.use_pre_status = use_pre_status;
+        a.queue = (int*)(w + g.off_queue);
+        a.meta = (int2*)(w + g.off_meta);
+        a.envt = (int*)(w + g.off_envt);
+        a.cum1 = (double*)(w + g.off_cum1); a.cum2 = (double*)(w + g.off_cum2);
+        a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
+        a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
+        a.dbg = nullptr;
+        if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+        if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * 2 * g.blocks, stream) != hipSuccess) return PO_E_HIP;
+        hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_CTC>, dim3(g.blocks), dim3(64), 0, stream, a);
+        return PO_OK;
+    }
     const B2Geom g = b2_geometry(n, mr1, mr2, W, model, method);
     if (ws_bytes < g.total) return PO_E_CAP;
     char* w = (char*)ws;
@@ -852,14 +1454,17 @@ extern "C" int po_launch_beam2d(const double* y1, const int64_t* y1_off, const d
         hipMemcpyAsync(h + n + 1, y2_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess)
         rc = PO_E_HIP;
-    int64_t m1 = 0, m2 = 0;
-    if (rc == PO_OK)
+    int64_t m1 = 0, m2 = 0, tr1 = 0, tr2 = 0;
+    if (rc == PO_OK) {
         for (int i = 0; i < n; ++i) {
             m1 = std::max<int64_t>(m1, h[i + 1] - h[i]);
             m2 = std::max<int64_t>(m2, h[n + 1 + i + 1] - h[n + 1 + i]);
         }
+        tr1 = h[n] - h[0];
+        tr2 = h[n + 1 + n] - h[n + 1];
+    }
     free(h);
     if (rc != PO_OK) return rc;
-    return po_launch_beam2d_geom(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, m1, m2, seq, seq_off,
-                                 seq_len, status, 0, ws, ws_bytes, stream);
+    return po_launch_beam2d_geom(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, tr1, tr2, m1, m2, seq,
+                                 seq_off, seq_len, status, 0, ws, ws_bytes, stream);
 }

@@ -361,8 +361,8 @@ int po_launch_viterbi_strided(const double*, const int64_t*, int, int, int, uint
                               const int64_t*, int, int, int32_t*, int32_t*, int32_t*, int8_t*, int8_t*, hipStream_t);
 size_t po_beam2d_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, int, int, int);
 int po_launch_beam2d_geom(const double*, const int64_t*, const double*, const int64_t*, const int32_t*, int, int, int,
-                          uint32_t, int, int, int, int64_t, int64_t, char*, const int64_t*, int32_t*, int32_t*, int,
-                          void*, size_t, hipStream_t);
+                          uint32_t, int, int, int, int64_t, int64_t, int64_t, int64_t, char*, const int64_t*, int32_t*, int32_t*,
+                          int, void*, size_t, hipStream_t);
 void po_prof_stage(int kernel, hipStream_t s, int begin, void** tok);
 }
 
@@ -491,7 +491,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     // (3) the pair beam search inside the envelope (pair_decode.py:166-173,511)
     po_prof_stage(PO_K_BEAM2D, stream, 1, &tok);
     rc = po_launch_beam2d_geom(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, opt->beam_width, opt->model, opt->method,
-                               mr1, mr2, seq, seq_off, seq_len, status, 1, w + g.off_b2, g.b2_bytes, stream);
+                               tr1, tr2, mr1, mr2, seq, seq_off, seq_len, status, 1, w + g.off_b2, g.b2_bytes, stream);
     po_prof_stage(PO_K_BEAM2D, stream, 0, &tok);
     return rc;
 }
