@@ -75,11 +75,15 @@ struct B2Args {
     double* cum; long long tcap;       // 2 arrays of tcap doubles: blank prefix sums of each read
     int* envt; long long vcap;         // 2 * vcap ints: transposed envelope
     long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
+    const int2* only_meta;             // non-NULL: decode only the pairs the two-pairs-per-wave path deferred (meta.y == -2)
 };
 
 // F_PSLOT of an element whose parent does not move in the scan: a frozen parent (its values are read from
 // its ring row in the store), or the root (closed form / blank prefix sums)
 constexpr int PS_FROZEN = -1, PS_ROOT = -2;
+// meta.y of a pair the two-pairs-per-wave kernel hands to beam2d_kernel (window too wide for its store
+// geometry, or its row-group table ran out)
+constexpr int X2_DEFERRED = -2;
 
 // LDS hand-over between iterations.  One wave per workgroup: a wave's LDS operations execute in order,
 // only the compiler needs fencing.  More waves: LDS-only barrier (outstanding stores are not waited for).
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
         if (pi >= a.n) break;
         epoch++;
         TK_START();
+        if (a.only_meta && a.only_meta[pi].y != X2_DEFERRED) continue;  // done by beam2d_x2_kernel
         if (a.use_pre_status && a.status[pi] != PO_OK) {  // skipped upstream (pair_decode.py:372-375,395-398)
             if (tid == 0) a.seq_len[pi] = 0;
             continue;
@@ -736,7 +741,14 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
 // and transpose, widest window, blank prefix sums) is a separate, fully parallel kernel.
 // Results are identical to beam2d_kernel's (same arithmetic, same order within every chain).
 namespace {
-constexpr int X2_NGL = 256;   // row groups tracked per pair
+#ifndef X2_NGL_
+#define X2_NGL_ 128
+#endif
+constexpr int X2_NGL = X2_NGL_;   // row groups tracked per pair
+#ifndef X2_YD_
+#define X2_YD_ 256
+#endif
+constexpr int X2_YD = X2_YD_;    // doubles in the per-pair y window buffer (256: 51 rows of 5, 32 rows of 8)
 
 struct X2Args {
     const double* y1; const int64_t* y1_off;
@@ -753,12 +765,13 @@ struct X2Args {
     char* pool; size_t pool_bytes; // value store per half-wave
     int* arena; long long arena_cap;  // per half-wave: 3 int arrays
     long long* dbg;
+    int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
 };
 
 template <int K>
 struct X2Half {
     int e[F_COUNT][32];
-    int nx[F_COUNT][8];
+    int nx[F_COUNT][6];
     int bps[8];              // beam slot -> slot of its parent in the beam, or -1
     int sel[8];
     int newfc[8];
@@ -767,6 +780,7 @@ struct X2Half {
     int sh[8];
     double score[32];
     double xch[2][32][K];
+    double ybuf[X2_YD];      // the y rows of the current step's windows
 };
 template <int K>
 struct X2Smem {
@@ -824,9 +838,10 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             while (R < wmax + 2) R <<= 1;
             const long long pool_entries = (long long)(a.pool_bytes / sizeof(Entry<K>));
             const long long ng = pool_entries / ((long long)PO_A * 2 * R);
-            if (min((long long)X2_NGL, ng) < 2 * max(W, PO_A) + 4) st = PO_E_NOMEM;
             const long long need = 1 + A + (long long)A * max(W, A) * ((long long)min(U, V) + 1);
-            if (st == PO_OK && (need > a.arena_cap || need >= (1 << 24))) st = PO_E_NOMEM;
+            if (need > a.arena_cap || need >= (1 << 24)) st = PO_E_NOMEM;
+            // too few row groups for this window width here, or (test hook) odd pairs: beam2d_kernel takes it
+            else if (min((long long)X2_NGL, ng) < 8 * max(W, PO_A) || (a.defer_odd && (pi & 1))) R = X2_DEFERRED;
         }
     }
     if (st == PO_OK && MODEL == PO_MODEL_CTC && (tid == 0 || tid == 64)) {  // serial: the reference's rounding
@@ -861,8 +876,12 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
     int* const apl = a.arena + (size_t)hid * 3 * a.arena_cap;
     int* const afc = apl + a.arena_cap;
     int* const acrow = afc + a.arena_cap;
+#ifdef PO_LAE_POLY
+    const PoLaePoly lae;
+#else
     po_lae_tables_load(&sm.lae, lane, 64);
     const PoLaeFast lae{&sm.lae};
+#endif
     x2_sync();
 
     // ---- half-uniform state of the pair in flight
@@ -911,6 +930,9 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
         return gg;
     };
 
+#ifdef PO_B2_TIMING
+    long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+#endif
     for (;;) {
         // ------------------------------------------------------------ a half without a pair pulls one
         if (!have && !done) {
@@ -923,7 +945,9 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                 pi = p;
                 epoch++;
                 const int2 m = a.meta[pi];
-                if (m.x != PO_OK || m.y < 0) {  // refused by the pre-pass, or skipped upstream
+                if (m.y == X2_DEFERRED) {
+                    // beam2d_kernel decodes it after this kernel
+                } else if (m.x != PO_OK || m.y < 0) {  // refused by the pre-pass, or skipped upstream
                     if (s == 0) {
                         a.seq_len[pi] = 0;
                         if (m.y >= 0) a.status[pi] = m.x;
@@ -983,6 +1007,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             continue;
         }
 
+        TK(0);  // queue + per-pair setup
         // ------------------------------------------------------------ catch-up steps (BeamSearch.h:314-336)
         // only one of u, v advances and only the beam nodes are updated, at that one time; every
         // value read is a t-1 value already in the store, so the lanes are independent
@@ -1025,6 +1050,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
         }
         x2_sync();
 
+        TK(1);  // catch-up steps
         // ------------------------------------------------------------ MAIN step at (u, v)  (:342-375)
         // windows [u, ece) on read 0 and [v, ere) on read 1; every lane flows through, predicated
         const bool dm = have && !fin;
@@ -1060,7 +1086,11 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             h.sh[2] = next_id;
         }
         x2_sync();
-        if (dm && h.sh[4] != PO_OK) { st = h.sh[4]; fin = true; }
+        TK(2);  // expansion (serial)
+        if (dm && h.sh[4] != PO_OK) {  // out of row groups: hand the pair to beam2d_kernel
+            if (s == 0) a.meta[pi] = make_int2(PO_OK, X2_DEFERRED);
+            have = false; fin = true;
+        }
         const bool dmm = dm && !fin;
         const int ne = dmm ? nb * (A + 1) : 0;
         int my_fc = -1, my_cr = -1;  // a child's own expansion state (arena), loaded behind the scan
@@ -1086,6 +1116,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
         x2_sync();
         if (s < nb && s < ne && h.e[F_PSLOT][s] >= nb) h.e[F_PROW][s] = h.e[F_ROW][h.e[F_PSLOT][s]];  // parent's current row
 
+        TK(3);  // element table
         // ---- the scan: read 0's window, then read 1's, one t per iteration
         {
             const int len0 = dmm ? ece - u : 0, len1 = dmm ? ere - v : 0;
@@ -1119,27 +1150,49 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             }
             const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
             int t = u;                                  // time of the current iteration
-            const double* yp = yA + (int64_t)u * C;     // fetch context: y row, root sums, time of the next fetch
-            const double* cump = cumA;
+            const double* cump = cumA;                  // fetch context of a non-moving parent: root sums, next time
             int tf = u;
-            double ya_n = 0.0, yb_n = 0.0, pr_n[K];
+            double pr_n[K];
             Ent pe_n;
             pe_n.tag = 0;
 #pragma unroll
             for (int q = 0; q < K; ++q) { pr_n[q] = PO_NEG_INF; pe_n.v[q] = PO_NEG_INF; }
-            auto fetch = [&]() {
-                ya_n = yp[ca]; yb_n = yp[cb];
-                yp += C;
-                if (pslot < 0) {
-                    const int tp = tf - 1;
-                    if (pslot == PS_ROOT) root_at(cump, tp, pr_n);
-                    else if (tp >= 0) pe_n = prow[tp & Rm];
-                }
+            auto fetch = [&]() {  // value at t-1 of a parent that does not move, one iteration ahead (rare)
+                const int tp = tf - 1;
+                if (pslot == PS_ROOT) root_at(cump, tp, pr_n);
+                else if (tp >= 0) pe_n = prow[tp & Rm];
                 tf++;
             };
-            if (part) fetch();
+            if (part && pslot < 0) fetch();
+#ifdef X2_SHFL
+            // parent's value of the previous iteration, handed over lane to lane (ds_bpermute) instead of
+            // through an LDS write + read
+            const int psrc = (lane & 32) + (pslot >= 0 ? pslot : s);
+            double ppn[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) ppn[q] = __shfl(self[q], psrc);
+#endif
+            // The y rows of both windows go through LDS, one copy per step (two contiguous runs of rows;
+            // buffer row = iteration index).  With no vector-memory LOAD left in the iteration loop, the
+            // wave never waits there for the acknowledgement of its value-store writes (vmcnt counts loads
+            // and stores in order: waiting for any load also waits for every store issued before it).
+            const int yrows = X2_YD / C;  // iterations per buffer fill
+            for (int k0 = 0; k0 < Ltot; k0 += yrows) {
+            {
+                const int kend = min(tot, k0 + yrows);
+                const int ka1 = min(kend, len0);                 // read-0 iterations [k0, ka1)
+                const int nA = max(0, ka1 - k0) * C;
+                const double* srcA = yA + (int64_t)(u + k0) * C;
+                for (int i = s; i < nA; i += 32) h.ybuf[i] = srcA[i];
+                const int kb0 = max(k0, len0);                   // read-1 iterations [kb0, kend)
+                const int nB = max(0, kend - kb0) * C;
+                const double* srcB = yB + (int64_t)(v + kb0 - len0) * C;
+                for (int i = s; i < nB; i += 32) h.ybuf[nA + i] = srcB[i];
+            }
             x2_sync();
-            for (int kv = 0; kv < Ltot; ++kv) {
+            TK(4);  // scan: seeds + y window copy
+            const int kchunk = min(Ltot, k0 + yrows);
+            for (int kv = k0; kv < kchunk; ++kv) {
                 const int k = __builtin_amdgcn_readfirstlane(kv);
                 if (part && k < tot) {
                     if (k == len0) {  // read 0's window is done: continue on read 1 from its seed
@@ -1147,17 +1200,23 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
 #pragma unroll
                         for (int q = 0; q < K; ++q) self[q] = self1[q];
                     }
-                    const double ya = ya_n, yb = yb_n;
+                    const double* yrow = h.ybuf + (k - k0) * C;
+                    const double ya = yrow[ca], yb = yrow[cb];
                     double pp[K], out[K];
+#ifdef X2_SHFL
+#pragma unroll
+                    for (int q = 0; q < K; ++q) pp[q] = ppn[q];
+#else
 #pragma unroll
                     for (int q = 0; q < K; ++q) pp[q] = h.xch[(k + 1) & 1][pslot >= 0 ? pslot : s][q];
+#endif
                     if (pslot < 0) {  // rare: the parent does not move in this scan
                         const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
 #pragma unroll
                         for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
                     }
-                    if (k + 1 < tot) {
-                        if (k + 1 == len0) { yp = yB + (int64_t)v * C; cump = cumB; prow = prow1; tf = v; }
+                    if (pslot < 0 && k + 1 < tot) {
+                        if (k + 1 == len0) { cump = cumB; prow = prow1; tf = v; }
                         fetch();
                     }
                     po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
@@ -1167,18 +1226,26 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                     for (int q = 0; q < K; ++q) e.v[q] = out[q];
                     myrow[t & Rm] = e;
                     const bool sw = (k + 1 == len0);  // the next iteration starts read 1: hand its seed over
+#ifdef X2_SHFL
+#pragma unroll
+                    for (int q = 0; q < K; ++q) { self[q] = out[q]; ppn[q] = __shfl(sw ? self1[q] : out[q], psrc); }
+#else
 #pragma unroll
                     for (int q = 0; q < K; ++q) { self[q] = out[q]; h.xch[k & 1][s][q] = sw ? self1[q] : out[q]; }
+#endif
                     mx = fmax(mx, out[0]);
                     t++;
                 }
                 x2_sync();
+            }
+            TK(5);  // scan: iterations
             }
             if (part) h.score[s] = mx0 + mx;  // node_greater_max_sym: max over read 0 + max over read 1
             if (part && s >= nb) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
         }
         x2_sync();
 
+        TK(6);  // scores
         // ---- prune (Beam.h:93-108) + next beam table
         {
             int d = 0;
@@ -1237,6 +1304,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             x2_sync();
         }
 
+        TK(7);  // prune + next beam
         // ------------------------------------------------------------ label of the top node
         if (have && fin) {
             if (s == 0) {
@@ -1259,7 +1327,12 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             }
             have = false;
         }
+        TK(8);  // label walk
     }
+#ifdef PO_B2_TIMING
+    if (lane == 0 && a.dbg && blockIdx.x == 0)
+        for (int i = 0; i < 12; ++i) a.dbg[i] = tk[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1283,7 +1356,7 @@ int b2_num_cus() {
     return cus;
 }
 
-B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method) {
+B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method, int max_blocks = 0) {
     B2Geom g;
     const int K = (model == PO_MODEL_CTC) ? 1 : 3;
     g.wclass = W <= 6 ? 6 : (W <= 12 ? 12 : 25);
@@ -1293,6 +1366,7 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     const int wps = (K == 1) ? 4 : 3;
     const int per_cu = 4 * wps / waves;
     g.blocks = b2_num_cus() * per_cu;
+    if (max_blocks > 0 && g.blocks > max_blocks) g.blocks = max_blocks;
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
     g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << 20);  // value store per workgroup
     const int64_t WM = W > PO_A ? W : PO_A;
@@ -1314,8 +1388,9 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
 struct X2Geom {
     int blocks;
     size_t pool_bytes, arena_cap;
-    size_t off_queue, off_meta, off_envt, off_cum1, off_cum2, off_pool, off_arena, total;
+    size_t off_queue, off_meta, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
 };
+constexpr int X2_FB_BLOCKS = 256;  // workgroups of the beam2d_kernel pass over deferred pairs
 bool x2_eligible(int W, int model, int method) {
     static const bool legacy = getenv("PO_B2_LEGACY") != nullptr;  // A/B switch: always use beam2d_kernel
     return !legacy && method == PO_METHOD_ROW_COL && W <= 6 && model == PO_MODEL_CTC;
@@ -1346,6 +1421,9 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.off_cum2 = o; o += al256(sizeof(double) * (size_t)tr2);
     g.off_pool = o; o += g.pool_bytes * 2 * g.blocks;
     g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * 2 * g.blocks);
+    g.off_fb = o;
+    g.fb_bytes = b2_geometry(n, mr1, mr2, W, PO_MODEL_CTC, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
+    o += al256(g.fb_bytes);
     g.total = o + 256;
     return g;
 }
@@ -1368,6 +1446,54 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
     if (x2_eligible(W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total;
 }
+
+namespace {
+int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off, const int32_t* env,
+                     int n, int C, int A, uint32_t alphabet, int W, int model, int method, int64_t mr1, int64_t mr2,
+                     char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status, int use_pre_status, void* ws,
+                     size_t ws_bytes, hipStream_t stream, int max_blocks, const int2* only_meta) {
+    const B2Geom g = b2_geometry(n, mr1, mr2, W, model, method, max_blocks);
+    if (ws_bytes < g.total) return PO_E_CAP;
+    char* w = (char*)ws;
+    B2Args a;
+    a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
+    a.n = n; a.A = A; a.W = W; a.C = C; a.method = method; a.alphabet = alphabet;
+    a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status;
+    a.use_pre_status = use_pre_status;
+    a.queue = (int*)(w + g.off_queue);
+    a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
+    a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
+    a.cum = (double*)(w + g.off_cum); a.tcap = (long long)g.tcap;
+    a.envt = (int*)(w + g.off_envt); a.vcap = (long long)g.vcap;
+    a.dbg = nullptr;
+    a.only_meta = only_meta;
+#ifdef PO_B2_TIMING
+    static long long* dbg_buf = nullptr;
+    if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 12 * sizeof(long long));
+    a.dbg = dbg_buf;
+#endif
+    // queue counter and the store's tags start from zero on every launch
+    if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
+    if (model == PO_MODEL_CTC) b2_launch_w<PO_MODEL_CTC>(g, a, stream);
+    else if (model == PO_MODEL_MERGE) b2_launch_w<PO_MODEL_MERGE>(g, a, stream);
+    else if (model == PO_MODEL_FLIPFLOP) b2_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
+    else return PO_E_ARG;
+#ifdef PO_B2_TIMING
+    {
+        long long h[12];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const char* nm[12] = {"prepass+init", "main:prune+nextbeam", "main:expand+table", "main:scan selfread", "main:scan staging",
+                              "main:scan iterations", "catchup:setup", "catchup:selfread", "catchup:staging", "catchup:iterations",
+                              "label walk", "#catchup steps"};
+        fprintf(stderr, "[po_b2_timing] block 0, wall_clock64 ticks (100 MHz => 10 ns each):\n");
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-24s %12lld\n", nm[i], h[i]);
+    }
+#endif
+    return PO_OK;
+}
+}  // namespace
 
 extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
                                      const int32_t* env, int n, int C, int A, uint32_t alphabet, int W, int model,
@@ -1394,51 +1520,34 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
         a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
         a.dbg = nullptr;
+        a.defer_odd = getenv("PO_X2_DEFER_ODD") != nullptr;
+#ifdef PO_B2_TIMING
+        static long long* dbg_x2 = nullptr;
+        if (!dbg_x2) (void)hipMalloc((void**)&dbg_x2, 12 * sizeof(long long));
+        a.dbg = dbg_x2;
+#endif
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
         if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * 2 * g.blocks, stream) != hipSuccess) return PO_E_HIP;
         hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_CTC>, dim3(g.blocks), dim3(64), 0, stream, a);
-        return PO_OK;
-    }
-    const B2Geom g = b2_geometry(n, mr1, mr2, W, model, method);
-    if (ws_bytes < g.total) return PO_E_CAP;
-    char* w = (char*)ws;
-    B2Args a;
-    a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
-    a.n = n; a.A = A; a.W = W; a.C = C; a.method = method; a.alphabet = alphabet;
-    a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status;
-    a.use_pre_status = use_pre_status;
-    a.queue = (int*)(w + g.off_queue);
-    a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
-    a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
-    a.cum = (double*)(w + g.off_cum); a.tcap = (long long)g.tcap;
-    a.envt = (int*)(w + g.off_envt); a.vcap = (long long)g.vcap;
-    a.dbg = nullptr;
 #ifdef PO_B2_TIMING
-    static long long* dbg_buf = nullptr;
-    if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 12 * sizeof(long long));
-    a.dbg = dbg_buf;
+        {
+            long long hh[12];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(hh, a.dbg, sizeof(hh), hipMemcpyDeviceToHost);
+            const char* nm[9] = {"queue+setup", "catch-up steps", "expansion (serial)", "element table", "scan: seeds + y copy",
+                                 "scan: iterations", "scores", "prune + next beam", "label walk"};
+            fprintf(stderr, "[po_b2_timing x2] block 0, wall_clock64 ticks (100 MHz => 10 ns each):\n");
+            for (int i = 0; i < 9; ++i) fprintf(stderr, "   %-24s %12lld\n", nm[i], hh[i]);
+        }
 #endif
-    // queue counter and the store's tags start from zero on every launch
-    if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-    if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
-    if (model == PO_MODEL_CTC) b2_launch_w<PO_MODEL_CTC>(g, a, stream);
-    else if (model == PO_MODEL_MERGE) b2_launch_w<PO_MODEL_MERGE>(g, a, stream);
-    else if (model == PO_MODEL_FLIPFLOP) b2_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
-    else return PO_E_ARG;
-#ifdef PO_B2_TIMING
-    {
-        long long h[12];
-        (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
-        const char* nm[12] = {"prepass+init", "main:prune+nextbeam", "main:expand+table", "main:scan selfread", "main:scan staging",
-                              "main:scan iterations", "catchup:setup", "catchup:selfread", "catchup:staging", "catchup:iterations",
-                              "label walk", "#catchup steps"};
-        fprintf(stderr, "[po_b2_timing] block 0, wall_clock64 ticks (100 MHz => 10 ns each):\n");
-        for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-24s %12lld\n", nm[i], h[i]);
+        // pairs the pre-pass or the kernel deferred (window too wide for its store geometry, row groups
+        // exhausted): one small pass of beam2d_kernel, a no-op when there are none
+        return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off,
+                                seq_len, status, use_pre_status, w + g.off_fb, g.fb_bytes, stream, X2_FB_BLOCKS, a.meta);
     }
-#endif
-    return PO_OK;
+    return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off, seq_len,
+                            status, use_pre_status, ws, ws_bytes, stream, 0, nullptr);
 }
 
 // max rows are not part of the device-pointer ABI: read them back from the offset arrays

@@ -103,6 +103,61 @@ struct PoLaeFast {
     }
 };
 
+// PoLaePoly: table-free variant of the same formula (no LDS lookups): exp by k*ln2 range reduction and a
+// degree-12 polynomial, log1p(e) as 2*atanh(e / (2 + e)) with an odd series.  More f64 instructions, no
+// LDS round trips.
+struct PoLaePoly {
+    __device__ __forceinline__ double f(double d) const {
+        double res = 0.0;
+        if (d > -40.0) {
+            const double kf = rint(d * 1.4426950408889634);
+            const int k = (int)kf;
+            double r = __builtin_fma(-kf, 6.93147180369123816490e-01, d);
+            r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
+            double p = 1.0 / 479001600;
+            p = __builtin_fma(r, p, 1.0 / 39916800);
+            p = __builtin_fma(r, p, 1.0 / 3628800);
+            p = __builtin_fma(r, p, 1.0 / 362880);
+            p = __builtin_fma(r, p, 1.0 / 40320);
+            p = __builtin_fma(r, p, 1.0 / 5040);
+            p = __builtin_fma(r, p, 1.0 / 720);
+            p = __builtin_fma(r, p, 1.0 / 120);
+            p = __builtin_fma(r, p, 1.0 / 24);
+            p = __builtin_fma(r, p, 1.0 / 6);
+            p = __builtin_fma(r, p, 0.5);
+            p = __builtin_fma(r * r, p, r);
+            const double e = ldexp(1.0 + p, k);
+            const double s = e / (2.0 + e);
+            const double s2 = s * s;
+            double q = 1.0 / 33;
+            q = __builtin_fma(s2, q, 1.0 / 31);
+            q = __builtin_fma(s2, q, 1.0 / 29);
+            q = __builtin_fma(s2, q, 1.0 / 27);
+            q = __builtin_fma(s2, q, 1.0 / 25);
+            q = __builtin_fma(s2, q, 1.0 / 23);
+            q = __builtin_fma(s2, q, 1.0 / 21);
+            q = __builtin_fma(s2, q, 1.0 / 19);
+            q = __builtin_fma(s2, q, 1.0 / 17);
+            q = __builtin_fma(s2, q, 1.0 / 15);
+            q = __builtin_fma(s2, q, 1.0 / 13);
+            q = __builtin_fma(s2, q, 1.0 / 11);
+            q = __builtin_fma(s2, q, 1.0 / 9);
+            q = __builtin_fma(s2, q, 1.0 / 7);
+            q = __builtin_fma(s2, q, 1.0 / 5);
+            q = __builtin_fma(s2, q, 1.0 / 3);
+            const double s3 = s2 * s;
+            res = 2.0 * __builtin_fma(s3, q, s);
+        }
+        return (d == d) ? res : PO_NEG_INF;
+    }
+    __device__ __forceinline__ double operator()(double x1, double x2) const {
+        const bool ge = (x1 >= x2);
+        const double hi = ge ? x1 : x2;
+        const double d = ge ? (x2 - x1) : (x1 - x2);
+        return hi + f(d);
+    }
+};
+
 __device__ __forceinline__ int po_lane() { return threadIdx.x & (PO_WAVE - 1); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every

@@ -61,6 +61,27 @@ def test_rowcol_matches_oracle_batch(eng, oracle, model, ff, W):
     assert got == want
 
 
+def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
+    """row_col / W <= 6 / ctc runs two pairs per wave (beam2d_x2_kernel); pairs that kernel defers are
+    decoded by beam2d_kernel in the same call.  PO_X2_DEFER_ODD sends every odd pair down the second
+    path: one batch, both kernels, every string equal to the oracle's."""
+    monkeypatch.setenv("PO_X2_DEFER_ODD", "1")
+    y1s, y2s, envs, want = [], [], [], []
+    for i in range(9):
+        y1, y2 = synth_pair(4200 + i, T=250 + 60 * i)
+        env = oracle.pair_decode(y1, y2, "poreover", 5, "row_col")["envelope"]
+        y1s.append(y1); y2s.append(y2); envs.append(env)
+        want.append(oracle.cpp_beam_search_2d(y1, y2, env, 5, method_="row_col"))
+    assert eng.beam_search_2d_batch(y1s, y2s, envs, 5, method="row_col") == want
+    monkeypatch.delenv("PO_X2_DEFER_ODD")
+    assert eng.beam_search_2d_batch(y1s, y2s, envs, 5, method="row_col") == want
+    # wide windows: fewer row groups fit the store; a pair whose groups run out there is deferred too
+    y1, y2 = synth_pair(4300, T=700)
+    env = oracle.diagonal_envelope(len(y1), len(y2), 100)
+    assert eng.beam_search_2d_batch([y1], [y2], [env], 3, method="row_col") == \
+        [oracle.cpp_beam_search_2d(y1, y2, env, 3, method_="row_col")]
+
+
 def test_rowcol_full_size(eng, oracle):
     """BASELINE config 3: pairs of T ~ 4000 reads, W = 5 (CLI default) and W = 10"""
     y1s, y2s, envs = [], [], []
