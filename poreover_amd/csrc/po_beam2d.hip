@@ -47,7 +47,7 @@
 
 namespace {
 
-constexpr int B2_NGL = 256;  // row groups tracked per pair (LDS bookkeeping)
+constexpr int B2_YD = 256;   // doubles per read in the y window buffer (51 rows of 5, 32 rows of 8)
 
 template <int K>
 struct alignas(K == 1 ? 16 : 32) Entry {
@@ -114,11 +114,14 @@ struct B2Smem {
     int nx[F_COUNT][WMAX];  // next beam under construction
     int sel[WMAX];
     int dup[NCM];
-    int g_owner[B2_NGL], g_hi0[B2_NGL], g_hi1[B2_NGL];
+    // row groups tracked per pair: a step can open up to W new ones and a group lives for about a window
+    static constexpr int NGL = (WMAX > 12) ? 768 : 256;
+    int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[16];
     double score[NCM];
     double mxs[2][NCP];
     double xch[2][2][NCP][K];
+    double ybuf[2][B2_YD];  // the y rows of the current step's windows, per read
     PoLaeTables lae;        // tables of the specialised logaddexp (po_device.h)
 };
 
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 wmax = sm.sh[1];
                 while (R < wmax + 2) R <<= 1;
                 const long long ng = pool_entries / ((long long)PO_A * 2 * R);
-                NG = (int)min((long long)B2_NGL, ng);
+                NG = (int)min((long long)SM::NGL, ng);
                 if (NG < 2 * max(W, PO_A) + 4) st = PO_E_NOMEM;  // band too wide for the per-pair value store
             }
         }
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                     if (t0 + q < Tn) { acc += b[q]; cw[t0 + q] = acc; }
             }
         }
-        for (int g = tid; g < B2_NGL; g += nthr) { sm.g_owner[g] = -1; sm.g_hi0[g] = 0; sm.g_hi1[g] = 0; }
+        for (int g = tid; g < SM::NGL; g += nthr) { sm.g_owner[g] = -1; sm.g_hi0[g] = 0; sm.g_hi1[g] = 0; }
         __syncthreads();
 
         // ---------------------------------------------------------------- store access helpers
@@ -400,32 +403,39 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 }
             }
             const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
-            const double* yp = yr_ + (int64_t)t0 * C;  // y row of the next fetch
-            // Loads of iteration k that do not depend on the chain — the y row, and the value at t-1 of a
-            // parent that does not move in this scan (frozen: from its ring row; root: its closed form)
-            // — are issued one iteration ahead.
-            double ya_n = 0.0, yb_n = 0.0, pr_n[K];
+            // The value at t-1 of a parent that does not move in this scan (frozen: from its ring row; root:
+            // its closed form) is loaded one iteration ahead (rare).
+            double pr_n[K];
             Ent pe_n;
             pe_n.tag = 0;
 #pragma unroll
             for (int q = 0; q < K; ++q) { pr_n[q] = PO_NEG_INF; pe_n.v[q] = PO_NEG_INF; }
             auto fetch = [&](int k) {
-                ya_n = yp[ca]; yb_n = yp[cb];
-                yp += C;
-                if (pslot < 0) {
-                    const int tp = t0 + k - 1;
-                    if (pslot == PS_ROOT) root_at(r, tp, pr_n);
-                    else if (tp >= 0) pe_n = prow[tp & Rm];
-                }
+                const int tp = t0 + k - 1;
+                if (pslot == PS_ROOT) root_at(r, tp, pr_n);
+                else if (tp >= 0) pe_n = prow[tp & Rm];
             };
-            if (part) fetch(0);
-            b2_sync_lds<nthr>();  // the seeds in xch[1] -> visible to the first iteration
-            TK(is_main ? 3 : 7);  // scan: self read
-            for (int kv = 0; kv < Lmax; ++kv) {
+            if (part && pslot < 0) fetch(0);
+            // The y rows of both windows go through LDS, B2_YD doubles per read at a time (buffer row =
+            // iteration index).  With no vector-memory LOAD left in the iteration loop the wave never
+            // waits there for the acknowledgement of its value-store writes: vmcnt counts loads and stores
+            // in order, so waiting for any load also waits for every store issued before it.
+            const int yrows = B2_YD / C;
+            for (int k0 = 0; k0 < Lmax; k0 += yrows) {
+            {
+                const int nrow = min(len, k0 + yrows) - k0;  // this read's rows in the chunk (<= 0: none)
+                const double* src = yr_ + (int64_t)(t0 + k0) * C;
+                for (int i = s; i < nrow * C; i += NCP) sm.ybuf[r][i] = src[i];
+            }
+            b2_sync_lds<nthr>();  // y rows (and, first time, the seeds in xch[1]) -> visible to the iterations
+            TK(is_main ? 3 : 7);  // scan: self read + y rows
+            const int kchunk = min(Lmax, k0 + yrows);
+            for (int kv = k0; kv < kchunk; ++kv) {
                 const int k = __builtin_amdgcn_readfirstlane(kv);  // keeps the loop counter and branch scalar
                 if (part && k < len) {
                     const int t = t0 + k;
-                    const double ya = ya_n, yb = yb_n;
+                    const double* yrow = sm.ybuf[r] + (k - k0) * C;
+                    const double ya = yrow[ca], yb = yrow[cb];
                     double pp[K], out[K];
 #pragma unroll
                     for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][pslot >= 0 ? pslot : s][q];
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
 #pragma unroll
                         for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
                     }
-                    if (k + 1 < len) fetch(k + 1);
+                    if (pslot < 0 && k + 1 < len) fetch(k + 1);
                     po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
                     // direct 16-byte store per lane.  (Tried: buffering 8 iterations in LDS and flushing
                     // row-contiguous 128-byte bursts to cut L2 requests — the flush's extra instructions
@@ -455,6 +465,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 b2_sync_lds<nthr>();  // only xch crosses iterations; the stores stay in flight
             }
             TK(is_main ? 5 : 9);  // scan: iterations
+            }
             if (s < nelem) sm.mxs[r][s] = mx;
         };
 
@@ -1356,19 +1367,38 @@ int b2_num_cus() {
     return cus;
 }
 
+// resident workgroups per CU of one kernel instance (registers and LDS decide), asked once from the runtime
+template <int MODEL, int WMAX>
+int b2_occ() {
+    int nblk = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_kernel<MODEL, WMAX>, B2_THREADS(WMAX), 0) !=
+            hipSuccess || nblk <= 0)
+        nblk = 12 * 64 / B2_THREADS(WMAX);
+    return nblk;
+}
+int b2_blocks_per_cu(int model, int wclass) {
+    static int cache[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    const int mi = model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2), wi = wclass == 6 ? 0 : (wclass == 12 ? 1 : 2);
+    if (!cache[mi][wi]) {
+        int v = 0;
+        if (mi == 0) v = wi == 0 ? b2_occ<PO_MODEL_CTC, 6>() : (wi == 1 ? b2_occ<PO_MODEL_CTC, 12>() : b2_occ<PO_MODEL_CTC, 25>());
+        else if (mi == 1) v = wi == 0 ? b2_occ<PO_MODEL_MERGE, 6>() : (wi == 1 ? b2_occ<PO_MODEL_MERGE, 12>() : b2_occ<PO_MODEL_MERGE, 25>());
+        else v = wi == 0 ? b2_occ<PO_MODEL_FLIPFLOP, 6>() : (wi == 1 ? b2_occ<PO_MODEL_FLIPFLOP, 12>() : b2_occ<PO_MODEL_FLIPFLOP, 25>());
+        cache[mi][wi] = v;
+    }
+    return cache[mi][wi];
+}
+
 B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method, int max_blocks = 0) {
     B2Geom g;
     const int K = (model == PO_MODEL_CTC) ? 1 : 3;
     g.wclass = W <= 6 ? 6 : (W <= 12 ? 12 : 25);
     g.threads = g.wclass == 6 ? 64 : (g.wclass == 12 ? 128 : 256);
-    const int waves = g.threads / PO_WAVE;
-    // waves per SIMD the register budget allows: 4 for the one-value model (<= 128 VGPRs), 3 for the others
-    const int wps = (K == 1) ? 4 : 3;
-    const int per_cu = 4 * wps / waves;
+    const int per_cu = b2_blocks_per_cu(model, g.wclass);
     g.blocks = b2_num_cus() * per_cu;
     if (max_blocks > 0 && g.blocks > max_blocks) g.blocks = max_blocks;
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
-    g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << 20);  // value store per workgroup
+    g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << (g.wclass == 25 ? 21 : 20));  // value store per workgroup
     const int64_t WM = W > PO_A ? W : PO_A;
     const int64_t steps = (method == PO_METHOD_ROW) ? mr1 : std::min(mr1, mr2);
     g.arena_cap = ((size_t)(1 + PO_A + (int64_t)PO_A * WM * (steps + 1)) + 1) & ~size_t(1);  // even: a double array follows

@@ -89,9 +89,10 @@ def test_rowcol_full_size(eng, oracle):
         y1, y2 = synth_pair(5000 + i, T=4000)
         y1s.append(y1); y2s.append(y2)
         envs.append(oracle.pair_decode(y1, y2, "poreover", 5, "row_col")["envelope"])
-    for W in (5, 10):
-        got = eng.beam_search_2d_batch(y1s, y2s, envs, W, method="row_col")
-        want = [oracle.cpp_beam_search_2d(a, b, e, W, method_="row_col") for a, b, e in zip(y1s, y2s, envs)]
+    for W, npair in ((5, 6), (10, 6), (25, 2)):   # W = 25: up to 25 new row groups per step
+        got = eng.beam_search_2d_batch(y1s[:npair], y2s[:npair], envs[:npair], W, method="row_col")
+        want = [oracle.cpp_beam_search_2d(a, b, e, W, method_="row_col")
+                for a, b, e in zip(y1s[:npair], y2s[:npair], envs[:npair])]
         assert got == want, W
 
 
