@@ -229,13 +229,13 @@ def main():
                                    "HBM" % (P, T, args.beam_width),
                        "pairs_per_gpu": P, "T": T, "beam_width": args.beam_width, "method": "row_col",
                        "decoded_pairs_rank0": decoded, "parallelism": "shard%d (no collective)" % args.gpus},
-            "roofline": {"bound": "hbm", "kernel": "beam2d_rowcol_kernel", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": "beam2d_x2_kernel (+ beam2d_prepass_kernel, store memset)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(b2_avg, 3),
                          "launches": b2_n,
-                         "note": "f64 log-space beam search: bound by dependent exp/log chains and LDS/L2 "
-                                 "latency, not by HBM (SURVEY.md §8(d)); the streaming Viterbi kernel is the "
-                                 "HBM-bound one, see viterbi_roofline"},
+                         "note": "f64 log-space beam search: bound by the f64 instruction stream of logaddexp and "
+                                 "per-step bookkeeping latency, not by HBM (SURVEY.md §8(d), DESIGN.md §3.3); the "
+                                 "streaming Viterbi kernel is the HBM-bound one, see viterbi_roofline"},
             "viterbi_roofline": {"bound": "hbm", "kernel": "viterbi_ctc_kernel (2 launches per step)",
                                  "achieved": round(vt_bytes / (vt_avg * 1e-3) / 1e9, 3) if vt_avg > 0 else 0.0,
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -777,6 +777,7 @@ struct X2Args {
     int* arena; long long arena_cap;  // per half-wave: 3 int arrays
     long long* dbg;
     int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
+    int pre_vcols;                    // pre-pass: columns its LDS table holds
 };
 
 template <int K>
@@ -807,8 +808,9 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
     constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
     constexpr int nthr = 256;
+    extern __shared__ __attribute__((aligned(16))) int colbuf[];  // first[vcols] then cnt[vcols] (a.pre_vcols columns)
     __shared__ int shw;
-    const int pi = blockIdx.x, tid = threadIdx.x;
+    const int pi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.use_pre_status && a.status[pi] != PO_OK) {
         if (tid == 0) a.meta[pi] = make_int2(a.status[pi], -1);
         return;
@@ -828,19 +830,40 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             if (lo < hi && (lo < 0 || hi > V)) bad = 1;
             wmax = max(wmax, hi - lo);
         }
-        for (int x = tid; x < V; x += nthr) { envt[2 * x] = -1; envt[2 * x + 1] = -1; }
         if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
         if (st == PO_OK) {
-            for (int u = 0; u < U; ++u) {  // column x is always visited by thread x % nthr, rows in order
-                const int lo = env[2 * u], hi = env[2 * u + 1];
-                int x = lo + ((tid - lo) % nthr + nthr) % nthr;
-                for (; x < hi; x += nthr) {
-                    if (envt[2 * x] < 0) { envt[2 * x] = u; envt[2 * x + 1] = u + 1; }
-                    else envt[2 * x + 1]++;
+            // transposed envelope (BeamSearch.h:270-284): the first row that covers column x starts its range
+            // and every further covering row extends it by one, i.e. [first row, first row + number of rows)
+            if (V <= a.pre_vcols) {  // columns in LDS, rows in parallel
+                int* first = colbuf;
+                int* cnt = colbuf + a.pre_vcols;
+                for (int x = tid; x < V; x += nthr) { first[x] = 0x7fffffff; cnt[x] = 0; }
+                __syncthreads();
+                for (int u = tid; u < U; u += nthr) {
+                    const int lo = env[2 * u], hi = env[2 * u + 1];
+                    for (int x = lo; x < hi; ++x) { atomicMin(&first[x], u); atomicAdd(&cnt[x], 1); }
                 }
+                __syncthreads();
+                for (int x = tid; x < V; x += nthr) {
+                    const int c = cnt[x], f = first[x];
+                    envt[2 * x] = c ? f : -1;
+                    envt[2 * x + 1] = c ? f + c : -1;
+                    wmax = max(wmax, c);
+                }
+            } else {  // very long reads: column x is always visited by thread x % nthr, rows in order
+                for (int x = tid; x < V; x += nthr) { envt[2 * x] = -1; envt[2 * x + 1] = -1; }
+                __syncthreads();
+                for (int u = 0; u < U; ++u) {
+                    const int lo = env[2 * u], hi = env[2 * u + 1];
+                    int x = lo + ((tid - lo) % nthr + nthr) % nthr;
+                    for (; x < hi; x += nthr) {
+                        if (envt[2 * x] < 0) { envt[2 * x] = u; envt[2 * x + 1] = u + 1; }
+                        else envt[2 * x + 1]++;
+                    }
+                }
+                __syncthreads();
+                for (int x = tid; x < V; x += nthr) wmax = max(wmax, envt[2 * x + 1] - envt[2 * x]);
             }
-            __syncthreads();
-            for (int x = tid; x < V; x += nthr) wmax = max(wmax, envt[2 * x + 1] - envt[2 * x]);
             if (tid == 0) shw = 0;
             __syncthreads();
             atomicMax(&shw, wmax);
@@ -855,19 +878,26 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             else if (min((long long)X2_NGL, ng) < 8 * max(W, PO_A) || (a.defer_odd && (pi & 1))) R = X2_DEFERRED;
         }
     }
-    if (st == PO_OK && MODEL == PO_MODEL_CTC && (tid == 0 || tid == 64)) {  // serial: the reference's rounding
-        const int rr = tid ? 1 : 0;
+    // blank prefix sums = the CTC root's alpha (PrefixTree.h:509-515): serial in t so the rounding is the
+    // reference's; one wave per read loads 64 frames at a time (coalesced) and adds them in lane order
+    if (st == PO_OK && MODEL == PO_MODEL_CTC && wave < 2) {
+        const int rr = wave;
         const double* yr = rr ? a.y2 + o2 * C : a.y1 + o1 * C;
         double* cw = rr ? a.cum2 + (o2 - b2) : a.cum1 + (o1 - b1);
         const int Tn = rr ? V : U;
         double acc = 0.0;
-        for (int t0 = 0; t0 < Tn; t0 += 8) {
-            double b[8];
+        for (int t0 = 0; t0 < Tn; t0 += 64) {
+            const int t = t0 + lane;
+            const double x = (t < Tn) ? yr[(int64_t)t * C + A] : 0.0;
+            double mine = 0.0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) b[q] = (t0 + q < Tn) ? yr[(int64_t)(t0 + q) * C + A] : 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (t0 + q < Tn) { acc += b[q]; cw[t0 + q] = acc; }
+            for (int j = 0; j < 64; ++j) {
+                const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), j),
+                                                   __builtin_amdgcn_readlane(__double2loint(x), j));
+                if (t0 + j < Tn) acc += xj;   // uniform condition
+                if (lane == j) mine = acc;
+            }
+            if (t < Tn) cw[t] = mine;
         }
     }
     if (tid == 0) a.meta[pi] = make_int2(st, R);
@@ -1558,7 +1588,8 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
 #endif
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
         if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * 2 * g.blocks, stream) != hipSuccess) return PO_E_HIP;
-        hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), 0, stream, a);
+        a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);  // 2 ints per column: <= 48 KB of LDS
+        hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), sizeof(int) * 2 * (size_t)a.pre_vcols, stream, a);
         hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_CTC>, dim3(g.blocks), dim3(64), 0, stream, a);
 #ifdef PO_B2_TIMING
         {
