@@ -215,6 +215,21 @@ def main():
         n1d = int(d_l1.sum().item() + d_l2.sum().item())
         vt_bytes = 8.0 * Cc * (tr1 + tr2) + 5.0 * n1d  # log-probs in; per base one character + one int32 frame index out
         vt_avg = vt_ms / max(vt_n, 1)
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
+        # committed rocprofv3 passes (profiles/r01_pmc_hbm_v3.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # 1250 pairs per launch, same T / W) are scaled to this launch's pair count
+        traffic, traffic_src = None, None
+        try:
+            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_v3.json")
+            with open(pj) as f:
+                pm = json.load(f)
+            kk = pm["kernels"]["beam2d_x2_kernel<0>"]
+            per_pair = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0 / 1250.0
+            if T == 4000 and args.beam_width == 5:
+                traffic = per_pair * P
+                traffic_src = "profiles/r01_pmc_hbm_v3.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes at 1250 pairs per launch), scaled by pairs"
+        except Exception:
+            pass
         out = {
             "metric": "decoded Mbases/s + read-pairs/s, 10k synthetic pairs T~4000, 1/2/4/8 MI355X",
             "value": round(tot_pairs / tmax, 3),
@@ -231,7 +246,7 @@ def main():
                        "decoded_pairs_rank0": decoded, "parallelism": "shard%d (no collective)" % args.gpus},
             "roofline": {"bound": "hbm", "kernel": "beam2d_x2_kernel (+ beam2d_prepass_kernel, store memset)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                         "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(b2_avg, 3),
+                         "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(b2_avg, 3),
                          "launches": b2_n,
                          "note": "f64 log-space beam search: bound by the f64 instruction stream of logaddexp and "
                                  "per-step bookkeeping latency, not by HBM (SURVEY.md §8(d), DESIGN.md §3.3); the "
