@@ -178,6 +178,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    d_upd = torch.zeros(1, dtype=torch.int64, device=dev)   # update_prob evaluations of the pair beam kernels
+    lib.po_profile_update_counter(d_upd.data_ptr())
     lib.po_profile_enable(1)
     lib.po_profile_reset()
     t0 = time.perf_counter()
@@ -186,6 +188,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     lib.po_profile_enable(0)
+    lib.po_profile_update_counter(None)
+    n_upd = int(d_upd.item())
+    lae_peak = C.c_double(0.0)
+    if rank == 0:   # outside the timed region: the device's peak rate of the engine's logaddexp
+        _lib.check(lib.po_lae_peak(20000, C.byref(lae_peak), stream), "po_lae_peak")
 
     st = d_st.cpu().numpy()
     lens = d_len.cpu().numpy()
@@ -259,6 +266,15 @@ def main():
             "stage_ms_per_step": {"viterbi_x2": round(vt_avg, 3), "align_envelope": round(al_ms / max(al_n, 1), 3),
                                   "pair_beam": round(b2_avg, 3)},
         }
+        # the pair beam search priced against what actually bounds it: one logaddexp per update_prob (ctc)
+        lae_rate = n_upd / (b2_ms * 1e-3) if b2_ms > 0 else 0.0
+        out["compute_roofline"] = {"bound": "f64 logaddexp stream (VALU)", "unit": "logaddexp/s",
+                                   "achieved": round(lae_rate, 1), "peak": round(lae_peak.value, 1),
+                                   "frac": round(lae_rate / lae_peak.value, 5) if lae_peak.value > 0 else None,
+                                   "updates_per_step": n_upd // max(args.steps, 1),
+                                   "note": "achieved = update_prob evaluations counted by the kernels / pair-beam stage "
+                                           "time; peak = po_lae_peak micro-benchmark on this device (all lanes busy, "
+                                           "4 independent chains per lane, same table-driven logaddexp)"}
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
             out["gpu_over_cpu_all_cores"] = round(out["value"] / cpu_base["value"], 1)

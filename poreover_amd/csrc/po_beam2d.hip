@@ -76,6 +76,7 @@ struct B2Args {
     int* envt; long long vcap;         // 2 * vcap ints: transposed envelope
     long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
     const int2* only_meta;             // non-NULL: decode only the pairs the two-pairs-per-wave path deferred (meta.y == -2)
+    unsigned long long* upd_count;     // optional (po_profile_update_counter): total update_prob evaluations
 };
 
 // F_PSLOT of an element whose parent does not move in the scan: a frozen parent (its values are read from
@@ -122,6 +123,7 @@ struct B2Smem {
     double mxs[2][NCP];
     double xch[2][2][NCP][K];
     double ybuf[2][B2_YD];  // the y rows of the current step's windows, per read
+    unsigned long long nupd;  // profiling: update_prob evaluations of the current pair
     PoLaeTables lae;        // tables of the specialised logaddexp (po_device.h)
 };
 
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             if (r == 1) amax[1 + s] = out[0];
         }
         int nb = A;  // beam size
+        if (tid == 0) sm.nupd = 0;  // update_prob evaluations of this pair (profiling only; kept in LDS)
         __syncthreads();
         TK(0);  // pre-pass + init
 
@@ -467,6 +470,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             TK(is_main ? 5 : 9);  // scan: iterations
             }
             if (s < nelem) sm.mxs[r][s] = mx;
+            if (tid == 0) sm.nupd += (unsigned)(nelem * (len0 + len1));  // profiling (skipped slots counted too)
         };
 
         // parent slot of beam slot j: the parent is an element if it is a beam node or a child of a
@@ -730,6 +734,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             a.seq_len[pi] = nout;
             a.status[pi] = st;
         }
+        if (a.upd_count && tid == 0) atomicAdd(a.upd_count, sm.nupd);
         TK(10);  // label walk
     }
 #ifdef PO_B2_TIMING
@@ -778,6 +783,7 @@ struct X2Args {
     long long* dbg;
     int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
     int pre_vcols;                    // pre-pass: columns its LDS table holds
+    unsigned long long* upd_count;    // optional (po_profile_update_counter): total update_prob evaluations
 };
 
 template <int K>
@@ -793,6 +799,7 @@ struct X2Half {
     double score[32];
     double xch[2][32][K];
     double ybuf[X2_YD];      // the y rows of the current step's windows
+    unsigned long long nupd; // profiling: update_prob evaluations
 };
 template <int K>
 struct X2Smem {
@@ -926,6 +933,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
     x2_sync();
 
     // ---- half-uniform state of the pair in flight
+    if (s == 0) h.nupd = 0;  // update_prob evaluations of this half-wave's pairs (profiling only; kept in LDS)
     bool have = false, done = false;
     int pi = 0, U = 1, V = 1, u = 0, v = 0, nb = 0, R = 32, Rm = 31, NG = 0, st = PO_OK;
     unsigned epoch = 0;
@@ -1083,6 +1091,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) e.v[k] = out[k];
                 myrow[t & Rm] = e;
+                if (s == 0) h.nupd += (unsigned)min(W, nb);
                 if (rr) atomicMax(&h.g_hi1[row / PO_A], t + 1);
                 else atomicMax(&h.g_hi0[row / PO_A], t + 1);
             }
@@ -1282,6 +1291,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             TK(5);  // scan: iterations
             }
             if (part) h.score[s] = mx0 + mx;  // node_greater_max_sym: max over read 0 + max over read 1
+            if (part && s == 0) h.nupd += (unsigned)(ne * tot);
             if (part && s >= nb) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
         }
         x2_sync();
@@ -1370,6 +1380,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
         }
         TK(8);  // label walk
     }
+    if (a.upd_count && s == 0) atomicAdd(a.upd_count, h.nupd);
 #ifdef PO_B2_TIMING
     if (lane == 0 && a.dbg && blockIdx.x == 0)
         for (int i = 0; i < 12; ++i) a.dbg[i] = tk[i];
@@ -1508,6 +1519,45 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
 }
 
 namespace {
+unsigned long long* g_b2_upd_counter = nullptr;
+}
+// profiling: a device counter that the pair beam kernels add their number of update_prob evaluations to
+extern "C" void po_b2_set_update_counter(unsigned long long* dev_counter) { g_b2_upd_counter = dev_counter; }
+
+// ---- logaddexp micro-benchmark: the peak rate of the specialised logaddexp on this device (4 independent
+// chains per lane, tables in LDS, every lane busy) — the compute ceiling the pair kernels are priced against
+__global__ __launch_bounds__(256) void lae_peak_kernel(int iters, double* sink) {
+    __shared__ PoLaeTables tb;
+    po_lae_tables_load(&tb, threadIdx.x, 256);
+    __syncthreads();
+    const PoLaeFast lae{&tb};
+    const double seed = -1.0 - 1e-3 * (threadIdx.x + 1);
+    double a0 = seed, a1 = seed - 0.5, a2 = seed - 1.5, a3 = seed - 2.5;
+    const double y0 = -0.11, y1 = -2.3;
+    for (int i = 0; i < iters; ++i) {
+        a0 = lae(a0 + y1, a1 + y0); a1 = lae(a1 + y1, a2 + y0); a2 = lae(a2 + y1, a3 + y0); a3 = lae(a3 + y1, a0 + y0);
+    }
+    if (a0 + a1 + a2 + a3 == 12345.678) sink[0] = a0;
+}
+extern "C" int po_launch_lae_peak(int iters, double* lae_per_s, hipStream_t stream) {
+    double* sink = nullptr;
+    if (hipMalloc((void**)&sink, 8) != hipSuccess) return PO_E_HIP;
+    const int blocks = b2_num_cus() * 8;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(lae_peak_kernel, dim3(blocks), dim3(256), 0, stream, 64, sink);  // warm-up
+    (void)hipEventRecord(e0, stream);
+    hipLaunchKernelGGL(lae_peak_kernel, dim3(blocks), dim3(256), 0, stream, iters, sink);
+    (void)hipEventRecord(e1, stream);
+    int rc = PO_OK;
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) rc = PO_E_HIP;
+    else *lae_per_s = 4.0 * iters * 256.0 * blocks / (ms * 1e-3);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+    return rc;
+}
+
+namespace {
 int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off, const int32_t* env,
                      int n, int C, int A, uint32_t alphabet, int W, int model, int method, int64_t mr1, int64_t mr2,
                      char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status, int use_pre_status, void* ws,
@@ -1527,6 +1577,7 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     a.envt = (int*)(w + g.off_envt); a.vcap = (long long)g.vcap;
     a.dbg = nullptr;
     a.only_meta = only_meta;
+    a.upd_count = g_b2_upd_counter;
 #ifdef PO_B2_TIMING
     static long long* dbg_buf = nullptr;
     if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 12 * sizeof(long long));
@@ -1580,6 +1631,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
         a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
         a.dbg = nullptr;
+        a.upd_count = g_b2_upd_counter;
         a.defer_odd = getenv("PO_X2_DEFER_ODD") != nullptr;
 #ifdef PO_B2_TIMING
         static long long* dbg_x2 = nullptr;

@@ -23,6 +23,8 @@ size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const
 size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
 size_t po_prefix_ws_bytes(int, int64_t);
 size_t po_gamma_ws_bytes(int, int64_t, int64_t, int64_t);
+void po_b2_set_update_counter(unsigned long long*);
+int po_launch_lae_peak(int, double*, hipStream_t);
 int po_launch_pair_decode_from_1d(const double*, const int64_t*, const double*, const int64_t*, int, int, const po_pair_options*,
                                   int64_t, int64_t, int64_t, int64_t, const int32_t*, const int32_t*, char*, const int64_t*,
                                   int32_t*, int32_t*, double*, int32_t*, char*, const int64_t*, int32_t*, int32_t*, void*, size_t,
@@ -850,6 +852,16 @@ int po_event_elapsed_ms(void* start, void* stop, float* ms) {
 }
 void po_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 
+int po_profile_update_counter(uint64_t* device_counter) {
+    po_b2_set_update_counter((unsigned long long*)device_counter);
+    return PO_OK;
+}
+int po_lae_peak(int iters, double* lae_per_s, void* stream) {
+    if (iters < 1 || !lae_per_s) { g_err = "po_lae_peak: bad argument"; return PO_E_ARG; }
+    int rc = po_launch_lae_peak(iters, lae_per_s, (hipStream_t)stream);
+    if (rc != PO_OK) g_err = "po_lae_peak: launch failed";
+    return rc;
+}
 void po_profile_enable(int on) { g_prof_on = on != 0; }
 void po_profile_reset(void) {
     prof_drain();
