@@ -228,6 +228,13 @@ int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* a
                         const int32_t* map1_h, const int64_t* map1_off_h, const int32_t* map2_h,
                         const int64_t* map2_off_h, const int32_t* U_h, const int32_t* V_h, int padding,
                         int32_t* env_h, const int64_t* env_off_h, int32_t* status_h);
+/* prefix_search.pair_prefix_search_log / _cy (prefix_search.py:247-385) on small boxes: dense gamma
+ * (pair_gamma_log of the same flavour) computed on the device, then the pair prefix search.
+ * flavor 0: prefix_search.py arithmetic, 1: decoding_cy.  seq at seq_h + seq_off_h[i], capacity
+ * seq_off_h[i+1] - seq_off_h[i] (max(U, V) + 1 always suffices). */
+int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                                  int n, int C, const char* alphabet, int flavor, char* seq_h, const int64_t* seq_off_h,
+                                  int32_t* seq_len_h, double* logp_h, int32_t* status_h);
 int po_pair_gamma_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
                           const int32_t* env_h, const int64_t* env_off_h, int n, int C, int flavor, double* gamma00_h,
                           double* dense_out_h, const int64_t* dense_off_h, int32_t* status_h);

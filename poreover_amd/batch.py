@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib as L
 
 __all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows",
-           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "align_batch", "envelope_batch", "ingest_batch", "pair_gamma_batch"]
+           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "pair_prefix_search_batch", "align_batch", "envelope_batch", "ingest_batch", "pair_gamma_batch"]
 
 
 def pack_rows(arrays, C_expected=None):
@@ -238,6 +238,28 @@ def prefix_search_batch(y, offsets, alphabet="ACGT"):
     for i in range(n):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "prefix search of window %d" % i)
+    return list(zip(_strings(seq, so, lens), [float(x) for x in lp[:n]]))
+
+
+def pair_prefix_search_batch(arrays1, arrays2, alphabet="ACGT", flavor="cy"):
+    """prefix_search.pair_prefix_search_log_cy (flavor "cy") / pair_prefix_search_log ("py") for a batch of
+    small boxes (dense gamma on the device).  Returns [(label, log-probability), ...]."""
+    lib = L.load()
+    y1, o1, Cc = pack_rows(arrays1)
+    y2, o2, _ = pack_rows(arrays2, Cc)
+    n = len(arrays1)
+    so = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([max(len(a), len(b)) + 2 for a, b in zip(arrays1, arrays2)], out=so[1:])
+    seq = np.zeros(max(int(so[-1]), 1), dtype=np.uint8)
+    lens = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    lp = np.zeros(max(n, 1), dtype=np.float64)
+    L.check(lib.po_pair_prefix_search_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), n, Cc, alphabet.encode(),
+                                              {"py": 0, "cy": 1}[flavor], _ptr(seq), _ptr(so), _ptr(lens), _ptr(lp),
+                                              _ptr(st)), "po_pair_prefix_search_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "pair prefix search of box %d" % i)
     return list(zip(_strings(seq, so, lens), [float(x) for x in lp[:n]]))
 
 

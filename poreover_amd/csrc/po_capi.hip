@@ -23,6 +23,10 @@ size_t po_pair_ws_bytes_impl(int, int64_t, int64_t, int64_t, int64_t, int, const
 size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
 size_t po_prefix_ws_bytes(int, int64_t);
 size_t po_gamma_ws_bytes(int, int64_t, int64_t, int64_t);
+size_t po_pair_prefix_ws_bytes(int, int64_t);
+int po_launch_pair_prefix_search(const double*, const int64_t*, const double*, const int64_t*, const double*, const int64_t*, int, int,
+                                 int, uint32_t, int, int64_t, char*, const int64_t*, int32_t*, double*, int32_t*, void*, size_t,
+                                 hipStream_t);
 void po_b2_set_update_counter(unsigned long long*);
 int po_launch_lae_peak(int, double*, hipStream_t);
 int po_launch_pair_decode_from_1d(const double*, const int64_t*, const double*, const int64_t*, int, int, const po_pair_options*,
@@ -542,6 +546,62 @@ int po_pair_gamma_batch_h(const double* y1_h, const int64_t* y1_off_h, const dou
     DOWN(gamma00_h, g0, sizeof(double) * n);
     if (dense_out_h) DOWN(dense_out_h, dn, sizeof(double) * (size_t)dense_off_h[n]);
     DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                                  int n, int C, const char* alphabet, int flavor, char* seq_h, const int64_t* seq_off_h,
+                                  int32_t* seq_len_h, double* logp_h, int32_t* status_h) {
+    if (n <= 0) return PO_OK;
+    uint32_t ap = 0;
+    const int A = pack_alphabet(alphabet, &ap);
+    if (A < 0) { g_err = "po_pair_prefix_search_batch_h: alphabet must have 1..4 symbols"; return PO_E_ARG; }
+    const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
+    int64_t m1 = 0, m2 = 0, mc = 0;
+    std::vector<int64_t> dof((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        const int64_t U = y1_off_h[i + 1] - y1_off_h[i], V = y2_off_h[i + 1] - y2_off_h[i];
+        m1 = std::max(m1, U); m2 = std::max(m2, V);
+        mc = std::max(mc, (U + 1) * (V + 1));
+        dof[i + 1] = dof[i] + (U + 1) * (V + 1);
+    }
+    DevBuf a, ao, b, bo, g0, dn, dfo, st, st2, ws, so, sq, sl, lp, ws2;
+    UP(a, y1_h + y1_off_h[0] * C, sizeof(double) * r1 * C);
+    UP(b, y2_h + y2_off_h[0] * C, sizeof(double) * r2 * C);
+    std::vector<int64_t> o1(y1_off_h, y1_off_h + n + 1), o2(y2_off_h, y2_off_h + n + 1);
+    for (auto& o : o1) o -= y1_off_h[0];
+    for (auto& o : o2) o -= y2_off_h[0];
+    UP(ao, o1.data(), sizeof(int64_t) * (n + 1));
+    UP(bo, o2.data(), sizeof(int64_t) * (n + 1));
+    UP(g0, nullptr, sizeof(double) * n);
+    UP(dn, nullptr, sizeof(double) * (size_t)dof[n]);
+    UP(dfo, dof.data(), sizeof(int64_t) * (n + 1));
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const size_t wsb = po_pair_gamma_workspace_bytes(n, mc, m1, m2);
+    UP(ws, nullptr, wsb);
+    int rc = po_pair_gamma_batch((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p, nullptr,
+                                 nullptr, n, C, flavor, mc, (double*)g0.p, (double*)dn.p, (const int64_t*)dfo.p,
+                                 (int32_t*)st.p, ws.p, wsb, nullptr);
+    if (rc != PO_OK) return rc;
+    const int64_t seqb = seq_off_h[n];
+    UP(so, seq_off_h, sizeof(int64_t) * (n + 1));
+    UP(sq, nullptr, (size_t)seqb);
+    UP(sl, nullptr, sizeof(int32_t) * n);
+    UP(lp, nullptr, sizeof(double) * n);
+    UP(st2, nullptr, sizeof(int32_t) * n);
+    const int64_t mr = std::max(m1, m2);
+    const size_t wsb2 = po_pair_prefix_ws_bytes(n, mr);
+    UP(ws2, nullptr, wsb2);
+    rc = po_launch_pair_prefix_search((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p,
+                                      (const double*)dn.p, (const int64_t*)dfo.p, n, C, A, ap, flavor, mr, (char*)sq.p,
+                                      (const int64_t*)so.p, (int32_t*)sl.p, (double*)lp.p, (int32_t*)st2.p, ws2.p, wsb2, nullptr);
+    if (rc != PO_OK) { g_err = "po_pair_prefix_search_batch_h: box too long for the LDS rows, or bad C"; return rc; }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(seq_h, sq, (size_t)seqb);
+    DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(logp_h, lp, sizeof(double) * n);
+    DOWN(status_h, st2, sizeof(int32_t) * n);
     return PO_OK;
 }
 

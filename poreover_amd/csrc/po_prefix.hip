@@ -194,3 +194,227 @@ extern "C" int po_launch_prefix_search(const double* y, const int64_t* y_off, in
     hipLaunchKernelGGL(prefix_search_kernel, dim3(n), dim3(PS_THREADS), lds, stream, a);
     return PO_OK;
 }
+
+// ================================================================================================
+// Batched PAIR prefix search on small boxes of two reads (dense gamma).
+//
+// Replaces prefix_search.pair_prefix_search_log / _cy (reference prefix_search.py:247-385) with
+// pair_prefix_prob_log (:240-245): per search level and symbol c
+//   alpha_ast_r[t] = (t == 0 ? (level == 1 ? 0 : -inf) : alpha_prev_r[t-1]) + y_r[t][c]        r = 1, 2
+//   prefix_prob[c] = logsumexp_{u,v}(alpha_ast_1[u] + alpha_ast_2[v] + gamma[u+1][v+1]) - gamma[0][0]
+//   alpha_c_r      = forward_vec_log(c, level, y_r, alpha_prev_r)                               (serial in t)
+//   label_prob[c]  = alpha_c_1[U-1] + alpha_c_2[V-1] - gamma[0][0]
+// and the reference's bookkeeping: label_prob is a dict over every label scored so far; while the best
+// prefix probability is not below label_prob[top_label], top_label becomes the first maximum of the dict
+// (insertion order) and the best prefix is extended.  gamma = the dense (U+1) x (V+1) matrix of
+// pair_gamma_log (po_gamma.hip, either flavour).  flavor 0: prefix_search.py arithmetic (-inf,
+// np.logaddexp); flavor 1: decoding_cy (LOG_0 = -9999, log(exp(a) + exp(b))).
+//
+// Mapping: one workgroup (256 threads) per box; alpha rows in LDS; the 2 x A forward recurrences run on
+// 2A lanes side by side; the U x V log-sum-exp uses all threads (max-shifted like scipy; summation order
+// differs from numpy's pairwise sum, so probabilities agree to rounding, as in the 1-D kernel).
+namespace {
+struct PPSArgs {
+    const double* y1; const int64_t* y1_off; const double* y2; const int64_t* y2_off;
+    const double* gm; const int64_t* gm_off;
+    int n, C, A, flavor;
+    uint32_t alphabet;
+    char* seq; const int64_t* seq_off; int32_t* seq_len; double* logp; int32_t* status;
+    char* curr; long long curr_cap;
+    int tcap;   // LDS rows hold tcap doubles
+};
+__device__ __forceinline__ double pps_lae(double a, double b, int flavor) {
+    if (flavor) return log(exp(a) + exp(b));
+    // np.logaddexp: equal -> a + ln2; else max + log1p(exp(-|a-b|)); NaN only from NaN inputs
+    if (a == b) return a + 0.6931471805599453;
+    const double d = a - b;
+    if (d > 0) return a + log1p(exp(-d));
+    if (d <= 0) return b + log1p(exp(d));
+    return d;  // NaN
+}
+}  // namespace
+
+__global__ __launch_bounds__(PS_THREADS) void pair_prefix_search_kernel(PPSArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[PS_WAVES];
+    __shared__ double shd[16];
+    __shared__ int shi[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pi = blockIdx.x;
+    const int A = a.A, C = a.C, blank = a.A, tc = a.tcap;
+    const int64_t r1 = a.y1_off[pi], r2 = a.y2_off[pi];
+    const int U = (int)(a.y1_off[pi + 1] - r1), V = (int)(a.y2_off[pi + 1] - r2);
+    const double* y1 = a.y1 + r1 * C;
+    const double* y2 = a.y2 + r2 * C;
+    const double* gm = a.gm + a.gm_off[pi];
+    const int W1 = V + 1;
+    // LDS rows: prev[2], ast[2], cand[2][PO_A]  (each tc doubles)
+    double* prev1 = (double*)smem;
+    double* prev2 = prev1 + tc;
+    double* ast1 = prev2 + tc;
+    double* ast2 = ast1 + tc;
+    double* cand = ast2 + tc;  // [r][c][tc]
+    char* curr = a.curr + (size_t)blockIdx.x * a.curr_cap;
+    const double LOG0 = a.flavor ? -9999.0 : PO_NEG_INF;
+    const int M = max(U, V);
+    if (U < 1 || V < 1 || U > tc || V > tc || M + 4 > a.curr_cap) {
+        if (tid == 0) { a.seq_len[pi] = 0; a.logp[pi] = 0.0; a.status[pi] = (U < 1 || V < 1) ? PO_E_ARG : PO_E_CAP; }
+        return;
+    }
+    auto block_max = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        double r = red[0];
+        for (int w = 1; w < PS_WAVES; ++w) r = fmax(r, red[w]);
+        __syncthreads();
+        return r;
+    };
+    auto block_sum = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        double r = 0;
+        for (int w = 0; w < PS_WAVES; ++w) r += red[w];
+        __syncthreads();
+        return r;
+    };
+    // label_prob[''] = sum of blanks of both reads; alpha_prev = forward_vec_log(-1, 0, y) (:262-268)
+    if (tid < 2) {
+        const double* y = tid ? y2 : y1;
+        double* pv = tid ? prev2 : prev1;
+        const int T = tid ? V : U;
+        double g = 0.0, acc = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double b = y[(int64_t)t * C + blank];
+            g += b;
+            acc = (t == 0) ? b : b + acc;
+            pv[t] = acc;
+        }
+        shd[12 + tid] = g;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        shd[0] = shd[12] + shd[13];  // label_prob[top_label]
+        shi[0] = 0;  // len(curr_label)
+        shi[1] = 0;  // level at which top_label was scored (0: the empty label)
+        shi[2] = 0;  // its last symbol
+        shi[3] = 0;  // stop flag
+    }
+    __syncthreads();
+    const double g00 = gm[0];
+    int st = PO_OK;
+    for (int level = 1;; ++level) {
+        const int curr_len = shi[0];
+        const bool depth_stop = curr_len > M;  // 'Max search depth exceeded' (:277-279): finish this level, then stop
+        for (int c = 0; c < A; ++c) {
+            for (int t = tid; t < U; t += PS_THREADS)
+                ast1[t] = ((t == 0) ? (curr_len + 1 == 1 ? 0.0 : PO_NEG_INF) : prev1[t - 1]) + y1[(int64_t)t * C + c];
+            for (int t = tid; t < V; t += PS_THREADS)
+                ast2[t] = ((t == 0) ? (curr_len + 1 == 1 ? 0.0 : PO_NEG_INF) : prev2[t - 1]) + y2[(int64_t)t * C + c];
+            __syncthreads();
+            const int64_t N = (int64_t)U * V;
+            double m = PO_NEG_INF;
+            for (int64_t i = tid; i < N; i += PS_THREADS) {
+                const int u = (int)(i / V), v = (int)(i - (int64_t)u * V);
+                m = fmax(m, ast1[u] + ast2[v] + gm[(int64_t)(u + 1) * W1 + v + 1]);
+            }
+            m = block_max(m);
+            const double ms = (m > PO_NEG_INF && m < __builtin_inf()) ? m : 0.0;  // scipy: non-finite max -> 0
+            double sacc = 0;
+            for (int64_t i = tid; i < N; i += PS_THREADS) {
+                const int u = (int)(i / V), v = (int)(i - (int64_t)u * V);
+                sacc += exp(ast1[u] + ast2[v] + gm[(int64_t)(u + 1) * W1 + v + 1] - ms);
+            }
+            sacc = block_sum(sacc);
+            if (tid == 0) shd[4 + c] = log(sacc) + ms - g00;  // prefix_prob[curr + c]
+            __syncthreads();
+        }
+        // forward rows of the A candidate labels on both reads: 2A serial recurrences side by side
+        if (tid < 2 * A) {
+            const int rr = tid / A, c = tid - rr * A;
+            const double* y = rr ? y2 : y1;
+            const double* pv = rr ? prev2 : prev1;
+            const int T = rr ? V : U;
+            double* al = cand + ((size_t)rr * PO_A + c) * tc;
+            double fw = (level == 1) ? y[c] : LOG0;  // t == 0: i == 1 -> y[0, s], else stays LOG_0
+            al[0] = fw;
+            for (int t = 1; t < T; ++t) {
+                fw = pps_lae(y[(int64_t)t * C + blank] + fw, y[(int64_t)t * C + c] + pv[t - 1], a.flavor);
+                al[t] = fw;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // label_prob of the A new labels; the dict's first maximum (insertion order) incl. them
+            double top = shd[0];
+            int tlev = shi[1], tsym = shi[2];
+            for (int c = 0; c < A; ++c) {
+                const double lp = cand[((size_t)0 * PO_A + c) * tc + U - 1] + cand[((size_t)1 * PO_A + c) * tc + V - 1] - g00;
+                if (lp > top) { top = lp; tlev = level; tsym = c; }
+            }
+            int best = 0;
+            for (int c = 1; c < A; ++c) if (shd[4 + c] > shd[4 + best]) best = c;
+            if (shd[4 + best] < shd[0]) shi[3] = 1;  // compared with the top label BEFORE this level's labels
+            else {
+                shd[0] = top; shi[1] = tlev; shi[2] = tsym;
+                curr[curr_len] = (char)((a.alphabet >> (8 * best)) & 0xffu);
+                shi[0] = curr_len + 1;
+                shi[4] = best;
+                if (depth_stop) shi[3] = 1;
+            }
+        }
+        __syncthreads();
+        if (shi[3]) {
+            // the rows are copied before the reference leaves the loop on depth_stop; nothing reads them after
+            break;
+        }
+        const int best = shi[4];
+        for (int t = tid; t < U; t += PS_THREADS) prev1[t] = cand[((size_t)0 * PO_A + best) * tc + t];
+        for (int t = tid; t < V; t += PS_THREADS) prev2[t] = cand[((size_t)1 * PO_A + best) * tc + t];
+        __syncthreads();
+        if (level > M + 8) { st = PO_E_DIVERGE; break; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nout = 0;
+        if (st == PO_OK) {
+            nout = shi[1];  // 0 for the empty label; label = curr[:level-1] + symbol
+            char* out = a.seq + a.seq_off[pi];
+            const int cap = (int)(a.seq_off[pi + 1] - a.seq_off[pi]);
+            if (nout > cap) { st = PO_E_CAP; nout = 0; }
+            else if (nout > 0) {
+                for (int i = 0; i < nout - 1; ++i) out[i] = curr[i];
+                out[nout - 1] = (char)((a.alphabet >> (8 * shi[2])) & 0xffu);
+            }
+        }
+        a.seq_len[pi] = nout;
+        a.logp[pi] = shd[0];
+        a.status[pi] = st;
+    }
+}
+
+extern "C" size_t po_pair_prefix_ws_bytes(int n, int64_t max_rows) { return al256((size_t)max_rows + 16) * (size_t)(n > 0 ? n : 1) + 256; }
+
+extern "C" int po_launch_pair_prefix_search(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
+                                            const double* gm, const int64_t* gm_off, int n, int C, int A, uint32_t alphabet,
+                                            int flavor, int64_t max_rows, char* seq, const int64_t* seq_off,
+                                            int32_t* seq_len, double* logp, int32_t* status, void* ws, size_t ws_bytes,
+                                            hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    if (A < 1 || A > PO_A || C != A + 1) return PO_E_ARG;
+    const size_t lds = sizeof(double) * (size_t)(4 + 2 * PO_A) * (size_t)max_rows;
+    if (lds > 150 * 1024) return PO_E_UNSUPPORTED;  // boxes longer than ~1600 frames per read do not fit the LDS rows
+    const size_t per = al256((size_t)max_rows + 16);
+    if (ws_bytes < per * n) return PO_E_CAP;
+    PPSArgs a;
+    a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.gm = gm; a.gm_off = gm_off;
+    a.n = n; a.C = C; a.A = A; a.flavor = flavor; a.alphabet = alphabet;
+    a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.logp = logp; a.status = status;
+    a.curr = (char*)ws; a.curr_cap = (long long)per; a.tcap = (int)max_rows;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)pair_prefix_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(pair_prefix_search_kernel, dim3(n), dim3(PS_THREADS), lds, stream, a);
+    return PO_OK;
+}

@@ -29,4 +29,17 @@ def prefix_search_log_cy(y_, alphabet=DNA_alphabet, return_forward=False):
     return _batch.prefix_search_batch(y, [0, len(y)], sym)[0]
 
 
+def pair_prefix_search_log_cy(y1_, y2_, alphabet=DNA_alphabet):
+    """prefix_search.py:316-385 -> (label, log-probability): pair prefix search over the dense gamma matrix
+    of two small boxes (decoding_cy arithmetic)"""
+    sym = "".join(alphabet.keys())
+    return _batch.pair_prefix_search_batch([np.asarray(y1_, dtype=np.float64)], [np.asarray(y2_, dtype=np.float64)], sym, "cy")[0]
+
+
+def pair_prefix_search_log(y1_, y2_, alphabet=DNA_alphabet):
+    """prefix_search.py:247-314: the numpy twin (-inf instead of LOG_0, np.logaddexp)"""
+    sym = "".join(alphabet.keys())
+    return _batch.pair_prefix_search_batch([np.asarray(y1_, dtype=np.float64)], [np.asarray(y2_, dtype=np.float64)], sym, "py")[0]
+
+
 prefix_search_log = prefix_search_log_cy   # the pure-python twin computes the same quantity (prefix_search.py:115)

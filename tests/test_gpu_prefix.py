@@ -64,3 +64,36 @@ def test_prefix_matches_oracle_batch(ps, oracle):
         assert lab == wl, (lo, hi)
         assert np.isclose(lp, wp, rtol=1e-10, atol=0)
     assert ps.greedy_search(y[:300]) == oracle.viterbi_decode(y[:300])[0]
+
+
+def test_pair_prefix_search(ps, oracle, golden, golden_inputs):
+    """pair_prefix_search_log / _cy (prefix_search.py:247-385): the reference's toy pairs (test_prefix.py:106-162),
+    a synthetic box, and a batch of random boxes against the oracle"""
+    from collections import OrderedDict
+    from poreover_amd import batch
+    toy_alpha = OrderedDict([("A", 0), ("B", 1)])
+    pm = golden["prefix_prob"]
+    with np.errstate(divide="ignore"):
+        for k, rec in golden["pair_prefix_toy"].items():
+            a, b = k.split("_")
+            ya, yb = np.log(np.array(pm[a])), np.log(np.array(pm[b]))
+            for flavor, fn in (("py", ps.pair_prefix_search_log), ("cy", ps.pair_prefix_search_log_cy)):
+                lab, lp = fn(ya, yb, alphabet=toy_alpha)
+                assert lab == rec[flavor][0], (k, flavor)
+                assert np.isclose(lp, hexf(rec[flavor][1]), rtol=1e-9)
+    y = golden_inputs["prefix_y"]
+    lab, lp = ps.pair_prefix_search_log_cy(y[:20], y[:20])
+    assert lab == golden["pair_prefix_synth"][0]
+    assert np.isclose(lp, hexf(golden["pair_prefix_synth"][1]), rtol=1e-9)
+    b1, b2, want = [], [], {"py": [], "cy": []}
+    for i in range(8):
+        y1, y2 = synth_pair(9700 + i, T=60 + 25 * i)[:2]
+        lo = 7 * i
+        y1, y2 = y1[lo:lo + 30 + 12 * i], y2[lo:lo + 25 + 14 * i]     # ragged boxes
+        b1.append(y1); b2.append(y2)
+        for f in ("py", "cy"):
+            want[f].append(oracle.pair_prefix_search_log(y1, y2, f))
+    for f in ("py", "cy"):
+        got = batch.pair_prefix_search_batch(b1, b2, flavor=f)
+        assert [g[0] for g in got] == [w[0] for w in want[f]], f
+        assert np.allclose([g[1] for g in got], [w[1] for w in want[f]], rtol=1e-9, atol=0)
