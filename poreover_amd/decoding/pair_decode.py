@@ -20,8 +20,9 @@ def _check_supported(args):
                                "only the envelope method (the reference's default) is built")
     if getattr(args, 'algorithm', 'beam') != 'beam':
         raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --algorithm %s" % args.algorithm)
-    if getattr(args, 'skip_matches', False):
-        raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --skip_matches")
+    if getattr(args, 'skip_matches', False) and (getattr(args, 'diagonal_envelope', False) or
+                                                 getattr(args, 'single', 'viterbi') != 'viterbi'):
+        raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --skip_matches with --diagonal_envelope / --single beam")
 
 
 def _load_pair(in_path, args):
@@ -38,12 +39,118 @@ def _load_pair(in_path, args):
     return path1, path2, model1, model2
 
 
+def get_anchors(alignment, matches, indels):
+    """pair_decode.py:53-89: runs of >= `matches` identical columns ('mat') or >= `indels` gap columns
+    ('ins' / 'del') of a 2-row alignment -> ([(start, end), ...], [type, ...]).  A mismatch column ends any
+    run and never starts one; the run open at the end of the alignment is not reported."""
+    ranges, types = [], []
+    start, count, prev = 0, 1, 'START'
+    need = {'ins': indels, 'del': indels, 'mat': matches}
+    for i, (a1, a2) in enumerate(zip(alignment[0], alignment[1])):
+        state = 'mat' if a1 == a2 else ('ins' if a1 == '-' else ('del' if a2 == '-' else 'mis'))
+        if state == prev and state != 'mis':
+            count += 1
+            continue
+        if prev in need and count >= need[prev]:
+            ranges.append((start, i))
+            types.append(prev)
+        prev, count, start = state, 1, i
+    return ranges, types
+
+
+def _decode_pairs_skip_matches(in_paths, loaded, args, out):
+    """--skip_matches (pair_decode.py:412-467,512-522): long runs of matching columns are copied from read 1's
+    basecall, the stretches between them ("boxes") are decoded with the pair beam search inside their slice of
+    the envelope, and the pieces are joined in signal order.  Viterbi, alignment, envelope and every box of
+    every pair run as batched GPU calls."""
+    import numpy as np
+    by_kind = {}
+    for i, (_, _, m1, _) in enumerate(loaded):
+        by_kind.setdefault(m1.kind, []).append(i)
+    for kind, idx in by_kind.items():
+        model = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}[kind]
+        ys1 = [loaded[i][2].log_prob for i in idx]
+        ys2 = [loaded[i][3].log_prob for i in idx]
+        seq1, map1, st1 = _batch.viterbi_batch(ys1, kind, return_map=True)
+        seq2, map2, st2 = _batch.viterbi_batch(ys2, kind, return_map=True)
+        live = []
+        for j, i in enumerate(idx):
+            in_path = in_paths[i]
+            summary = {'read1': in_path[0], 'read2': in_path[1], 'length1': len(seq1[j]), 'length2': len(seq2[j])}
+            if abs(len(seq1[j]) - len(seq2[j])) > 1000:
+                summary['skipped'] = 1
+                out[i] = [summary]
+            elif st1[j] != 0 or st2[j] != 0:   # the reference's assert on the frame map (pair_decode.py:379,382)
+                raise _lib.EngineError(_lib.E_ARG, "pair decode of pair %d" % i, "frame map and basecall lengths differ")
+            else:
+                live.append((j, i, summary))
+        alns = _batch.align_batch([(seq1[j], seq2[j]) for j, _, _ in live], 0 if args.alignment == "full" else 500)
+        keep = []
+        for (j, i, summary), (a1, a2) in zip(live, alns):
+            ident = sum(x == y for x, y in zip(a1, a2)) / len(a1)
+            summary['sequence_identity'] = ident
+            if ident < 0.5:
+                summary['skipped'] = 1
+                out[i] = [summary]
+            else:
+                summary['skipped'] = 0
+                keep.append((j, i, summary, (a1, a2)))
+        envs = _batch.envelope_batch([k[3] for k in keep], [map1[k[0]] for k in keep], [map2[k[0]] for k in keep],
+                                     [len(ys1[k[0]]) for k in keep], [len(ys2[k[0]]) for k in keep], args.padding)
+        box_y1, box_y2, box_env, box_owner, anchors_of = [], [], [], [], {}
+        for (j, i, summary, aln), env in zip(keep, envs):
+            s2s1, s2s2 = map1[j], map2[j]
+            # alignment column -> number of bases of each read up to and including it; column 0 looks at
+            # "column -1", i.e. the still-zero last entry (pair_decode.py:403-410)
+            a2s = np.zeros((2, len(aln[0])), dtype=np.int64)
+            for r in range(2):
+                acc = 0
+                for c, ch in enumerate(aln[r]):
+                    acc = acc if ch == '-' else acc + 1
+                    a2s[r, c] = acc
+            ranges, types = get_anchors(aln, matches=args.skip_threshold, indels=100)
+            assert len(ranges) > 0, 'No matches/indels of sufficient length found in alignment. Try decreasing --matches or --indels'
+            anchors, boxes = [], []
+            for k, (cs, ce) in enumerate(ranges):
+                row = 1 if types[k] == 'ins' else 0
+                anchors.append((int(s2s1[a2s[0, cs]]), aln[row][cs:ce]))
+                if k > 0:
+                    pe = ranges[k - 1][1]
+                    boxes.append((int(s2s1[a2s[0, pe]]), int(s2s1[a2s[0, cs]]), int(s2s2[a2s[1, pe]]), int(s2s2[a2s[1, cs]])))
+                else:
+                    boxes.append((0, int(s2s1[a2s[0, cs]]), 0, int(s2s2[a2s[1, cs]])))
+            le = ranges[-1][1]
+            boxes.append((int(s2s1[a2s[0, le]]), len(ys1[j]), int(s2s2[a2s[1, le]]), len(ys2[j])))
+            anchors_of[i] = anchors
+            for b in boxes:
+                e = np.array(env[b[0]:b[1]], dtype=np.int64)
+                lo = int(e[0, 0])            # an empty box raises here, as in the reference
+                box_y1.append(ys1[j][b[0]:b[1]])
+                box_y2.append(ys2[j][lo:int(e[-1, 1])])
+                box_env.append(e - lo)
+                box_owner.append((i, b[0]))
+        calls = _batch.beam_search_2d_batch(box_y1, box_y2, box_env, args.beam_width, model=model,
+                                            method=args.beam_search_method)
+        pieces = {}
+        for (i, pos), sq in zip(box_owner, calls):
+            pieces.setdefault(i, []).append((pos, sq))
+        for j, i, summary, aln in keep:
+            in_path = in_paths[i]
+            path1, path2 = loaded[i][0], loaded[i][1]
+            joined = ''.join(x[1] for x in sorted(pieces.get(i, []) + anchors_of[i]))
+            out[i] = (fasta_format(in_path[0], seq1[j]) + fasta_format(in_path[1], seq2[j]),
+                      fasta_format('consensus;{};{}'.format(path1.stem, path2.stem), joined), summary)
+    return out
+
+
 def decode_pairs(in_paths, args):
     """pair_decode_helper for a LIST of pairs: returns a list of the reference's return tuples
     (1-, 2- or 3-tuples, pair_decode.py:375,398,526-529)."""
     _check_supported(args)
     loaded = [_load_pair(p, args) for p in in_paths]
     out = [None] * len(loaded)
+    if getattr(args, 'skip_matches', False):
+        return _decode_pairs_skip_matches(in_paths, loaded, args, out)
     by_kind = {}
     for i, (_, _, m1, _) in enumerate(loaded):
         by_kind.setdefault(m1.kind, []).append(i)

@@ -299,6 +299,14 @@ def main():
         if kind == "poreover" and idx < 2:
             out = ref_pd.pair_decode_helper(ns(diagonal_envelope=True, diagonal_width=30))
             rec["runs"]["diag30"] = {"n_out": len(out), "fasta_2d": out[0]}
+        # --skip_matches (pair_decode.py:412-467,512-522): anchors copied, boxes between them decoded
+        if kind == "poreover" and idx < 8:
+            for thr in (10, 6):
+                try:
+                    out = ref_pd.pair_decode_helper(ns(skip_matches=True, skip_threshold=thr))
+                    rec["runs"]["skip%d" % thr] = {"n_out": len(out), "fasta_2d": out[1] if len(out) == 3 else None}
+                except Exception as ex:   # empty boxes make the reference itself raise (IndexError / assert)
+                    rec["runs"]["skip%d" % thr] = {"n_out": 0, "error": type(ex).__name__}
         pair_recs.append(rec)
     G["pairs"] = pair_recs
 

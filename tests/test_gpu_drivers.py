@@ -101,7 +101,7 @@ def test_pair_decode_driver_matches_reference_outputs(eng, tmp_path, monkeypatch
     assert len(out) == 2 and out[0].startswith(">consensus;envelope;p%d_a\n" % recs[0]["index"])
     assert out[0].split("\n", 1)[1] == recs[0]["runs"]["diag30"]["fasta_2d"].split("\n", 1)[1]
     # unsupported routes are refused loudly
-    for kw in (dict(method="split"), dict(algorithm="prefix"), dict(skip_matches=True)):
+    for kw in (dict(method="split"), dict(algorithm="prefix"), dict(skip_matches=True, diagonal_envelope=True)):
         bad = _pair_args(**kw)
         setattr(bad, "in", a0)
         with pytest.raises(eng.EngineError):
@@ -139,3 +139,28 @@ def test_pair_decode_single_beam(eng, monkeypatch, golden_inputs):
     assert np.array_equal(got["envelope"], env)
     assert got["sequence_identity"] == sum(x == y for x, y in zip(a1, a2)) / len(a1)
     assert got["consensus"] == O.cpp_beam_search_2d(y1, y2, env, 5, method_="row_col")
+
+
+def test_pair_decode_skip_matches(eng, tmp_path, monkeypatch, golden, golden_inputs):
+    """--skip_matches (pair_decode.py:412-467,512-522): anchors copied, boxes decoded inside their envelope slice,
+    pieces joined in signal order — the consensus records the reference's helper produced, for 8 pairs x 2
+    thresholds, all boxes of all pairs in one batched GPU call"""
+    from poreover_amd.decoding import decode, pair_decode, transducer
+    recs = [r for r in golden["pairs"] if "skip10" in r["runs"]]
+    assert len(recs) >= 8
+    mats, in_paths = {}, []
+    for r in recs:
+        a, b = "p%d_a.npy" % r["index"], "p%d_b.npy" % r["index"]
+        mats[a], mats[b] = golden_inputs["pair%d_y1" % r["index"]], golden_inputs["pair%d_y2" % r["index"]]
+        in_paths.append([a, b])
+    monkeypatch.setattr(decode, "model_from_trace",
+                        lambda f, basecaller="": transducer.poreover(mats[os.path.basename(str(f))]))
+    for thr in (10, 6):
+        res = pair_decode.decode_pairs(in_paths, _pair_args(skip_matches=True, skip_threshold=thr))
+        for r, got in zip(recs, res):
+            want = r["runs"]["skip%d" % thr]
+            assert want["n_out"] == 3 and len(got) == 3
+            assert got[1].split("\n", 1)[1] == want["fasta_2d"].split("\n", 1)[1], (r["index"], thr)
+    # get_anchors restated: the reference's own small cases
+    assert pair_decode.get_anchors(("AAAAA-CC", "AAAAATCC"), matches=3, indels=1) == ([(0, 5), (5, 6)], ["mat", "ins"])
+    assert pair_decode.get_anchors(("ACGT", "ACGT"), matches=2, indels=100) == ([], [])   # the open run at the end is not reported

@@ -78,3 +78,15 @@ def test_cli_flag_surface():
         assert q[k] == v, k
     with pytest.raises(SystemExit):
         p.parse_args(["pair-decode", "x", "--beam_search_method", "diagonal"])
+
+
+def test_get_anchors_host_logic():
+    """pair_decode.get_anchors (reference pair_decode.py:53-89) restated on the host: hand-checked cases"""
+    from poreover_amd.decoding import pair_decode
+    ga = pair_decode.get_anchors
+    assert ga(("AAAAA-CC", "AAAAATCC"), matches=3, indels=1) == ([(0, 5), (5, 6)], ["mat", "ins"])
+    assert ga(("ACGT", "ACGT"), matches=2, indels=100) == ([], [])            # the run still open at the end is dropped
+    assert ga(("ACGTA", "ACGTC"), matches=4, indels=100) == ([(0, 4)], ["mat"])  # a mismatch closes the run
+    assert ga(("AC--GT", "ACTTGT"), matches=2, indels=2) == ([(0, 2), (2, 4)], ["mat", "ins"])
+    assert ga(("ACTTGT", "AC--GT"), matches=5, indels=2) == ([(2, 4)], ["del"])
+    assert ga(("ACAC", "AGAG"), matches=1, indels=1) == ([(0, 1), (2, 3)], ["mat", "mat"])  # mismatches never count
