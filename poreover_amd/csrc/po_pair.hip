@@ -61,6 +61,9 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
     __shared__ int wsum[PP_WAVES];
     __shared__ int sh[8];
     __shared__ int lo_s[PP_THREADS], hi_s[PP_THREADS], pm[PP_THREADS];
+    // the DP row just filled, for the next row's reads: the fill never reads the table back from HBM (a
+    // store -> barrier -> load round trip per row); the table is only written, for the trace-back
+    __shared__ int rowbuf[2][8 * PP_THREADS + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* dp = a.dp + (size_t)blockIdx.x * a.dp_cap;
     int* r_start = a.rowinfo + (size_t)blockIdx.x * 4 * a.row_cap;
@@ -191,21 +194,32 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
         };
 
         // ------------------------------------------------------------------ DP fill, row by row
+        int ps = 0, pe = 0;  // computed cells [ps, pe) of the previous row (none before row 0)
         for (int i = 0; i < nrows; ++i) {
             const int js = r_start[i], je = r_end[i], w = je - js;
             int* row = dp + r_off[i];
+            int* cur = rowbuf[i & 1];
+            const int* prv = rowbuf[(i & 1) ^ 1];
             if (full && i == 0) {  // dpMatrix[0, j] = gap * j (align.pyx:44-45)
-                for (int j = tid; j < w; j += PP_THREADS) row[j] = NW_GAP * j;
+                if (w > 8 * PP_THREADS + 1) {
+                    if (tid == 0) sh[1] = 1;
+                    __syncthreads();
+                    break;
+                }
+                for (int j = tid; j < w; j += PP_THREADS) { row[j] = NW_GAP * j; cur[j] = NW_GAP * j; }
                 __syncthreads();
+                ps = js; pe = je;
                 continue;
             }
+            // cell (i-1, j) with SparseMatrix's default 0 outside the computed cells
+            auto getp = [&](int j) -> int { return (j >= ps && j < pe) ? prv[j - ps] : 0; };
             // left boundary value and the character of seq1 this row scores against
             //   banded: cell(i, js-1) reads 0 (out of range); seq1[i-1] wraps at i == 0
             //   full:   cell(i, 0) = gap * i, filled cells start at j = 1; seq1[i-1]
             const int jfirst = full ? 1 : js;
             const int left0 = full ? NW_GAP * i : 0;
             const char c1 = s1[py_idx(i - 1, l1)];
-            if (full && tid == 0) row[0] = left0;
+            if (full && tid == 0) { row[0] = left0; cur[0] = left0; }
             const int cnt = je - jfirst;
             const int per = (cnt + PP_THREADS - 1) / PP_THREADS;  // consecutive columns per thread
             if (per > 8) {  // a row wider than 2048 cells (only --alignment full on very long reads)
@@ -223,8 +237,8 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
                 int val = INT_MIN;
                 if (q < per && j < je) {
                     const char c2 = s2[py_idx(j - 1, l2)];
-                    const int diag = get(i - 1, j - 1) + (c1 == c2 ? NW_MATCH : NW_MISMATCH);
-                    const int up = get(i - 1, j) + NW_GAP;
+                    const int diag = getp(j - 1) + (c1 == c2 ? NW_MATCH : NW_MISMATCH);
+                    const int up = getp(j) + NW_GAP;
                     val = max(diag, up) + j;
                 }
                 m = max(m, val);
@@ -239,9 +253,10 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int j = j0 + q;
-                if (q < per && j < je) row[j - js] = max(loc[q], excl) - j;
+                if (q < per && j < je) { const int cell = max(loc[q], excl) - j; row[j - js] = cell; cur[j - js] = cell; }
             }
             __syncthreads();
+            ps = js; pe = je;
         }
         if (sh[1]) {
             if (tid == 0) { a.status[pi] = PO_E_UNSUPPORTED; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
