@@ -6,7 +6,7 @@ float64 — the form the reference's decoders receive (decode.py:34-51).
 """
 import numpy as np
 
-__all__ = ["synth_pair", "synth_read", "log_softmax"]
+__all__ = ["synth_pair", "synth_read", "synth_truth", "log_softmax"]
 
 
 def log_softmax(logits):
@@ -66,3 +66,10 @@ def synth_pair(index, T=4000, base_seed=0, flipflop=False):
 
 def synth_read(index, T=4000, base_seed=0, flipflop=False):
     return synth_pair(index, T, base_seed, flipflop)[0]
+
+
+def synth_truth(index, T=4000, base_seed=0):
+    """The reference sequence both reads of synth_pair(index, T, base_seed) were mutated from (its first draw)."""
+    rng = np.random.default_rng(base_seed + index)
+    ref = rng.integers(4, size=max(1, int(T / 9.4)))
+    return "".join("ACGT"[b] for b in ref)
