@@ -27,8 +27,6 @@
 
 namespace {
 
-constexpr int PP_THREADS = 256;
-constexpr int PP_WAVES = PP_THREADS / PO_WAVE;
 constexpr int NW_MATCH = 2, NW_MISMATCH = -1, NW_GAP = -1, NW_BAND = 500;
 
 struct PPArgs {
@@ -57,13 +55,16 @@ __device__ __forceinline__ int py_idx(int i, int len) { return i < 0 ? i + len :
 
 }  // namespace
 
-__global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
-    __shared__ int wsum[PP_WAVES];
+template <int NT>
+__global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
+    constexpr int PERMAX = (NT == 64) ? 16 : 8;  // consecutive DP cells per thread: a banded row (<= 1001 cells) fits one wave
+    constexpr int NWAVES = NT / PO_WAVE;
+    __shared__ int wsum[NWAVES];
     __shared__ int sh[8];
-    __shared__ int lo_s[PP_THREADS], hi_s[PP_THREADS], pm[PP_THREADS];
+    __shared__ int lo_s[NT], hi_s[NT], pm[NT];
     // the DP row just filled, for the next row's reads: the fill never reads the table back from HBM (a
     // store -> barrier -> load round trip per row); the table is only written, for the trace-back
-    __shared__ int rowbuf[2][8 * PP_THREADS + 4];
+    __shared__ int rowbuf[2][PERMAX * NT + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* dp = a.dp + (size_t)blockIdx.x * a.dp_cap;
     int* r_start = a.rowinfo + (size_t)blockIdx.x * 4 * a.row_cap;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
         if (lane == PO_WAVE - 1) wsum[wave] = inc;
         __syncthreads();
         int base = 0, tot = 0;
-        for (int w = 0; w < PP_WAVES; ++w) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
+        for (int w = 0; w < NWAVES; ++w) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
         __syncthreads();
         *total = tot;
         return base + inc - v;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
         int32_t* env = (a.mode == 1) ? nullptr : a.env + 2 * ((a.mode == 2) ? a.env_off[pi] : o1);
 
         if (a.mode == 0 && a.diagonal_envelope) {  // pair_decode.py:497-498, python float arithmetic u/U*V
-            for (int u = tid; u < U; u += PP_THREADS) {
+            for (int u = tid; u < U; u += NT) {
                 const int c = (int)((double)u / (double)U * (double)V);
                 env[2 * u] = max(c - a.diagonal_width, 0);
                 env[2 * u + 1] = min(c + a.diagonal_width, V);
@@ -157,14 +158,14 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             }
             const char* g1 = a.aln_out1 + a.aln_off[pi];
             const char* g2 = a.aln_out2 + a.aln_off[pi];
-            for (int k = tid; k < ncol; k += PP_THREADS) { al1[ncol - 1 - k] = g1[k]; al2[ncol - 1 - k] = g2[k]; }
+            for (int k = tid; k < ncol; k += NT) { al1[ncol - 1 - k] = g1[k]; al2[ncol - 1 - k] = g2[k]; }
             __syncthreads();
         } else {
 
         // ------------------------------------------------------------------ DP row geometry
         // banded (align.pyx:119-125): center = int(np.round(l2 / l1 * i)); computed cells [start, end)
         // with end = min(center + band, l2 - 1); full: columns [0, l2] all computed
-        for (int i = tid; i < nrows; i += PP_THREADS) {
+        for (int i = tid; i < nrows; i += NT) {
             int st_, en_;
             if (full) { st_ = 0; en_ = l2 + 1; }
             else {
@@ -201,12 +202,12 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             int* cur = rowbuf[i & 1];
             const int* prv = rowbuf[(i & 1) ^ 1];
             if (full && i == 0) {  // dpMatrix[0, j] = gap * j (align.pyx:44-45)
-                if (w > 8 * PP_THREADS + 1) {
+                if (w > PERMAX * NT + 1) {
                     if (tid == 0) sh[1] = 1;
                     __syncthreads();
                     break;
                 }
-                for (int j = tid; j < w; j += PP_THREADS) { row[j] = NW_GAP * j; cur[j] = NW_GAP * j; }
+                for (int j = tid; j < w; j += NT) { row[j] = NW_GAP * j; cur[j] = NW_GAP * j; }
                 __syncthreads();
                 ps = js; pe = je;
                 continue;
@@ -221,18 +222,18 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             const char c1 = s1[py_idx(i - 1, l1)];
             if (full && tid == 0) { row[0] = left0; cur[0] = left0; }
             const int cnt = je - jfirst;
-            const int per = (cnt + PP_THREADS - 1) / PP_THREADS;  // consecutive columns per thread
-            if (per > 8) {  // a row wider than 2048 cells (only --alignment full on very long reads)
+            const int per = (cnt + NT - 1) / NT;  // consecutive columns per thread
+            if (per > PERMAX) {  // a row wider than PERMAX * NT cells (only --alignment full on very long reads)
                 if (tid == 0) sh[1] = 1;
                 __syncthreads();
                 break;
             }
             // local running max of c(k) + k over this thread's columns ...
             const int j0 = jfirst + tid * per;
-            int loc[8];
+            int loc[PERMAX];
             int m = INT_MIN;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < PERMAX; ++q) {
                 const int j = j0 + q;
                 int val = INT_MIN;
                 if (q < per && j < je) {
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             __syncthreads();
             const int excl = max(left0 + (jfirst - 1), tid > 0 ? pm[tid - 1] : INT_MIN);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < PERMAX; ++q) {
                 const int j = j0 + q;
                 if (q < per && j < je) { const int cell = max(loc[q], excl) - j; row[j - js] = cell; cur[j - js] = cell; }
             }
@@ -296,14 +297,14 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             const int64_t ao = a.aln_off[pi];
             const int capo = (int)(a.aln_off[pi + 1] - ao);
             if (ncol > capo) { if (tid == 0) { a.status[pi] = PO_E_CAP; a.ncol_out[pi] = 0; } continue; }
-            for (int k = tid; k < ncol; k += PP_THREADS) { a.aln_out1[ao + k] = al1[ncol - 1 - k]; a.aln_out2[ao + k] = al2[ncol - 1 - k]; }
+            for (int k = tid; k < ncol; k += NT) { a.aln_out1[ao + k] = al1[ncol - 1 - k]; a.aln_out2[ao + k] = al2[ncol - 1 - k]; }
             if (tid == 0) { a.ncol_out[pi] = ncol; a.status[pi] = PO_OK; }
             continue;
         }
         // alignment is stored reversed: column k of the forward alignment is index ncol-1-k
         // identity = matches / columns (pair_decode.py:391-393)
         int matches = 0;
-        for (int k = tid; k < ncol; k += PP_THREADS) matches += (al1[k] == al2[k]);
+        for (int k = tid; k < ncol; k += NT) matches += (al1[k] == al2[k]);
         int tot_m;
         (void)block_excl_sum(matches, &tot_m);
         const double identity = (double)tot_m / (double)ncol;
@@ -313,11 +314,11 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
         }
 
         // ------------------------------------------------------------------ envelope (envelope.py:46-87)
-        for (int u = tid; u < U; u += PP_THREADS) { env[2 * u] = INT_MAX; env[2 * u + 1] = -1; }
+        for (int u = tid; u < U; u += NT) { env[2 * u] = INT_MAX; env[2 * u + 1] = -1; }
         __syncthreads();
         // get_alignment_columns (:26-44): x_index / y_index = running count of non-gap characters - 1
         int xbase = -1, ybase = -1;
-        for (int k0 = 0; k0 < ncol; k0 += PP_THREADS) {
+        for (int k0 = 0; k0 < ncol; k0 += NT) {
             const int k = k0 + tid;  // forward column index
             const bool in = k < ncol;
             const char ca = in ? al1[ncol - 1 - k] : '-', cb = in ? al2[ncol - 1 - k] : '-';
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
         __syncthreads();
         // padding (:73-75), then the sequential fix-ups (:78-85): prev_end only moves inside the 2nd if
         int prev_end = 0;
-        for (int u0 = 0; u0 < U; u0 += PP_THREADS) {
+        for (int u0 = 0; u0 < U; u0 += NT) {
             const int u = u0 + tid;
             if (u < U) {
                 int lo = env[2 * u], hi = env[2 * u + 1];
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(PP_THREADS) void pair_prep_kernel(PPArgs a) {
             }
             __syncthreads();
             if (tid == 0) {
-                const int cnt = min(PP_THREADS, U - u0);
+                const int cnt = min(NT, U - u0);
                 for (int q = 0; q < cnt; ++q) {
                     int lo = lo_s[q];
                     const int hi = hi_s[q];
@@ -382,10 +383,17 @@ void po_prof_stage(int kernel, hipStream_t s, int begin, void** tok);
 }
 
 namespace {
+void pp_launch(const PPArgs& a, int blocks, int one_wave, hipStream_t stream) {
+    if (one_wave) hipLaunchKernelGGL(pair_prep_kernel<64>, dim3(blocks), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(pair_prep_kernel<256>, dim3(blocks), dim3(256), 0, stream, a);
+}
+}  // namespace
+
+namespace {
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 
 struct PPGeom {
-    int blocks;
+    int blocks, one_wave;
     size_t dp_cap, row_cap, aln_cap;
     size_t off_queue, off_map1, off_map2, off_st1, off_st2, off_dp, off_rows, off_aln, off_ff, off_env, off_b2, total;
     size_t ff_bytes, b2_bytes;
@@ -404,7 +412,10 @@ int pp_num_cus() {
 
 PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, const po_pair_options* opt) {
     PPGeom g;
-    g.blocks = std::min(n > 0 ? n : 1, pp_num_cus() * 4);
+    // a banded DP row (<= 2 * 500 + 1 cells) fits one wave at 16 cells per lane: one-wave workgroups need no
+    // block barriers and three times as many pairs are in flight; full alignment keeps 256 threads
+    g.one_wave = opt->full_alignment ? 0 : 1;
+    g.blocks = std::min(n > 0 ? n : 1, pp_num_cus() * (g.one_wave ? 16 : 4));
     // a basecall has at most one base per frame, so lengths are bounded by the row counts; the DP
     // budget assumes basecalls of at most max_rows / 4 bases (nanopore basecallers emit roughly one
     // base per 8-10 frames) — longer ones are reported per pair as PO_E_CAP, never overrun
@@ -501,7 +512,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     a.aln = w + g.off_aln; a.aln_cap = (long long)g.aln_cap;
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
     po_prof_stage(PO_K_ALIGN, stream, 1, &tok);
-    hipLaunchKernelGGL(pair_prep_kernel, dim3(g.blocks), dim3(PP_THREADS), 0, stream, a);
+    pp_launch(a, g.blocks, g.one_wave, stream);
     po_prof_stage(PO_K_ALIGN, stream, 0, &tok);
     // (3) the pair beam search inside the envelope (pair_decode.py:166-173,511)
     po_prof_stage(PO_K_BEAM2D, stream, 1, &tok);
@@ -556,6 +567,7 @@ extern "C" int po_launch_align(const char* seqs, const int64_t* seq_off, int n, 
     const int blocks = std::min(n, pp_num_cus() * 4);
     const int64_t width = band > 0 ? std::min<int64_t>(max_len2 + 1, 2 * (int64_t)band + 1) : max_len2 + 1;
     char* w = (char*)ws;
+    const int one_wave = band > 0 ? 1 : 0;
     PPArgs a = {};
     a.n = n; a.seq1d = seqs; a.seq1d_off = seq_off; a.mode = 1;
     a.full_alignment = band > 0 ? 0 : 1; a.band = band > 0 ? band : 0;
@@ -566,7 +578,7 @@ extern "C" int po_launch_align(const char* seqs, const int64_t* seq_off, int n, 
     a.row_cap = (long long)(max_len1 + 2); a.rowinfo = (int*)(w + o); o += al256(sizeof(int) * 4 * (size_t)a.row_cap * blocks);
     a.aln_cap = (long long)(max_len1 + max_len2 + 16); a.aln = w + o;
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-    hipLaunchKernelGGL(pair_prep_kernel, dim3(blocks), dim3(PP_THREADS), 0, stream, a);
+    pp_launch(a, blocks, one_wave, stream);
     return PO_OK;
 }
 
@@ -584,6 +596,7 @@ extern "C" int po_launch_envelope(const char* aln1, const char* aln2, const int6
     if (ws_bytes < po_envelope_ws_bytes(n, max_ncol)) return PO_E_CAP;
     const int blocks = std::min(n, pp_num_cus() * 4);
     char* w = (char*)ws;
+    const int one_wave = 0;
     PPArgs a = {};
     a.n = n; a.mode = 2; a.padding = padding;
     a.aln_out1 = const_cast<char*>(aln1); a.aln_out2 = const_cast<char*>(aln2); a.aln_off = aln_off;
@@ -594,7 +607,7 @@ extern "C" int po_launch_envelope(const char* aln1, const char* aln2, const int6
     a.aln_cap = (long long)(max_ncol + 16); a.aln = w + 256;
     a.dp = nullptr; a.dp_cap = 0; a.rowinfo = (int*)w; a.row_cap = 0;
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-    hipLaunchKernelGGL(pair_prep_kernel, dim3(blocks), dim3(PP_THREADS), 0, stream, a);
+    pp_launch(a, blocks, one_wave, stream);
     return PO_OK;
 }
 
