@@ -1473,6 +1473,10 @@ int x2_blocks_per_cu() {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_x2_kernel<PO_MODEL_CTC>, 64, 0) != hipSuccess ||
             nblk <= 0)
             nblk = 8;
+        if (const char* e = getenv("PO_X2_PER_CU")) {  // experiment knob: fewer resident workgroups per CU
+            const int v = atoi(e);
+            if (v > 0 && v < nblk) nblk = v;
+        }
         per_cu = nblk;
     }
     return per_cu;
