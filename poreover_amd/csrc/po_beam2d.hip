@@ -789,7 +789,6 @@ struct X2Args {
 template <int K>
 struct X2Half {
     int e[F_COUNT][32];
-    int nx[F_COUNT][6];
     int bps[8];              // beam slot -> slot of its parent in the beam, or -1
     int sel[8];
     int newfc[8];
@@ -1297,20 +1296,23 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
         x2_sync();
 
         TK(6);  // scores
-        // ---- prune (Beam.h:93-108) + next beam table
+        // ---- prune (Beam.h:93-108) + next beam table.  Loops have constant bounds (predicated) so that their
+        // LDS reads are issued together instead of one round trip per trip.
         {
             int d = 0;
             if (s < ne && s >= nb) {
                 const int x = h.e[F_ID][s];
-                for (int j = 0; j < nb; ++j) d |= (h.e[F_ID][j] == x);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) d |= (j < nb && h.e[F_ID][j] == x);
             }
-            if (s < 32) h.dup[s] = (s < ne) ? d : 1;
+            h.dup[s] = (s < ne) ? d : 1;
             x2_sync();
             int rank = 0;
             if (s < ne && !d) {
                 const double sc = h.score[s];
                 const int id = h.e[F_ID][s];
-                for (int o = 0; o < ne; ++o)
+#pragma unroll 8
+                for (int o = 0; o < 32; ++o)
                     if (!h.dup[o] && po_better(h.score[o], h.e[F_ID][o], sc, id)) rank++;
                 if (rank < W) h.sel[rank] = s;
             }
@@ -1318,30 +1320,34 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             const int ncand = __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
             x2_sync();
             const int nbn = dmm ? min(W, ncand) : 0;
+            int nf[F_COUNT];
+#pragma unroll
+            for (int f = 0; f < F_COUNT; ++f) nf[f] = 0;
             if (s < nbn) {
                 const int e = h.sel[s];
                 if (e < nb) {
 #pragma unroll
-                    for (int f = 0; f < F_COUNT; ++f) h.nx[f][s] = h.e[f][e];
+                    for (int f = 0; f < F_COUNT; ++f) nf[f] = h.e[f][e];
                 } else {  // a child enters the beam
                     const int p = h.e[F_PSLOT][e];
-                    h.nx[F_ID][s] = h.e[F_ID][e]; h.nx[F_ROW][s] = h.e[F_ROW][e]; h.nx[F_PSLOT][s] = PS_FROZEN;
-                    h.nx[F_SYM][s] = sym_pack(sym_last(h.e[F_SYM][e]), sym_last(h.e[F_SYM][p]), false);
-                    h.nx[F_PAR][s] = h.e[F_ID][p]; h.nx[F_GPAR][s] = h.e[F_PAR][p];
-                    h.nx[F_PROW][s] = h.e[F_ROW][p]; h.nx[F_DEPTH][s] = h.e[F_DEPTH][p] + 1;
-                    h.nx[F_FC][s] = h.e[F_FC][e]; h.nx[F_CROW][s] = h.e[F_CROW][e];
+                    nf[F_ID] = h.e[F_ID][e]; nf[F_ROW] = h.e[F_ROW][e]; nf[F_PSLOT] = PS_FROZEN;
+                    nf[F_SYM] = sym_pack(sym_last(h.e[F_SYM][e]), sym_last(h.e[F_SYM][p]), false);
+                    nf[F_PAR] = h.e[F_ID][p]; nf[F_GPAR] = h.e[F_PAR][p];
+                    nf[F_PROW] = h.e[F_ROW][p]; nf[F_DEPTH] = h.e[F_DEPTH][p] + 1;
+                    nf[F_FC] = h.e[F_FC][e]; nf[F_CROW] = h.e[F_CROW][e];
                 }
             }
-            x2_sync();
+            x2_sync();  // every lane has read its source slot before any slot is overwritten
             if (s < nbn) {
 #pragma unroll
-                for (int f = 0; f < F_COUNT; ++f) h.e[f][s] = h.nx[f][s];
+                for (int f = 0; f < F_COUNT; ++f) h.e[f][s] = nf[f];
             }
             x2_sync();
             if (s < nbn) {  // parent's slot in the new beam; its row is where its values are written from now on
-                const int par = h.e[F_PAR][s];
+                const int par = nf[F_PAR];
                 int bp = -1;
-                for (int i = 0; i < nbn; ++i) if (h.e[F_ID][i] == par) bp = i;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (i < nbn && h.e[F_ID][i] == par) bp = i;
                 h.bps[s] = bp;
                 if (bp >= 0) h.e[F_PROW][s] = h.e[F_ROW][bp];
             }
