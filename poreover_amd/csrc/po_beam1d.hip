@@ -134,13 +134,22 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     int Wc = A;  // beam size entering step 1 (all root children; the first prune is at t = 1)
     __syncthreads();
 
+    // y[t] is loaded one step ahead: a load issued at the top of a step would be waited for right away, and
+    // (vmcnt counts in order) together with every arena store of the previous step
+    double yn[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) yn[c] = (c < C && T > 1) ? yr0[(int64_t)C + c] : 0.0;
     for (int t = 1; t < T; ++t) {
         const Table P = cur ? T1 : T0;
         const Table Q = cur ? T0 : T1;
         const bool first = (t == 1);
         double yr[CMAX];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) yr[c] = (c < C) ? yr0[(int64_t)t * C + c] : 0.0;
+        for (int c = 0; c < CMAX; ++c) yr[c] = yn[c];
+        if (t + 1 < T) {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) yn[c] = (c < C) ? yr0[(int64_t)(t + 1) * C + c] : 0.0;
+        }
 
         // ---- phase 1: beam slots
         bool need = false;
@@ -156,9 +165,12 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 par = P.par[s]; gpar = P.gpar[s]; plast = P.plast[s]; last = P.last[s];
                 if (par == 0) pslot = -1;
                 else {
+#pragma unroll 4
                     for (int i = 0; i < Pnb; ++i) if (P.id[i] == par) pslot = i;
-                    if (pslot < 0)
+                    if (pslot < 0) {
+#pragma unroll 4
                         for (int i = 0; i < Pnb; ++i) if (P.id[i] == gpar) pslot = Pnb + A * i + plast;
+                    }
                 }
             }
             double sp[3], pp[3], out[3];
@@ -209,6 +221,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             const int x = Q.fc[j] + c, sj = sel[j];
             int slot = -2, fcx = isnew[j] ? -1 : -2;
             if (!isnew[j] && !first) {
+#pragma unroll 4
                 for (int i = 0; i < Pnb; ++i) if (P.id[i] == x) slot = i;
                 if (slot < 0 && sj < Pnb) slot = Pnb + A * sj + c;
             }
@@ -228,6 +241,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             int d = 0;
             if (s >= Wc) {
                 const int x = Q.id[s];
+#pragma unroll 4
                 for (int j = 0; j < Wc; ++j) d |= (Q.id[j] == x);
             }
             dup[s] = d;
@@ -241,6 +255,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 const double sc = Q.val[s];
                 const int id = Q.id[s];
                 int rank = 0;
+#pragma unroll 8
                 for (int o = 0; o < NCc; ++o)
                     if (!dup[o] && po_better(Q.val[o], Q.id[o], sc, id)) rank++;
                 if (rank < W) nsel[rank] = s;
