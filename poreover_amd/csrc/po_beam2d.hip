@@ -479,9 +479,11 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             const int par = sm.e[F_PAR][j];
             if (par == 0) return PS_ROOT;
             int ps = PS_FROZEN;
+#pragma unroll 4
             for (int i = 0; i < nbm; ++i) if (sm.e[F_ID][i] == par) ps = i;
             if (ps < 0 && with_children) {
                 const int gp = sm.e[F_GPAR][j];
+#pragma unroll 4
                 for (int i = 0; i < nbm; ++i) if (sm.e[F_ID][i] == gp) ps = nbm + A * i + sym_plast(sm.e[F_SYM][j]);
             }
             return ps;
@@ -593,8 +595,10 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 int d = 0;
                 const int x = sm.e[F_ID][tid];
                 if (regular) {
-                    if (tid >= nb)
+                    if (tid >= nb) {
+#pragma unroll 4
                         for (int j = 0; j < nb; ++j) d |= (sm.e[F_ID][j] == x);
+                    }
                 } else {
                     for (int j = 0; j < tid; ++j) d |= (sm.e[F_ID][j] == x);
                 }
@@ -606,6 +610,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 const double sc = sm.score[tid];
                 const int id = sm.e[F_ID][tid];
                 int rank = 0;
+#pragma unroll 8
                 for (int o = 0; o < ne; ++o)
                     if (!sm.dup[o] && po_better(sm.score[o], sm.e[F_ID][o], sc, id)) rank++;
                 if (rank < W) sm.sel[rank] = tid;
