@@ -749,7 +749,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
 }
 
 // =================================================================================================
-// row_col with an envelope, W <= 6: TWO PAIRS PER WAVE (beam2d_x2_kernel).
+// row_col with an envelope, W <= 6, any tree model: TWO PAIRS PER WAVE (beam2d_x2_kernel).
 //
 // With one pair per wave and lane = (read, slot), a step costs max(len0, len1) iterations and at most
 // 25 + 25 of 64 lanes work; the per-step bookkeeping (expansion, prune) uses <= 30 lanes.  Here a
@@ -1475,28 +1475,30 @@ struct X2Geom {
 constexpr int X2_FB_BLOCKS = 256;  // workgroups of the beam2d_kernel pass over deferred pairs
 bool x2_eligible(int W, int model, int method) {
     static const bool legacy = getenv("PO_B2_LEGACY") != nullptr;  // A/B switch: always use beam2d_kernel
-    return !legacy && method == PO_METHOD_ROW_COL && W <= 6 && model == PO_MODEL_CTC;
+    (void)model;  // all three tree models (the 3-value ones run 2 waves per SIMD: +8 % / +13 % over beam2d_kernel)
+    return !legacy && method == PO_METHOD_ROW_COL && W <= 6;
 }
-int x2_blocks_per_cu() {
-    static int per_cu = 0;
-    if (!per_cu) {
+int x2_blocks_per_cu(int model) {
+    static int per_cu[3] = {0, 0, 0};
+    const int mi = model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2);
+    if (!per_cu[mi]) {
         int nblk = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_x2_kernel<PO_MODEL_CTC>, 64, 0) != hipSuccess ||
-            nblk <= 0)
-            nblk = 8;
+        const void* fn = mi == 0 ? (const void*)beam2d_x2_kernel<PO_MODEL_CTC>
+                                 : (mi == 1 ? (const void*)beam2d_x2_kernel<PO_MODEL_MERGE> : (const void*)beam2d_x2_kernel<PO_MODEL_FLIPFLOP>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, 64, 0) != hipSuccess || nblk <= 0) nblk = 8;
         if (const char* e = getenv("PO_X2_PER_CU")) {  // experiment knob: fewer resident workgroups per CU
             const int v = atoi(e);
             if (v > 0 && v < nblk) nblk = v;
         }
-        per_cu = nblk;
+        per_cu[mi] = nblk;
     }
-    return per_cu;
+    return per_cu[mi];
 }
-X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W) {
+X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model) {
     X2Geom g;
-    g.blocks = b2_num_cus() * x2_blocks_per_cu();
+    g.blocks = b2_num_cus() * x2_blocks_per_cu(model);
     if (g.blocks > (n + 1) / 2) g.blocks = n > 1 ? (n + 1) / 2 : 1;
-    g.pool_bytes = al256((size_t)4 << 20);
+    g.pool_bytes = al256((size_t)(model == PO_MODEL_CTC ? 4 : 8) << 20);
     const int64_t WM = W > PO_A ? W : PO_A;
     g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 1));
     size_t o = 0;
@@ -1508,7 +1510,7 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.off_pool = o; o += g.pool_bytes * 2 * g.blocks;
     g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * 2 * g.blocks);
     g.off_fb = o;
-    g.fb_bytes = b2_geometry(n, mr1, mr2, W, PO_MODEL_CTC, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
+    g.fb_bytes = b2_geometry(n, mr1, mr2, W, model, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
     o += al256(g.fb_bytes);
     g.total = o + 256;
     return g;
@@ -1529,7 +1531,7 @@ void b2_launch_w(const B2Geom& g, const B2Args& a, hipStream_t stream) {
 extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, int W,
                                           int model, int method) {
     (void)C;
-    if (x2_eligible(W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W).total;
+    if (x2_eligible(W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total;
 }
 
@@ -1632,7 +1634,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
     if (!env && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // the reference routes these to grid
     if ((model == PO_MODEL_FLIPFLOP) ? (C != 2 * A) : (C != A + 1)) return PO_E_ARG;
     if (x2_eligible(W, model, method)) {
-        const X2Geom g = x2_geometry(n, tr1, tr2, mr1, mr2, W);
+        const X2Geom g = x2_geometry(n, tr1, tr2, mr1, mr2, W, model);
         if (ws_bytes < g.total) return PO_E_CAP;
         char* w = (char*)ws;
         X2Args a;
@@ -1656,8 +1658,17 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
         if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * 2 * g.blocks, stream) != hipSuccess) return PO_E_HIP;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);  // 2 ints per column: <= 48 KB of LDS
-        hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), sizeof(int) * 2 * (size_t)a.pre_vcols, stream, a);
-        hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_CTC>, dim3(g.blocks), dim3(64), 0, stream, a);
+        const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
+        if (model == PO_MODEL_CTC) {
+            hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
+            hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_CTC>, dim3(g.blocks), dim3(64), 0, stream, a);
+        } else if (model == PO_MODEL_MERGE) {
+            hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(256), plds, stream, a);
+            hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_MERGE>, dim3(g.blocks), dim3(64), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(256), plds, stream, a);
+            hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_FLIPFLOP>, dim3(g.blocks), dim3(64), 0, stream, a);
+        }
 #ifdef PO_B2_TIMING
         {
             long long hh[12];
