@@ -788,26 +788,30 @@ struct X2Args {
     long long* dbg;
     int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
     int pre_vcols;                    // pre-pass: columns its LDS table holds
+    int ngl;                          // row groups the main kernel tracks per pair
     unsigned long long* upd_count;    // optional (po_profile_update_counter): total update_prob evaluations
 };
 
-template <int K>
+// SG = lanes (element slots) per pair: 32 -> two pairs per wave (W <= 6), 64 -> one pair per wave (W <= 12)
+template <int K, int SG>
 struct X2Half {
-    int e[F_COUNT][32];
-    int bps[8];              // beam slot -> slot of its parent in the beam, or -1
-    int sel[8];
-    int newfc[8];
-    int dup[32];
-    int g_owner[X2_NGL], g_hi0[X2_NGL], g_hi1[X2_NGL];
+    static constexpr int WB = (SG == 32) ? 6 : 12;   // beam slots
+    static constexpr int NGL = (SG == 32) ? X2_NGL : 2 * X2_NGL;  // row groups tracked per pair
+    int e[F_COUNT][SG];
+    int bps[16];             // beam slot -> slot of its parent in the beam, or -1
+    int sel[16];
+    int newfc[16];
+    int dup[SG];
+    int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[8];
-    double score[32];
-    double xch[2][32][K];
+    double score[SG];
+    double xch[2][SG][K];
     double ybuf[X2_YD];      // the y rows of the current step's windows
     unsigned long long nupd; // profiling: update_prob evaluations
 };
-template <int K>
+template <int K, int SG>
 struct X2Smem {
-    X2Half<K> h[2];
+    X2Half<K, SG> h[64 / SG];
     PoLaeTables lae;
 };
 __device__ __forceinline__ void x2_sync() { b2_sync_lds<64>(); }
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             const long long need = 1 + A + (long long)A * max(W, A) * ((long long)min(U, V) + 1);
             if (need > a.arena_cap || need >= (1 << 24)) st = PO_E_NOMEM;
             // too few row groups for this window width here, or (test hook) odd pairs: beam2d_kernel takes it
-            else if (min((long long)X2_NGL, ng) < 8 * max(W, PO_A) || (a.defer_odd && (pi & 1))) R = X2_DEFERRED;
+            else if (min((long long)a.ngl, ng) < 8 * max(W, PO_A) || (a.defer_odd && (pi & 1))) R = X2_DEFERRED;
         }
     }
     // blank prefix sums = the CTC root's alpha (PrefixTree.h:509-515): serial in t so the rounding is the
@@ -914,15 +918,17 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
     if (tid == 0) a.meta[pi] = make_int2(st, R);
 }
 
-template <int MODEL>
+template <int MODEL, int SG>
 __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
     constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
+    constexpr int NPW = 64 / SG;                 // pairs per wave
+    constexpr int WB = X2Half<K, SG>::WB, HNGL = X2Half<K, SG>::NGL;
     using Ent = Entry<K>;
-    __shared__ X2Smem<K> sm;
-    const int lane = threadIdx.x, g = lane >> 5, s = lane & 31;
-    X2Half<K>& h = sm.h[g];
+    __shared__ X2Smem<K, SG> sm;
+    const int lane = threadIdx.x, g = lane / SG, s = lane & (SG - 1);
+    X2Half<K, SG>& h = sm.h[g];
     const int A = a.A, W = a.W, C = a.C;
-    const int hid = blockIdx.x * 2 + g;
+    const int hid = blockIdx.x * NPW + g;
     Ent* const pool = (Ent*)(a.pool + (size_t)hid * a.pool_bytes);
     const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
     int* const apl = a.arena + (size_t)hid * 3 * a.arena_cap;
@@ -991,7 +997,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
         if (!have && !done) {
             int p = 0;
             if (s == 0) p = atomicAdd(a.queue, 1);
-            p = __shfl(p, lane & 32);
+            p = __shfl(p, lane & ~(SG - 1));
             if (p >= a.n) {
                 done = true;
             } else {
@@ -1013,11 +1019,11 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                     env2 = (const int2*)(a.env + 2 * o1);
                     envt2 = (const int2*)(a.envt + 2 * (o2 - a.y2_off[0]));
                     R = m.y; Rm = R - 1;
-                    NG = (int)min((long long)X2_NGL, pool_entries / ((long long)PO_A * 2 * R));
+                    NG = (int)min((long long)HNGL, pool_entries / ((long long)PO_A * 2 * R));
                     st = PO_OK; u = 0; v = 0;
                     er = env2[0]; ec = envt2[0];
                     er_n = env2[min(1, U - 1)]; ec_n = envt2[min(1, V - 1)];
-                    for (int q = s; q < X2_NGL; q += 32) { h.g_owner[q] = -1; h.g_hi0[q] = 0; h.g_hi1[q] = 0; }
+                    for (int q = s; q < HNGL; q += SG) { h.g_owner[q] = -1; h.g_hi0[q] = 0; h.g_hi1[q] = 0; }
                     x2_sync();
                     // root = node 0; its A children = nodes 1..A in row group 0 (BeamSearch.h:286-293)
                     if (s == 0) {
@@ -1175,7 +1181,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
         {
             const int len0 = dmm ? ece - u : 0, len1 = dmm ? ere - v : 0;
             const int tot = len0 + len1;
-            const int Ltot = max(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 32));
+            const int Ltot = max(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 64 - SG));
             const bool part = s < ne;
             int pslot = PS_ROOT, sym = 0;
             bool same = false, rootpar = false;
@@ -1221,7 +1227,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
 #ifdef X2_SHFL
             // parent's value of the previous iteration, handed over lane to lane (ds_bpermute) instead of
             // through an LDS write + read
-            const int psrc = (lane & 32) + (pslot >= 0 ? pslot : s);
+            const int psrc = (lane & ~(SG - 1)) + (pslot >= 0 ? pslot : s);
             double ppn[K];
 #pragma unroll
             for (int q = 0; q < K; ++q) ppn[q] = __shfl(self[q], psrc);
@@ -1237,11 +1243,11 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                 const int ka1 = min(kend, len0);                 // read-0 iterations [k0, ka1)
                 const int nA = max(0, ka1 - k0) * C;
                 const double* srcA = yA + (int64_t)(u + k0) * C;
-                for (int i = s; i < nA; i += 32) h.ybuf[i] = srcA[i];
+                for (int i = s; i < nA; i += SG) h.ybuf[i] = srcA[i];
                 const int kb0 = max(k0, len0);                   // read-1 iterations [kb0, kend)
                 const int nB = max(0, kend - kb0) * C;
                 const double* srcB = yB + (int64_t)(v + kb0 - len0) * C;
-                for (int i = s; i < nB; i += 32) h.ybuf[nA + i] = srcB[i];
+                for (int i = s; i < nB; i += SG) h.ybuf[nA + i] = srcB[i];
             }
             x2_sync();
             TK(4);  // scan: seeds + y window copy
@@ -1308,7 +1314,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             if (s < ne && s >= nb) {
                 const int x = h.e[F_ID][s];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) d |= (j < nb && h.e[F_ID][j] == x);
+                for (int j = 0; j < WB; ++j) d |= (j < nb && h.e[F_ID][j] == x);
             }
             h.dup[s] = (s < ne) ? d : 1;
             x2_sync();
@@ -1317,12 +1323,12 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                 const double sc = h.score[s];
                 const int id = h.e[F_ID][s];
 #pragma unroll 8
-                for (int o = 0; o < 32; ++o)
+                for (int o = 0; o < SG; ++o)
                     if (!h.dup[o] && po_better(h.score[o], h.e[F_ID][o], sc, id)) rank++;
                 if (rank < W) h.sel[rank] = s;
             }
             const unsigned long long cand = __ballot(s < ne && !d);
-            const int ncand = __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
+            const int ncand = (SG == 64) ? __popcll(cand) : __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
             x2_sync();
             const int nbn = dmm ? min(W, ncand) : 0;
             int nf[F_COUNT];
@@ -1352,7 +1358,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                 const int par = nf[F_PAR];
                 int bp = -1;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) if (i < nbn && h.e[F_ID][i] == par) bp = i;
+                for (int i = 0; i < WB; ++i) if (i < nbn && h.e[F_ID][i] == par) bp = i;
                 h.bps[s] = bp;
                 if (bp >= 0) h.e[F_PROW][s] = h.e[F_ROW][bp];
             }
@@ -1468,36 +1474,52 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
 
 // ---- two-pairs-per-wave path (row_col, envelope, W <= 6, one-value model)
 struct X2Geom {
-    int blocks;
+    int blocks, npw;
     size_t pool_bytes, arena_cap;
     size_t off_queue, off_meta, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
 };
 constexpr int X2_FB_BLOCKS = 256;  // workgroups of the beam2d_kernel pass over deferred pairs
-bool x2_eligible(int W, int model, int method) {
+bool x2_eligible(int n, int W, int model, int method) {
     static const bool legacy = getenv("PO_B2_LEGACY") != nullptr;  // A/B switch: always use beam2d_kernel
     (void)model;  // all three tree models (the 3-value ones run 2 waves per SIMD: +8 % / +13 % over beam2d_kernel)
-    return !legacy && method == PO_METHOD_ROW_COL && W <= 6;
+    if (legacy || method != PO_METHOD_ROW_COL) return false;
+    if (W <= 6) return true;   // two pairs per wave
+    // 7 <= W <= 12: one pair per wave with the reads one after the other.  More pairs in flight but a longer
+    // per-pair latency than beam2d_kernel's two waves per pair: +3 % on batches of several rounds, -15 % on
+    // one round — used for large batches only (PO_X2_WIDE forces it, for the tests)
+    return W <= 12 && (n >= 8192 || getenv("PO_X2_WIDE") != nullptr);
 }
-int x2_blocks_per_cu(int model) {
-    static int per_cu[3] = {0, 0, 0};
-    const int mi = model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2);
-    if (!per_cu[mi]) {
+template <int MODEL>
+void x2_launch(const X2Args& a, int n, int W, int blocks, size_t plds, hipStream_t stream) {
+    hipLaunchKernelGGL(beam2d_prepass_kernel<MODEL>, dim3(n), dim3(256), plds, stream, a);
+    if (W <= 6) hipLaunchKernelGGL((beam2d_x2_kernel<MODEL, 32>), dim3(blocks), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((beam2d_x2_kernel<MODEL, 64>), dim3(blocks), dim3(64), 0, stream, a);
+}
+template <int MODEL>
+const void* x2_fn(int W) {
+    return W <= 6 ? (const void*)beam2d_x2_kernel<MODEL, 32> : (const void*)beam2d_x2_kernel<MODEL, 64>;
+}
+int x2_blocks_per_cu(int model, int W) {
+    static int per_cu[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    const int mi = model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2), wi = W <= 6 ? 0 : 1;
+    if (!per_cu[mi][wi]) {
         int nblk = 0;
-        const void* fn = mi == 0 ? (const void*)beam2d_x2_kernel<PO_MODEL_CTC>
-                                 : (mi == 1 ? (const void*)beam2d_x2_kernel<PO_MODEL_MERGE> : (const void*)beam2d_x2_kernel<PO_MODEL_FLIPFLOP>);
+        const void* fn = mi == 0 ? x2_fn<PO_MODEL_CTC>(W) : (mi == 1 ? x2_fn<PO_MODEL_MERGE>(W) : x2_fn<PO_MODEL_FLIPFLOP>(W));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, 64, 0) != hipSuccess || nblk <= 0) nblk = 8;
         if (const char* e = getenv("PO_X2_PER_CU")) {  // experiment knob: fewer resident workgroups per CU
             const int v = atoi(e);
             if (v > 0 && v < nblk) nblk = v;
         }
-        per_cu[mi] = nblk;
+        per_cu[mi][wi] = nblk;
     }
-    return per_cu[mi];
+    return per_cu[mi][wi];
 }
 X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model) {
     X2Geom g;
-    g.blocks = b2_num_cus() * x2_blocks_per_cu(model);
-    if (g.blocks > (n + 1) / 2) g.blocks = n > 1 ? (n + 1) / 2 : 1;
+    const int npw = W <= 6 ? 2 : 1;  // pairs per wave
+    g.npw = npw;
+    g.blocks = b2_num_cus() * x2_blocks_per_cu(model, W);
+    if (g.blocks > (n + npw - 1) / npw) g.blocks = n > 1 ? (n + npw - 1) / npw : 1;
     g.pool_bytes = al256((size_t)(model == PO_MODEL_CTC ? 4 : 8) << 20);
     const int64_t WM = W > PO_A ? W : PO_A;
     g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 1));
@@ -1507,8 +1529,8 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.off_envt = o; o += al256(sizeof(int) * 2 * (size_t)tr2);
     g.off_cum1 = o; o += al256(sizeof(double) * (size_t)tr1);
     g.off_cum2 = o; o += al256(sizeof(double) * (size_t)tr2);
-    g.off_pool = o; o += g.pool_bytes * 2 * g.blocks;
-    g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * 2 * g.blocks);
+    g.off_pool = o; o += g.pool_bytes * npw * g.blocks;
+    g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * npw * g.blocks);
     g.off_fb = o;
     g.fb_bytes = b2_geometry(n, mr1, mr2, W, model, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
     o += al256(g.fb_bytes);
@@ -1531,7 +1553,7 @@ void b2_launch_w(const B2Geom& g, const B2Args& a, hipStream_t stream) {
 extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, int W,
                                           int model, int method) {
     (void)C;
-    if (x2_eligible(W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
+    if (x2_eligible(n, W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total;
 }
 
@@ -1633,7 +1655,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
     if (method != PO_METHOD_ROW_COL && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // grid: not on the GPU yet
     if (!env && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // the reference routes these to grid
     if ((model == PO_MODEL_FLIPFLOP) ? (C != 2 * A) : (C != A + 1)) return PO_E_ARG;
-    if (x2_eligible(W, model, method)) {
+    if (x2_eligible(n, W, model, method)) {
         const X2Geom g = x2_geometry(n, tr1, tr2, mr1, mr2, W, model);
         if (ws_bytes < g.total) return PO_E_CAP;
         char* w = (char*)ws;
@@ -1656,19 +1678,13 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.dbg = dbg_x2;
 #endif
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-        if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * 2 * g.blocks, stream) != hipSuccess) return PO_E_HIP;
+        if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.npw * g.blocks, stream) != hipSuccess) return PO_E_HIP;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);  // 2 ints per column: <= 48 KB of LDS
         const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
-        if (model == PO_MODEL_CTC) {
-            hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
-            hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_CTC>, dim3(g.blocks), dim3(64), 0, stream, a);
-        } else if (model == PO_MODEL_MERGE) {
-            hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(256), plds, stream, a);
-            hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_MERGE>, dim3(g.blocks), dim3(64), 0, stream, a);
-        } else {
-            hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(256), plds, stream, a);
-            hipLaunchKernelGGL(beam2d_x2_kernel<PO_MODEL_FLIPFLOP>, dim3(g.blocks), dim3(64), 0, stream, a);
-        }
+        a.ngl = (W <= 6) ? X2_NGL : 2 * X2_NGL;
+        if (model == PO_MODEL_CTC) x2_launch<PO_MODEL_CTC>(a, n, W, g.blocks, plds, stream);
+        else if (model == PO_MODEL_MERGE) x2_launch<PO_MODEL_MERGE>(a, n, W, g.blocks, plds, stream);
+        else x2_launch<PO_MODEL_FLIPFLOP>(a, n, W, g.blocks, plds, stream);
 #ifdef PO_B2_TIMING
         {
             long long hh[12];

@@ -82,6 +82,24 @@ def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
         [oracle.cpp_beam_search_2d(y1, y2, env, 3, method_="row_col")]
 
 
+@pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
+def test_rowcol_wide_beam_one_pair_per_wave(eng, oracle, monkeypatch, model, ff):
+    """7 <= W <= 12 on large batches runs beam2d_x2_kernel with one pair per wave (PO_X2_WIDE forces that path
+    for a small batch); same strings as the oracle and as beam2d_kernel"""
+    kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
+    y1s, y2s, envs = [], [], []
+    for i in range(5):
+        y1, y2 = synth_pair(4400 + i, T=280 + 70 * i, flipflop=ff)
+        y1s.append(y1); y2s.append(y2)
+        envs.append(oracle.pair_decode(y1, y2, kind, 5, "row_col")["envelope"])
+    for W in (7, 10, 12):
+        want = [oracle.cpp_beam_search_2d(a, b, e, W, model_=model, method_="row_col") for a, b, e in zip(y1s, y2s, envs)]
+        assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want
+        monkeypatch.setenv("PO_X2_WIDE", "1")
+        assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want, W
+        monkeypatch.delenv("PO_X2_WIDE")
+
+
 def test_rowcol_full_size(eng, oracle):
     """BASELINE config 3: pairs of T ~ 4000 reads, W = 5 (CLI default) and W = 10"""
     y1s, y2s, envs = [], [], []
