@@ -40,6 +40,7 @@
 //     per beam-width class (W <= 6 / 12 / 25 -> 64 / 128 / 256 threads).  Workgroups are persistent
 //     and pull pairs from an atomic queue.
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -800,7 +801,8 @@ struct X2Half {
     int e[F_COUNT][SG];
     int bps[16];             // beam slot -> slot of its parent in the beam, or -1
     int sel[16];
-    int newfc[16];
+    int newfc[16];           // bit 0: children created in this step; bit 1: children got a new row group
+    int stay[16];            // beam slot was a beam slot in the previous main step (so its children were elements)
     int dup[SG];
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[8];
@@ -919,7 +921,7 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
 }
 
 template <int MODEL, int SG>
-__global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
+__global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2_kernel(X2Args a) {
     constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
     constexpr int NPW = 64 / SG;                 // pairs per wave
     constexpr int WB = X2Half<K, SG>::WB, HNGL = X2Half<K, SG>::NGL;
@@ -1032,7 +1034,9 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                         h.sh[2] = 1 + A;  // next node id
                         h.sh[3] = 1;      // group allocation cursor
                         h.sh[4] = PO_OK;
+                        h.sh[5] = INT_MIN; h.sh[6] = INT_MIN;  // window ends of the previous main step: none yet
                     }
+                    if (s < 16) h.stay[s] = 0;
                     if (s < A) {
                         apl[1 + s] = po_pack_node(0, s); afc[1 + s] = -1; acrow[1 + s] = -1;
                         h.e[F_ID][s] = 1 + s; h.e[F_ROW][s] = s; h.e[F_PROW][s] = -1; h.e[F_PAR][s] = 0;
@@ -1133,7 +1137,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                 } else if (h.e[F_CROW][j] < 0 || h.e[F_CROW][j] >= NG || h.g_owner[h.e[F_CROW][j]] != id) {
                     need_group = true;  // its old rows were recycled: every value in them was dead
                 }
-                h.newfc[j] = isnew;
+                h.newfc[j] = isnew | (need_group ? 2 : 0);
                 if (need_group) {
                     const int gg = alloc_group(id, lo0, lo1);
                     h.e[F_CROW][j] = gg;
@@ -1170,7 +1174,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                 h.e[F_ID][s] = id; h.e[F_ROW][s] = h.e[F_CROW][j] * PO_A + c;
                 h.e[F_SYM][s] = sym_pack(c, sym_last(h.e[F_SYM][j]), false);
                 h.e[F_PSLOT][s] = j;
-                if (!h.newfc[j]) { my_fc = afc[id]; my_cr = acrow[id]; }
+                if (!(h.newfc[j] & 1)) { my_fc = afc[id]; my_cr = acrow[id]; }
             }
         }
         x2_sync();
@@ -1208,6 +1212,20 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) h.xch[1][s][k] = self[k];
             }
+            // Redundant stores.  An element that was an element in the previous main step too recomputes, over
+            // the part of its window that step already covered, exactly the bits that are stored — IF every
+            // ancestor of it inside the element set is in the same situation (same seed, same parent values,
+            // same y).  Beam nodes always come out of the previous step's element set; children were elements
+            // iff their parent was a beam node then and kept its row group.  "bad" marks the others and is
+            // pushed down the parent links; everyone else only stores from the previous window end on.
+            bool bad = false;
+            if (part && s >= nb) { const int j = pslot; bad = !(h.stay[j] && h.newfc[j] == 0); }
+            for (int round = 0; round < WB + 1; ++round) {
+                const unsigned long long bm = __ballot(bad);
+                const unsigned long long hm = (SG == 64) ? bm : (g ? (bm >> 32) : (bm & 0xffffffffull));
+                if (part && pslot >= 0 && ((hm >> pslot) & 1ull)) bad = true;
+            }
+            int sfrom = bad ? INT_MIN : h.sh[5];        // first time whose value must be written (current read)
             const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
             int t = u;                                  // time of the current iteration
             const double* cump = cumA;                  // fetch context of a non-moving parent: root sums, next time
@@ -1257,6 +1275,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                 if (part && k < tot) {
                     if (k == len0) {  // read 0's window is done: continue on read 1 from its seed
                         mx0 = mx; mx = PO_NEG_INF; t = v; myrow = row1;
+                        sfrom = bad ? INT_MIN : h.sh[6];
 #pragma unroll
                         for (int q = 0; q < K; ++q) self[q] = self1[q];
                     }
@@ -1280,11 +1299,17 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
                         fetch();
                     }
                     po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
-                    Ent e;
-                    e.tag = tag0 + (unsigned)t;
+#ifdef PO_ABL_NOSTORE   // timing ablation only (results are wrong)
+                    if (out[0] == 12345.678) pool[0].tag = 1;
+#else
+                    if (t >= sfrom) {
+                        Ent e;
+                        e.tag = tag0 + (unsigned)t;
 #pragma unroll
-                    for (int q = 0; q < K; ++q) e.v[q] = out[q];
-                    myrow[t & Rm] = e;
+                        for (int q = 0; q < K; ++q) e.v[q] = out[q];
+                        myrow[t & Rm] = e;
+                    }
+#endif
                     const bool sw = (k + 1 == len0);  // the next iteration starts read 1: hand its seed over
 #ifdef X2_SHFL
 #pragma unroll
@@ -1301,7 +1326,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             TK(5);  // scan: iterations
             }
             if (part) h.score[s] = mx0 + mx;  // node_greater_max_sym: max over read 0 + max over read 1
-            if (part && s == 0) h.nupd += (unsigned)(ne * tot);
+            if (part && s == 0) { h.nupd += (unsigned)(ne * tot); h.sh[5] = ece; h.sh[6] = ere; }
             if (part && s >= nb) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
         }
         x2_sync();
@@ -1352,6 +1377,7 @@ __global__ __launch_bounds__(64) void beam2d_x2_kernel(X2Args a) {
             if (s < nbn) {
 #pragma unroll
                 for (int f = 0; f < F_COUNT; ++f) h.e[f][s] = nf[f];
+                h.stay[s] = (h.sel[s] < nb) ? 1 : 0;
             }
             x2_sync();
             if (s < nbn) {  // parent's slot in the new beam; its row is where its values are written from now on
