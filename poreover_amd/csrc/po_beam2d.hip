@@ -115,6 +115,9 @@ struct B2Smem {
     int e[F_COUNT][NCM];    // element table: slots [0, nb) are the beam nodes in rank order
     int nx[F_COUNT][WMAX];  // next beam under construction
     int sel[WMAX];
+    int stay[WMAX];         // beam slot was a beam slot in the previous main step (its children were elements then)
+    int cnew[WMAX];         // its children got new rows in this step
+    int badf[NCM];          // element may not skip redundant stores (see scan)
     int dup[NCM];
     // row groups tracked per pair: a step can open up to W new ones and a group lives for about a window
     static constexpr int NGL = (WMAX > 12) ? 768 : 256;
@@ -134,7 +137,7 @@ struct B2Smem {
 #define B2_THREADS(WM) ((WM) * (PO_A + 1) <= 32 ? 64 : ((WM) * (PO_A + 1) <= 64 ? 128 : 256))
 
 template <int MODEL, int WMAX>
-__global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
+__global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <= 12) ? 4 : 1)) void beam2d_kernel(B2Args a) {
     using SM = B2Smem<MODEL, WMAX>;
     constexpr int K = SM::K, NCM = SM::NCM, NCP = SM::NCP, nthr = 2 * NCP;
     using Ent = Entry<K>;
@@ -344,7 +347,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             sm.sh[2] = 1 + A;  // next node id
             sm.sh[3] = 1;      // group allocation cursor
             sm.sh[4] = PO_OK;
+            sm.sh[8] = INT_MIN; sm.sh[9] = INT_MIN;  // window ends of the previous row_col main step: none yet
         }
+        if (tid < WMAX) sm.stay[tid] = 0;
         if (tid < A) {
             apl[1 + tid] = po_pack_node(0, tid); afc[1 + tid] = -1; acrow[1 + tid] = -1;
             sm.e[F_ID][tid] = 1 + tid; sm.e[F_ROW][tid] = tid; sm.e[F_PROW][tid] = -1; sm.e[F_PAR][tid] = 0;
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
         // Every participating element advances over its window, parent values flowing through the
         // LDS exchange buffer.  t0x / lenx: window start / length on read x (len 0 = read untouched);
         // slots [skip_lo, skip_hi) do not move on read 0 (row method: beam nodes beyond the first W).
-        auto scan = [&](bool is_main, int nelem, int skip_lo, int skip_hi, int t00, int len0_, int t01, int len1_) {
+        auto scan = [&](bool is_main, bool reuse, int nelem, int skip_lo, int skip_hi, int t00, int len0_, int t01, int len1_) {
             // the window bounds come from (wave-uniform) vector loads: pin them to SGPRs so the iteration
             // loop is a scalar loop
             const int len0 = __builtin_amdgcn_readfirstlane(len0_), len1 = __builtin_amdgcn_readfirstlane(len1_);
@@ -406,6 +411,27 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                     ptag0 = make_tag(epoch, sm.e[F_PAR][s], 0);
                 }
             }
+            // Redundant stores (row_col main steps, `reuse`).  An element that was an element in the previous
+            // main step too recomputes, over the part of its window that step already covered, exactly the
+            // bits that are stored — if every ancestor of it inside the element set is in the same situation.
+            // Beam nodes always come out of the previous step's element set; children were elements iff their
+            // parent was a beam node then and kept its row group.  badf marks the others and is pushed down
+            // the parent links; everyone else only stores from the previous window end on.
+            bool bad = true;
+            if (reuse) {
+                bad = false;
+                if (s < nelem && s >= nb) bad = !(sm.stay[pslot] && !sm.cnew[pslot]);
+                if (r == 0 && s < nelem) sm.badf[s] = bad;
+                __syncthreads();
+                for (;;) {
+                    int changed = 0;
+                    if (s < nelem && !bad && pslot >= 0 && sm.badf[pslot]) { bad = true; changed = 1; }
+                    if (!__syncthreads_or(changed)) break;
+                    if (r == 0 && bad && s < nelem) sm.badf[s] = 1;
+                    __syncthreads();
+                }
+            }
+            const int sfrom = bad ? INT_MIN : sm.sh[8 + r];  // first time whose value must be written
             const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
             // The value at t-1 of a parent that does not move in this scan (frozen: from its ring row; root:
             // its closed form) is loaded one iteration ahead (rare).
@@ -456,11 +482,13 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
 #ifdef PO_ABL_NOSTORE   // timing ablation only (results are wrong): keeps the value live, skips the store
                     if (out[0] == 12345.678) pool[0].tag = 1;
 #else
-                    Ent e;
-                    e.tag = tag0 + (unsigned)t;
+                    if (t >= sfrom) {
+                        Ent e;
+                        e.tag = tag0 + (unsigned)t;
 #pragma unroll
-                    for (int q = 0; q < K; ++q) e.v[q] = out[q];
-                    myrow[t & Rm] = e;
+                        for (int q = 0; q < K; ++q) e.v[q] = out[q];
+                        myrow[t & Rm] = e;
+                    }
 #endif
 #pragma unroll
                     for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }
@@ -510,6 +538,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                     } else if (sm.e[F_CROW][j] < 0 || sm.e[F_CROW][j] >= NG || sm.g_owner[sm.e[F_CROW][j]] != id) {
                         need_group = true;  // its old rows were recycled: every value in them was dead
                     }
+                    sm.cnew[j] = need_group ? 1 : 0;
                     if (need_group) {
                         const int g = alloc_group(id, lo0, lo1, nb);
                         sm.e[F_CROW][j] = g;
@@ -619,6 +648,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
             }
             po_lds_barrier();
             const int nbn = min(W, sm.sh[5]);
+            if (tid < nbn) sm.stay[tid] = (regular && sm.sel[tid] < nb) ? 1 : 0;
             if (tid < nbn) {
                 const int e = sm.sel[tid];
                 if (e < nb) {
@@ -664,8 +694,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                     }
                     __syncthreads();  // store writes of earlier steps -> visible to this scan's reads
                     TK(6);
-                    if (cu_v) scan(false, nbe, 0, 0, 0, 0, v, 1);
-                    else scan(false, nbe, 0, 0, u, 1, 0, 0);
+                    if (cu_v) scan(false, false, nbe, 0, 0, 0, 0, v, 1);
+                    else scan(false, false, nbe, 0, 0, u, 1, 0, 0);
                     po_lds_barrier();
                     TKC(11);
                     if (cu_v) v++; else u++;
@@ -677,8 +707,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 __syncthreads();  // arena + store writes -> visible to the reads below
                 if (sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
                 TK(2);
-                scan(true, ne, 0, 0, u, ece - u, v, ere - v);
+                scan(true, true, ne, 0, 0, u, ece - u, v, ere - v);
                 po_lds_barrier();
+                if (tid == 0) { sm.sh[8] = ece; sm.sh[9] = ere; }
                 if (tid < ne) sm.score[tid] = sm.mxs[0][tid] + sm.mxs[1][tid];  // node_greater_max_sym
                 prune_and_advance(ne, true);
                 TK(1);
@@ -700,7 +731,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX)) void beam2d_kernel(B2Args a) {
                 // every element is updated on read 0 at time u except beam nodes beyond the first W
                 // (possible only in the first row, when W < |alphabet|): `for b < beam_width` (:132)
                 const int skip_lo = min(nproc, nb), skip_hi = nb;
-                scan(true, ne, skip_lo, skip_hi, u, 1, rs, wlen);
+                scan(true, false, ne, skip_lo, skip_hi, u, 1, rs, wlen);
                 po_lds_barrier();
                 if (tid < ne) {  // node_greater_max: last_prob[0] + max_prob[1]
                     const int id = sm.e[F_ID][tid];
