@@ -1542,9 +1542,10 @@ bool x2_eligible(int n, int W, int model, int method) {
     if (legacy || method != PO_METHOD_ROW_COL) return false;
     if (W <= 6) return true;   // two pairs per wave
     // 7 <= W <= 12: one pair per wave with the reads one after the other.  More pairs in flight but a longer
-    // per-pair latency than beam2d_kernel's two waves per pair: +3 % on batches of several rounds, -15 % on
-    // one round — used for large batches only (PO_X2_WIDE forces it, for the tests)
-    return W <= 12 && (n >= 8192 || getenv("PO_X2_WIDE") != nullptr);
+    // per-pair latency than beam2d_kernel's two waves per pair (W = 10: 10.3k vs 12.0k pairs/s at 1024 pairs,
+    // equal at 3328, 23.9k vs 20.3k at 6656, 28.0k vs 22.5k at 13312) — used from 4096 pairs up
+    // (PO_X2_WIDE forces it, for the tests)
+    return W <= 12 && (n >= 4096 || getenv("PO_X2_WIDE") != nullptr);
 }
 template <int MODEL>
 void x2_launch(const X2Args& a, int n, int W, int blocks, size_t plds, hipStream_t stream) {
