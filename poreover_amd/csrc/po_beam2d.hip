@@ -839,7 +839,10 @@ struct X2Half {
     int sh[8];
     double score[SG];
     double xch[2][SG][K];
-    double ybuf[X2_YD];      // the y rows of the current step's windows
+    // doubles in the y window buffer: 208 (41 rows of 5) for the two-pairs-per-wave one-value kernel, so that 12
+    // workgroups fit a CU's LDS; 256 (32 rows of 8) elsewhere (those kernels are register-bound anyway)
+    static constexpr int YD = (K == 1 && SG == 32) ? (X2_YD < 208 ? X2_YD : 208) : X2_YD;
+    double ybuf[YD];         // the y rows of the current step's windows
     unsigned long long nupd; // profiling: update_prob evaluations
 };
 template <int K, int SG>
@@ -1285,7 +1288,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
             // buffer row = iteration index).  With no vector-memory LOAD left in the iteration loop, the
             // wave never waits there for the acknowledgement of its value-store writes (vmcnt counts loads
             // and stores in order: waiting for any load also waits for every store issued before it).
-            const int yrows = X2_YD / C;  // iterations per buffer fill
+            const int yrows = X2Half<K, SG>::YD / C;  // iterations per buffer fill
             for (int k0 = 0; k0 < Ltot; k0 += yrows) {
             {
                 const int kend = min(tot, k0 + yrows);
