@@ -62,6 +62,19 @@ __device__ __forceinline__ void po_lae_tables_load(PoLaeTables* t, int tid, int 
 struct PoLaeOcml {
     __device__ __forceinline__ double operator()(double x1, double x2) const { return po_lae(x1, x2); }
 };
+// v_fma_f64 with the constant addend in an SGPR pair and a free destination.  hipcc selects the two-address
+// v_fmac_f64 for fma(x, p, c) and then copies the (loop-invariant) constant c into the destination first: one
+// v_mov_b64 per polynomial step in the hottest loop.  Same instruction, same result bits.  (With the constant in
+// a VGPR instead, register pressure costs a wave per SIMD in beam2d_kernel: -22 % at W = 10.)
+#ifndef PO_FMA_PLAIN
+__device__ __forceinline__ double po_fma_c(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+#else   // A/B switch: let the compiler pick the instruction
+__device__ __forceinline__ double po_fma_c(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#endif
 struct PoLaeFast {
     const PoLaeTables* t;
     // f(d) = log(1 + exp(d)), d <= 0 (d = NaN for (-inf) - (-inf): Log.h's log_(NaN) = -inf)
@@ -73,10 +86,10 @@ struct PoLaeFast {
             const int j = k & 63, m = k >> 6;
             double r = __builtin_fma(-kf, PO_LN2_64_HI, d);
             r = __builtin_fma(-kf, PO_LN2_64_LO, r);
-            double p = __builtin_fma(r, 1.0 / 720, 1.0 / 120);
-            p = __builtin_fma(r, p, 1.0 / 24);
-            p = __builtin_fma(r, p, 1.0 / 6);
-            p = __builtin_fma(r, p, 0.5);
+            double p = po_fma_c(r, 1.0 / 720, 1.0 / 120);
+            p = po_fma_c(r, p, 1.0 / 24);
+            p = po_fma_c(r, p, 1.0 / 6);
+            p = po_fma_c(r, p, 0.5);
             p = __builtin_fma(r * r, p, r);
             const double th = t->exp_t[j][0], tl = t->exp_t[j][1];
             e = ldexp(th + __builtin_fma(th, p, tl), m);
@@ -85,10 +98,10 @@ struct PoLaeFast {
         const int i = (int)rint((z - 1.0) * 64.0);
         const double rc = t->log_t[i][0], lh = t->log_t[i][1], ll = t->log_t[i][2];
         const double w = __builtin_fma(z, rc, -1.0);
-        double q = __builtin_fma(w, 1.0 / 7, -1.0 / 6);
-        q = __builtin_fma(w, q, 1.0 / 5);
-        q = __builtin_fma(w, q, -1.0 / 4);
-        q = __builtin_fma(w, q, 1.0 / 3);
+        double q = po_fma_c(w, 1.0 / 7, -1.0 / 6);
+        q = po_fma_c(w, q, 1.0 / 5);
+        q = po_fma_c(w, q, -1.0 / 4);
+        q = po_fma_c(w, q, 1.0 / 3);
         const double s = w * w;
         double u = __builtin_fma(s * w, q, ll);
         u = __builtin_fma(-0.5, s, u);
