@@ -38,6 +38,7 @@ struct PPArgs {
     const int32_t* st1; const int32_t* st2;         // status of the two 1-D decodes
     int padding, full_alignment, diagonal_envelope, diagonal_width;
     int band;                                       // banded alignment half-width (align.pyx:13: 500)
+    long long seq_lds_cap;                          // bytes of dynamic LDS per basecall (0: read them from global memory)
     int mode;                                       // 0: align + skips + envelope; 1: align only; 2: envelope from a given alignment
     const int32_t* lenU; const int32_t* lenV;       // mode 2: U_i, V_i given explicitly (y*_off unused)
     const int64_t* map1_off; const int64_t* map2_off;  // mode 2: offsets of the frame maps
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
     // the DP row just filled, for the next row's reads: the fill never reads the table back from HBM (a
     // store -> barrier -> load round trip per row); the table is only written, for the trace-back
     __shared__ int rowbuf[2][PERMAX * NT + 4];
+    extern __shared__ __attribute__((aligned(16))) char seq_lds[];  // 2 x a.seq_lds_cap bytes: the two basecalls
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* dp = a.dp + (size_t)blockIdx.x * a.dp_cap;
     int* r_start = a.rowinfo + (size_t)blockIdx.x * 4 * a.row_cap;
@@ -110,6 +112,12 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         __syncthreads();
         const int pi = sh[0];
         if (pi >= a.n) break;
+#ifdef PO_PP_TIMING
+        long long tk_[4] = {0, 0, 0, 0}, tl_ = wall_clock64();
+#define PPTK(i) do { const long long n_ = wall_clock64(); tk_[i] += n_ - tl_; tl_ = n_; } while (0)
+#else
+#define PPTK(i) do {} while (0)
+#endif
         const int64_t o1 = (a.mode == 2) ? a.map1_off[pi] : (a.mode == 1 ? 0 : a.y1_off[pi]);
         const int64_t o2 = (a.mode == 2) ? a.map2_off[pi] : (a.mode == 1 ? 0 : a.y2_off[pi]);
         const int U = (a.mode == 2) ? a.lenU[pi] : (a.mode == 1 ? 0 : (int)(a.y1_off[pi + 1] - o1));
@@ -135,6 +143,17 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             l2 = (int)(a.seq1d_off[2 * pi + 2] - a.seq1d_off[2 * pi + 1]);
         } else { l1 = a.len1[pi]; l2 = a.len2[pi]; }
         if (a.mode != 2) { s1 = a.seq1d + a.seq1d_off[2 * pi]; s2 = a.seq1d + a.seq1d_off[2 * pi + 1]; }
+        // both basecalls go to LDS once: the DP reads one character per cell and the trace-back two per step;
+        // from global memory each of those is a dependent round trip
+        if (a.mode != 2 && a.seq_lds_cap > 0 && l1 >= 0 && l2 >= 0 && l1 <= a.seq_lds_cap && l2 <= a.seq_lds_cap) {
+            char* ls1 = seq_lds;
+            char* ls2 = seq_lds + a.seq_lds_cap;
+            __syncthreads();
+            for (int i = tid; i < l1; i += NT) ls1[i] = s1[i];
+            for (int i = tid; i < l2; i += NT) ls2[i] = s2[i];
+            __syncthreads();
+            s1 = ls1; s2 = ls2;
+        }
         const int32_t* m1 = (a.mode == 1) ? nullptr : a.map1 + o1;
         const int32_t* m2 = (a.mode == 1) ? nullptr : a.map2 + o2;
         int st = PO_OK;
@@ -194,6 +213,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             return dp[r_off[i] + (j - r_start[i])];
         };
 
+        PPTK(0);  // setup + row geometry
         // ------------------------------------------------------------------ DP fill, row by row
         int ps = 0, pe = 0;  // computed cells [ps, pe) of the previous row (none before row 0)
         for (int i = 0; i < nrows; ++i) {
@@ -264,6 +284,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             continue;
         }
 
+        PPTK(1);  // fill
         // ------------------------------------------------------------------ trace-back (align.pyx:56-95 == :137-174)
         if (tid == 0) {
             int i = l1, j = l2, n = 0;
@@ -313,6 +334,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             continue;
         }
 
+        PPTK(2);  // trace-back + identity
         // ------------------------------------------------------------------ envelope (envelope.py:46-87)
         for (int u = tid; u < U; u += NT) { env[2 * u] = INT_MAX; env[2 * u + 1] = -1; }
         __syncthreads();
@@ -368,6 +390,10 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             __syncthreads();
         }
         if (tid == 0) { a.status[pi] = PO_OK; if (a.identity) a.identity[pi] = identity; }
+        PPTK(3);  // envelope
+#ifdef PO_PP_TIMING
+        if (tid == 0 && pi == 0) printf("[pp timing] pair 0: setup %lld fill %lld traceback %lld envelope %lld ticks (10 ns)\n", tk_[0], tk_[1], tk_[2], tk_[3]);
+#endif
     }
 }
 
@@ -383,9 +409,14 @@ void po_prof_stage(int kernel, hipStream_t s, int begin, void** tok);
 }
 
 namespace {
-void pp_launch(const PPArgs& a, int blocks, int one_wave, hipStream_t stream) {
-    if (one_wave) hipLaunchKernelGGL(pair_prep_kernel<64>, dim3(blocks), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(pair_prep_kernel<256>, dim3(blocks), dim3(256), 0, stream, a);
+void pp_launch(PPArgs a, int blocks, int one_wave, hipStream_t stream) {
+    // dynamic LDS for the two basecalls, when they fit (row_cap bounds their length)
+    long long cap = (a.mode == 2) ? 0 : ((a.row_cap + 15) & ~15LL);
+    if (cap > 24 * 1024) cap = 0;
+    a.seq_lds_cap = cap;
+    const size_t lds = (size_t)(2 * cap);
+    if (one_wave) hipLaunchKernelGGL(pair_prep_kernel<64>, dim3(blocks), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL(pair_prep_kernel<256>, dim3(blocks), dim3(256), lds, stream, a);
 }
 }  // namespace
 
