@@ -687,16 +687,21 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 const bool cu_u = !cu_v && (!col_ok && u < ecs);        // catch-up on read 0 (:328-336)
                 if (cu_v || cu_u) {
                     const int nbe = min(W, nb);  // the reference indexes b < beam_width
-                    if (tid < nbe) {
-                        sm.e[F_PSLOT][tid] = beam_parent(tid, nbe, false);
-                        if (cu_v) atomicMax(&sm.g_hi1[sm.e[F_ROW][tid] / PO_A], v + 1);
-                        else atomicMax(&sm.g_hi0[sm.e[F_ROW][tid] / PO_A], u + 1);
+                    // (node, t) of a beam node is already stored with these very bits when the last main step's
+                    // window on this read covered t (see the store-skipping note in scan): nothing to do then
+                    const bool need = cu_v ? (v >= sm.sh[9]) : (u >= sm.sh[8]);
+                    if (need) {
+                        if (tid < nbe) {
+                            sm.e[F_PSLOT][tid] = beam_parent(tid, nbe, false);
+                            if (cu_v) atomicMax(&sm.g_hi1[sm.e[F_ROW][tid] / PO_A], v + 1);
+                            else atomicMax(&sm.g_hi0[sm.e[F_ROW][tid] / PO_A], u + 1);
+                        }
+                        __syncthreads();  // store writes of earlier steps -> visible to this scan's reads
+                        TK(6);
+                        if (cu_v) scan(false, false, nbe, 0, 0, 0, 0, v, 1);
+                        else scan(false, false, nbe, 0, 0, u, 1, 0, 0);
+                        po_lds_barrier();
                     }
-                    __syncthreads();  // store writes of earlier steps -> visible to this scan's reads
-                    TK(6);
-                    if (cu_v) scan(false, false, nbe, 0, 0, 0, 0, v, 1);
-                    else scan(false, false, nbe, 0, 0, u, 1, 0, 0);
-                    po_lds_barrier();
                     TKC(11);
                     if (cu_v) v++; else u++;
                     continue;
@@ -1119,7 +1124,10 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 break;
             }
             const int rr = cu_v ? 1 : 0, t = cu_v ? v : u;
-            if (s < min(W, nb)) {  // the reference indexes b < beam_width
+            // Every beam node was an element of the last main step, whose window on this read covered t when
+            // t < its end: (node, t) is then already stored with exactly the bits this update would produce
+            // (same t-1 inputs, unchanged since) — nothing to do.
+            if (s < min(W, nb) && t >= h.sh[5 + rr]) {  // the reference indexes b < beam_width
                 const int node = h.e[F_ID][s], row = h.e[F_ROW][s], sy = h.e[F_SYM][s], par = h.e[F_PAR][s];
                 const int bp = h.bps[s];
                 const int prow = (bp >= 0) ? h.e[F_ROW][bp] : h.e[F_PROW][s];
