@@ -818,6 +818,9 @@ struct X2Args {
     int use_pre_status;
     int* queue;
     int2* meta;                    // per pair: {status, R}; R < 0: skipped upstream, leave status alone
+    int4* sched;                   // the diagonal walk, one record per MAIN step: {u, v, column-window end, row-window
+                                   // end}, at the pair's read-1 row offset (a pair has at most min(U, V) main steps)
+    int* nmain;                    // per pair: number of main steps
     int* envt;                     // transposed envelope: 2 ints per read-1 row of the batch
     double* cum1; double* cum2;    // blank prefix sums at the batch row offsets (CTC root)
     char* pool; size_t pool_bytes; // value store per half-wave
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
     __shared__ int shw;
     const int pi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.use_pre_status && a.status[pi] != PO_OK) {
-        if (tid == 0) a.meta[pi] = make_int2(a.status[pi], -1);
+        if (tid == 0) { a.meta[pi] = make_int2(a.status[pi], -1); a.nmain[pi] = 0; }
         return;
     }
     const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
@@ -956,7 +959,45 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             if (t < Tn) cw[t] = mine;
         }
     }
-    if (tid == 0) a.meta[pi] = make_int2(st, R);
+    if (tid == 0) { a.meta[pi] = make_int2(st, R); a.nmain[pi] = 0; }
+}
+
+// ---- the diagonal walk itself (BeamSearch.h:300-341) depends on the envelope only: one wave per pair replays it
+// and records the main steps, so the beam kernel neither reads the envelope nor loops over catch-up steps.
+// Lane l caches envelope row ubase + l / column vbase + l; the walk reads them with v_readlane and refills a
+// cache when it is left (one global round trip per <= 64 steps).  No LDS: many waves per CU hide its latency.
+__global__ __launch_bounds__(64) void beam2d_walk_kernel(X2Args a) {
+    const int pi = blockIdx.x, lane = threadIdx.x;
+    const int2 mt = a.meta[pi];
+    if (mt.x != PO_OK || mt.y < 0) return;   // refused, skipped upstream or deferred: no schedule needed
+    const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi], b2 = a.y2_off[0];
+    const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
+    const int2* env2 = (const int2*)(a.env + 2 * o1);
+    const int2* envt2 = (const int2*)(a.envt + 2 * (o2 - b2));
+    int4* sc = a.sched + (o2 - b2);
+    int u = 0, v = 0, m = 0, werr = 0, ubase = -1000, vbase = -1000;
+    int2 erc = make_int2(0, 0), ecc = make_int2(0, 0);
+    int4 myrec = make_int4(0, 0, 0, 0);
+    while (u <= U - 1 && v <= V - 1) {
+        if (u < ubase || u >= ubase + 64) { ubase = u; erc = (ubase + lane < U) ? env2[ubase + lane] : make_int2(0, 0); }
+        if (v < vbase || v >= vbase + 64) { vbase = v; ecc = (vbase + lane < V) ? envt2[vbase + lane] : make_int2(0, 0); }
+        const int iu = __builtin_amdgcn_readfirstlane(u - ubase), iv = __builtin_amdgcn_readfirstlane(v - vbase);
+        const int ers = __builtin_amdgcn_readlane(erc.x, iu), ere = __builtin_amdgcn_readlane(erc.y, iu);
+        const int ecs = __builtin_amdgcn_readlane(ecc.x, iv), ece = __builtin_amdgcn_readlane(ecc.y, iv);
+        const bool row_ok = (v >= ers && v < ere), col_ok = (u >= ecs && u < ece);
+        if (!row_ok && v < ers) { v++; continue; }           // catch-up on read 1 (:314-322)
+        if (!col_ok && u < ecs) { u++; continue; }           // catch-up on read 0 (:328-336)
+        if (!row_ok || !col_ok) { werr = 1; break; }          // uninitialised bounds upstream (:309)
+        // records are collected one per lane and written 64 at a time
+        if (lane == (m & 63)) myrec = make_int4(u, v, ece, ere);
+        m++; u++; v++;
+        if ((m & 63) == 0) sc[m - 64 + lane] = myrec;
+    }
+    if ((m & 63) != 0 && lane < (m & 63)) sc[(m & ~63) + lane] = myrec;
+    if (lane == 0) {
+        a.nmain[pi] = m;
+        if (werr) a.meta[pi] = make_int2(PO_E_ENVELOPE, mt.y);
+    }
 }
 
 template <int MODEL, int SG>
@@ -989,8 +1030,10 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
     int pi = 0, U = 1, V = 1, u = 0, v = 0, nb = 0, R = 32, Rm = 31, NG = 0, st = PO_OK;
     unsigned epoch = 0;
     const double *yA = a.y1, *yB = a.y2, *cumA = a.cum1, *cumB = a.cum2;
-    const int2 *env2 = (const int2*)a.env, *envt2 = (const int2*)a.envt;
-    int2 er = make_int2(0, 0), ec = make_int2(0, 0), er_n = er, ec_n = ec;  // envelope row u / column v, and the next ones
+    const int4* sched = a.sched;   // this pair's main steps {u, v, column-window end, row-window end}
+    int mstep = 0, nmain = 0;      // next main step, their number
+    int up = -1, vp = -1;          // the previous main step
+    int4 rec = make_int4(0, 0, 0, 0), rec_n = rec;  // the next main step's record and the one after
 
     auto root_at = [&](const double* cump, int t, double* out) {
         if (MODEL == PO_MODEL_CTC) {
@@ -1057,13 +1100,12 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     U = (int)(a.y1_off[pi + 1] - o1); V = (int)(a.y2_off[pi + 1] - o2);
                     yA = a.y1 + o1 * C; yB = a.y2 + o2 * C;
                     cumA = a.cum1 + (o1 - a.y1_off[0]); cumB = a.cum2 + (o2 - a.y2_off[0]);
-                    env2 = (const int2*)(a.env + 2 * o1);
-                    envt2 = (const int2*)(a.envt + 2 * (o2 - a.y2_off[0]));
+                    sched = a.sched + (o2 - a.y2_off[0]);
+                    nmain = a.nmain[pi]; mstep = 0; up = -1; vp = -1;
+                    rec = sched[0]; rec_n = sched[min(1, max(nmain - 1, 0))];   // (read-1 rows >= 1: in bounds)
                     R = m.y; Rm = R - 1;
                     NG = (int)min((long long)HNGL, pool_entries / ((long long)PO_A * 2 * R));
                     st = PO_OK; u = 0; v = 0;
-                    er = env2[0]; ec = envt2[0];
-                    er_n = env2[min(1, U - 1)]; ec_n = envt2[min(1, V - 1)];
                     for (int q = s; q < HNGL; q += SG) { h.g_owner[q] = -1; h.g_hi0[q] = 0; h.g_hi1[q] = 0; }
                     x2_sync();
                     // root = node 0; its A children = nodes 1..A in row group 0 (BeamSearch.h:286-293)
@@ -1111,48 +1153,45 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
 
         TK(0);  // queue + per-pair setup
         // ------------------------------------------------------------ catch-up steps (BeamSearch.h:314-336)
-        // only one of u, v advances and only the beam nodes are updated, at that one time; every
-        // value read is a t-1 value already in the store, so the lanes are independent
+        // Between two main steps only one of u, v advances at a time and only the beam nodes are updated, at
+        // that one time, from t-1 values in the store.  The pre-pass has replayed the walk: the record of the
+        // next main step says where it is.  A catch-up at a time the previous main step's window already
+        // covered is a no-op (every beam node was an element of that step: (node, t) is stored with exactly
+        // the bits the update would write), so only times from that window's end on are computed — rare.
         bool fin = !have;
-        while (!fin) {
-            if (u > U - 1 || v > V - 1) { fin = true; break; }
-            const bool row_ok = (v >= er.x && v < er.y), col_ok = (u >= ec.x && u < ec.y);
-            const bool cu_v = (!row_ok && v < er.x);
-            const bool cu_u = !cu_v && (!col_ok && u < ec.x);
-            if (!(cu_v || cu_u)) {
-                if (!row_ok || !col_ok) { st = PO_E_ENVELOPE; fin = true; }  // uninitialised bounds upstream (:309)
-                break;
-            }
-            const int rr = cu_v ? 1 : 0, t = cu_v ? v : u;
-            // Every beam node was an element of the last main step, whose window on this read covered t when
-            // t < its end: (node, t) is then already stored with exactly the bits this update would produce
-            // (same t-1 inputs, unchanged since) — nothing to do.
-            if (s < min(W, nb) && t >= h.sh[5 + rr]) {  // the reference indexes b < beam_width
-                const int node = h.e[F_ID][s], row = h.e[F_ROW][s], sy = h.e[F_SYM][s], par = h.e[F_PAR][s];
-                const int bp = h.bps[s];
-                const int prow = (bp >= 0) ? h.e[F_ROW][bp] : h.e[F_PROW][s];
-                const int sym = sym_last(sy);
-                const bool same = (sym_plast(sy) == sym), rootpar = (sy >> 9) & 1;
-                Ent* myrow = pool + ((size_t)row * 2 + rr) * R;
-                const double* yr = (rr ? yB : yA) + (int64_t)t * C;
-                const double ya = yr[sym], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr[sym + A] : yr[A];
-                double self[K], pp[K], out[K];
-                const unsigned long long tg = make_tag(epoch, node, 0);
-                st_read(myrow, t - 1, tg, self);
-                if (par == 0) root_at(rr ? cumB : cumA, t - 1, pp);
-                else st_read(pool + ((size_t)prow * 2 + rr) * R, t - 1, make_tag(epoch, par, 0), pp);
-                po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
-                Ent e;
-                e.tag = tg + (unsigned)t;
+        if (have && mstep >= nmain) fin = true;   // no main step left: whatever catch-ups remain change nothing observable
+        if (!fin) {
+            u = rec.x; v = rec.y;
 #pragma unroll
-                for (int k = 0; k < K; ++k) e.v[k] = out[k];
-                myrow[t & Rm] = e;
-                if (s == 0) h.nupd += (unsigned)min(W, nb);
-                if (rr) atomicMax(&h.g_hi1[row / PO_A], t + 1);
-                else atomicMax(&h.g_hi0[row / PO_A], t + 1);
+            for (int rr = 0; rr < 2; ++rr) {
+                const int tend = rr ? v : u;
+                for (int t = max((rr ? vp : up) + 1, h.sh[5 + rr]); t < tend; ++t) {
+                    if (s < min(W, nb)) {  // the reference indexes b < beam_width
+                    const int node = h.e[F_ID][s], row = h.e[F_ROW][s], sy = h.e[F_SYM][s], par = h.e[F_PAR][s];
+                    const int bp = h.bps[s];
+                    const int prow = (bp >= 0) ? h.e[F_ROW][bp] : h.e[F_PROW][s];
+                    const int sym = sym_last(sy);
+                    const bool same = (sym_plast(sy) == sym), rootpar = (sy >> 9) & 1;
+                    Ent* myrow = pool + ((size_t)row * 2 + rr) * R;
+                    const double* yr = (rr ? yB : yA) + (int64_t)t * C;
+                    const double ya = yr[sym], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr[sym + A] : yr[A];
+                    double self[K], pp[K], out[K];
+                    const unsigned long long tg = make_tag(epoch, node, 0);
+                    st_read(myrow, t - 1, tg, self);
+                    if (par == 0) root_at(rr ? cumB : cumA, t - 1, pp);
+                    else st_read(pool + ((size_t)prow * 2 + rr) * R, t - 1, make_tag(epoch, par, 0), pp);
+                    po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
+                    Ent e;
+                    e.tag = tg + (unsigned)t;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) e.v[k] = out[k];
+                    myrow[t & Rm] = e;
+                    if (s == 0) h.nupd += (unsigned)min(W, nb);
+                    if (rr) atomicMax(&h.g_hi1[row / PO_A], t + 1);
+                    else atomicMax(&h.g_hi0[row / PO_A], t + 1);
+                    }
+                }
             }
-            if (cu_v) { v++; ec = ec_n; ec_n = envt2[min(v + 1, V - 1)]; }
-            else { u++; er = er_n; er_n = env2[min(u + 1, U - 1)]; }
         }
         x2_sync();
 
@@ -1160,7 +1199,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         // ------------------------------------------------------------ MAIN step at (u, v)  (:342-375)
         // windows [u, ece) on read 0 and [v, ere) on read 1; every lane flows through, predicated
         const bool dm = have && !fin;
-        const int ece = ec.y, ere = er.y;
+        const int ece = rec.z, ere = rec.w;
         // ---- expansion: children ids and row groups of the beam nodes (serial per half)
         if (dm && s == 0) {
             int next_id = h.sh[2];
@@ -1432,10 +1471,10 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
             }
             if (dmm) {
                 nb = nbn;
-                u++; v++;
-                er = er_n; er_n = env2[min(u + 1, U - 1)];
-                ec = ec_n; ec_n = envt2[min(v + 1, V - 1)];
-                if (u > U - 1 || v > V - 1) fin = true;
+                up = u; vp = v;
+                mstep++;
+                rec = rec_n; rec_n = sched[max(0, min(mstep + 1, nmain - 1))];
+                if (mstep >= nmain) fin = true;
             }
             x2_sync();
         }
@@ -1544,7 +1583,7 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
 struct X2Geom {
     int blocks, npw;
     size_t pool_bytes, arena_cap;
-    size_t off_queue, off_meta, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
+    size_t off_queue, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
 };
 constexpr int X2_FB_BLOCKS = 256;  // workgroups of the beam2d_kernel pass over deferred pairs
 bool x2_eligible(int n, int W, int model, int method) {
@@ -1561,6 +1600,7 @@ bool x2_eligible(int n, int W, int model, int method) {
 template <int MODEL>
 void x2_launch(const X2Args& a, int n, int W, int blocks, size_t plds, hipStream_t stream) {
     hipLaunchKernelGGL(beam2d_prepass_kernel<MODEL>, dim3(n), dim3(256), plds, stream, a);
+    hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
     if (W <= 6) hipLaunchKernelGGL((beam2d_x2_kernel<MODEL, 32>), dim3(blocks), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((beam2d_x2_kernel<MODEL, 64>), dim3(blocks), dim3(64), 0, stream, a);
 }
@@ -1595,6 +1635,8 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     size_t o = 0;
     g.off_queue = o; o += 256;
     g.off_meta = o; o += al256(sizeof(int2) * (size_t)(n > 0 ? n : 1));
+    g.off_nmain = o; o += al256(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    g.off_sched = o; o += al256(sizeof(int4) * (size_t)(tr2 > 0 ? tr2 : 1));
     g.off_envt = o; o += al256(sizeof(int) * 2 * (size_t)tr2);
     g.off_cum1 = o; o += al256(sizeof(double) * (size_t)tr1);
     g.off_cum2 = o; o += al256(sizeof(double) * (size_t)tr2);
@@ -1734,6 +1776,8 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status; a.use_pre_status = use_pre_status;
         a.queue = (int*)(w + g.off_queue);
         a.meta = (int2*)(w + g.off_meta);
+        a.nmain = (int*)(w + g.off_nmain);
+        a.sched = (int4*)(w + g.off_sched);
         a.envt = (int*)(w + g.off_envt);
         a.cum1 = (double*)(w + g.off_cum1); a.cum2 = (double*)(w + g.off_cum2);
         a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
