@@ -838,18 +838,19 @@ struct X2Half {
     static constexpr int WB = (SG == 32) ? 6 : 12;   // beam slots
     static constexpr int NGL = (SG == 32) ? X2_NGL : 2 * X2_NGL;  // row groups tracked per pair
     int e[F_COUNT][SG];
-    int bps[16];             // beam slot -> slot of its parent in the beam, or -1
-    int sel[16];
-    int newfc[16];           // bit 0: children created in this step; bit 1: children got a new row group
-    int stay[16];            // beam slot was a beam slot in the previous main step (so its children were elements)
+    static constexpr int WBP = (SG == 32) ? 8 : 16;  // beam-slot arrays, padded
+    int bps[WBP];            // beam slot -> slot of its parent in the beam, or -1
+    int sel[WBP];
+    int newfc[WBP];          // bit 0: children created in this step; bit 1: children got a new row group
+    int stay[WBP];           // beam slot was a beam slot in the previous main step (so its children were elements)
     int dup[SG];
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[8];
     double score[SG];
     double xch[2][SG][K];
-    // doubles in the y window buffer: 208 (41 rows of 5) for the two-pairs-per-wave one-value kernel, so that 12
+    // doubles in the y window buffer: 192 (38 rows of 5) for the two-pairs-per-wave one-value kernel, so that 12
     // workgroups fit a CU's LDS; 256 (32 rows of 8) elsewhere (those kernels are register-bound anyway)
-    static constexpr int YD = (K == 1 && SG == 32) ? (X2_YD < 208 ? X2_YD : 208) : X2_YD;
+    static constexpr int YD = (K == 1 && SG == 32) ? (X2_YD < 192 ? X2_YD : 192) : X2_YD;
     double ybuf[YD];         // the y rows of the current step's windows
     unsigned long long nupd; // profiling: update_prob evaluations
 };
@@ -1117,7 +1118,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                         h.sh[4] = PO_OK;
                         h.sh[5] = INT_MIN; h.sh[6] = INT_MIN;  // window ends of the previous main step: none yet
                     }
-                    if (s < 16) h.stay[s] = 0;
+                    if (s < X2Half<K, SG>::WBP) h.stay[s] = 0;
                     if (s < A) {
                         apl[1 + s] = po_pack_node(0, s); afc[1 + s] = -1; acrow[1 + s] = -1;
                         h.e[F_ID][s] = 1 + s; h.e[F_ROW][s] = s; h.e[F_PROW][s] = -1; h.e[F_PAR][s] = 0;
