@@ -1630,7 +1630,7 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.npw = npw;
     g.blocks = b2_num_cus() * x2_blocks_per_cu(model, W);
     if (g.blocks > (n + npw - 1) / npw) g.blocks = n > 1 ? (n + npw - 1) / npw : 1;
-    g.pool_bytes = al256((size_t)(model == PO_MODEL_CTC ? 4 : 8) << 20);
+    g.pool_bytes = al256((size_t)(model == PO_MODEL_CTC ? 2 : 4) << (W <= 6 ? 20 : 21));  // 128 (256) row groups of R <= 128 entries
     const int64_t WM = W > PO_A ? W : PO_A;
     g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 1));
     size_t o = 0;
