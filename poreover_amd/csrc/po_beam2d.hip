@@ -736,8 +736,11 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 // every element is updated on read 0 at time u except beam nodes beyond the first W
                 // (possible only in the first row, when W < |alphabet|): `for b < beam_width` (:132)
                 const int skip_lo = min(nproc, nb), skip_hi = nb;
-                scan(true, false, ne, skip_lo, skip_hi, u, 1, rs, wlen);
+                // the read-1 band of a row mostly repeats the previous row's: the same redundant-store rule as in
+                // row_col applies (regular shape; in the growing first rows every element stores everything)
+                scan(true, regular, ne, skip_lo, skip_hi, u, 1, rs, wlen);
                 po_lds_barrier();
+                if (tid == 0) { sm.sh[8] = u + 1; sm.sh[9] = (wlen > 0) ? re : sm.sh[9]; }
                 if (tid < ne) {  // node_greater_max: last_prob[0] + max_prob[1]
                     const int id = sm.e[F_ID][tid];
                     double m0 = sm.mxs[0][tid], m1 = sm.mxs[1][tid];

@@ -10,6 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 kind = sys.argv[3] if len(sys.argv) > 3 else "poreover"      # poreover | bonito | flipflop
 model = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}[kind]
+method = sys.argv[4] if len(sys.argv) > 4 else "row_col"    # row_col | row
 nb = 16
 base = []
 for i in range(nb):
@@ -20,8 +21,8 @@ lib = _lib.load()
 import ctypes as C
 for rep in range(2):
     lib.po_profile_enable(1); lib.po_profile_reset()
-    t0 = time.time(); out = batch.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col"); dt = time.time() - t0
+    t0 = time.time(); out = batch.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method=method); dt = time.time() - t0
     ms = C.c_double(); cnt = C.c_int64(); lib.po_profile_get(_lib.K_BEAM2D, C.byref(ms), C.byref(cnt))
     bases = sum(len(s) for s in out)
-    print("beam2d row_col " + model + " W=%d n=%d: call %.3f s; kernel %.1f ms (%d launch) -> %.0f pairs/s kernel-only, %.3f Mbases/s" % (
+    print("beam2d " + method + " " + model + " W=%d n=%d: call %.3f s; kernel %.1f ms (%d launch) -> %.0f pairs/s kernel-only, %.3f Mbases/s" % (
         W, n, dt, ms.value, cnt.value, n / (ms.value / 1e3), bases / (ms.value / 1e3) / 1e6))
