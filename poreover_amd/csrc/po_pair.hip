@@ -286,26 +286,40 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
 
         PPTK(1);  // fill
         // ------------------------------------------------------------------ trace-back (align.pyx:56-95 == :137-174)
-        if (tid == 0) {
+        // One wave walks the path.  Each step needs three table cells (a dependent global round trip), so lane q
+        // loads the cells of position (i - q, j - q) speculatively: while the path moves diagonally (most steps
+        // of two reads of the same molecule) the next step's cells are already in lane q + 1; any other move
+        // ends the batch.  The decisions are taken in the reference's order, from the same values.
+        if (tid < PO_WAVE) {
             int i = l1, j = l2, n = 0;
             const int cap = (int)a.aln_cap;
             bool ovf = false;
-#define PP_EMIT(c1_, c2_) do { if (n < cap) { al1[n] = (c1_); al2[n] = (c2_); } else ovf = true; n++; } while (0)
+#define PP_EMIT(c1_, c2_) do { if (lane == 0) { if (n < cap) { al1[n] = (c1_); al2[n] = (c2_); } } if (n >= cap) ovf = true; n++; } while (0)
             while (i > 0 && j > 0) {
-                const int sc = (s1[py_idx(i - 1, l1)] == s2[py_idx(j - 1, l2)]) ? NW_MATCH : NW_MISMATCH;
-                const int c0 = get(i - 1, j - 1) + sc, c1v = get(i - 1, j) + NW_GAP, c2v = get(i, j - 1) + NW_GAP;
-                const int mx = max(c0, max(c1v, c2v));
-                if (c0 == mx) { i--; j--; PP_EMIT(s1[py_idx(i, l1)], s2[py_idx(j, l2)]); }
-                if (c1v == mx) { i--; PP_EMIT(s1[py_idx(i, l1)], '-'); }
-                if (c2v == mx) { j--; PP_EMIT('-', s2[py_idx(j, l2)]); }
+                const int ii = i - lane, jj = j - lane;
+                int c0 = 0, c1v = 0, c2v = 0;
+                if (ii > 0 && jj > 0) {
+                    const int sc = (s1[py_idx(ii - 1, l1)] == s2[py_idx(jj - 1, l2)]) ? NW_MATCH : NW_MISMATCH;
+                    c0 = get(ii - 1, jj - 1) + sc; c1v = get(ii - 1, jj) + NW_GAP; c2v = get(ii, jj - 1) + NW_GAP;
+                }
+                for (int qv = 0; qv < PO_WAVE; ++qv) {
+                    const int q = __builtin_amdgcn_readfirstlane(qv);
+                    const int d0 = __builtin_amdgcn_readlane(c0, q), d1 = __builtin_amdgcn_readlane(c1v, q);
+                    const int d2 = __builtin_amdgcn_readlane(c2v, q);
+                    const int mx = max(d0, max(d1, d2));
+                    const bool diag_only = (d0 == mx) && (d1 != mx) && (d2 != mx);
+                    if (d0 == mx) { i--; j--; PP_EMIT(s1[py_idx(i, l1)], s2[py_idx(j, l2)]); }
+                    if (d1 == mx) { i--; PP_EMIT(s1[py_idx(i, l1)], '-'); }
+                    if (d2 == mx) { j--; PP_EMIT('-', s2[py_idx(j, l2)]); }
+                    if (!diag_only || !(i > 0 && j > 0)) break;   // the speculation holds only along the diagonal
+                }
             }
             while (i > 0 || j > 0) {
                 if (i > 0) { i--; PP_EMIT(s1[py_idx(i, l1)], '-'); }
                 else if (j > 0) { j--; PP_EMIT('-', s2[py_idx(j, l2)]); }
             }
 #undef PP_EMIT
-            sh[2] = n;
-            sh[3] = ovf ? 1 : 0;
+            if (lane == 0) { sh[2] = n; sh[3] = ovf ? 1 : 0; }
         }
         __syncthreads();
         ncol = sh[2];
