@@ -1204,6 +1204,25 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         // windows [u, ece) on read 0 and [v, ere) on read 1; every lane flows through, predicated
         const bool dm = have && !fin;
         const int ece = rec.z, ere = rec.w;
+        // The y rows of the step's first buffer fill are requested now, into registers: the window is known from
+        // the schedule, and the loads fly while the (serial) expansion and the element table are built.
+        // (One-value model only: the 3-value kernels have no registers to spare — it would cost them a wave per SIMD.)
+        constexpr bool YEARLY = (K == 1);
+        constexpr int YPRE = YEARLY ? (X2Half<K, SG>::YD + SG - 1) / SG : 1;   // doubles per lane of one buffer fill
+        double ypre[YPRE];
+        if (YEARLY) {
+            const int l0 = dm ? ece - u : 0, l1 = dm ? ere - v : 0;
+            const int yrows_ = X2Half<K, SG>::YD / C;
+            const int kend = min(l0 + l1, yrows_);
+            const int nA = min(kend, l0) * C, nT = kend * C;
+            const double* srcA = yA + (int64_t)u * C;
+            const double* srcB = yB + (int64_t)v * C - nA;   // buffer index i >= nA reads srcB[i]
+#pragma unroll
+            for (int q = 0; q < YPRE; ++q) {
+                const int i = s + q * SG;
+                ypre[q] = (i < nT) ? ((i < nA) ? srcA[i] : srcB[i]) : 0.0;
+            }
+        }
         // ---- expansion: children ids and row groups of the beam nodes (serial per half)
         if (dm && s == 0) {
             int next_id = h.sh[2];
@@ -1341,7 +1360,13 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
             // and stores in order: waiting for any load also waits for every store issued before it).
             const int yrows = X2Half<K, SG>::YD / C;  // iterations per buffer fill
             for (int k0 = 0; k0 < Ltot; k0 += yrows) {
-            {
+            if (YEARLY && k0 == 0) {   // the first fill was requested at the top of the step
+#pragma unroll
+                for (int q = 0; q < YPRE; ++q) {
+                    const int i = s + q * SG;
+                    if (i < X2Half<K, SG>::YD) h.ybuf[i] = ypre[q];
+                }
+            } else {
                 const int kend = min(tot, k0 + yrows);
                 const int ka1 = min(kend, len0);                 // read-0 iterations [k0, ka1)
                 const int nA = max(0, ka1 - k0) * C;
