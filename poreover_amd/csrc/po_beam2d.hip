@@ -1223,38 +1223,55 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 ypre[q] = (i < nT) ? ((i < nA) ? srcA[i] : srcB[i]) : 0.0;
             }
         }
-        // ---- expansion: children ids and row groups of the beam nodes (serial per half)
-        if (dm && s == 0) {
-            int next_id = h.sh[2];
-            const int lo0 = u - 1, lo1 = v - 1;
-            for (int j = 0; j < nb; ++j) {
-                bool need_group = false;
-                const int id = h.e[F_ID][j];
-                int isnew = 0;
-                if (h.e[F_FC][j] < 0) {
-                    h.e[F_FC][j] = next_id;
-                    afc[id] = next_id;
-                    for (int c = 0; c < A; ++c) { apl[next_id + c] = po_pack_node(id, c); afc[next_id + c] = -1; acrow[next_id + c] = -1; }
-                    next_id += A;
-                    need_group = true;
-                    isnew = 1;
-                } else if (h.e[F_CROW][j] < 0 || h.e[F_CROW][j] >= NG || h.g_owner[h.e[F_CROW][j]] != id) {
-                    need_group = true;  // its old rows were recycled: every value in them was dead
-                }
-                h.newfc[j] = isnew | (need_group ? 2 : 0);
-                if (need_group) {
-                    const int gg = alloc_group(id, lo0, lo1);
-                    h.e[F_CROW][j] = gg;
-                    acrow[id] = gg;
-                }
-                const int gc = h.e[F_CROW][j], go = h.e[F_ROW][j] / PO_A;
-                h.g_hi0[gc] = max(h.g_hi0[gc], ece); h.g_hi1[gc] = max(h.g_hi1[gc], ere);
-                h.g_hi0[go] = max(h.g_hi0[go], ece); h.g_hi1[go] = max(h.g_hi1[go], ere);
+        // ---- expansion: children ids and row groups of the beam nodes, one lane per beam node.  New node ids are
+        // handed out in beam order (a prefix count over the lanes that need them: ids break score ties); row
+        // groups, which only name storage, are allocated one lane after the other, after every group in use has
+        // been marked with this step's window ends.
+        {
+            const bool bl = dm && s < nb;
+            bool isnew = false, need_group = false;
+            int id = 0, crow = -1;
+            if (bl) {
+                id = h.e[F_ID][s];
+                crow = h.e[F_CROW][s];
+                if (h.e[F_FC][s] < 0) { isnew = true; need_group = true; }
+                else if (crow < 0 || crow >= NG || h.g_owner[crow] != id) need_group = true;  // old rows recycled: all dead
             }
-            h.sh[2] = next_id;
+            const unsigned long long bn = __ballot(isnew), bg = __ballot(need_group);
+            const unsigned long long hn = (SG == 64) ? bn : (g ? (bn >> 32) : (bn & 0xffffffffull));
+            unsigned long long hg = (SG == 64) ? bg : (g ? (bg >> 32) : (bg & 0xffffffffull));
+            const int base = h.sh[2];
+            if (isnew) {
+                const int fc = base + A * __popcll(hn & ((1ull << s) - 1ull));
+                h.e[F_FC][s] = fc;
+                afc[id] = fc;
+                for (int c = 0; c < A; ++c) { apl[fc + c] = po_pack_node(id, c); afc[fc + c] = -1; acrow[fc + c] = -1; }
+            }
+            if (bl) {
+                h.newfc[s] = (isnew ? 1 : 0) | (need_group ? 2 : 0);
+                const int go = h.e[F_ROW][s] / PO_A;
+                atomicMax(&h.g_hi0[go], ece); atomicMax(&h.g_hi1[go], ere);
+                if (!need_group) { atomicMax(&h.g_hi0[crow], ece); atomicMax(&h.g_hi1[crow], ere); }
+            }
+            x2_sync();
+            if (dm && s == 0) h.sh[2] = base + A * __popcll(hn);
+            // (the loop runs while either half still has a lane to serve)
+            while (__ballot(hg != 0) != 0) {
+                if (hg != 0) {
+                    const int j = __builtin_ctzll(hg);
+                    hg &= hg - 1;
+                    if (s == j) {
+                        const int gg = alloc_group(id, u - 1, v - 1);
+                        h.e[F_CROW][s] = gg;
+                        acrow[id] = gg;
+                        h.g_hi0[gg] = ece; h.g_hi1[gg] = ere;
+                    }
+                }
+                x2_sync();
+            }
         }
         x2_sync();
-        TK(2);  // expansion (serial)
+        TK(2);  // expansion
         if (dm && h.sh[4] != PO_OK) {  // out of row groups: hand the pair to beam2d_kernel
             if (s == 0) a.meta[pi] = make_int2(PO_OK, X2_DEFERRED);
             have = false; fin = true;
