@@ -835,6 +835,7 @@ struct X2Args {
     unsigned long long* upd_count;    // optional (po_profile_update_counter): total update_prob evaluations
 };
 
+struct alignas(16) X2Cand { double sc; int id; int dup; };
 // SG = lanes (element slots) per pair: 32 -> two pairs per wave (W <= 6), 64 -> one pair per wave (W <= 12)
 template <int K, int SG>
 struct X2Half {
@@ -846,10 +847,9 @@ struct X2Half {
     int sel[WBP];
     int newfc[WBP];          // bit 0: children created in this step; bit 1: children got a new row group
     int stay[WBP];           // beam slot was a beam slot in the previous main step (so its children were elements)
-    int dup[SG];
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[8];
-    double score[SG];
+    X2Cand cand[SG];         // prune candidates: score, node id, duplicate flag — one 16-byte read per comparison
     double xch[2][SG][K];
     // doubles in the y window buffer: 192 (38 rows of 5) for the two-pairs-per-wave one-value kernel, so that 12
     // workgroups fit a CU's LDS; 256 (32 rows of 8) elsewhere (those kernels are register-bound anyway)
@@ -1279,6 +1279,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         const bool dmm = dm && !fin;
         const int ne = dmm ? nb * (A + 1) : 0;
         int my_fc = -1, my_cr = -1;  // a child's own expansion state (arena), loaded behind the scan
+        int dupf = 0;                // a child slot whose node is also a beam slot is the same node pushed twice
         if (s < ne) {
             if (s < nb) {
                 int ps = h.bps[s];
@@ -1296,6 +1297,8 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 h.e[F_SYM][s] = sym_pack(c, sym_last(h.e[F_SYM][j]), false);
                 h.e[F_PSLOT][s] = j;
                 if (!(h.newfc[j] & 1)) { my_fc = afc[id]; my_cr = acrow[id]; }
+#pragma unroll
+                for (int i = 0; i < WB; ++i) dupf |= (i < nb && h.e[F_ID][i] == id);
             }
         }
         x2_sync();
@@ -1452,42 +1455,41 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
             }
             TK(5);  // scan: iterations
             }
-            if (part) h.score[s] = mx0 + mx;  // node_greater_max_sym: max over read 0 + max over read 1
+            {   // node_greater_max_sym: max over read 0 + max over read 1
+                X2Cand c;
+                c.sc = mx0 + mx; c.id = part ? h.e[F_ID][s] : 0; c.dup = part ? dupf : 1;
+                h.cand[s] = c;
+            }
             if (part && s == 0) { h.nupd += (unsigned)(ne * tot); h.sh[5] = ece; h.sh[6] = ere; }
             if (part && s >= nb) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
         }
         x2_sync();
 
         TK(6);  // scores
-        // ---- prune (Beam.h:93-108) + next beam table.  Loops have constant bounds (predicated) so that their
-        // LDS reads are issued together instead of one round trip per trip.
+        // ---- prune (Beam.h:93-108) + next beam table: rank by (score, id) among the distinct candidates, then the
+        // W best gather their fields from the old table (and find their parent in the new beam through `sel`)
         {
-            int d = 0;
-            if (s < ne && s >= nb) {
-                const int x = h.e[F_ID][s];
-#pragma unroll
-                for (int j = 0; j < WB; ++j) d |= (j < nb && h.e[F_ID][j] == x);
-            }
-            h.dup[s] = (s < ne) ? d : 1;
-            x2_sync();
+            const bool live = (s < ne) && !dupf;
             int rank = 0;
-            if (s < ne && !d) {
-                const double sc = h.score[s];
-                const int id = h.e[F_ID][s];
+            if (live) {
+                const X2Cand me = h.cand[s];
 #pragma unroll 8
-                for (int o = 0; o < SG; ++o)
-                    if (!h.dup[o] && po_better(h.score[o], h.e[F_ID][o], sc, id)) rank++;
+                for (int o = 0; o < SG; ++o) {
+                    const X2Cand c = h.cand[o];
+                    if (!c.dup && po_better(c.sc, c.id, me.sc, me.id)) rank++;
+                }
                 if (rank < W) h.sel[rank] = s;
             }
-            const unsigned long long cand = __ballot(s < ne && !d);
+            const unsigned long long cand = __ballot(live);
             const int ncand = (SG == 64) ? __popcll(cand) : __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
             x2_sync();
             const int nbn = dmm ? min(W, ncand) : 0;
-            int nf[F_COUNT];
+            int nf[F_COUNT], nbp = -1, nstay = 0;
 #pragma unroll
             for (int f = 0; f < F_COUNT; ++f) nf[f] = 0;
             if (s < nbn) {
                 const int e = h.sel[s];
+                nstay = (e < nb) ? 1 : 0;
                 if (e < nb) {
 #pragma unroll
                     for (int f = 0; f < F_COUNT; ++f) nf[f] = h.e[f][e];
@@ -1499,21 +1501,21 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     nf[F_PROW] = h.e[F_ROW][p]; nf[F_DEPTH] = h.e[F_DEPTH][p] + 1;
                     nf[F_FC] = h.e[F_FC][e]; nf[F_CROW] = h.e[F_CROW][e];
                 }
+                // the parent's element slot in this step -> its slot in the new beam (if it made it), and the row
+                // its values are being written to
+                const int oldpar = h.e[F_PSLOT][e];
+                if (oldpar >= 0) {
+                    nf[F_PROW] = h.e[F_ROW][oldpar];
+#pragma unroll
+                    for (int i = 0; i < WB; ++i) if (i < nbn && h.sel[i] == oldpar) nbp = i;
+                }
             }
             x2_sync();  // every lane has read its source slot before any slot is overwritten
             if (s < nbn) {
 #pragma unroll
                 for (int f = 0; f < F_COUNT; ++f) h.e[f][s] = nf[f];
-                h.stay[s] = (h.sel[s] < nb) ? 1 : 0;
-            }
-            x2_sync();
-            if (s < nbn) {  // parent's slot in the new beam; its row is where its values are written from now on
-                const int par = nf[F_PAR];
-                int bp = -1;
-#pragma unroll
-                for (int i = 0; i < WB; ++i) if (i < nbn && h.e[F_ID][i] == par) bp = i;
-                h.bps[s] = bp;
-                if (bp >= 0) h.e[F_PROW][s] = h.e[F_ROW][bp];
+                h.stay[s] = nstay;
+                h.bps[s] = nbp;
             }
             if (dmm) {
                 nb = nbn;
