@@ -139,6 +139,62 @@ def test_rowcol_errors(eng, oracle):
     assert seqs[0] == seqs[2] == oracle.cpp_beam_search_2d(y1, y2, good, 5, method_="row_col")
 
 
+def _jagged_envelope(rng, U, V, kind):
+    """irregular but usable envelopes: the diagonal walk then meets long catch-up runs, windows that jump past the
+    previous step's window end, single-cell rows, and rows much wider than their neighbours"""
+    env = np.zeros((U, 2), dtype=np.int64)
+    c = np.linspace(0, V - 1, U)
+    for u in range(U):
+        if kind == "stairs":        # flat runs then jumps: many catch-ups on one read, then on the other
+            lo = int(c[(u // 7) * 7]) - 2
+            hi = lo + 7 + 2 * V // U
+        elif kind == "wobble":      # width changes from row to row, starts move back and forth
+            w = int(rng.integers(2, 14))
+            lo = int(c[u]) - int(rng.integers(0, w))
+            hi = lo + w + int(rng.integers(1, 6))
+        else:                       # "bursts": mostly narrow, every now and then a very wide row
+            w = 40 if rng.random() < 0.08 else int(rng.integers(3, 7))
+            lo = int(c[u]) - w // 2
+            hi = lo + w
+        lo, hi = max(0, min(lo, V - 1)), max(1, min(hi, V))
+        if u > 0 and kind != "wobble":   # connected staircase: starts and ends never move back, rows overlap
+            lo = min(max(lo, env[u - 1, 0]), env[u - 1, 1] - 1)
+            hi = max(hi, env[u - 1, 1])
+        if lo >= hi:
+            lo = hi - 1
+        env[u] = (lo, hi)
+    if kind != "wobble":
+        env[-1, 1] = V
+    return env
+
+
+@pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
+def test_rowcol_irregular_envelopes(eng, oracle, model, ff):
+    """schedule kernel, skipped catch-ups and skipped stores against envelopes that are nothing like the
+    pipeline's: strings — or the refusal, when the reference would read uninitialised bounds — equal the oracle's"""
+    from poreover_amd import _lib
+    rng = np.random.default_rng(321)
+    y1s, y2s, envs = [], [], []
+    for i in range(18):
+        T = int(rng.integers(3, 260))
+        y1, y2 = synth_pair(4600 + i, T=T, flipflop=ff)
+        if i % 5 == 0:
+            y2 = y2[: max(2, len(y2) // 2)]          # very unequal lengths
+        y1s.append(y1); y2s.append(y2)
+        envs.append(_jagged_envelope(rng, len(y1), len(y2), ("stairs", "wobble", "bursts")[i % 3]))
+    for W in (1, 3, 5, 6, 9):
+        want, wst = [], []
+        for a, b, e in zip(y1s, y2s, envs):
+            try:
+                want.append(oracle.cpp_beam_search_2d(a, b, e, W, model_=model, method_="row_col")); wst.append(0)
+            except oracle.OracleError as ex:
+                want.append(""); wst.append(ex.code)
+        got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col", return_status=True)
+        assert st.tolist() == wst, (W, st.tolist(), wst)
+        assert [g if c == 0 else "" for g, c in zip(got, wst)] == want, W
+    assert any(c == 0 for c in wst) and len(set(wst)) >= 1
+
+
 # ------------------------------------------------------------------------------------------------
 # method "row" (the API default) and the no-envelope overload
 def test_row_golden_toys_and_csv(eng, golden, golden_inputs):
