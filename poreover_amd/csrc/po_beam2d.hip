@@ -1344,10 +1344,15 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
             // pushed down the parent links; everyone else only stores from the previous window end on.
             bool bad = false;
             if (part && s >= nb) { const int j = pslot; bad = !(h.stay[j] && h.newfc[j] == 0); }
-            for (int round = 0; round < WB + 1; ++round) {
-                const unsigned long long bm = __ballot(bad);
-                const unsigned long long hm = (SG == 64) ? bm : (g ? (bm >> 32) : (bm & 0xffffffffull));
-                if (part && pslot >= 0 && ((hm >> pslot) & 1ull)) bad = true;
+            {
+                unsigned long long bm = __ballot(bad);
+                for (int round = 0; round < WB + 1 && bm != 0; ++round) {   // until nothing changes (usually at once)
+                    const unsigned long long hm = (SG == 64) ? bm : (g ? (bm >> 32) : (bm & 0xffffffffull));
+                    if (part && pslot >= 0 && ((hm >> pslot) & 1ull)) bad = true;
+                    const unsigned long long nbm = __ballot(bad);
+                    if (nbm == bm) break;
+                    bm = nbm;
+                }
             }
             int sfrom = bad ? INT_MIN : h.sh[5];        // first time whose value must be written (current read)
             const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
