@@ -1371,14 +1371,6 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 tf++;
             };
             if (part && pslot < 0) fetch();
-#ifdef X2_SHFL
-            // parent's value of the previous iteration, handed over lane to lane (ds_bpermute) instead of
-            // through an LDS write + read
-            const int psrc = (lane & ~(SG - 1)) + (pslot >= 0 ? pslot : s);
-            double ppn[K];
-#pragma unroll
-            for (int q = 0; q < K; ++q) ppn[q] = __shfl(self[q], psrc);
-#endif
             // The y rows of both windows go through LDS, one copy per step (two contiguous runs of rows;
             // buffer row = iteration index).  With no vector-memory LOAD left in the iteration loop, the
             // wave never waits there for the acknowledgement of its value-store writes (vmcnt counts loads
@@ -1417,13 +1409,8 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     const double* yrow = h.ybuf + (k - k0) * C;
                     const double ya = yrow[ca], yb = yrow[cb];
                     double pp[K], out[K];
-#ifdef X2_SHFL
-#pragma unroll
-                    for (int q = 0; q < K; ++q) pp[q] = ppn[q];
-#else
 #pragma unroll
                     for (int q = 0; q < K; ++q) pp[q] = h.xch[(k + 1) & 1][pslot >= 0 ? pslot : s][q];
-#endif
                     if (pslot < 0) {  // rare: the parent does not move in this scan
                         const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
 #pragma unroll
@@ -1446,13 +1433,8 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     }
 #endif
                     const bool sw = (k + 1 == len0);  // the next iteration starts read 1: hand its seed over
-#ifdef X2_SHFL
-#pragma unroll
-                    for (int q = 0; q < K; ++q) { self[q] = out[q]; ppn[q] = __shfl(sw ? self1[q] : out[q], psrc); }
-#else
 #pragma unroll
                     for (int q = 0; q < K; ++q) { self[q] = out[q]; h.xch[k & 1][s][q] = sw ? self1[q] : out[q]; }
-#endif
                     mx = fmax(mx, out[0]);
                     t++;
                 }
