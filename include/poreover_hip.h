@@ -235,6 +235,12 @@ int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* a
 int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
                                   int n, int C, const char* alphabet, int flavor, char* seq_h, const int64_t* seq_off_h,
                                   int32_t* seq_len_h, double* logp_h, int32_t* status_h);
+/* decoding_cy.forward_vec_log (decoding_cy.pyx:127-156; flavor 1) / prefix_search.forward_vec_log
+ * (prefix_search.py:81-96; flavor 0): one row of the CTC forward matrix for symbol s (-1: blank) and label
+ * length i, for every item; previous_h (same layout as out_h: one double per frame, items back to back) is the row
+ * of the label without its last symbol and may be NULL for i == 0. */
+int po_forward_vec_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, int s, int i, int flavor,
+                           const double* previous_h, double* out_h);
 int po_pair_gamma_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
                           const int32_t* env_h, const int64_t* env_off_h, int n, int C, int flavor, double* gamma00_h,
                           double* dense_out_h, const int64_t* dense_off_h, int32_t* status_h);

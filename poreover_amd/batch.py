@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib as L
 
 __all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows",
-           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "pair_prefix_search_batch", "align_batch", "envelope_batch", "ingest_batch", "pair_gamma_batch"]
+           "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "pair_prefix_search_batch", "forward_vec_batch", "align_batch", "envelope_batch", "ingest_batch", "pair_gamma_batch"]
 
 
 def pack_rows(arrays, C_expected=None):
@@ -239,6 +239,21 @@ def prefix_search_batch(y, offsets, alphabet="ACGT"):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "prefix search of window %d" % i)
     return list(zip(_strings(seq, so, lens), [float(x) for x in lp[:n]]))
+
+
+def forward_vec_batch(arrays, s, i, previous=None, flavor="cy"):
+    """decoding_cy.forward_vec_log (flavor "cy") / prefix_search.forward_vec_log ("py") for a batch: one forward row
+    per item.  previous: list of rows (one per item) of the label without its last symbol; None for i == 0."""
+    lib = L.load()
+    y, off, Cc = pack_rows(arrays)
+    n = len(arrays)
+    out = np.zeros(max(int(off[-1]), 1), dtype=np.float64)
+    pv = None
+    if previous is not None:
+        pv = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64) for p in previous] + [np.zeros(1)]))
+    L.check(lib.po_forward_vec_batch_h(_ptr(y), _ptr(off), n, Cc, int(s), int(i), {"py": 0, "cy": 1}[flavor],
+                                       _ptr(pv), _ptr(out)), "po_forward_vec_batch_h")
+    return [out[off[k]:off[k + 1]].copy() for k in range(n)]
 
 
 def pair_prefix_search_batch(arrays1, arrays2, alphabet="ACGT", flavor="cy"):

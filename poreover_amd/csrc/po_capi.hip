@@ -24,6 +24,7 @@ size_t po_lattice_ws_bytes(int, int64_t, int64_t, int, int);
 size_t po_prefix_ws_bytes(int, int64_t);
 size_t po_gamma_ws_bytes(int, int64_t, int64_t, int64_t);
 size_t po_pair_prefix_ws_bytes(int, int64_t);
+int po_launch_forward_vec(const double*, const int64_t*, int, int, int, int, int, const double*, double*, hipStream_t);
 int po_launch_pair_prefix_search(const double*, const int64_t*, const double*, const int64_t*, const double*, const int64_t*, int, int,
                                  int, uint32_t, int, int64_t, char*, const int64_t*, int32_t*, double*, int32_t*, void*, size_t,
                                  hipStream_t);
@@ -602,6 +603,27 @@ int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, c
     DOWN(seq_len_h, sl, sizeof(int32_t) * n);
     DOWN(logp_h, lp, sizeof(double) * n);
     DOWN(status_h, st2, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_forward_vec_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, int s, int i, int flavor,
+                           const double* previous_h, double* out_h) {
+    if (n <= 0) return PO_OK;
+    if (!y_h || !y_off_h || !out_h) { g_err = "po_forward_vec_batch_h: null argument"; return PO_E_ARG; }
+    const int64_t rows = y_off_h[n] - y_off_h[0];
+    DevBuf y, yo, pv, out;
+    UP(y, y_h + y_off_h[0] * C, sizeof(double) * rows * C);
+    std::vector<int64_t> off(y_off_h, y_off_h + n + 1);
+    for (auto& o : off) o -= y_off_h[0];
+    UP(yo, off.data(), sizeof(int64_t) * (n + 1));
+    if (previous_h) UP(pv, previous_h, sizeof(double) * rows);
+    UP(out, nullptr, sizeof(double) * rows);
+    int rc = po_launch_forward_vec((const double*)y.p, (const int64_t*)yo.p, n, C, s, i, flavor,
+                                   previous_h ? (const double*)pv.p : nullptr, (double*)out.p, nullptr);
+    if (rc != PO_OK) { g_err = "po_forward_vec_batch_h: bad symbol / label length, or previous row missing"; return rc; }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(out_h, out, sizeof(double) * rows);
     return PO_OK;
 }
 

@@ -418,3 +418,46 @@ extern "C" int po_launch_pair_prefix_search(const double* y1, const int64_t* y1_
     hipLaunchKernelGGL(pair_prefix_search_kernel, dim3(n), dim3(PS_THREADS), lds, stream, a);
     return PO_OK;
 }
+
+// ================================================================================================
+// forward_vec_log (decoding_cy.pyx:127-156; prefix_search.py:81-96): one row of the CTC forward matrix —
+// the log-probability, for every frame t, of having emitted a label whose last symbol is s by frame t, given
+// the row `previous` of the label without that symbol.  i = length of the label (0: the empty label, whose row
+// is the running sum of column s; 1: the row starts at y[0][s]).  A serial recurrence in t; one lane per item.
+namespace {
+struct FVArgs {
+    const double* y; const int64_t* y_off; int n, C, s, i, flavor;
+    const double* previous;   // same offsets as the output; NULL only for i == 0
+    double* out;
+};
+}  // namespace
+
+__global__ __launch_bounds__(64) void forward_vec_kernel(FVArgs a) {
+    const int pi = blockIdx.x * 64 + threadIdx.x;
+    if (pi >= a.n) return;
+    const int64_t r0 = a.y_off[pi] - a.y_off[0];
+    const int T = (int)(a.y_off[pi + 1] - a.y_off[pi]);
+    const int C = a.C, sc = a.s < 0 ? C + a.s : a.s;   // s == -1 selects the blank column (python negative index)
+    const double* y = a.y + a.y_off[pi] * C;
+    const double* pv = a.previous ? a.previous + r0 : nullptr;
+    double* fw = a.out + r0;
+    const double LOG0 = a.flavor ? -9999.0 : PO_NEG_INF;
+    double cur = LOG0;
+    for (int t = 0; t < T; ++t) {
+        const double* r = y + (int64_t)t * C;
+        if (a.i == 0) cur = (t == 0) ? r[sc] : r[C - 1] + cur;
+        else if (t == 0) cur = (a.i == 1) ? r[sc] : LOG0;
+        else cur = pps_lae(r[C - 1] + cur, r[sc] + pv[t - 1], a.flavor);
+        fw[t] = cur;
+    }
+}
+
+extern "C" int po_launch_forward_vec(const double* y, const int64_t* y_off, int n, int C, int s, int i, int flavor,
+                                     const double* previous, double* out, hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    if (C < 2 || s < -1 || s >= C || i < 0 || (i != 0 && !previous)) return PO_E_ARG;
+    FVArgs a;
+    a.y = y; a.y_off = y_off; a.n = n; a.C = C; a.s = s; a.i = i; a.flavor = flavor; a.previous = previous; a.out = out;
+    hipLaunchKernelGGL(forward_vec_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, a);
+    return PO_OK;
+}

@@ -1,5 +1,5 @@
 """Mirror of the parts of poreover.decoding.decoding_cy (reference decoding_cy.pyx) that have a GPU
-implementation: the dense pair gamma DP and the banded-envelope helper."""
+implementation: the dense pair gamma DP, the forward row and the banded-envelope helper."""
 import numpy as np
 
 from .. import batch as _batch
@@ -9,6 +9,12 @@ def pair_gamma_log(y1, y2):
     """decoding_cy.pyx:177-220: the dense (U+1, V+1) gamma matrix (LOG_0 = -9999 arithmetic)"""
     return _batch.pair_gamma_batch([np.asarray(y1, dtype=np.float64)], [np.asarray(y2, dtype=np.float64)], None, "cy",
                                    return_matrix=True)[0]
+
+
+def forward_vec_log(s, i, y, previous=None):
+    """decoding_cy.pyx:127-156: forward row of a label of length i ending in symbol s (-1: blank), LOG_0 = -9999"""
+    return _batch.forward_vec_batch([np.asarray(y, dtype=np.float64)], s, i,
+                                    None if previous is None else [np.asarray(previous, dtype=np.float64)], "cy")[0]
 
 
 def diagonal_band_envelope(U, V, width):

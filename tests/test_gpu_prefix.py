@@ -97,3 +97,24 @@ def test_pair_prefix_search(ps, oracle, golden, golden_inputs):
         got = batch.pair_prefix_search_batch(b1, b2, flavor=f)
         assert [g[0] for g in got] == [w[0] for w in want[f]], f
         assert np.allclose([g[1] for g in got], [w[1] for w in want[f]], rtol=1e-9, atol=0)
+
+
+def test_forward_vec_log(oracle, golden_inputs):
+    """decoding_cy.forward_vec_log / prefix_search.forward_vec_log: the reference's rows (tests/golden) and the oracle"""
+    from poreover_amd import batch
+    from poreover_amd.decoding import decoding_cy
+    y = golden_inputs["prefix_y"][:100]
+    for flavor in ("cy", "py"):
+        fw0 = batch.forward_vec_batch([y], -1, 0, None, flavor)[0]
+        fw1 = batch.forward_vec_batch([y], 2, 1, [fw0], flavor)[0]
+        fw2 = batch.forward_vec_batch([y], 1, 2, [fw1], flavor)[0]
+        assert np.allclose(np.stack([fw0, fw1, fw2]), golden_inputs["fwvec_" + flavor], rtol=1e-13, atol=0)
+    assert np.allclose(decoding_cy.forward_vec_log(2, 1, y, decoding_cy.forward_vec_log(-1, 0, y)),
+                       golden_inputs["fwvec_cy"][1], rtol=1e-13, atol=0)
+    ys = [synth_pair(9800 + k, T=50 + 37 * k)[0] for k in range(5)]          # ragged batch vs the oracle
+    p0 = batch.forward_vec_batch(ys, -1, 0, None, "cy")
+    p1 = batch.forward_vec_batch(ys, 3, 1, p0, "cy")
+    for k, yk in enumerate(ys):
+        w0 = oracle.forward_vec_log(-1, 0, yk, None, "cy")
+        assert np.allclose(p0[k], w0, rtol=1e-13, atol=0)
+        assert np.allclose(p1[k], oracle.forward_vec_log(3, 1, yk, w0, "cy"), rtol=1e-13, atol=0)
