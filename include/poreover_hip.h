@@ -219,6 +219,13 @@ int po_forward_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, 
 int po_viterbi_acceptor_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
                                 int band_size, const char* labels_h, const int64_t* label_off_h, int32_t* path_h,
                                 int32_t* status_h);
+/* decoding_cy.viterbi_acceptor (decoding_cy.pyx:60-123), the Cython twin of the acceptor, reproduced as written
+ * (dense, '>' tie rule, its own band expression; band_size 0 = whole matrix).  A label character outside the
+ * alphabet is PO_E_ARG (KeyError upstream).  (Device-pointer form: po_viterbi_acceptor_batch with
+ * band_size = -(band + 1).) */
+int po_viterbi_acceptor_cy_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
+                                   int band_size, const char* labels_h, const int64_t* label_off_h, int32_t* path_h,
+                                   int32_t* status_h);
 int po_prefix_search_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
                              char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, double* logp_h,
                              int32_t* status_h);

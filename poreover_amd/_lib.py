@@ -108,6 +108,8 @@ PROTOTYPES = {
     "po_pair_prefix_search_batch_h": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _i32p,
                                                 _dp, _i32p]),
     "po_forward_vec_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
+    "po_viterbi_acceptor_cy_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _i32p,
+                                              _i32p]),
     "po_event_create": (C.c_void_p, []),
     "po_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "po_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

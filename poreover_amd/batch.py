@@ -205,16 +205,18 @@ def forward_batch(arrays, labels, alphabet="ACGT", model="ctc"):
     return out[:n].copy()
 
 
-def viterbi_acceptor_batch(arrays, labels, band_size=1000, alphabet="ACGT"):
-    """decoding_cpp.cpp_viterbi_acceptor for a batch: per-frame state paths (blank = len(alphabet))."""
+def viterbi_acceptor_batch(arrays, labels, band_size=1000, alphabet="ACGT", flavor="cpp"):
+    """decoding_cpp.cpp_viterbi_acceptor (flavor "cpp") / decoding_cy.viterbi_acceptor ("cy") for a batch:
+    per-frame state paths (blank = len(alphabet))."""
     lib = L.load()
     y, off, Cc = pack_rows(arrays)
     n = len(arrays)
     lb, lo = _pack_labels(labels)
     path = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
     st = np.zeros(max(n, 1), dtype=np.int32)
-    L.check(lib.po_viterbi_acceptor_batch_h(_ptr(y), _ptr(off), n, Cc, alphabet.encode(), int(band_size), _ptr(lb),
-                                            _ptr(lo), _ptr(path), _ptr(st)), "po_viterbi_acceptor_batch_h")
+    fn = lib.po_viterbi_acceptor_cy_batch_h if flavor == "cy" else lib.po_viterbi_acceptor_batch_h
+    L.check(fn(_ptr(y), _ptr(off), n, Cc, alphabet.encode(), int(band_size), _ptr(lb), _ptr(lo), _ptr(path), _ptr(st)),
+            "po_viterbi_acceptor_batch_h")
     for i in range(n):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "viterbi acceptor of item %d" % i)

@@ -779,6 +779,13 @@ int po_viterbi_acceptor_batch_h(const double* y_h, const int64_t* y_off_h, int n
     return PO_OK;
 }
 
+int po_viterbi_acceptor_cy_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
+                                   int band_size, const char* labels_h, const int64_t* label_off_h, int32_t* path_h,
+                                   int32_t* status_h) {
+    if (band_size < 0) { g_err = "po_viterbi_acceptor_cy_batch_h: negative band"; return PO_E_ARG; }
+    return po_viterbi_acceptor_batch_h(y_h, y_off_h, n, C, alphabet, -(band_size + 1), labels_h, label_off_h, path_h, status_h);
+}
+
 int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
                       const int32_t* env_h, int n, int C, const char* alphabet, int W, int model, int method,
                       char* seq_h,

@@ -205,6 +205,99 @@ __global__ __launch_bounds__(LT_THREADS) void acceptor_kernel(LTArgs a) {
     }
 }
 
+// decoding_cy.viterbi_acceptor (decoding_cy.pyx:60-123), the Cython twin of the acceptor above, as it is written:
+// dense matrices, row 0 = running blank sum, '>' (not '>=') between emit and stay, cells only for t >= l, pointer
+// matrix initialised to the blank index (non-zero: a cell that was never computed reads as "emit" in the
+// trace-back), trace-back with Python's negative-index wrap-around, and the band centre (l / L) * t that reuses
+// the loop variable t of the previous loop (integer division: 0 for l < L, the last t of row L - 1 for l = L).
+__global__ __launch_bounds__(LT_THREADS) void acceptor_cy_kernel(LTArgs a) {
+    __shared__ double xch[2][LT_THREADS];
+    const int tid = threadIdx.x, pi = blockIdx.x;
+    const int A = a.A, C = a.C, gap = a.A;
+    const int64_t r0 = a.y_off[pi];
+    const int T = (int)(a.y_off[pi + 1] - r0);
+    const double* y = a.y + r0 * C;
+    const char* lab = a.labels + a.label_off[pi];
+    const int L = (int)(a.label_off[pi + 1] - a.label_off[pi]);
+    int32_t* path = a.path + r0;
+    double* rowA = a.rows + (size_t)blockIdx.x * 2 * a.row_cap;
+    double* rowB = rowA + a.row_cap;
+    int8_t* ptr = a.ptr + (size_t)blockIdx.x * a.ptr_cap;
+    if (T < 1 || L < 1 || T > a.row_cap || (long long)(L + 1) * T > a.ptr_cap) {
+        if (tid == 0) a.status[pi] = (T < 1 || L < 1) ? PO_E_ARG : PO_E_CAP;
+        return;
+    }
+    int badsym = 0;  // a label character outside the alphabet is a KeyError upstream
+    for (int i = tid; i < L; i += LT_THREADS) {
+        bool found = false;
+        for (int k = 0; k < A; ++k) found |= ((char)((a.alphabet >> (8 * k)) & 0xffu) == lab[i]);
+        badsym |= !found;
+    }
+    if (__syncthreads_or(badsym)) {
+        if (tid == 0) a.status[pi] = PO_E_ARG;
+        return;
+    }
+    for (int64_t i = tid; i < (int64_t)(L + 1) * T; i += LT_THREADS) ptr[i] = (int8_t)gap;
+    for (int t = tid; t < T; t += LT_THREADS) path[t] = gap;
+    __syncthreads();
+    if (tid == 0) ptr[0] = 1;
+    const int band_ = a.band > 0 ? a.band : T;
+    const int hcommon = min(T, band_);                                   // rows l < L: [1, hcommon)
+    const int tlast = (L > 1 && hcommon > 1) ? hcommon - 1 : T - 1;      // the loop variable when row L starts
+    for (int c0 = 0; c0 < L; c0 += LT_THREADS) {
+        const int nl = min(LT_THREADS, L - c0);
+        const bool on = tid < nl;
+        const int l = c0 + tid + 1;
+        const int sym = on ? sym_index(a.alphabet, A, lab[l - 1]) : 0;
+        const int lo = (l < L) ? 1 : max(1, tlast - band_);
+        const int hi = (l < L) ? hcommon : min(T, tlast + band_);
+        const double* prow = ((c0 / LT_THREADS) & 1) ? rowA : rowB;
+        double* nrow = ((c0 / LT_THREADS) & 1) ? rowB : rowA;
+        double cur = PO_NEG_INF;  // v(l, t-1)
+        double cum = 0.0;         // row 0 (lane of l == 1): running blank sum
+        xch[1][tid] = PO_NEG_INF;
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            double val = PO_NEG_INF;
+            if (on) {
+                double left;  // v(l-1, t-1)
+                if (tid > 0) left = xch[(t + 1) & 1][tid - 1];
+                else if (l == 1) left = (t >= 1) ? cum : PO_NEG_INF;
+                else left = (t >= 1) ? prow[t - 1] : PO_NEG_INF;
+                if (l == 1 && t == 0) val = y[sym];                      // v[1, 0] = y[0, label[0]]
+                if (t >= lo && t < hi && t >= l) {
+                    const double emit = y[(int64_t)t * C + sym] + left;
+                    const double stay = y[(int64_t)t * C + gap] + cur;
+                    const bool take_emit = (emit > stay);
+                    val = take_emit ? emit : stay;
+                    ptr[(size_t)l * T + t] = take_emit ? 1 : 0;
+                }
+                cur = val;
+                xch[t & 1][tid] = val;
+                if (tid == nl - 1) nrow[t] = val;
+                if (l == 1) cum += y[(int64_t)t * C + gap];
+            }
+            po_lds_barrier();
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int l = L, st = PO_OK;
+        long long tt = T - 1;
+        while (l > 0) {
+            if (tt < -(long long)T) { st = PO_E_DIVERGE; break; }   // IndexError upstream
+            const long long idx = tt < 0 ? tt + T : tt;              // wraparound
+            if (ptr[(size_t)l * T + idx] != 0) {
+                path[idx] = sym_index(a.alphabet, A, lab[l - 1]);
+                l -= 1;
+            }
+            tt -= 1;
+        }
+        a.status[pi] = st;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 namespace {
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
@@ -251,6 +344,11 @@ extern "C" int po_launch_acceptor(const double* y, const int64_t* y_off, int n, 
     a.alphabet = alphabet; a.band = band; a.path = path; a.status = status;
     a.rows = (double*)ws; a.row_cap = (long long)(per_rows / (sizeof(double) * 2));
     a.ptr = (int8_t*)ws + per_rows * n; a.ptr_cap = (long long)per_ptr;
-    hipLaunchKernelGGL(acceptor_kernel, dim3(n), dim3(LT_THREADS), 0, stream, a);
+    if (band < 0) {   // negative band: the Cython twin, band = -band - 1 (0: the whole matrix)
+        a.band = -band - 1;
+        hipLaunchKernelGGL(acceptor_cy_kernel, dim3(n), dim3(LT_THREADS), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(acceptor_kernel, dim3(n), dim3(LT_THREADS), 0, stream, a);
+    }
     return PO_OK;
 }

@@ -17,6 +17,13 @@ def forward_vec_log(s, i, y, previous=None):
                                     None if previous is None else [np.asarray(previous, dtype=np.float64)], "cy")[0]
 
 
+def viterbi_acceptor(y, label_, alphabet="ACGT", band_size=0):
+    """decoding_cy.pyx:60-123: best alignment path of a known label, the Cython twin of cpp_viterbi_acceptor
+    (its own tie rule and band expression, reproduced as written); alphabet may be a dict like the reference's"""
+    sym = "".join(alphabet.keys()) if hasattr(alphabet, "keys") else "".join(alphabet)
+    return _batch.viterbi_acceptor_batch([np.asarray(y, dtype=np.float64)], [label_], band_size, sym, "cy")[0]
+
+
 def diagonal_band_envelope(U, V, width):
     """decoding_cy.pyx:41-56: inclusive (start, end) per row around the main diagonal -> (U, 2) array"""
     out = []

@@ -73,3 +73,23 @@ def test_acceptor_golden_and_oracle(dec, oracle, golden, golden_inputs):
     lab = oracle.cpp_beam_search(y1, 10)
     assert len(lab) > 256
     assert dec.cpp_viterbi_acceptor(y1, lab).tolist() == oracle.cpp_viterbi_acceptor(y1, lab).tolist()
+
+
+def test_acceptor_cython_twin(oracle, golden, golden_inputs):
+    """decoding_cy.viterbi_acceptor: the reference's path on its csv fixture, and the oracle on synthetic reads with
+    several band sizes (the twin's band expression and '>' tie rule are reproduced as written)"""
+    from poreover_amd import _lib, batch
+    from poreover_amd.decoding import decoding_cy
+    y = np.log(golden_inputs["poreover_csv_prob"])
+    seq = golden["csv"]["viterbi"]
+    assert decoding_cy.viterbi_acceptor(y, seq).tolist() == golden["csv"]["acceptor_cy"]
+    ys, labs = [], []
+    for i in range(6):
+        y1 = synth_pair(9900 + i, T=120 + 90 * i)[0]
+        ys.append(y1); labs.append(oracle.viterbi_decode(y1)[0][: 5 + 9 * i] or "A")
+    for band in (0, 7, 40, 1000):
+        got = batch.viterbi_acceptor_batch(ys, labs, band, flavor="cy")
+        for g, yk, lb in zip(got, ys, labs):
+            assert g.tolist() == oracle.viterbi_acceptor(yk, lb, "ACGT", band).tolist(), band
+    with pytest.raises(_lib.EngineError):
+        batch.viterbi_acceptor_batch([ys[0]], ["ACXT"], 0, flavor="cy")
