@@ -15,11 +15,21 @@ fasta_format = decode.fasta_format
 
 
 def _check_supported(args):
-    if getattr(args, 'method', 'envelope') != 'envelope':
-        raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --method %s" % args.method,
-                               "only the envelope method (the reference's default) is built")
+    method = getattr(args, 'method', 'envelope')
+    if method == 'split':
+        # pair_decode.py:336-354: upstream this route only returns together with --diagonal_envelope (the other
+        # branch of its final return needs 1-D basecalls the split route never makes: NameError)
+        if not getattr(args, 'diagonal_envelope', False):
+            raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --method split without --diagonal_envelope",
+                                   "the reference raises NameError on this combination")
+    elif method != 'envelope':
+        raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --method %s" % method,
+                               "only the envelope and split methods are built ('align' only prints statistics)")
     if getattr(args, 'algorithm', 'beam') != 'beam':
-        raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --algorithm %s" % args.algorithm)
+        # pair_decode.py:222: assert(self.kind == "poreover") compares the model name 'ctc' with 'poreover' and
+        # always fails; the pair prefix search itself is available as prefix_search.pair_prefix_search_log_cy
+        raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --algorithm %s" % args.algorithm,
+                               "the reference's own assert refuses it for every basecaller")
     if getattr(args, 'skip_matches', False) and (getattr(args, 'diagonal_envelope', False) or
                                                  getattr(args, 'single', 'viterbi') != 'viterbi'):
         raise _lib.EngineError(_lib.E_UNSUPPORTED, "pair-decode --skip_matches with --diagonal_envelope / --single beam")
@@ -143,12 +153,54 @@ def _decode_pairs_skip_matches(in_paths, loaded, args, out):
     return out
 
 
+def _decode_pairs_split(in_paths, loaded, args, out):
+    """--method split (pair_decode.py:336-354, parallel_decoder._beam_search_2d :149-165): boxes of --window frames
+    of read 1 along the main diagonal, each decoded on its own — pair beam search without an envelope (method
+    "row"), or 1-D prefix search when a box has no extent on one read — and the pieces joined in order.  All
+    boxes of all pairs go to the GPU in one batched call per kind of box."""
+    from . import prefix_search
+    by_kind = {}
+    for i, (_, _, m1, _) in enumerate(loaded):
+        by_kind.setdefault(m1.kind, []).append(i)
+    for kind, idx in by_kind.items():
+        model = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}[kind]
+        b1, b2, owner, pieces = [], [], [], {}
+        for i in idx:
+            y1, y2 = loaded[i][2].log_prob, loaded[i][3].log_prob
+            U, V = len(y1), len(y2)
+            boxes = [(u - args.window, u, int(V / U * (u - args.window)), int(V / U * u))
+                     for u in range(args.window, U, args.window)]
+            boxes.append((boxes[-1][1], U, boxes[-1][3], V))   # IndexError for reads shorter than a window, as upstream
+            pieces[i] = [None] * len(boxes)
+            for k, (u1, u2, v1, v2) in enumerate(boxes):
+                size = (u2 - u1 + 1) * (v2 - v1 + 1)
+                if size <= 1:
+                    pieces[i][k] = ''
+                elif (u2 - u1) < 1:
+                    pieces[i][k] = prefix_search.prefix_search_log_cy(y2[v1:v2])[0]
+                elif (v2 - v1) < 1:
+                    pieces[i][k] = prefix_search.prefix_search_log_cy(y1[u1:u2])[0]
+                else:
+                    b1.append(y1[u1:u2]); b2.append(y2[v1:v2]); owner.append((i, k))
+        calls = _batch.beam_search_2d_batch(b1, b2, None, args.beam_width, model=model, method="row") if b1 else []
+        for (i, k), sq in zip(owner, calls):
+            pieces[i][k] = sq
+        for i in idx:
+            path1, path2 = loaded[i][0], loaded[i][1]
+            # the header keeps the quirk of pair_decode.py:527 (the format string drops its third argument)
+            out[i] = (fasta_format('consensus;{};{}'.format(args.method, path1.stem, path2.stem), ''.join(pieces[i])),
+                      {'read1': in_paths[i][0], 'read2': in_paths[i][1]})
+    return out
+
+
 def decode_pairs(in_paths, args):
     """pair_decode_helper for a LIST of pairs: returns a list of the reference's return tuples
     (1-, 2- or 3-tuples, pair_decode.py:375,398,526-529)."""
     _check_supported(args)
     loaded = [_load_pair(p, args) for p in in_paths]
     out = [None] * len(loaded)
+    if getattr(args, 'method', 'envelope') == 'split':
+        return _decode_pairs_split(in_paths, loaded, args, out)
     if getattr(args, 'skip_matches', False):
         return _decode_pairs_skip_matches(in_paths, loaded, args, out)
     by_kind = {}

@@ -307,6 +307,15 @@ def main():
                     rec["runs"]["skip%d" % thr] = {"n_out": len(out), "fasta_2d": out[1] if len(out) == 3 else None}
                 except Exception as ex:   # empty boxes make the reference itself raise (IndexError / assert)
                     rec["runs"]["skip%d" % thr] = {"n_out": 0, "error": type(ex).__name__}
+        # --method split (pair_decode.py:336-354; only returns with --diagonal_envelope, whose branch of the final
+        # return does not touch the 1-D basecalls): boxes along the diagonal, beam search or pair prefix search each
+        if kind == "poreover" and idx < 4:
+            for alg, win in (("beam", 100), ("prefix", 60)):
+                try:
+                    out = ref_pd.pair_decode_helper(ns(method="split", algorithm=alg, window=win, diagonal_envelope=True))
+                    rec["runs"]["split_%s_%d" % (alg, win)] = {"n_out": len(out), "fasta_2d": out[0]}
+                except Exception as ex:
+                    rec["runs"]["split_%s_%d" % (alg, win)] = {"n_out": 0, "error": type(ex).__name__}
         pair_recs.append(rec)
     G["pairs"] = pair_recs
 

@@ -101,7 +101,8 @@ def test_pair_decode_driver_matches_reference_outputs(eng, tmp_path, monkeypatch
     assert len(out) == 2 and out[0].startswith(">consensus;envelope;p%d_a\n" % recs[0]["index"])
     assert out[0].split("\n", 1)[1] == recs[0]["runs"]["diag30"]["fasta_2d"].split("\n", 1)[1]
     # unsupported routes are refused loudly
-    for kw in (dict(method="split"), dict(algorithm="prefix"), dict(skip_matches=True, diagonal_envelope=True)):
+    for kw in (dict(method="split"), dict(method="align"), dict(algorithm="prefix"),
+               dict(skip_matches=True, diagonal_envelope=True)):
         bad = _pair_args(**kw)
         setattr(bad, "in", a0)
         with pytest.raises(eng.EngineError):
@@ -164,3 +165,24 @@ def test_pair_decode_skip_matches(eng, tmp_path, monkeypatch, golden, golden_inp
     # get_anchors restated: the reference's own small cases
     assert pair_decode.get_anchors(("AAAAA-CC", "AAAAATCC"), matches=3, indels=1) == ([(0, 5), (5, 6)], ["mat", "ins"])
     assert pair_decode.get_anchors(("ACGT", "ACGT"), matches=2, indels=100) == ([], [])   # the open run at the end is not reported
+
+
+def test_pair_decode_split_method(eng, monkeypatch, golden, golden_inputs):
+    """--method split --diagonal_envelope (the only combination that returns upstream): boxes of --window frames
+    along the diagonal, pair beam search without an envelope in each; the reference's consensus records"""
+    from poreover_amd.decoding import decode, pair_decode, transducer
+    recs = [r for r in golden["pairs"] if "split_beam_100" in r["runs"]]
+    assert len(recs) >= 4
+    mats, in_paths = {}, []
+    for r in recs:
+        a, b = "p%d_a.npy" % r["index"], "p%d_b.npy" % r["index"]
+        mats[a], mats[b] = golden_inputs["pair%d_y1" % r["index"]], golden_inputs["pair%d_y2" % r["index"]]
+        in_paths.append([a, b])
+    monkeypatch.setattr(decode, "model_from_trace",
+                        lambda f, basecaller="": transducer.poreover(mats[os.path.basename(str(f))]))
+    res = pair_decode.decode_pairs(in_paths, _pair_args(method="split", window=100, diagonal_envelope=True))
+    for r, got in zip(recs, res):
+        want = r["runs"]["split_beam_100"]
+        assert want["n_out"] == 2 and len(got) == 2
+        assert got[0].startswith(">consensus;split;p%d_a\n" % r["index"])
+        assert got[0].split("\n", 1)[1] == want["fasta_2d"].split("\n", 1)[1], r["index"]
