@@ -82,17 +82,23 @@ __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
         const int rows = min(VT_TILE, T - t0);
         const int nval = rows * C;
         const double* src = yr + (int64_t)t0 * C;
-        double reg[VT_LD];
+        // 16-byte loads (two doubles per lane and instruction), all issued before any use; a tile's byte offset in
+        // the read is a multiple of 16, the read's own start only of 8 (dwordx4 needs 4-byte alignment)
+        double2 reg[VT_LD / 2];
+        const double2* src2 = (const double2*)src;
+        const int nval2 = nval >> 1;
 #pragma unroll
-        for (int q = 0; q < VT_LD; ++q) {  // all loads issued before any use
+        for (int q = 0; q < VT_LD / 2; ++q) {
             const int i = tid + q * VT_THREADS;
-            reg[q] = (i < nval) ? src[i] : 0.0;
+            reg[q] = (i < nval2) ? src2[i] : make_double2(0.0, 0.0);
         }
+        const double tail = (nval & 1) ? src[nval - 1] : 0.0;   // odd number of values in a short last tile
 #pragma unroll
-        for (int q = 0; q < VT_LD; ++q) {
+        for (int q = 0; q < VT_LD / 2; ++q) {
             const int i = tid + q * VT_THREADS;
-            if (i < nval) tile[i] = reg[q];
+            if (i < nval2) { tile[2 * i] = reg[q].x; tile[2 * i + 1] = reg[q].y; }
         }
+        if ((nval & 1) && tid == 0) tile[nval - 1] = tail;
         __syncthreads();
         int p[VT_FPT];
 #pragma unroll
