@@ -158,8 +158,10 @@ __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
             *total = tot;
             return base + inc - v;
         };
-        int tot_s, tot_m;
-        int pos_s = n_seq + block_excl(ne, &tot_s);
+        // one scan for both compactions: bases in the low half, frame-map entries in the high half (<= 512 each)
+        int tot_p;
+        const int excl = block_excl(ne | (nm << 16), &tot_p);
+        int pos_s = n_seq + (excl & 0xffff);
 #pragma unroll
         for (int f = 0; f < VT_FPT; ++f)
             if (emit[f]) {
@@ -167,13 +169,13 @@ __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
                 else st = PO_E_CAP;
                 pos_s++;
             }
-        n_seq += tot_s;
+        n_seq += tot_p & 0xffff;
         if (mp) {
-            int pos_m = n_map + block_excl(nm, &tot_m);
+            int pos_m = n_map + (excl >> 16);
 #pragma unroll
             for (int f = 0; f < VT_FPT; ++f)
                 if (emit_map[f]) mp[pos_m++] = t0 + tid * VT_FPT + f;
-            n_map += tot_m;
+            n_map += tot_p >> 16;
         }
         if (tid == 0) pth[0] = pth[rows];
         __syncthreads();
