@@ -855,6 +855,10 @@ struct X2Half {
     // workgroups fit a CU's LDS; 256 (32 rows of 8) elsewhere (those kernels are register-bound anyway)
     static constexpr int YD = (K == 1 && SG == 32) ? (X2_YD < 192 ? X2_YD : 192) : X2_YD;
     double ybuf[YD];         // the y rows of the current step's windows
+    // between two scans the buffer keeps, per element slot, the maxima of the step's two windows and their times
+    static_assert(YD >= 3 * SG, "y buffer too small for the carried maxima");
+    __device__ double* stg_v() { return ybuf; }                    // [2][SG]
+    __device__ int* stg_t() { return (int*)(ybuf + 2 * SG); }      // [2][SG]
     unsigned long long nupd; // profiling: update_prob evaluations
 };
 template <int K, int SG>
@@ -1032,6 +1036,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
     if (s == 0) h.nupd = 0;  // update_prob evaluations of this half-wave's pairs (profiling only; kept in LDS)
     bool have = false, done = false;
     int pi = 0, U = 1, V = 1, u = 0, v = 0, nb = 0, R = 32, Rm = 31, NG = 0, st = PO_OK;
+    int nbq = 0;                   // beam nodes in the previous main step (its element slots name the carried maxima)
     unsigned epoch = 0;
     const double *yA = a.y1, *yB = a.y2, *cumA = a.cum1, *cumB = a.cum2;
     const int4* sched = a.sched;   // this pair's main steps {u, v, column-window end, row-window end}
@@ -1204,6 +1209,32 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         // windows [u, ece) on read 0 and [v, ere) on read 1; every lane flows through, predicated
         const bool dm = have && !fin;
         const int ece = rec.z, ere = rec.w;
+        // ---- expansion state of the beam nodes, one lane per beam node
+        const bool bl = dm && s < nb;
+        bool isnew = false, need_group = false;
+        int id = 0, crow = -1;
+        if (bl) {
+            id = h.e[F_ID][s];
+            crow = h.e[F_CROW][s];
+            if (h.e[F_FC][s] < 0) { isnew = true; need_group = true; }
+            else if (crow < 0 || crow >= NG || h.g_owner[crow] != id) need_group = true;  // old rows recycled: all dead
+        }
+        // ---- INCREMENTAL step.  If every beam node was a beam node in the previous main step and keeps its children
+        // and their rows, every element of this step was an element of the previous one, with the same parent links:
+        // over the part of its windows that step covered, each would recompute exactly the bits that are stored (see
+        // "redundant stores" below).  Such a step only computes the times the windows have grown by, seeded from the
+        // store at the previous window ends; the score's maximum over the rest of the window is carried over (or
+        // re-read from the store when its position has left the window).  About 3 of 4 steps are of this kind.
+        bool fastH;
+        {
+            const unsigned long long nf_ = __ballot(bl && (isnew || need_group || !h.stay[s]));
+            fastH = dm && ((SG == 64) ? nf_ : (g ? (nf_ >> 32) : (nf_ & 0xffffffffull))) == 0;
+#ifdef PO_X2_NOFAST
+            fastH = false;
+#endif
+        }
+        const int su = fastH ? min(max(h.sh[5], u), ece) : u;   // first time to compute on read 0
+        const int sv = fastH ? min(max(h.sh[6], v), ere) : v;   // ... on read 1
         // The y rows of the step's first buffer fill are requested now, into registers: the window is known from
         // the schedule, and the loads fly while the (serial) expansion and the element table are built.
         // (One-value model only: the 3-value kernels have no registers to spare — it would cost them a wave per SIMD.)
@@ -1211,32 +1242,23 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         constexpr int YPRE = YEARLY ? (X2Half<K, SG>::YD + SG - 1) / SG : 1;   // doubles per lane of one buffer fill
         double ypre[YPRE];
         if (YEARLY) {
-            const int l0 = dm ? ece - u : 0, l1 = dm ? ere - v : 0;
+            const int l0 = dm ? ece - su : 0, l1 = dm ? ere - sv : 0;
             const int yrows_ = X2Half<K, SG>::YD / C;
             const int kend = min(l0 + l1, yrows_);
             const int nA = min(kend, l0) * C, nT = kend * C;
-            const double* srcA = yA + (int64_t)u * C;
-            const double* srcB = yB + (int64_t)v * C - nA;   // buffer index i >= nA reads srcB[i]
+            const double* srcA = yA + (int64_t)su * C;
+            const double* srcB = yB + (int64_t)sv * C - nA;   // buffer index i >= nA reads srcB[i]
 #pragma unroll
             for (int q = 0; q < YPRE; ++q) {
                 const int i = s + q * SG;
                 ypre[q] = (i < nT) ? ((i < nA) ? srcA[i] : srcB[i]) : 0.0;
             }
         }
-        // ---- expansion: children ids and row groups of the beam nodes, one lane per beam node.  New node ids are
+        // ---- expansion: children ids and row groups of the beam nodes.  New node ids are
         // handed out in beam order (a prefix count over the lanes that need them: ids break score ties); row
         // groups, which only name storage, are allocated one lane after the other, after every group in use has
         // been marked with this step's window ends.
         {
-            const bool bl = dm && s < nb;
-            bool isnew = false, need_group = false;
-            int id = 0, crow = -1;
-            if (bl) {
-                id = h.e[F_ID][s];
-                crow = h.e[F_CROW][s];
-                if (h.e[F_FC][s] < 0) { isnew = true; need_group = true; }
-                else if (crow < 0 || crow >= NG || h.g_owner[crow] != id) need_group = true;  // old rows recycled: all dead
-            }
             const unsigned long long bn = __ballot(isnew), bg = __ballot(need_group);
             const unsigned long long hn = (SG == 64) ? bn : (g ? (bn >> 32) : (bn & 0xffffffffull));
             unsigned long long hg = (SG == 64) ? bg : (g ? (bg >> 32) : (bg & 0xffffffffull));
@@ -1307,13 +1329,16 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         TK(3);  // element table
         // ---- the scan: read 0's window, then read 1's, one t per iteration
         {
-            const int len0 = dmm ? ece - u : 0, len1 = dmm ? ere - v : 0;
+            const int len0 = dmm ? ece - su : 0, len1 = dmm ? ere - sv : 0;
             const int tot = len0 + len1;
             const int Ltot = max(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 64 - SG));
             const bool part = s < ne;
             int pslot = PS_ROOT, sym = 0;
             bool same = false, rootpar = false;
             double self[K], self1[K], mx0 = PO_NEG_INF, mx = PO_NEG_INF;
+            int mt0 = -1, mt = -1;                      // where the maxima are (the latest such time)
+            double c1 = PO_NEG_INF;                     // read 1: maximum carried over from the previous step
+            int ct1 = -1;
             Ent *myrow = pool, *row1 = pool;
             const Ent *prow = pool, *prow1 = pool;
             unsigned long long tag0 = 0, ptag0 = 0;
@@ -1326,16 +1351,96 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 myrow = pool + (size_t)h.e[F_ROW][s] * 2 * R;
                 row1 = myrow + R;
                 tag0 = make_tag(epoch, h.e[F_ID][s], 0);
-                st_read(myrow, u - 1, tag0, self);
-                st_read(row1, v - 1, tag0, self1);
+                st_read(myrow, su - 1, tag0, self);
+                st_read(row1, sv - 1, tag0, self1);
                 if (pslot == PS_FROZEN) {
                     prow = pool + (size_t)h.e[F_PROW][s] * 2 * R;
                     prow1 = prow + R;
                     ptag0 = make_tag(epoch, h.e[F_PAR][s], 0);
                 }
 #pragma unroll
-                for (int k = 0; k < K; ++k) h.xch[1][s][k] = self[k];
+                for (int k = 0; k < K; ++k) h.xch[1][s][k] = (len0 > 0) ? self[k] : self1[k];
             }
+            // The part [u, su) / [v, sv) of an incremental step's windows is not recomputed: its maximum comes from
+            // the previous step's (kept per element slot in the y buffer, which is idle between scans) — unless that
+            // maximum sat at a time the window has left.  Then the stored values are read back: the half-wave shares
+            // the work, 4 lanes per (element, read) with 4 loads in flight each, so that a step pays one or two
+            // memory round trips for it, not one per value.
+            {
+                bool need0 = false, need1 = false;
+                int ps = 0;
+                if (part && fastH) {
+                    ps = h.sel[min(s, WB - 1)];
+                    if (s >= nb) { const int j = (s - nb) / A; ps = nbq + A * h.sel[j] + ((s - nb) - j * A); }
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int lo = rr ? v : u, hi = rr ? sv : su;
+                        if (hi > lo) {
+                            const double pm = h.stg_v()[rr * SG + ps];
+                            const int pt = h.stg_t()[rr * SG + ps];
+                            if (pm == PO_NEG_INF || (pt >= lo && pt < hi)) {
+                                if (rr) { c1 = pm; ct1 = pt; } else { mx = pm; mt = pt; }
+                            } else if (rr) need1 = true;
+                            else need0 = true;
+                        }
+                    }
+                }
+                const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
+                if ((b0 | b1) != 0) {   // (wave-uniform)
+                    const unsigned long long hm0 = (SG == 64) ? b0 : (g ? (b0 >> 32) : (b0 & 0xffffffffull));
+                    const unsigned long long hm1 = (SG == 64) ? b1 : (g ? (b1 >> 32) : (b1 & 0xffffffffull));
+                    const unsigned long long below = (1ull << s) - 1ull;
+                    const int n0 = __popcll(hm0), nit = n0 + __popcll(hm1);
+                    int* const list = (int*)&h.xch[0][0][0];   // free until the first iteration ends
+                    if (need0) list[__popcll(hm0 & below)] = s;
+                    if (need1) list[n0 + __popcll(hm1 & below)] = s;
+                    x2_sync();
+                    constexpr int G = 4, PER = SG / G;
+                    const int rounds_h = (nit + PER - 1) / PER;
+                    const int rounds = max(__builtin_amdgcn_readlane(rounds_h, 0), __builtin_amdgcn_readlane(rounds_h, 64 - SG));
+#ifdef PO_B2_TIMING
+                    if (g == 0 && s == 0) { tk[0] += 1000000; tk[1] += 1000000ll * nit; }
+#endif
+                    for (int r = 0; r < rounds; ++r) {
+                        const int item = r * PER + s / G, sub = s & (G - 1);
+                        const bool act = item < nit;
+                        double c = PO_NEG_INF;
+                        int ct = -1, wr = 0;
+                        if (act) {
+                            const int rr = (item >= n0) ? 1 : 0;
+                            const int sl = list[item];
+                            const int lo = rr ? v : u, hi = rr ? sv : su;
+                            const Ent* rp = pool + ((size_t)h.e[F_ROW][sl] * 2 + rr) * R;
+                            const unsigned long long tg = make_tag(epoch, h.e[F_ID][sl], 0);
+                            int psl = h.sel[min(sl, WB - 1)];
+                            if (sl >= nb) { const int j = (sl - nb) / A; psl = nbq + A * h.sel[j] + ((sl - nb) - j * A); }
+                            wr = rr * SG + psl;
+                            for (int bt = lo + sub; bt < hi; bt += 4 * G) {
+                                Ent e4[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) e4[q] = rp[(bt + q * G) & Rm];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int tq = bt + q * G;
+                                    const double val = (tq < hi && e4[q].tag == tg + (unsigned)tq) ? e4[q].v[0] : PO_NEG_INF;
+                                    if (tq < hi && val >= c) { c = val; ct = tq; }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int off = 1; off < G; off <<= 1) {   // the latest time among equal maxima
+                            const double oc = __shfl_xor(c, off);
+                            const int ot = __shfl_xor(ct, off);
+                            if (oc > c || (oc == c && ot > ct)) { c = oc; ct = ot; }
+                        }
+                        if (act && sub == 0) { h.stg_v()[wr] = c; h.stg_t()[wr] = ct; }
+                    }
+                    x2_sync();
+                    if (need0) { mx = h.stg_v()[ps]; mt = h.stg_t()[ps]; }
+                    if (need1) { c1 = h.stg_v()[SG + ps]; ct1 = h.stg_t()[SG + ps]; }
+                }
+            }
+            x2_sync();   // the carried maxima are read before the y buffer is filled
             // Redundant stores.  An element that was an element in the previous main step too recomputes, over
             // the part of its window that step already covered, exactly the bits that are stored — IF every
             // ancestor of it inside the element set is in the same situation (same seed, same parent values,
@@ -1354,11 +1459,19 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     bm = nbm;
                 }
             }
+#ifdef PO_B2_TIMING
+            {   // statistics: steps of this half without any element that needs its full window
+                const unsigned long long bmm = __ballot(bad && part);
+                const unsigned long long hmm = (SG == 64) ? bmm : (g ? (bmm >> 32) : (bmm & 0xffffffffull));
+                if (dmm && g == 0 && s == 0) { tk[10] += 1; if (fastH) tk[11] += 1; tk[9] += __popcll(hmm); }
+            }
+#endif
             int sfrom = bad ? INT_MIN : h.sh[5];        // first time whose value must be written (current read)
             const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
-            int t = u;                                  // time of the current iteration
+            int t = su;                                 // time of the current iteration
             const double* cump = cumA;                  // fetch context of a non-moving parent: root sums, next time
-            int tf = u;
+            int tf = su;
+            if (len0 == 0) { cump = cumB; prow = prow1; tf = sv; }
             double pr_n[K];
             Ent pe_n;
             pe_n.tag = 0;
@@ -1387,11 +1500,11 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 const int kend = min(tot, k0 + yrows);
                 const int ka1 = min(kend, len0);                 // read-0 iterations [k0, ka1)
                 const int nA = max(0, ka1 - k0) * C;
-                const double* srcA = yA + (int64_t)(u + k0) * C;
+                const double* srcA = yA + (int64_t)(su + k0) * C;
                 for (int i = s; i < nA; i += SG) h.ybuf[i] = srcA[i];
                 const int kb0 = max(k0, len0);                   // read-1 iterations [kb0, kend)
                 const int nB = max(0, kend - kb0) * C;
-                const double* srcB = yB + (int64_t)(v + kb0 - len0) * C;
+                const double* srcB = yB + (int64_t)(sv + kb0 - len0) * C;
                 for (int i = s; i < nB; i += SG) h.ybuf[nA + i] = srcB[i];
             }
             x2_sync();
@@ -1401,7 +1514,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 const int k = __builtin_amdgcn_readfirstlane(kv);
                 if (part && k < tot) {
                     if (k == len0) {  // read 0's window is done: continue on read 1 from its seed
-                        mx0 = mx; mx = PO_NEG_INF; t = v; myrow = row1;
+                        mx0 = mx; mt0 = mt; mx = c1; mt = ct1; t = sv; myrow = row1;
                         sfrom = bad ? INT_MIN : h.sh[6];
 #pragma unroll
                         for (int q = 0; q < K; ++q) self[q] = self1[q];
@@ -1417,7 +1530,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                         for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
                     }
                     if (pslot < 0 && k + 1 < tot) {
-                        if (k + 1 == len0) { cump = cumB; prow = prow1; tf = v; }
+                        if (k + 1 == len0) { cump = cumB; prow = prow1; tf = sv; }
                         fetch();
                     }
                     po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
@@ -1435,19 +1548,25 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     const bool sw = (k + 1 == len0);  // the next iteration starts read 1: hand its seed over
 #pragma unroll
                     for (int q = 0; q < K; ++q) { self[q] = out[q]; h.xch[k & 1][s][q] = sw ? self1[q] : out[q]; }
-                    mx = fmax(mx, out[0]);
+                    if (out[0] >= mx) { mx = out[0]; mt = t; }
                     t++;
                 }
                 x2_sync();
             }
             TK(5);  // scan: iterations
             }
+            if (len1 == 0) { mx0 = mx; mt0 = mt; mx = c1; mt = ct1; }   // (no iteration switched to read 1)
+            if (part) {   // this step's maxima, for the next one
+                h.stg_v()[s] = mx0; h.stg_v()[SG + s] = mx;
+                h.stg_t()[s] = mt0; h.stg_t()[SG + s] = mt;
+            }
             {   // node_greater_max_sym: max over read 0 + max over read 1
                 X2Cand c;
                 c.sc = mx0 + mx; c.id = part ? h.e[F_ID][s] : 0; c.dup = part ? dupf : 1;
                 h.cand[s] = c;
             }
-            if (part && s == 0) { h.nupd += (unsigned)(ne * tot); h.sh[5] = ece; h.sh[6] = ere; }
+            // (the counter counts the evaluations the reference's step makes: ne over both full windows)
+            if (part && s == 0) { h.nupd += (unsigned)(ne * ((ece - u) + (ere - v))); h.sh[5] = ece; h.sh[6] = ere; }
             if (part && s >= nb) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
         }
         x2_sync();
@@ -1505,6 +1624,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 h.bps[s] = nbp;
             }
             if (dmm) {
+                nbq = nb;
                 nb = nbn;
                 up = u; vp = v;
                 mstep++;
@@ -1842,6 +1962,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
                                  "scan: iterations", "scores", "prune + next beam", "label walk"};
             fprintf(stderr, "[po_b2_timing x2] block 0, wall_clock64 ticks (100 MHz => 10 ns each):\n");
             for (int i = 0; i < 9; ++i) fprintf(stderr, "   %-24s %12lld\n", nm[i], hh[i]);
+            fprintf(stderr, "   main steps %lld, of which without a new element %lld; new elements in all %lld\n", hh[10], hh[11], hh[9]);
         }
 #endif
         // pairs the pre-pass or the kernel deferred (window too wide for its store geometry, row groups
