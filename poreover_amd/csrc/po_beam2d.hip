@@ -1340,6 +1340,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
             double c1 = PO_NEG_INF;                     // read 1: maximum carried over from the previous step
             int ct1 = -1;
             Ent *myrow = pool, *row1 = pool;
+            Ent seed0, seed1;
             const Ent *prow = pool, *prow1 = pool;
             unsigned long long tag0 = 0, ptag0 = 0;
 #pragma unroll
@@ -1351,15 +1352,15 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 myrow = pool + (size_t)h.e[F_ROW][s] * 2 * R;
                 row1 = myrow + R;
                 tag0 = make_tag(epoch, h.e[F_ID][s], 0);
-                st_read(myrow, su - 1, tag0, self);
-                st_read(row1, sv - 1, tag0, self1);
+                // the seeds are only requested here; they are looked at after the re-read of maxima below, so that
+                // the two memory round trips overlap
+                seed0 = myrow[(su - 1) & Rm];
+                seed1 = row1[(sv - 1) & Rm];
                 if (pslot == PS_FROZEN) {
                     prow = pool + (size_t)h.e[F_PROW][s] * 2 * R;
                     prow1 = prow + R;
                     ptag0 = make_tag(epoch, h.e[F_PAR][s], 0);
                 }
-#pragma unroll
-                for (int k = 0; k < K; ++k) h.xch[1][s][k] = (len0 > 0) ? self[k] : self1[k];
             }
             // The part [u, su) / [v, sv) of an incremental step's windows is not recomputed: its maximum comes from
             // the previous step's (kept per element slot in the y buffer, which is idle between scans) — unless that
@@ -1438,6 +1439,16 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     x2_sync();
                     if (need0) { mx = h.stg_v()[ps]; mt = h.stg_t()[ps]; }
                     if (need1) { c1 = h.stg_v()[SG + ps]; ct1 = h.stg_t()[SG + ps]; }
+                }
+            }
+            if (part) {
+                const bool hit0 = (su >= 1) && (seed0.tag == tag0 + (unsigned)(su - 1));
+                const bool hit1 = (sv >= 1) && (seed1.tag == tag0 + (unsigned)(sv - 1));
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    self[k] = hit0 ? seed0.v[k] : PO_NEG_INF;
+                    self1[k] = hit1 ? seed1.v[k] : PO_NEG_INF;
+                    h.xch[1][s][k] = (len0 > 0) ? self[k] : self1[k];
                 }
             }
             x2_sync();   // the carried maxima are read before the y buffer is filled
