@@ -1627,6 +1627,12 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     for (int i = 0; i < WB; ++i) if (i < nbn && h.sel[i] == oldpar) nbp = i;
                 }
             }
+#ifdef PO_B2_TIMING
+            {
+                const unsigned long long mv = __ballot(s < nbn && h.sel[s] != s);
+                if (dmm && g == 0 && s == 0 && (mv & 0xffffffffull) == 0 && nbn == nb) tk[8] += 1000000;
+            }
+#endif
             x2_sync();  // every lane has read its source slot before any slot is overwritten
             if (s < nbn) {
 #pragma unroll
