@@ -850,7 +850,7 @@ struct X2Half {
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[8];
     X2Cand cand[SG];         // prune candidates: score, node id, duplicate flag — one 16-byte read per comparison
-    double xch[2][SG][2][K];   // [iteration parity][slot][read]: the value a child reads as its parent's at t-1
+    double xch[2][SG][K];
     // doubles in the y window buffer: 192 (38 rows of 5) for the two-pairs-per-wave one-value kernel, so that 12
     // workgroups fit a CU's LDS; 256 (32 rows of 8) elsewhere (those kernels are register-bound anyway)
     static constexpr int YD = (K == 1 && SG == 32) ? (X2_YD < 192 ? X2_YD : 192) : X2_YD;
@@ -1241,16 +1241,17 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         constexpr bool YEARLY = (K == 1);
         constexpr int YPRE = YEARLY ? (X2Half<K, SG>::YD + SG - 1) / SG : 1;   // doubles per lane of one buffer fill
         double ypre[YPRE];
-        const int KH = (X2Half<K, SG>::YD / C) / 2;   // y rows per read in one buffer fill
         if (YEARLY) {
             const int l0 = dm ? ece - su : 0, l1 = dm ? ere - sv : 0;
-            const int nA = min(l0, KH) * C, nB = min(l1, KH) * C, oB = KH * C;
+            const int yrows_ = X2Half<K, SG>::YD / C;
+            const int kend = min(l0 + l1, yrows_);
+            const int nA = min(kend, l0) * C, nT = kend * C;
             const double* srcA = yA + (int64_t)su * C;
-            const double* srcB = yB + (int64_t)sv * C - oB;   // buffer index i >= oB reads srcB[i]
+            const double* srcB = yB + (int64_t)sv * C - nA;   // buffer index i >= nA reads srcB[i]
 #pragma unroll
             for (int q = 0; q < YPRE; ++q) {
                 const int i = s + q * SG;
-                ypre[q] = (i < nA) ? srcA[i] : ((i >= oB && i < oB + nB) ? srcB[i] : 0.0);
+                ypre[q] = (i < nT) ? ((i < nA) ? srcA[i] : srcB[i]) : 0.0;
             }
         }
         // ---- expansion: children ids and row groups of the beam nodes.  New node ids are
@@ -1326,18 +1327,18 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         if (s < nb && s < ne && h.e[F_PSLOT][s] >= nb) h.e[F_PROW][s] = h.e[F_ROW][h.e[F_PSLOT][s]];  // parent's current row
 
         TK(3);  // element table
-        // ---- the scan: both windows at once, one t of each per iteration.  The two reads' recurrences are
-        // independent, so a lane runs them as two interleaved dependency chains: the step takes
-        // max(len0, len1) iterations instead of len0 + len1, and the chains' latencies overlap.
+        // ---- the scan: read 0's window, then read 1's, one t per iteration
         {
             const int len0 = dmm ? ece - su : 0, len1 = dmm ? ere - sv : 0;
-            const int Lh = max(len0, len1);
-            const int Ltot = max(__builtin_amdgcn_readlane(Lh, 0), __builtin_amdgcn_readlane(Lh, 64 - SG));
+            const int tot = len0 + len1;
+            const int Ltot = max(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 64 - SG));
             const bool part = s < ne;
             int pslot = PS_ROOT, sym = 0;
             bool same = false, rootpar = false;
-            double self[K], self1[K], mx0 = PO_NEG_INF, mx = PO_NEG_INF;   // (…0 / plain: read 0; …1 / mx, mt: read 1)
+            double self[K], self1[K], mx0 = PO_NEG_INF, mx = PO_NEG_INF;
             int mt0 = -1, mt = -1;                      // where the maxima are (the latest such time)
+            double c1 = PO_NEG_INF;                     // read 1: maximum carried over from the previous step
+            int ct1 = -1;
             Ent *myrow = pool, *row1 = pool;
             Ent seed0, seed1;
             const Ent *prow = pool, *prow1 = pool;
@@ -1379,7 +1380,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                             const double pm = h.stg_v()[rr * SG + ps];
                             const int pt = h.stg_t()[rr * SG + ps];
                             if (pm == PO_NEG_INF || (pt >= lo && pt < hi)) {
-                                if (rr) { mx = pm; mt = pt; } else { mx0 = pm; mt0 = pt; }
+                                if (rr) { c1 = pm; ct1 = pt; } else { mx = pm; mt = pt; }
                             } else if (rr) need1 = true;
                             else need0 = true;
                         }
@@ -1391,7 +1392,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     const unsigned long long hm1 = (SG == 64) ? b1 : (g ? (b1 >> 32) : (b1 & 0xffffffffull));
                     const unsigned long long below = (1ull << s) - 1ull;
                     const int n0 = __popcll(hm0), nit = n0 + __popcll(hm1);
-                    int* const list = (int*)&h.xch[0][0][0][0];   // free until the first iteration ends
+                    int* const list = (int*)&h.xch[0][0][0];   // free until the first iteration ends
                     if (need0) list[__popcll(hm0 & below)] = s;
                     if (need1) list[n0 + __popcll(hm1 & below)] = s;
                     x2_sync();
@@ -1436,8 +1437,8 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                         if (act && sub == 0) { h.stg_v()[wr] = c; h.stg_t()[wr] = ct; }
                     }
                     x2_sync();
-                    if (need0) { mx0 = h.stg_v()[ps]; mt0 = h.stg_t()[ps]; }
-                    if (need1) { mx = h.stg_v()[SG + ps]; mt = h.stg_t()[SG + ps]; }
+                    if (need0) { mx = h.stg_v()[ps]; mt = h.stg_t()[ps]; }
+                    if (need1) { c1 = h.stg_v()[SG + ps]; ct1 = h.stg_t()[SG + ps]; }
                 }
             }
             if (part) {
@@ -1447,8 +1448,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 for (int k = 0; k < K; ++k) {
                     self[k] = hit0 ? seed0.v[k] : PO_NEG_INF;
                     self1[k] = hit1 ? seed1.v[k] : PO_NEG_INF;
-                    h.xch[1][s][0][k] = self[k];
-                    h.xch[1][s][1][k] = self1[k];
+                    h.xch[1][s][k] = (len0 > 0) ? self[k] : self1[k];
                 }
             }
             x2_sync();   // the carried maxima are read before the y buffer is filled
@@ -1477,38 +1477,30 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 if (dmm && g == 0 && s == 0) { tk[10] += 1; if (fastH) tk[11] += 1; tk[9] += __popcll(hmm); }
             }
 #endif
-            const int sfrom0 = bad ? INT_MIN : h.sh[5], sfrom1 = bad ? INT_MIN : h.sh[6];  // first times to write
+            int sfrom = bad ? INT_MIN : h.sh[5];        // first time whose value must be written (current read)
             const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
-            int t0 = su, t1 = sv;                       // times of the current iteration
-            // a parent that does not move in this scan (rare): its value at t-1 is fetched one iteration ahead
-            int tf0 = su, tf1 = sv;
-            double pr0_n[K], pr1_n[K];
-            Ent pe0_n, pe1_n;
-            pe0_n.tag = 0; pe1_n.tag = 0;
+            int t = su;                                 // time of the current iteration
+            const double* cump = cumA;                  // fetch context of a non-moving parent: root sums, next time
+            int tf = su;
+            if (len0 == 0) { cump = cumB; prow = prow1; tf = sv; }
+            double pr_n[K];
+            Ent pe_n;
+            pe_n.tag = 0;
 #pragma unroll
-            for (int q = 0; q < K; ++q) { pr0_n[q] = PO_NEG_INF; pe0_n.v[q] = PO_NEG_INF; pr1_n[q] = PO_NEG_INF; pe1_n.v[q] = PO_NEG_INF; }
-            auto fetch0 = [&]() {
-                const int tp = tf0 - 1;
-                if (pslot == PS_ROOT) root_at(cumA, tp, pr0_n);
-                else if (tp >= 0) pe0_n = prow[tp & Rm];
-                tf0++;
+            for (int q = 0; q < K; ++q) { pr_n[q] = PO_NEG_INF; pe_n.v[q] = PO_NEG_INF; }
+            auto fetch = [&]() {  // value at t-1 of a parent that does not move, one iteration ahead (rare)
+                const int tp = tf - 1;
+                if (pslot == PS_ROOT) root_at(cump, tp, pr_n);
+                else if (tp >= 0) pe_n = prow[tp & Rm];
+                tf++;
             };
-            auto fetch1 = [&]() {
-                const int tp = tf1 - 1;
-                if (pslot == PS_ROOT) root_at(cumB, tp, pr1_n);
-                else if (tp >= 0) pe1_n = prow1[tp & Rm];
-                tf1++;
-            };
-            if (part && pslot < 0) {
-                if (len0 > 0) fetch0();
-                if (len1 > 0) fetch1();
-            }
-            // The y rows of both windows go through LDS, one copy per step: read 0's rows in the first half of
-            // the buffer, read 1's in the second, row = iteration index.  With no vector-memory LOAD left in the
-            // iteration loop, the wave never waits there for the acknowledgement of its value-store writes (vmcnt
-            // counts loads and stores in order: waiting for any load also waits for every store issued before it).
-            const int oB = KH * C;
-            for (int k0 = 0; k0 < Ltot; k0 += KH) {
+            if (part && pslot < 0) fetch();
+            // The y rows of both windows go through LDS, one copy per step (two contiguous runs of rows;
+            // buffer row = iteration index).  With no vector-memory LOAD left in the iteration loop, the
+            // wave never waits there for the acknowledgement of its value-store writes (vmcnt counts loads
+            // and stores in order: waiting for any load also waits for every store issued before it).
+            const int yrows = X2Half<K, SG>::YD / C;  // iterations per buffer fill
+            for (int k0 = 0; k0 < Ltot; k0 += yrows) {
             if (YEARLY && k0 == 0) {   // the first fill was requested at the top of the step
 #pragma unroll
                 for (int q = 0; q < YPRE; ++q) {
@@ -1516,75 +1508,65 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     if (i < X2Half<K, SG>::YD) h.ybuf[i] = ypre[q];
                 }
             } else {
-                const int nA = min(max(len0 - k0, 0), KH) * C, nB = min(max(len1 - k0, 0), KH) * C;
+                const int kend = min(tot, k0 + yrows);
+                const int ka1 = min(kend, len0);                 // read-0 iterations [k0, ka1)
+                const int nA = max(0, ka1 - k0) * C;
                 const double* srcA = yA + (int64_t)(su + k0) * C;
                 for (int i = s; i < nA; i += SG) h.ybuf[i] = srcA[i];
-                const double* srcB = yB + (int64_t)(sv + k0) * C;
-                for (int i = s; i < nB; i += SG) h.ybuf[oB + i] = srcB[i];
+                const int kb0 = max(k0, len0);                   // read-1 iterations [kb0, kend)
+                const int nB = max(0, kend - kb0) * C;
+                const double* srcB = yB + (int64_t)(sv + kb0 - len0) * C;
+                for (int i = s; i < nB; i += SG) h.ybuf[nA + i] = srcB[i];
             }
             x2_sync();
             TK(4);  // scan: seeds + y window copy
-            const int kchunk = min(Ltot, k0 + KH);
+            const int kchunk = min(Ltot, k0 + yrows);
             for (int kv = k0; kv < kchunk; ++kv) {
                 const int k = __builtin_amdgcn_readfirstlane(kv);
-                if (part && k < Lh) {
-                    const bool a0 = k < len0, a1 = k < len1;
-                    const double* yr0 = h.ybuf + (k - k0) * C;
-                    const double* yr1 = yr0 + oB;
-                    const double ya0 = yr0[ca], yb0 = yr0[cb], ya1 = yr1[ca], yb1 = yr1[cb];
-                    double pp0[K], pp1[K], out0[K], out1[K];
-                    const int psrc = pslot >= 0 ? pslot : s;
+                if (part && k < tot) {
+                    if (k == len0) {  // read 0's window is done: continue on read 1 from its seed
+                        mx0 = mx; mt0 = mt; mx = c1; mt = ct1; t = sv; myrow = row1;
+                        sfrom = bad ? INT_MIN : h.sh[6];
 #pragma unroll
-                    for (int q = 0; q < K; ++q) { pp0[q] = h.xch[(k + 1) & 1][psrc][0][q]; pp1[q] = h.xch[(k + 1) & 1][psrc][1][q]; }
-                    if (pslot < 0) {
-                        const bool hit0 = (t0 >= 1) && (pe0_n.tag == ptag0 + (unsigned)(t0 - 1));
-                        const bool hit1 = (t1 >= 1) && (pe1_n.tag == ptag0 + (unsigned)(t1 - 1));
-#pragma unroll
-                        for (int q = 0; q < K; ++q) {
-                            pp0[q] = (pslot == PS_ROOT) ? pr0_n[q] : (hit0 ? pe0_n.v[q] : PO_NEG_INF);
-                            pp1[q] = (pslot == PS_ROOT) ? pr1_n[q] : (hit1 ? pe1_n.v[q] : PO_NEG_INF);
-                        }
-                        if (k + 1 < len0) fetch0();
-                        if (k + 1 < len1) fetch1();
+                        for (int q = 0; q < K; ++q) self[q] = self1[q];
                     }
-                    po_update<MODEL>(self, pp0, ya0, yb0, same, rootpar && t0 == 0, out0, lae);
-                    po_update<MODEL>(self1, pp1, ya1, yb1, same, rootpar && t1 == 0, out1, lae);
+                    const double* yrow = h.ybuf + (k - k0) * C;
+                    const double ya = yrow[ca], yb = yrow[cb];
+                    double pp[K], out[K];
+#pragma unroll
+                    for (int q = 0; q < K; ++q) pp[q] = h.xch[(k + 1) & 1][pslot >= 0 ? pslot : s][q];
+                    if (pslot < 0) {  // rare: the parent does not move in this scan
+                        const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
+#pragma unroll
+                        for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
+                    }
+                    if (pslot < 0 && k + 1 < tot) {
+                        if (k + 1 == len0) { cump = cumB; prow = prow1; tf = sv; }
+                        fetch();
+                    }
+                    po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
 #ifdef PO_ABL_NOSTORE   // timing ablation only (results are wrong)
-                    if (out0[0] == 12345.678 || out1[0] == 12345.678) pool[0].tag = 1;
+                    if (out[0] == 12345.678) pool[0].tag = 1;
 #else
-                    if (a0 && t0 >= sfrom0) {
+                    if (t >= sfrom) {
                         Ent e;
-                        e.tag = tag0 + (unsigned)t0;
+                        e.tag = tag0 + (unsigned)t;
 #pragma unroll
-                        for (int q = 0; q < K; ++q) e.v[q] = out0[q];
-                        myrow[t0 & Rm] = e;
-                    }
-                    if (a1 && t1 >= sfrom1) {
-                        Ent e;
-                        e.tag = tag0 + (unsigned)t1;
-#pragma unroll
-                        for (int q = 0; q < K; ++q) e.v[q] = out1[q];
-                        row1[t1 & Rm] = e;
+                        for (int q = 0; q < K; ++q) e.v[q] = out[q];
+                        myrow[t & Rm] = e;
                     }
 #endif
+                    const bool sw = (k + 1 == len0);  // the next iteration starts read 1: hand its seed over
 #pragma unroll
-                    for (int q = 0; q < K; ++q) { h.xch[k & 1][s][0][q] = out0[q]; h.xch[k & 1][s][1][q] = out1[q]; }
-                    if (a0) {
-#pragma unroll
-                        for (int q = 0; q < K; ++q) self[q] = out0[q];
-                        if (out0[0] >= mx0) { mx0 = out0[0]; mt0 = t0; }
-                    }
-                    if (a1) {
-#pragma unroll
-                        for (int q = 0; q < K; ++q) self1[q] = out1[q];
-                        if (out1[0] >= mx) { mx = out1[0]; mt = t1; }
-                    }
-                    t0++; t1++;
+                    for (int q = 0; q < K; ++q) { self[q] = out[q]; h.xch[k & 1][s][q] = sw ? self1[q] : out[q]; }
+                    if (out[0] >= mx) { mx = out[0]; mt = t; }
+                    t++;
                 }
                 x2_sync();
             }
             TK(5);  // scan: iterations
             }
+            if (len1 == 0) { mx0 = mx; mt0 = mt; mx = c1; mt = ct1; }   // (no iteration switched to read 1)
             if (part) {   // this step's maxima, for the next one
                 h.stg_v()[s] = mx0; h.stg_v()[SG + s] = mx;
                 h.stg_t()[s] = mt0; h.stg_t()[SG + s] = mt;
