@@ -287,9 +287,11 @@ void po_profile_enable(int on);
 void po_profile_reset(void);
 int po_profile_get(int kernel, double* total_ms, int64_t* launches);
 /* Compute-side pricing of the pair beam search (its roofline is the f64 logaddexp stream, not HBM):
- * po_profile_update_counter - device counter (uint64, or NULL to stop) the pair beam kernels add their
- *   number of update_prob evaluations to (PrefixTree.h:478-704; ctc: one logaddexp each, merge-repeats
- *   two, flip-flop three or four);
+ * po_profile_update_counter - two device counters (uint64[2], or NULL to stop) the pair beam kernels add
+ *   update_prob evaluations to (PrefixTree.h:478-704; ctc: one logaddexp each, merge-repeats two, flip-flop
+ *   three or four): [0] those the reference's schedule makes for the same input (every element over its
+ *   full windows in every step, every catch-up step), [1] those the kernels executed (they leave out the
+ *   ones whose result is provably already stored);
  * po_lae_peak - measured peak rate of the engine's logaddexp on this device (micro-benchmark, all lanes
  *   busy, 4 independent chains per lane). */
 int po_profile_update_counter(uint64_t* device_counter);

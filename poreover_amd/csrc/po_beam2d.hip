@@ -77,7 +77,7 @@ struct B2Args {
     int* envt; long long vcap;         // 2 * vcap ints: transposed envelope
     long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
     const int2* only_meta;             // non-NULL: decode only the pairs the two-pairs-per-wave path deferred (meta.y == -2)
-    unsigned long long* upd_count;     // optional (po_profile_update_counter): total update_prob evaluations
+    unsigned long long* upd_count;     // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
 };
 
 // F_PSLOT of an element whose parent does not move in the scan: a frozen parent (its values are read from
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
     const int r = tid / NCP;           // read handled by this thread
     const int s = tid - r * NCP;       // element slot handled by this thread
     const int A = a.A, W = a.W, C = a.C;
+    const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here (x < 1024, A <= 8)
     const bool is_row = (a.method == PO_METHOD_ROW);
 
     // ---- per-workgroup workspace
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 if (tid < nb) {
                     sm.e[F_PSLOT][tid] = beam_parent(tid, nb, true);
                 } else {
-                    const int j = (tid - nb) / A, c = (tid - nb) - j * A;
+                    const int j = ((tid - nb) * divA) >> 16, c = (tid - nb) - j * A;
                     sm.e[F_ID][tid] = sm.e[F_FC][j] + c; sm.e[F_ROW][tid] = sm.e[F_CROW][j] * PO_A + c;
                     sm.e[F_SYM][tid] = sym_pack(c, sym_last(sm.e[F_SYM][j]), false);
                     sm.e[F_PSLOT][tid] = j; sm.e[F_FC][tid] = -2; sm.e[F_CROW][tid] = -2;
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             a.seq_len[pi] = nout;
             a.status[pi] = st;
         }
-        if (a.upd_count && tid == 0) atomicAdd(a.upd_count, sm.nupd);
+        if (a.upd_count && tid == 0) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd); }
         TK(10);  // label walk
     }
 #ifdef PO_B2_TIMING
@@ -832,7 +833,7 @@ struct X2Args {
     int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
     int pre_vcols;                    // pre-pass: columns its LDS table holds
     int ngl;                          // row groups the main kernel tracks per pair
-    unsigned long long* upd_count;    // optional (po_profile_update_counter): total update_prob evaluations
+    unsigned long long* upd_count;    // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
 };
 
 struct alignas(16) X2Cand { double sc; int id; int dup; };
@@ -859,7 +860,8 @@ struct X2Half {
     static_assert(YD >= 3 * SG, "y buffer too small for the carried maxima");
     __device__ double* stg_v() { return ybuf; }                    // [2][SG]
     __device__ int* stg_t() { return (int*)(ybuf + 2 * SG); }      // [2][SG]
-    unsigned long long nupd; // profiling: update_prob evaluations
+    unsigned long long nupd;   // profiling: update_prob evaluations the reference's schedule makes for these pairs
+    unsigned long long nupd_x; // ... and those this kernel executed (incremental steps, no-op catch-ups)
 };
 template <int K, int SG>
 struct X2Smem {
@@ -1018,6 +1020,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
     const int lane = threadIdx.x, g = lane / SG, s = lane & (SG - 1);
     X2Half<K, SG>& h = sm.h[g];
     const int A = a.A, W = a.W, C = a.C;
+    const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here (x < 1024, A <= 8)
     const int hid = blockIdx.x * NPW + g;
     Ent* const pool = (Ent*)(a.pool + (size_t)hid * a.pool_bytes);
     const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
@@ -1033,10 +1036,12 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
     x2_sync();
 
     // ---- half-uniform state of the pair in flight
-    if (s == 0) h.nupd = 0;  // update_prob evaluations of this half-wave's pairs (profiling only; kept in LDS)
+    if (s == 0) { h.nupd = 0; h.nupd_x = 0; }  // update_prob evaluations of this half-wave's pairs (profiling only; kept in LDS)
     bool have = false, done = false;
     int pi = 0, U = 1, V = 1, u = 0, v = 0, nb = 0, R = 32, Rm = 31, NG = 0, st = PO_OK;
     int nbq = 0;                   // beam nodes in the previous main step (its element slots name the carried maxima)
+    bool steadyH = false;          // the previous prune left the beam exactly as it was (same nodes, same order)
+    int dupf = 0;                  // a child slot whose node is also a beam slot is the same node pushed twice
     unsigned epoch = 0;
     const double *yA = a.y1, *yB = a.y2, *cumA = a.cum1, *cumB = a.cum2;
     const int4* sched = a.sched;   // this pair's main steps {u, v, column-window end, row-window end}
@@ -1110,7 +1115,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     yA = a.y1 + o1 * C; yB = a.y2 + o2 * C;
                     cumA = a.cum1 + (o1 - a.y1_off[0]); cumB = a.cum2 + (o2 - a.y2_off[0]);
                     sched = a.sched + (o2 - a.y2_off[0]);
-                    nmain = a.nmain[pi]; mstep = 0; up = -1; vp = -1;
+                    nmain = a.nmain[pi]; mstep = 0; up = -1; vp = -1; steadyH = false;
                     rec = sched[0]; rec_n = sched[min(1, max(nmain - 1, 0))];   // (read-1 rows >= 1: in bounds)
                     R = m.y; Rm = R - 1;
                     NG = (int)min((long long)HNGL, pool_entries / ((long long)PO_A * 2 * R));
@@ -1174,6 +1179,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int tend = rr ? v : u;
+                if (s == 0) h.nupd += (unsigned)(max(tend - (rr ? vp : up) - 1, 0) * min(W, nb));
                 for (int t = max((rr ? vp : up) + 1, h.sh[5 + rr]); t < tend; ++t) {
                     if (s < min(W, nb)) {  // the reference indexes b < beam_width
                     const int node = h.e[F_ID][s], row = h.e[F_ROW][s], sy = h.e[F_SYM][s], par = h.e[F_PAR][s];
@@ -1195,7 +1201,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
 #pragma unroll
                     for (int k = 0; k < K; ++k) e.v[k] = out[k];
                     myrow[t & Rm] = e;
-                    if (s == 0) h.nupd += (unsigned)min(W, nb);
+                    if (s == 0) h.nupd_x += (unsigned)min(W, nb);
                     if (rr) atomicMax(&h.g_hi1[row / PO_A], t + 1);
                     else atomicMax(&h.g_hi0[row / PO_A], t + 1);
                     }
@@ -1254,6 +1260,19 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 ypre[q] = (i < nT) ? ((i < nA) ? srcA[i] : srcB[i]) : 0.0;
             }
         }
+        // A STEADY step: the previous prune kept every beam node in its slot and nothing is created or moved now, so
+        // the element table of the previous step is this step's, entry for entry (about 2 of 3 steps).  When that
+        // holds for both pairs of the wave, expansion and table building reduce to marking the row groups in use.
+        const bool steady = steadyH && fastH;
+        const bool wsteady = __ballot(dm && !steady) == 0;
+        if (wsteady) {
+            if (bl) {
+                h.newfc[s] = 0;
+                const int go = h.e[F_ROW][s] / PO_A;
+                atomicMax(&h.g_hi0[go], ece); atomicMax(&h.g_hi1[go], ere);
+                atomicMax(&h.g_hi0[crow], ece); atomicMax(&h.g_hi1[crow], ere);
+            }
+        } else
         // ---- expansion: children ids and row groups of the beam nodes.  New node ids are
         // handed out in beam order (a prefix count over the lanes that need them: ids break score ties); row
         // groups, which only name storage, are allocated one lane after the other, after every group in use has
@@ -1301,7 +1320,8 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         const bool dmm = dm && !fin;
         const int ne = dmm ? nb * (A + 1) : 0;
         int my_fc = -1, my_cr = -1;  // a child's own expansion state (arena), loaded behind the scan
-        int dupf = 0;                // a child slot whose node is also a beam slot is the same node pushed twice
+        if (!wsteady) {
+        dupf = 0;
         if (s < ne) {
             if (s < nb) {
                 int ps = h.bps[s];
@@ -1313,7 +1333,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 }
                 h.e[F_PSLOT][s] = ps;
             } else {
-                const int j = (s - nb) / A, c = (s - nb) - j * A;
+                const int j = ((s - nb) * divA) >> 16, c = (s - nb) - j * A;
                 const int id = h.e[F_FC][j] + c;
                 h.e[F_ID][s] = id; h.e[F_ROW][s] = h.e[F_CROW][j] * PO_A + c;
                 h.e[F_SYM][s] = sym_pack(c, sym_last(h.e[F_SYM][j]), false);
@@ -1325,6 +1345,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         }
         x2_sync();
         if (s < nb && s < ne && h.e[F_PSLOT][s] >= nb) h.e[F_PROW][s] = h.e[F_ROW][h.e[F_PSLOT][s]];  // parent's current row
+        }
 
         TK(3);  // element table
         // ---- the scan: read 0's window, then read 1's, one t per iteration
@@ -1372,7 +1393,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 int ps = 0;
                 if (part && fastH) {
                     ps = h.sel[min(s, WB - 1)];
-                    if (s >= nb) { const int j = (s - nb) / A; ps = nbq + A * h.sel[j] + ((s - nb) - j * A); }
+                    if (s >= nb) { const int j = ((s - nb) * divA) >> 16; ps = nbq + A * h.sel[j] + ((s - nb) - j * A); }
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
                         const int lo = rr ? v : u, hi = rr ? sv : su;
@@ -1414,7 +1435,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                             const Ent* rp = pool + ((size_t)h.e[F_ROW][sl] * 2 + rr) * R;
                             const unsigned long long tg = make_tag(epoch, h.e[F_ID][sl], 0);
                             int psl = h.sel[min(sl, WB - 1)];
-                            if (sl >= nb) { const int j = (sl - nb) / A; psl = nbq + A * h.sel[j] + ((sl - nb) - j * A); }
+                            if (sl >= nb) { const int j = ((sl - nb) * divA) >> 16; psl = nbq + A * h.sel[j] + ((sl - nb) - j * A); }
                             wr = rr * SG + psl;
                             for (int bt = lo + sub; bt < hi; bt += 4 * G) {
                                 Ent e4[4];
@@ -1577,8 +1598,11 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 h.cand[s] = c;
             }
             // (the counter counts the evaluations the reference's step makes: ne over both full windows)
-            if (part && s == 0) { h.nupd += (unsigned)(ne * ((ece - u) + (ere - v))); h.sh[5] = ece; h.sh[6] = ere; }
-            if (part && s >= nb) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
+            if (part && s == 0) {
+                h.nupd += (unsigned)(ne * ((ece - u) + (ere - v))); h.nupd_x += (unsigned)(ne * tot);
+                h.sh[5] = ece; h.sh[6] = ere;
+            }
+            if (part && s >= nb && !wsteady) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
         }
         x2_sync();
 
@@ -1601,6 +1625,16 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
             const int ncand = (SG == 64) ? __popcll(cand) : __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
             x2_sync();
             const int nbn = dmm ? min(W, ncand) : 0;
+            // the beam comes out as it went in (same nodes, same slots): nothing to move
+            const unsigned long long mvb = __ballot(dmm && ((s < nbn && h.sel[s] != s) || nbn != nb));
+            const bool ident = dmm && ((SG == 64) ? mvb : (g ? (mvb >> 32) : (mvb & 0xffffffffull))) == 0;
+            steadyH = ident;
+            if (mvb == 0) {
+                if (s < nbn) h.stay[s] = 1;
+#ifdef PO_B2_TIMING
+                if (dmm && g == 0 && s == 0) tk[8] += 1000000;
+#endif
+            } else {
             int nf[F_COUNT], nbp = -1, nstay = 0;
 #pragma unroll
             for (int f = 0; f < F_COUNT; ++f) nf[f] = 0;
@@ -1627,18 +1661,13 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                     for (int i = 0; i < WB; ++i) if (i < nbn && h.sel[i] == oldpar) nbp = i;
                 }
             }
-#ifdef PO_B2_TIMING
-            {
-                const unsigned long long mv = __ballot(s < nbn && h.sel[s] != s);
-                if (dmm && g == 0 && s == 0 && (mv & 0xffffffffull) == 0 && nbn == nb) tk[8] += 1000000;
-            }
-#endif
             x2_sync();  // every lane has read its source slot before any slot is overwritten
             if (s < nbn) {
 #pragma unroll
                 for (int f = 0; f < F_COUNT; ++f) h.e[f][s] = nf[f];
                 h.stay[s] = nstay;
                 h.bps[s] = nbp;
+            }
             }
             if (dmm) {
                 nbq = nb;
@@ -1676,7 +1705,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         }
         TK(8);  // label walk
     }
-    if (a.upd_count && s == 0) atomicAdd(a.upd_count, h.nupd);
+    if (a.upd_count && s == 0) { atomicAdd(a.upd_count, h.nupd); atomicAdd(a.upd_count + 1, h.nupd_x); }
 #ifdef PO_B2_TIMING
     if (lane == 0 && a.dbg && blockIdx.x == 0)
         for (int i = 0; i < 12; ++i) a.dbg[i] = tk[i];
