@@ -1611,8 +1611,19 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         // W best gather their fields from the old table (and find their parent in the new beam through `sel`)
         {
             const bool live = (s < ne) && !dupf;
-            int rank = 0;
-            if (live) {
+            // Most steps keep the beam as it is.  That is the case iff the beam nodes are still in order and the
+            // last of them still beats every child — two comparisons per lane instead of a full ranking.
+            bool viol = false;
+            if (dmm && nb != W) viol = true;
+            else if (live) {
+                const X2Cand me = h.cand[s];
+                if (s >= nb) { const X2Cand lb = h.cand[nb - 1]; viol = !po_better(lb.sc, lb.id, me.sc, me.id); }
+                else if (s + 1 < nb) { const X2Cand nx = h.cand[s + 1]; viol = !po_better(me.sc, me.id, nx.sc, nx.id); }
+            }
+            if (__ballot(viol) == 0) {
+                if (dmm && s < nb) h.sel[s] = s;
+            } else if (live) {
+                int rank = 0;
                 const X2Cand me = h.cand[s];
 #pragma unroll 8
                 for (int o = 0; o < SG; ++o) {
