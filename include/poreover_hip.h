@@ -43,6 +43,7 @@ extern "C" {
 #define PO_METHOD_ROW 0
 #define PO_METHOD_ROW_COL 1
 #define PO_METHOD_GRID 2
+#define PO_METHOD_GRID_NOENV 3 /* po_beam2d_workspace_bytes only: grid without an envelope (env == NULL, method != row) */
 
 #define PO_KIND_POREOVER 0
 #define PO_KIND_BONITO 1
@@ -107,7 +108,13 @@ int po_beam1d_batch(const double* y, const int64_t* y_off, int n, int C, const c
 /* ---- decoding_cpp.cpp_beam_search_2d ------------------------------------------------------
  * replaces decoding_cpp.pyx:107-139 -> BeamSearch.h:411-458 beam_search(y1, y2, U, V, alphabet,
  * envelope_ranges, beam_width, model, method): method row_col = :262-397 (CLI default,
- * __main__.py:89), row = :110-172.  env rows are [lo, hi) per row of y1.  */
+ * __main__.py:89), row = :110-172 / :175-260, grid = BeamSearch2.h:33-184 (hidden upstream option).
+ * env rows are [lo, hi) per row of y1; env == NULL: "row" runs its no-envelope form and every other
+ * method runs grid without an envelope, as the reference's dispatcher does (BeamSearch.h:441-458) —
+ * size the workspace with PO_METHOD_GRID_NOENV in that case.  grid needs row starts that do not move
+ * backwards (PO_E_UNSUPPORTED otherwise) and keeps 2 x V x beam_width nodes of cell beams per pair in
+ * flight; without an envelope every read-1 time of a node stays readable, so it only fits short reads
+ * (PO_E_NOMEM otherwise).  */
 size_t po_beam2d_workspace_bytes(int n, int64_t total_rows1, int64_t total_rows2, int64_t max_rows1,
                                  int64_t max_rows2, int C, int beam_width, int model, int method);
 int po_beam2d_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,

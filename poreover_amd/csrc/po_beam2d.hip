@@ -77,6 +77,7 @@ struct B2Args {
     int* envt; long long vcap;         // 2 * vcap ints: transposed envelope
     long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
     const int2* only_meta;             // non-NULL: decode only the pairs the two-pairs-per-wave path deferred (meta.y == -2)
+    int* cellb;                        // grid method: two rows of per-cell beams per workgroup (2 * vcap * (1 + 6 W) ints)
     unsigned long long* upd_count;     // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
 };
 
@@ -1723,6 +1724,308 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
 #endif
 }
 
+// =================================================================================================
+// method "grid" (beam_search_2d_grid, BeamSearch2.h:33-184; hidden upstream option): ONE BEAM PER CELL.
+// Cell (u, v) of the band takes the beam of cell (u-1, v-1) — or the seed beam (the root's children) when
+// that cell was never visited — updates every node of it and every child at (read 0, u) and (read 1, v),
+// and keeps the W best by alpha0[u] + alpha1[v].  The cells are visited in row-major order and all beams
+// share one tree whose per-node time maps are overwritten by later visits, so the order is part of the
+// result: a pair is walked cell by cell by one workgroup, thread = (read, candidate slot); parallelism is
+// the candidates of a cell and the pairs of the batch.  Within a cell every update reads times u-1 / v-1
+// and writes u / v, so the candidates are independent; values live in the same tagged ring store as the
+// other methods' (R >= widest row band + 2), a row group is recycled when nothing written to it can be
+// read again (read 0: times < u-1; read 1: times < row start - 1, row starts must not move backwards),
+// and the beams of the previous row are kept in HBM (6 ints per node).
+namespace {
+enum { G_ID, G_ROW, G_PAR, G_PROW, G_SYM, G_DEPTH, G_COUNT };
+template <int MODEL, int WMAX>
+struct GridSmem {
+    static constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
+    static constexpr int NCM = WMAX * (PO_A + 1);
+    static constexpr int NCP = (NCM <= 32) ? 32 : 128;   // threads per read
+    static constexpr int NGL = 3072;   // row groups tracked per pair (GRID_NGL on the host side)
+    int e[G_COUNT][NCM];
+    int fc[WMAX], crow[WMAX], isnew[WMAX];
+    int dup[NCM];
+    int sel[WMAX];
+    int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
+    int sh[8];
+    double sc[2][NCP];
+    unsigned long long nupd;
+    PoLaeTables lae;
+};
+}  // namespace
+#define GRID_THREADS(WM) ((WM) * (PO_A + 1) <= 32 ? 64 : 256)
+
+template <int MODEL, int WMAX>
+__global__ __launch_bounds__(GRID_THREADS(WMAX)) void beam2d_grid_kernel(B2Args a) {
+    using SM = GridSmem<MODEL, WMAX>;
+    static_assert(SM::NGL == 3072, "GRID_NGL");
+    constexpr int K = SM::K, NCP = SM::NCP, nthr = 2 * NCP;
+    using Ent = Entry<K>;
+    __shared__ SM sm;
+    const int tid = threadIdx.x;
+    const int r = tid / NCP, s = tid - r * NCP;
+    const int A = a.A, W = a.W, C = a.C;
+    const int divA = (65536 + A - 1) / A;
+    Ent* pool = (Ent*)(a.pool + (size_t)blockIdx.x * a.pool_bytes);
+    const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
+    int* apl = a.arena + (size_t)blockIdx.x * 3 * a.arena_cap;
+    int* afc = apl + a.arena_cap;
+    int* acrow = afc + a.arena_cap;
+    double* cum0 = a.cum + (size_t)blockIdx.x * 2 * a.tcap;
+    double* cum1 = cum0 + a.tcap;
+    const int CI = 1 + W * G_COUNT;                                     // ints per stored cell: n, then the entries
+    int* cellb = a.cellb + (size_t)blockIdx.x * 2 * a.vcap * CI;          // two rows of cells, indexed by column
+    unsigned epoch = 0;
+    po_lae_tables_load(&sm.lae, tid, nthr);
+    const PoLaeFast lae{&sm.lae};
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) sm.sh[0] = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int pi = sm.sh[0];
+        if (pi >= a.n) break;
+        epoch++;
+        if (a.use_pre_status && a.status[pi] != PO_OK) {
+            if (tid == 0) a.seq_len[pi] = 0;
+            continue;
+        }
+        const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
+        const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
+        const double* yr_ = r ? a.y2 + o2 * C : a.y1 + o1 * C;
+        const int32_t* env = a.env ? a.env + 2 * o1 : nullptr;
+        int st = PO_OK;
+        if (U < 1 || V < 1 || U > a.tcap || V > a.vcap || V > a.tcap || U >= (1 << 24) || V >= (1 << 24)) st = PO_E_ARG;
+        int R = 32, NG = 0;
+        if (st == PO_OK) {
+            int bad = 0, unsup = 0, wmax = env ? 0 : V;
+            if (env)
+                for (int u = tid; u < U; u += nthr) {
+                    const int lo = env[2 * u], hi = env[2 * u + 1];
+                    if (lo < 0 || hi > V) bad = 1;                       // BeamSearch2.h reads y2 out of bounds there
+                    if (u > 0 && lo < env[2 * u - 2]) unsup = 1;         // a later row would read times the store has dropped
+                    wmax = max(wmax, hi - lo);
+                }
+            if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
+            if (__syncthreads_or(unsup) && st == PO_OK) st = PO_E_UNSUPPORTED;
+            if (st == PO_OK) {
+                if (tid == 0) sm.sh[1] = 0;
+                __syncthreads();
+                atomicMax(&sm.sh[1], wmax);
+                __syncthreads();
+                wmax = sm.sh[1];
+                while (R < wmax + 2) R <<= 1;
+                NG = (int)min((long long)SM::NGL, pool_entries / ((long long)PO_A * 2 * R));
+                if (NG < 2 * max(W, PO_A) + 4) st = PO_E_NOMEM;
+            }
+        }
+        if (st != PO_OK) {
+            if (tid == 0) { a.status[pi] = st; a.seq_len[pi] = 0; }
+            continue;
+        }
+        const int Rm = R - 1;
+        if (MODEL == PO_MODEL_CTC && s == 0) {   // blank prefix sums = the CTC root's alpha, serial in t
+            double* cw = r ? cum1 : cum0;
+            const int Tn = r ? V : U;
+            double acc = 0.0;
+            for (int t = 0; t < Tn; ++t) { acc += yr_[(int64_t)t * C + A]; cw[t] = acc; }
+        }
+        for (int g = tid; g < SM::NGL; g += nthr) { sm.g_owner[g] = -1; sm.g_hi0[g] = 0; sm.g_hi1[g] = 0; }
+        __syncthreads();
+        auto st_read = [&](int row, int rr, int t, int node, double* out) {
+            bool hit = false;
+            if (t >= 0 && row >= 0) {
+                const Ent e = pool[((size_t)row * 2 + rr) * R + (t & Rm)];
+                hit = (e.tag == make_tag(epoch, node, t));
+                if (hit) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) out[k] = e.v[k];
+                }
+            }
+            if (!hit) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) out[k] = PO_NEG_INF;
+            }
+        };
+        auto st_write = [&](int row, int rr, int t, int node, const double* v) {
+            Ent e;
+            e.tag = make_tag(epoch, node, t);
+#pragma unroll
+            for (int k = 0; k < K; ++k) e.v[k] = v[k];
+            pool[((size_t)row * 2 + rr) * R + (t & Rm)] = e;
+        };
+        auto root_at = [&](int rr, int t, double* out) {
+            if (MODEL == PO_MODEL_CTC) {
+                out[0] = (t < 0) ? 0.0 : (rr ? cum1 : cum0)[t];
+            } else {
+                double tmp[3];
+                root_values<MODEL>(t, 0.0, tmp);
+#pragma unroll
+                for (int k = 0; k < K; ++k) out[k] = tmp[k];
+            }
+        };
+        // tree: root = node 0, its children = nodes 1..A in row group 0, which is never recycled (the seed
+        // beam can come back at any cell); beam2d_seed (update at t = 0 on both reads)
+        if (tid == 0) {
+            apl[0] = po_pack_node(-1, A); afc[0] = 1; acrow[0] = 0;
+            sm.g_owner[0] = 0; sm.g_hi0[0] = 1; sm.g_hi1[0] = 1;
+            sm.sh[2] = 1 + A;   // next node id
+            sm.sh[3] = 1;       // group allocation cursor
+            sm.sh[4] = PO_OK;
+            sm.nupd = 0;
+        }
+        if (tid < A) { apl[1 + tid] = po_pack_node(0, tid); afc[1 + tid] = -1; acrow[1 + tid] = -1; }
+        if (s < A) {
+            double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, pp[3], out[3];
+            root_at(r, -1, pp);
+            const double ya = yr_[s], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr_[s + A] : yr_[A];
+            po_update<MODEL>(sp, pp, ya, yb, false, true, out, lae);
+            st_write(s, r, 0, 1 + s, out);
+        }
+        __syncthreads();
+
+        int prs = 0, pre = 0;   // the previous row's band
+        for (int u = 0; u < U && st == PO_OK; ++u) {
+            const int rs = env ? env[2 * u] : 0, re = env ? env[2 * u + 1] : V;
+            int* cur = cellb + (size_t)(u & 1) * a.vcap * CI;
+            const int* prv = cellb + (size_t)((u + 1) & 1) * a.vcap * CI;
+            for (int v = rs; v < re; ++v) {
+                // ---- 1. the predecessor's beam (BeamSearch2.h:137-146)
+                const bool hp = u > 0 && v > 0 && (v - 1) >= prs && (v - 1) < pre;
+                int nb = A;
+                if (hp) {
+                    const int* pc = prv + (size_t)(v - 1) * CI;
+                    nb = pc[0];
+                    if (tid < nb * G_COUNT) sm.e[tid % G_COUNT][tid / G_COUNT] = pc[1 + tid];
+                } else if (tid < A) {
+                    sm.e[G_ID][tid] = 1 + tid; sm.e[G_ROW][tid] = tid; sm.e[G_PAR][tid] = 0; sm.e[G_PROW][tid] = -1;
+                    sm.e[G_SYM][tid] = sym_pack(tid, A, true); sm.e[G_DEPTH][tid] = 1;
+                }
+                __syncthreads();
+                // ---- 2. expansion: children ids in beam order (ids break score ties), row groups
+                if (tid < nb) {
+                    const int id = sm.e[G_ID][tid];
+                    sm.fc[tid] = afc[id]; sm.crow[tid] = acrow[id];
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int next = sm.sh[2];
+                    for (int j = 0; j < nb; ++j) {
+                        const int id = sm.e[G_ID][j];
+                        int fcj = sm.fc[j], cr = sm.crow[j];
+                        sm.isnew[j] = fcj < 0;
+                        if (fcj < 0) {
+                            if ((long long)next + A > a.arena_cap || next + A >= (1 << 24)) { sm.sh[4] = PO_E_NOMEM; break; }
+                            fcj = next; next += A;
+                            afc[id] = fcj;
+                        }
+                        if (cr < 0 || cr >= NG || sm.g_owner[cr] != id) {   // children never stored, or their rows recycled
+                            int cursor = sm.sh[3], g = -1;
+                            for (int tries = 0; tries < NG; ++tries) {
+                                const int c = cursor;
+                                cursor = (cursor + 1 == NG) ? 0 : cursor + 1;
+                                if (c != 0 && (sm.g_owner[c] < 0 || (sm.g_hi0[c] <= u - 1 && sm.g_hi1[c] <= rs - 1))) { g = c; break; }
+                            }
+                            sm.sh[3] = cursor;
+                            if (g < 0) { sm.sh[4] = PO_E_NOMEM; break; }
+                            sm.g_owner[g] = id;
+                            cr = g;
+                            acrow[id] = g;
+                        }
+                        sm.g_hi0[cr] = u + 1; sm.g_hi1[cr] = v + 1;   // written below
+                        sm.fc[j] = fcj; sm.crow[j] = cr;
+                    }
+                    sm.sh[2] = next;
+                }
+                __syncthreads();
+                if (sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
+                // ---- 3. candidate table: slots [0, nb) the beam, then the children
+                const int ne = nb * (A + 1);
+                if (r == 0 && s >= nb && s < ne) {
+                    const int j = ((s - nb) * divA) >> 16, c = (s - nb) - j * A;
+                    const int id = sm.fc[j] + c;
+                    sm.e[G_ID][s] = id; sm.e[G_ROW][s] = sm.crow[j] * PO_A + c;
+                    sm.e[G_PAR][s] = sm.e[G_ID][j]; sm.e[G_PROW][s] = sm.e[G_ROW][j];
+                    sm.e[G_SYM][s] = sym_pack(c, sym_last(sm.e[G_SYM][j]), false);
+                    sm.e[G_DEPTH][s] = sm.e[G_DEPTH][j] + 1;
+                    if (sm.isnew[j]) { apl[id] = po_pack_node(sm.e[G_ID][j], c); afc[id] = -1; acrow[id] = -1; }
+                    int d = 0;
+                    for (int i = 0; i < nb; ++i) d |= (sm.e[G_ID][i] == id);   // Beam::prune dedupes by identity
+                    sm.dup[s] = d;
+                } else if (r == 0 && s < nb) {
+                    sm.dup[s] = 0;
+                    atomicMax(&sm.g_hi0[sm.e[G_ROW][s] / PO_A], u + 1);
+                    atomicMax(&sm.g_hi1[sm.e[G_ROW][s] / PO_A], v + 1);
+                }
+                __syncthreads();
+                // ---- 4. update_prob(node, 0, u) and (node, 1, v) of every candidate
+                if (s < ne) {
+                    const int id = sm.e[G_ID][s], row = sm.e[G_ROW][s], par = sm.e[G_PAR][s], sy = sm.e[G_SYM][s];
+                    const int t = r ? v : u;
+                    const int sym = sym_last(sy);
+                    double self[K], pp[K], out[K];
+                    st_read(row, r, t - 1, id, self);
+                    if (par == 0) root_at(r, t - 1, pp);
+                    else st_read(sm.e[G_PROW][s], r, t - 1, par, pp);
+                    const double* yrow = yr_ + (int64_t)t * C;
+                    const double ya = yrow[sym], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yrow[sym + A] : yrow[A];
+                    po_update<MODEL>(self, pp, ya, yb, sym_plast(sy) == sym, ((sy >> 9) & 1) && t == 0, out, lae);
+                    st_write(row, r, t, id, out);
+                    sm.sc[r][s] = out[0];
+                }
+                if (tid == 0) sm.nupd += 2u * (unsigned)ne;
+                __syncthreads();
+                // ---- 5. prune: the W best of the distinct candidates by alpha0[u] + alpha1[v], ties by node id
+                const bool live = (r == 0) && s < ne && !sm.dup[s];
+                if (live) {
+                    const double my = sm.sc[0][s] + sm.sc[1][s];
+                    const int myid = sm.e[G_ID][s];
+                    int rank = 0;
+                    for (int o = 0; o < ne; ++o)
+                        if (!sm.dup[o] && po_better(sm.sc[0][o] + sm.sc[1][o], sm.e[G_ID][o], my, myid)) rank++;
+                    if (rank < W) sm.sel[rank] = s;
+                }
+                const int ncand = __syncthreads_count(live);
+                const int nn = min(W, ncand);
+                // ---- 6. the cell's beam goes to HBM for cell (u+1, v+1)
+                int* cc = cur + (size_t)v * CI;
+                if (tid < nn * G_COUNT) cc[1 + tid] = sm.e[tid % G_COUNT][sm.sel[tid / G_COUNT]];
+                if (tid == 0) cc[0] = nn;
+                __syncthreads();
+            }
+            prs = rs; pre = re;
+        }
+        // ---- the top of the last cell's beam, or of the seed beam if (U-1, V-1) was never visited (:176-183)
+        __syncthreads();
+        if (tid == 0) {
+            int nout = 0;
+            if (st == PO_OK) {
+                int node = 1, depth = 1;
+                const int rsl = env ? env[2 * (U - 1)] : 0, rel = env ? env[2 * (U - 1) + 1] : V;
+                if (V - 1 >= rsl && V - 1 < rel) {
+                    const int* lc = cellb + (size_t)((U - 1) & 1) * a.vcap * CI + (size_t)(V - 1) * CI;
+                    node = lc[1 + G_ID]; depth = lc[1 + G_DEPTH];
+                }
+                nout = depth;
+                char* out = a.seq + a.seq_off[pi];
+                const int cap = (int)(a.seq_off[pi + 1] - a.seq_off[pi]);
+                if (nout > cap) { st = PO_E_CAP; nout = 0; }
+                else
+                    for (int i = nout - 1; i >= 0; --i) {
+                        const int pk = apl[node];
+                        out[i] = (char)((a.alphabet >> (8 * (po_node_last(pk) & 3))) & 0xffu);
+                        node = po_node_parent(pk);
+                    }
+            }
+            a.seq_len[pi] = nout;
+            a.status[pi] = st;
+            if (a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd); }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side: geometry, workspace layout, launch
 namespace {
@@ -1861,6 +2164,49 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     return g;
 }
 
+// ---- grid method: one workgroup per pair in flight; per workgroup a value store, the tree arena, the blank
+// prefix sums and two rows of cell beams
+struct GridGeom {
+    int threads, blocks, wclass;
+    size_t pool_bytes, arena_cap, tcap, vcap, cell_ints;
+    size_t off_queue, off_pool, off_arena, off_cum, off_cell, total;
+};
+constexpr int GRID_NGL = 3072;
+GridGeom grid_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, bool has_env) {
+    GridGeom g;
+    const int K = (model == PO_MODEL_CTC) ? 1 : 3;
+    g.wclass = W <= 6 ? 6 : 25;
+    g.threads = g.wclass == 6 ? 64 : 256;
+    // value store: with an envelope, room for every row group at bands up to 62 wide (R = 64; wider bands get
+    // fewer groups); without one a node keeps all V read-1 times (R >= V + 2), which only fits short reads
+    int64_t Rh = 64;
+    if (!has_env) while (Rh < mr2 + 2) Rh <<= 1;
+    g.pool_bytes = al256(std::min<size_t>((size_t)GRID_NGL * PO_A * 2 * (size_t)Rh * (K == 1 ? 16 : 32), (size_t)1 << 30));
+    // nodes: every beam node of every cell may be expanded; distinct ones per row are a few times W
+    const int64_t WM = W > PO_A ? W : PO_A;
+    g.arena_cap = (size_t)std::min<int64_t>((int64_t)1 << 24, 1 + PO_A + (int64_t)PO_A * WM * 8 * (mr1 + mr2 + 2));
+    g.tcap = (size_t)std::max(mr1, mr2);
+    g.vcap = (size_t)mr2;
+    g.cell_ints = 2 * g.vcap * (size_t)(1 + W * G_COUNT);
+    const size_t per_block = g.pool_bytes + sizeof(int) * 3 * g.arena_cap + sizeof(double) * 2 * g.tcap + sizeof(int) * g.cell_ints;
+    g.blocks = b2_num_cus() * (g.wclass == 6 ? 4 : 1);
+    g.blocks = (int)std::min<size_t>((size_t)g.blocks, std::max<size_t>(1, ((size_t)16 << 30) / per_block));  // <= 16 GB in all
+    if (g.blocks > n) g.blocks = n > 0 ? n : 1;
+    size_t o = 0;
+    g.off_queue = o; o += 256;
+    g.off_pool = o; o += g.pool_bytes * g.blocks;
+    g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * g.blocks);
+    g.off_cum = o; o += al256(sizeof(double) * 2 * g.tcap * g.blocks);
+    g.off_cell = o; o += al256(sizeof(int) * g.cell_ints * g.blocks);
+    g.total = o + 256;
+    return g;
+}
+template <int MODEL>
+void grid_launch_w(const GridGeom& g, const B2Args& a, hipStream_t stream) {
+    if (g.wclass == 6) hipLaunchKernelGGL((beam2d_grid_kernel<MODEL, 6>), dim3(g.blocks), dim3(g.threads), 0, stream, a);
+    else hipLaunchKernelGGL((beam2d_grid_kernel<MODEL, 25>), dim3(g.blocks), dim3(g.threads), 0, stream, a);
+}
+
 template <int MODEL, int WMAX>
 void b2_launch(const B2Geom& g, const B2Args& a, hipStream_t stream) {
     hipLaunchKernelGGL((beam2d_kernel<MODEL, WMAX>), dim3(g.blocks), dim3(g.threads), 0, stream, a);
@@ -1876,6 +2222,8 @@ void b2_launch_w(const B2Geom& g, const B2Args& a, hipStream_t stream) {
 extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, int W,
                                           int model, int method) {
     (void)C;
+    if (method == PO_METHOD_GRID) return grid_geometry(n, mr1, mr2, W, model, true).total;
+    if (method == PO_METHOD_GRID_NOENV) return grid_geometry(n, mr1, mr2, W, model, false).total;
     if (x2_eligible(n, W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total;
 }
@@ -1939,6 +2287,7 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     a.envt = (int*)(w + g.off_envt); a.vcap = (long long)g.vcap;
     a.dbg = nullptr;
     a.only_meta = only_meta;
+    a.cellb = nullptr;
     a.upd_count = g_b2_upd_counter;
 #ifdef PO_B2_TIMING
     static long long* dbg_buf = nullptr;
@@ -1975,9 +2324,34 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
                                      void* ws, size_t ws_bytes, hipStream_t stream) {
     if (n <= 0) return PO_OK;
     if (A < 1 || A > PO_A || W < 1 || W > 25) return PO_E_ARG;
-    if (method != PO_METHOD_ROW_COL && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // grid: not on the GPU yet
-    if (!env && method != PO_METHOD_ROW) return PO_E_UNSUPPORTED;  // the reference routes these to grid
+    if (method != PO_METHOD_ROW_COL && method != PO_METHOD_ROW && method != PO_METHOD_GRID) return PO_E_ARG;
     if ((model == PO_MODEL_FLIPFLOP) ? (C != 2 * A) : (C != A + 1)) return PO_E_ARG;
+    if (model != PO_MODEL_CTC && model != PO_MODEL_MERGE && model != PO_MODEL_FLIPFLOP) return PO_E_ARG;
+    // without an envelope the reference's dispatcher knows "row" and sends everything else to grid (BeamSearch.h:441-458)
+    if (method == PO_METHOD_GRID || (!env && method != PO_METHOD_ROW)) {
+        const GridGeom g = grid_geometry(n, mr1, mr2, W, model, env != nullptr);
+        if (ws_bytes < g.total) return PO_E_CAP;
+        char* w = (char*)ws;
+        B2Args a;
+        a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
+        a.n = n; a.A = A; a.W = W; a.C = C; a.method = PO_METHOD_GRID; a.alphabet = alphabet;
+        a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status;
+        a.use_pre_status = use_pre_status;
+        a.queue = (int*)(w + g.off_queue);
+        a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
+        a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
+        a.cum = (double*)(w + g.off_cum); a.tcap = (long long)g.tcap;
+        a.envt = nullptr; a.vcap = (long long)g.vcap;
+        a.cellb = (int*)(w + g.off_cell);
+        a.dbg = nullptr; a.only_meta = nullptr;
+        a.upd_count = g_b2_upd_counter;
+        if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+        if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
+        if (model == PO_MODEL_CTC) grid_launch_w<PO_MODEL_CTC>(g, a, stream);
+        else if (model == PO_MODEL_MERGE) grid_launch_w<PO_MODEL_MERGE>(g, a, stream);
+        else grid_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
+        return PO_OK;
+    }
     if (x2_eligible(n, W, model, method)) {
         const X2Geom g = x2_geometry(n, tr1, tr2, mr1, mr2, W, model);
         if (ws_bytes < g.total) return PO_E_CAP;

@@ -811,7 +811,9 @@ int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double*
     UP(sq, nullptr, (size_t)seqb);
     UP(sl, nullptr, sizeof(int32_t) * n);
     UP(st, nullptr, sizeof(int32_t) * n);
-    const size_t wsb = po_beam2d_workspace_bytes(n, r1, r2, m1, m2, C, W, model, method);
+    // (without an envelope everything but "row" runs the grid method, as in the reference's dispatcher)
+    const size_t wsb = po_beam2d_workspace_bytes(n, r1, r2, m1, m2, C, W, model,
+                                                 (!env_h && method != PO_METHOD_ROW) ? PO_METHOD_GRID_NOENV : method);
     UP(ws, nullptr, wsb);
     int rc = po_beam2d_batch((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p,
                              env_h ? (const int32_t*)ev.p : nullptr, n, C, alphabet, W, model, method, (char*)sq.p,

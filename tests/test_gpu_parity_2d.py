@@ -263,10 +263,65 @@ def test_row_full_size_and_limits(eng, oracle):
     env = oracle.pair_decode(y1, y2, "poreover", 5, "row")["envelope"]
     assert eng.beam_search_2d_batch([y1], [y2], [env], 5, method="row")[0] == \
         oracle.cpp_beam_search_2d(y1, y2, env, 5, method_="row")
-    # methods this engine does not run on the GPU yet are refused, not approximated
-    with pytest.raises(_lib.EngineError) as ei:
-        eng.beam_search_2d_batch([y1[:50]], [y2[:50]], [env[:50]], 5, method="grid")
-    assert ei.value.code == _lib.E_UNSUPPORTED
     # row without an envelope keeps V+2 times per node: refused when that exceeds the per-pair store
     seqs, st = eng.beam_search_2d_batch([y1], [y2], None, 5, method="row", return_status=True)
     assert st[0] == _lib.E_NOMEM
+
+
+# ---- method grid (hidden upstream option): one beam per cell
+def test_grid_golden(eng, golden, golden_grid, golden_inputs):
+    from conftest import grid_cases
+    cases = grid_cases(golden, golden_grid, golden_inputs)
+    for name, y1, y2, env, W, model, alphabet, want in cases:
+        got = eng.beam_search_2d_batch([y1], [y2], None if env is None else [env], W, alphabet=alphabet, model=model,
+                                       method="grid")[0]
+        assert got == want, name
+    # without an envelope every method but "row" runs grid (BeamSearch.h:441-458)
+    name, y1, y2, env, W, model, alphabet, want = [c for c in cases if c[0] == "synth_9004"][0]
+    assert eng.beam_search_2d_batch([y1], [y2], None, W, model=model, method="row_col")[0] == want
+
+
+@pytest.mark.parametrize("W", [1, 3, 5, 8, 25])
+def test_grid_envelope_matches_oracle_batch(eng, oracle, W):
+    """ctc with an envelope (for the other models the reference's order in a narrow band is heap-address order)"""
+    y1s, y2s, envs, want = [], [], [], []
+    for i in range(6):
+        y1, y2 = synth_pair(7100 + i, T=150 + 30 * i)
+        if i % 2 == 0:
+            env = oracle.pair_decode(y1, y2, "poreover", 5, "row_col")["envelope"]   # pipeline envelope
+        else:
+            env = oracle.diagonal_envelope(len(y1), len(y2), 5 + i)
+        y1s.append(y1); y2s.append(y2); envs.append(env)
+        want.append(oracle.cpp_beam_search_2d(y1, y2, env, W, method_="grid"))
+    assert eng.beam_search_2d_batch(y1s, y2s, envs, W, method="grid") == want
+
+
+@pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
+@pytest.mark.parametrize("W", [2, 4, 7])
+def test_grid_no_envelope_matches_oracle(eng, oracle, model, ff, W):
+    y1s, y2s, want = [], [], []
+    for i in range(4):
+        y1, y2 = synth_pair(7200 + i, T=40 + 10 * i, flipflop=ff)
+        y1s.append(y1); y2s.append(y2)
+        want.append(oracle.cpp_beam_search_2d(y1, y2, None, W, model_=model, method_="grid"))
+    assert eng.beam_search_2d_batch(y1s, y2s, None, W, model=model, method="grid") == want
+
+
+def test_grid_limits(eng, oracle):
+    from poreover_amd import _lib
+    y1, y2 = synth_pair(7300, T=300)
+    U, V = len(y1), len(y2)
+    env = np.array(oracle.diagonal_envelope(U, V, 8))
+    # row starts that move backwards: the ring store would have dropped what a later row reads
+    bad = env.copy(); bad[100] = (max(0, bad[99][0] - 3), bad[100][1])
+    seqs, st = eng.beam_search_2d_batch([y1, y1], [y2, y2], [env, bad], 5, method="grid", return_status=True)
+    assert st.tolist() == [0, _lib.E_UNSUPPORTED]
+    assert seqs[0] == oracle.cpp_beam_search_2d(y1, y2, env, 5, method_="grid")
+    # out-of-range bounds, where the reference reads past y2
+    oob = env.copy(); oob[50] = (oob[50][0], V + 2)
+    _, st = eng.beam_search_2d_batch([y1], [y2], [oob], 5, method="grid", return_status=True)
+    assert st[0] == _lib.E_ENVELOPE
+    # a row with an empty band: its successors fall back to the seed beam
+    gap = env.copy(); gap[120] = (gap[120][0], gap[120][0])
+    assert eng.beam_search_2d_batch([y1], [y2], [gap], 5, method="grid")[0] == \
+        oracle.cpp_beam_search_2d(y1, y2, gap, 5, method_="grid")

@@ -116,3 +116,14 @@ def test_pipeline_long_reads(eng, oracle):
     assert got["sequence_identity"] == want["sequence_identity"]
     assert np.array_equal(got["envelope"], want["envelope"])
     assert got["consensus"] == want["consensus"]
+
+
+def test_pipeline_grid_method(eng, oracle):
+    """--beam_search_method grid (hidden upstream option) through the whole stage chain, small and full size"""
+    y1s, y2s = zip(*([synth_pair(6100 + i, T=300 + 50 * i) for i in range(4)] + [synth_pair(7000, T=4000)]))
+    got = eng.pair_decode_batch(list(y1s), list(y2s), "poreover", 5, "grid")
+    for i in range(len(y1s)):
+        want = oracle.pair_decode(y1s[i], y2s[i], "poreover", 5, "grid")
+        assert got[i]["status"] == want["status"] == 0, i
+        assert np.array_equal(got[i]["envelope"], want["envelope"]), i
+        assert got[i]["consensus"] == want["consensus"], i

@@ -169,3 +169,11 @@ def test_pairs_end_to_end(oracle, golden, golden_inputs):
 def test_revcomp_fixture_shape(golden_inputs):
     a, b = golden_inputs["revcomp_poreover_in"], golden_inputs["revcomp_poreover_out"]
     assert np.array_equal(a[::-1][:, [3, 2, 1, 0, 4]], b)
+
+
+def test_grid_method_golden(oracle, golden, golden_grid, golden_inputs):
+    """the hidden `grid` pair method (BeamSearch2.h:33-184) against outputs of the reference"""
+    from conftest import grid_cases
+    for name, y1, y2, env, W, model, alphabet, want in grid_cases(golden, golden_grid, golden_inputs):
+        got = oracle.cpp_beam_search_2d(y1, y2, env, W, alphabet_=alphabet, model_=model, method_="grid")
+        assert got == want, name
