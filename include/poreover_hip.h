@@ -289,7 +289,8 @@ void po_event_destroy(void* ev);
 #define PO_K_BEAM2D 2
 #define PO_K_ALIGN 3
 #define PO_K_ENVELOPE 4
-#define PO_K_COUNT 5
+#define PO_K_BEAM2D_MAIN 5 /* the pair beam search kernel alone (PO_K_BEAM2D = the stage: + pre-pass, walk, store memset) */
+#define PO_K_COUNT 6
 void po_profile_enable(int on);
 void po_profile_reset(void);
 int po_profile_get(int kernel, double* total_ms, int64_t* launches);

@@ -17,7 +17,7 @@ SKIP_LENGTH, SKIP_IDENTITY = -10, -11
 MODELS = {"ctc": 0, "ctc_merge_repeats": 1, "ctc_flipflop": 2}
 METHODS = {"row": 0, "row_col": 1, "grid": 2}
 KINDS = {"poreover": 0, "bonito": 1, "flipflop": 2}
-K_VITERBI, K_BEAM1D, K_BEAM2D, K_ALIGN, K_ENVELOPE = range(5)
+K_VITERBI, K_BEAM1D, K_BEAM2D, K_ALIGN, K_ENVELOPE, K_BEAM2D_MAIN = range(6)
 _CODE_NAMES = {E_CAP: "PO_E_CAP (buffer too small)", E_ARG: "PO_E_ARG (bad argument)",
                E_ENVELOPE: "PO_E_ENVELOPE (envelope undefined for the reference)",
                E_NOMEM: "PO_E_NOMEM (node arena / band capacity exceeded)",

@@ -2112,12 +2112,15 @@ bool x2_eligible(int n, int W, int model, int method) {
     // (PO_X2_WIDE forces it, for the tests)
     return W <= 12 && (n >= 4096 || getenv("PO_X2_WIDE") != nullptr);
 }
+void (*g_b2_mark_fwd)(int begin, hipStream_t stream) = nullptr;   // set through po_b2_set_mark
 template <int MODEL>
 void x2_launch(const X2Args& a, int n, int W, int blocks, size_t plds, hipStream_t stream) {
     hipLaunchKernelGGL(beam2d_prepass_kernel<MODEL>, dim3(n), dim3(256), plds, stream, a);
     hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
+    if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
     if (W <= 6) hipLaunchKernelGGL((beam2d_x2_kernel<MODEL, 32>), dim3(blocks), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((beam2d_x2_kernel<MODEL, 64>), dim3(blocks), dim3(64), 0, stream, a);
+    if (g_b2_mark_fwd) g_b2_mark_fwd(0, stream);
 }
 template <int MODEL>
 const void* x2_fn(int W) {
@@ -2230,7 +2233,9 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
 
 namespace {
 unsigned long long* g_b2_upd_counter = nullptr;
+void (*g_b2_mark)(int begin, hipStream_t stream) = nullptr;   // profiling: brackets the main pair beam kernel
 }
+extern "C" void po_b2_set_mark(void (*f)(int, hipStream_t)) { g_b2_mark = f; g_b2_mark_fwd = f; }
 // profiling: a device counter that the pair beam kernels add their number of update_prob evaluations to
 extern "C" void po_b2_set_update_counter(unsigned long long* dev_counter) { g_b2_upd_counter = dev_counter; }
 
@@ -2297,10 +2302,12 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     // queue counter and the store's tags start from zero on every launch
     if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
     if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
+    if (g_b2_mark && !only_meta) g_b2_mark(1, stream);
     if (model == PO_MODEL_CTC) b2_launch_w<PO_MODEL_CTC>(g, a, stream);
     else if (model == PO_MODEL_MERGE) b2_launch_w<PO_MODEL_MERGE>(g, a, stream);
     else if (model == PO_MODEL_FLIPFLOP) b2_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
     else return PO_E_ARG;
+    if (g_b2_mark && !only_meta) g_b2_mark(0, stream);
 #ifdef PO_B2_TIMING
     {
         long long h[12];

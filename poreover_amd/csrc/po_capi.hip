@@ -29,6 +29,7 @@ int po_launch_pair_prefix_search(const double*, const int64_t*, const double*, c
                                  int, uint32_t, int, int64_t, char*, const int64_t*, int32_t*, double*, int32_t*, void*, size_t,
                                  hipStream_t);
 void po_b2_set_update_counter(unsigned long long*);
+void po_b2_set_mark(void (*)(int, hipStream_t));
 int po_launch_lae_peak(int, double*, hipStream_t);
 int po_launch_pair_decode_from_1d(const double*, const int64_t*, const double*, const int64_t*, int, int, const po_pair_options*,
                                   int64_t, int64_t, int64_t, int64_t, const int32_t*, const int32_t*, char*, const int64_t*,
@@ -106,6 +107,22 @@ struct ProfScope {
         }
     }
 };
+// brackets the main pair beam kernel (called from po_beam2d.hip around its launch)
+hipEvent_t g_mark_a = nullptr;
+void b2_mark(int begin, hipStream_t s) {
+    if (!g_prof_on) return;
+    if (begin) {
+        (void)hipEventCreate(&g_mark_a);
+        (void)hipEventRecord(g_mark_a, s);
+    } else if (g_mark_a) {
+        hipEvent_t b = nullptr;
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back({g_mark_a, b, PO_K_BEAM2D_MAIN});
+        g_mark_a = nullptr;
+    }
+}
 void prof_drain() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
@@ -953,7 +970,10 @@ int po_lae_peak(int iters, double* lae_per_s, void* stream) {
     if (rc != PO_OK) g_err = "po_lae_peak: launch failed";
     return rc;
 }
-void po_profile_enable(int on) { g_prof_on = on != 0; }
+void po_profile_enable(int on) {
+    g_prof_on = on != 0;
+    po_b2_set_mark(g_prof_on ? b2_mark : nullptr);
+}
 void po_profile_reset(void) {
     prof_drain();
     std::lock_guard<std::mutex> lk(g_prof_mu);
