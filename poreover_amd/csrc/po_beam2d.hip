@@ -894,21 +894,40 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
     int st = PO_OK, R = 32;
     if (U < 1 || V < 1 || U >= (1 << 24) || V >= (1 << 24)) st = PO_E_ARG;
     if (st == PO_OK) {
-        int bad = 0, wmax = 0;
+        int bad = 0, wmax = 0, nonmono = 0;
         for (int u = tid; u < U; u += nthr) {
             const int lo = env[2 * u], hi = env[2 * u + 1];
             if (lo < hi && (lo < 0 || hi > V)) bad = 1;
+            if (lo < 0 || hi > V || (u > 0 && (lo < env[2 * u - 2] || hi < env[2 * u - 1]))) nonmono = 1;
             wmax = max(wmax, hi - lo);
         }
         if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
+        const bool mono = !__syncthreads_or(nonmono);   // row starts and ends never move backwards (what build_envelope makes)
         if (st == PO_OK) {
             // transposed envelope (BeamSearch.h:270-284): the first row that covers column x starts its range
             // and every further covering row extends it by one, i.e. [first row, first row + number of rows)
             if (V <= a.pre_vcols) {  // columns in LDS, rows in parallel
                 int* first = colbuf;
                 int* cnt = colbuf + a.pre_vcols;
-                for (int x = tid; x < V; x += nthr) { first[x] = 0x7fffffff; cnt[x] = 0; }
+                for (int x = tid; x < V; x += nthr) { first[x] = 0x7fffffff; cnt[x] = mono ? -1 : 0; }
                 __syncthreads();
+                if (mono) {
+                    // The rows covering column x are then the contiguous range [a(x), b(x)], a = the first row whose end
+                    // lies beyond x, b = the last row that starts at or before x: row u is a(x) for the columns between
+                    // the previous row's end and its own, and b(x) for the columns between its start and the next
+                    // row's — every column is written once, no atomics.  (cnt holds b here.)
+                    for (int u = tid; u < U; u += nthr) {
+                        const int lo = env[2 * u], hi = env[2 * u + 1];
+                        const int hp = (u > 0) ? env[2 * u - 1] : 0, ln = (u + 1 < U) ? env[2 * u + 2] : V;
+                        for (int x = hp; x < hi; ++x) first[x] = u;
+                        for (int x = lo; x < ln; ++x) cnt[x] = u;
+                    }
+                    __syncthreads();
+                    for (int x = tid; x < V; x += nthr) {
+                        const int a_ = first[x], b_ = cnt[x];
+                        cnt[x] = (a_ != 0x7fffffff && b_ >= a_) ? b_ - a_ + 1 : 0;
+                    }
+                } else
                 for (int u = tid; u < U; u += nthr) {
                     const int lo = env[2 * u], hi = env[2 * u + 1];
                     for (int x = lo; x < hi; ++x) { atomicMin(&first[x], u); atomicAdd(&cnt[x], 1); }
@@ -956,9 +975,11 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
         double* cw = rr ? a.cum2 + (o2 - b2) : a.cum1 + (o1 - b1);
         const int Tn = rr ? V : U;
         double acc = 0.0;
+        double xn = (lane < Tn) ? yr[(int64_t)lane * C + A] : 0.0;   // (the next 64 frames are requested a round ahead)
         for (int t0 = 0; t0 < Tn; t0 += 64) {
             const int t = t0 + lane;
-            const double x = (t < Tn) ? yr[(int64_t)t * C + A] : 0.0;
+            const double x = xn;
+            xn = (t + 64 < Tn) ? yr[(int64_t)(t + 64) * C + A] : 0.0;
             double mine = 0.0;
 #pragma unroll
             for (int j = 0; j < 64; ++j) {
@@ -986,25 +1007,34 @@ __global__ __launch_bounds__(64) void beam2d_walk_kernel(X2Args a) {
     const int2* env2 = (const int2*)(a.env + 2 * o1);
     const int2* envt2 = (const int2*)(a.envt + 2 * (o2 - b2));
     int4* sc = a.sched + (o2 - b2);
+    // Main steps come in runs along a diagonal (u + l, v + l), l = 0, 1, ...: the wave tests 64 of them at once
+    // (lane l looks at row u + l and column v + l, cached 64 at a time in registers and fetched with a lane
+    // permute), records the run up to the first position that is not a main step, and resolves that one position
+    // by the reference's rule (catch-up on read 1, catch-up on read 0, or uninitialised bounds).
     int u = 0, v = 0, m = 0, werr = 0, ubase = -1000, vbase = -1000;
     int2 erc = make_int2(0, 0), ecc = make_int2(0, 0);
-    int4 myrec = make_int4(0, 0, 0, 0);
     while (u <= U - 1 && v <= V - 1) {
         if (u < ubase || u >= ubase + 64) { ubase = u; erc = (ubase + lane < U) ? env2[ubase + lane] : make_int2(0, 0); }
         if (v < vbase || v >= vbase + 64) { vbase = v; ecc = (vbase + lane < V) ? envt2[vbase + lane] : make_int2(0, 0); }
-        const int iu = __builtin_amdgcn_readfirstlane(u - ubase), iv = __builtin_amdgcn_readfirstlane(v - vbase);
-        const int ers = __builtin_amdgcn_readlane(erc.x, iu), ere = __builtin_amdgcn_readlane(erc.y, iu);
-        const int ecs = __builtin_amdgcn_readlane(ecc.x, iv), ece = __builtin_amdgcn_readlane(ecc.y, iv);
-        const bool row_ok = (v >= ers && v < ere), col_ok = (u >= ecs && u < ece);
-        if (!row_ok && v < ers) { v++; continue; }           // catch-up on read 1 (:314-322)
-        if (!col_ok && u < ecs) { u++; continue; }           // catch-up on read 0 (:328-336)
-        if (!row_ok || !col_ok) { werr = 1; break; }          // uninitialised bounds upstream (:309)
-        // records are collected one per lane and written 64 at a time
-        if (lane == (m & 63)) myrec = make_int4(u, v, ece, ere);
-        m++; u++; v++;
-        if ((m & 63) == 0) sc[m - 64 + lane] = myrec;
+        const int ul = u + lane, vl = v + lane;
+        const int iu = ul - ubase, iv = vl - vbase;                    // cache slots of this lane's row / column
+        const bool have = iu < 64 && iv < 64 && ul < U && vl < V;       // (lane 0 always has both)
+        const int ers = __shfl(erc.x, iu & 63), ere = __shfl(erc.y, iu & 63);
+        const int ecs = __shfl(ecc.x, iv & 63), ece = __shfl(ecc.y, iv & 63);
+        const bool row_ok = (vl >= ers && vl < ere), col_ok = (ul >= ecs && ul < ece);
+        const unsigned long long okb = __ballot(have && row_ok && col_ok);
+        const unsigned long long haveb = __ballot(have);
+        const int run = (~okb == 0ull) ? 64 : __builtin_ctzll(~okb);   // main steps from (u, v) on
+        if (lane < run) sc[m + lane] = make_int4(ul, vl, ece, ere);
+        m += run; u += run; v += run;
+        if (run < 64 && ((haveb >> run) & 1ull)) {   // the position after the run is in range and is not a main step
+            const unsigned long long c1 = __ballot(!row_ok && vl < ers), c0 = __ballot(!col_ok && ul < ecs);
+            if ((c1 >> run) & 1ull) v++;              // catch-up on read 1 (:314-322)
+            else if ((c0 >> run) & 1ull) u++;         // catch-up on read 0 (:328-336)
+            else { werr = 1; break; }                  // uninitialised bounds upstream (:309)
+        }
+        // (a run that ends where the caches or the reads end is simply continued by the next round)
     }
-    if ((m & 63) != 0 && lane < (m & 63)) sc[(m & ~63) + lane] = myrec;
     if (lane == 0) {
         a.nmain[pi] = m;
         if (werr) a.meta[pi] = make_int2(PO_E_ENVELOPE, mt.y);
