@@ -195,6 +195,32 @@ def test_rowcol_irregular_envelopes(eng, oracle, model, ff):
     assert any(c == 0 for c in wst) and len(set(wst)) >= 1
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_rowcol_irregular_envelopes_long(eng, oracle, seed):
+    """the same at lengths where the incremental / steady step machinery has room to run (hundreds of main steps
+    per pair, windows that shrink, jump and stall)"""
+    rng = np.random.default_rng(seed)
+    y1s, y2s, envs = [], [], []
+    for i in range(24):
+        T = int(rng.integers(300, 1200))
+        y1, y2 = synth_pair(5200 + 100 * seed + i, T=T)
+        if i % 6 == 0:
+            y2 = y2[: max(2, (2 * len(y2)) // 3)]
+        y1s.append(y1); y2s.append(y2)
+        envs.append(_jagged_envelope(rng, len(y1), len(y2), ("stairs", "wobble", "bursts")[i % 3]))
+    for W in (4, 5):
+        want, wst = [], []
+        for a, b, e in zip(y1s, y2s, envs):
+            try:
+                want.append(oracle.cpp_beam_search_2d(a, b, e, W, method_="row_col")); wst.append(0)
+            except oracle.OracleError as ex:
+                want.append(""); wst.append(ex.code)
+        got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, method="row_col", return_status=True)
+        assert st.tolist() == wst, (W, st.tolist(), wst)
+        assert [g if c == 0 else "" for g, c in zip(got, wst)] == want, W
+    assert sum(c == 0 for c in wst) >= 4
+
+
 # ------------------------------------------------------------------------------------------------
 # method "row" (the API default) and the no-envelope overload
 def test_row_golden_toys_and_csv(eng, golden, golden_inputs):
