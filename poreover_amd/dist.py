@@ -5,7 +5,8 @@ data-path collective; torch.distributed (RCCL on GPUs, gloo in the CPU tests) is
 barrier, the timing reduce and the optional gather of results only."""
 import os
 
-__all__ = ["env_rank_world", "shard_range", "shard_seeds", "job_aggregate", "gather_strings"]
+__all__ = ["env_rank_world", "shard_range", "shard_seeds", "shard_by_cost", "job_aggregate", "gather_strings",
+           "gather_in_order"]
 
 
 def env_rank_world():
@@ -23,6 +24,21 @@ def shard_range(n_items, rank, world):
 def shard_seeds(per_rank, rank):
     """Weak scaling: every rank decodes `per_rank` items of its own; global item id = seed."""
     return range(rank * per_rank, (rank + 1) * per_rank)
+
+
+def shard_by_cost(costs, world):
+    """Greedy longest-processing-time split of items with unequal cost (frames U + V of a pair before its envelope
+    exists, envelope cells after): items sorted by decreasing cost, each to the least loaded rank.  Returns one
+    index list per rank, each in decreasing cost (the persistent kernels pull work in index order, so a rank's long
+    pairs start first and its tail is made of short ones).  Deterministic: ties keep input order."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0] * world
+    shards = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += costs[i]
+    return shards
 
 
 def job_aggregate(dist, elapsed_s, units, device=None):
@@ -47,3 +63,21 @@ def gather_strings(dist, local_strings, dst=0):
     if out is None:
         return None
     return [s for part in out for s in part]
+
+
+def gather_in_order(dist, local_items, local_indices, n_items, dst=0):
+    """Gather results of a shard_by_cost split back into INPUT order on rank dst (None elsewhere)."""
+    if dist is None or not dist.is_initialized():
+        out = [None] * n_items
+        for i, x in zip(local_indices, local_items):
+            out[i] = x
+        return out
+    parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object((list(local_indices), list(local_items)), parts, dst=dst)
+    if parts is None:
+        return None
+    out = [None] * n_items
+    for idx, items in parts:
+        for i, x in zip(idx, items):
+            out[i] = x
+    return out

@@ -20,9 +20,12 @@ mine = ["item%02d" % i for i in range(lo, hi)]                 # stands in for d
 tmax, (units, bases) = podist.job_aggregate(dist, 1.0 + rank, [hi - lo, 10 * (hi - lo)])
 allstr = podist.gather_strings(dist, mine)
 seeds = list(podist.shard_seeds(5, rank))
+costs = [5, 1, 9, 3, 3, 7, 2, 8, 1, 1, 6]                      # unequal pairs: greedy LPT split, results back in input order
+idx = podist.shard_by_cost(costs, world)[rank]
+ordered = podist.gather_in_order(dist, ["r%d" % costs[i] for i in idx], idx, len(costs))
 dist.barrier()
 if rank == 0:
-    print(json.dumps({"tmax": tmax, "units": units, "bases": bases, "all": allstr, "seeds0": seeds}))
+    print(json.dumps({"tmax": tmax, "units": units, "bases": bases, "all": allstr, "seeds0": seeds, "ordered": ordered}))
 dist.destroy_process_group()
 '''
 
@@ -54,3 +57,18 @@ def test_two_ranks_gloo(tmp_path):
     assert res["units"] == 11 and res["bases"] == 110
     assert res["all"] == ["item%02d" % i for i in range(11)]   # global order preserved
     assert res["seeds0"] == [0, 1, 2, 3, 4]
+    assert res["ordered"] == ["r%d" % c for c in [5, 1, 9, 3, 3, 7, 2, 8, 1, 1, 6]]
+
+
+def test_shard_by_cost_properties():
+    import random
+    from poreover_amd.dist import shard_by_cost
+    rnd = random.Random(3)
+    for world in (1, 2, 4, 8):
+        costs = [rnd.randint(1, 9000) for _ in range(257)]
+        shards = shard_by_cost(costs, world)
+        assert sorted(i for sh in shards for i in sh) == list(range(len(costs)))      # disjoint and covering
+        loads = [sum(costs[i] for i in sh) for sh in shards]
+        assert max(loads) - min(loads) <= max(costs)                                   # the LPT bound
+        for sh in shards:
+            assert [costs[i] for i in sh] == sorted((costs[i] for i in sh), reverse=True)
