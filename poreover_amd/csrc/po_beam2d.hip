@@ -2132,15 +2132,13 @@ struct X2Geom {
 };
 constexpr int X2_FB_BLOCKS = 256;  // workgroups of the beam2d_kernel pass over deferred pairs
 bool x2_eligible(int n, int W, int model, int method) {
-    static const bool legacy = getenv("PO_B2_LEGACY") != nullptr;  // A/B switch: always use beam2d_kernel
-    (void)model;  // all three tree models (the 3-value ones run 2 waves per SIMD: +8 % / +13 % over beam2d_kernel)
+    const bool legacy = getenv("PO_B2_LEGACY") != nullptr;  // A/B and test switch: always use beam2d_kernel
+    (void)model; (void)n;  // all three tree models (the 3-value ones run 2 waves per SIMD)
     if (legacy || method != PO_METHOD_ROW_COL) return false;
-    if (W <= 6) return true;   // two pairs per wave
-    // 7 <= W <= 12: one pair per wave with the reads one after the other.  More pairs in flight but a longer
-    // per-pair latency than beam2d_kernel's two waves per pair (W = 10: 10.3k vs 12.0k pairs/s at 1024 pairs,
-    // equal at 3328, 23.9k vs 20.3k at 6656, 28.0k vs 22.5k at 13312) — used from 4096 pairs up
-    // (PO_X2_WIDE forces it, for the tests)
-    return W <= 12 && (n >= 4096 || getenv("PO_X2_WIDE") != nullptr);
+    // W <= 6: two pairs per wave.  7 <= W <= 12: one pair per wave with the reads one after the other — since the
+    // incremental steps it beats beam2d_kernel's two waves per pair at every batch size (W = 10: 6.5k vs 3.5k pairs/s
+    // at 256 pairs, 22.9k vs 12.7k at 1024, 36.6k vs 19.6k at 3328, 55k at 13k).
+    return W <= 12;
 }
 void (*g_b2_mark_fwd)(int begin, hipStream_t stream) = nullptr;   // set through po_b2_set_mark
 template <int MODEL>

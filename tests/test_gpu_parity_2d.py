@@ -84,8 +84,8 @@ def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
 
 @pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
 def test_rowcol_wide_beam_one_pair_per_wave(eng, oracle, monkeypatch, model, ff):
-    """7 <= W <= 12 on large batches runs beam2d_x2_kernel with one pair per wave (PO_X2_WIDE forces that path
-    for a small batch); same strings as the oracle and as beam2d_kernel"""
+    """7 <= W <= 12 runs beam2d_x2_kernel with one pair per wave (PO_B2_LEGACY forces beam2d_kernel): same strings
+    as the oracle from both"""
     kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
     y1s, y2s, envs = [], [], []
     for i in range(5):
@@ -95,9 +95,9 @@ def test_rowcol_wide_beam_one_pair_per_wave(eng, oracle, monkeypatch, model, ff)
     for W in (7, 10, 12):
         want = [oracle.cpp_beam_search_2d(a, b, e, W, model_=model, method_="row_col") for a, b, e in zip(y1s, y2s, envs)]
         assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want
-        monkeypatch.setenv("PO_X2_WIDE", "1")
+        monkeypatch.setenv("PO_B2_LEGACY", "1")
         assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want, W
-        monkeypatch.delenv("PO_X2_WIDE")
+        monkeypatch.delenv("PO_B2_LEGACY")
 
 
 def test_rowcol_full_size(eng, oracle):
