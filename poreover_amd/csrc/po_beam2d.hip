@@ -638,6 +638,24 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             }
             if (tid == 0) sm.sh[5] = 0;
             po_lds_barrier();
+            // Most steps keep the beam as it is: that holds iff the beam nodes are still in order and the last of
+            // them still beats every child — two comparisons per thread instead of a ranking against everybody.
+            bool same_beam = false;
+            if (regular && nb == W) {
+                bool viol = false;
+                if (tid < ne && !sm.dup[tid]) {
+                    const double sc = sm.score[tid];
+                    const int id = sm.e[F_ID][tid];
+                    if (tid >= nb) viol = !po_better(sm.score[nb - 1], sm.e[F_ID][nb - 1], sc, id);
+                    else if (tid + 1 < nb) viol = !po_better(sc, id, sm.score[tid + 1], sm.e[F_ID][tid + 1]);
+                }
+                same_beam = !__syncthreads_or(viol);
+            }
+            if (same_beam) {
+                if (tid < nb) sm.stay[tid] = 1;
+                po_lds_barrier();
+                return;
+            }
             if (tid < ne && !sm.dup[tid]) {
                 const double sc = sm.score[tid];
                 const int id = sm.e[F_ID][tid];
