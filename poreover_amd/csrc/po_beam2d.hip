@@ -523,35 +523,49 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
         // expansion of the processed elements + children slots.  Regular shape: every beam node is
         // processed, child c of beam node j sits at nb + A*j + c.  lo0/lo1: see alloc_group.
         auto build_regular = [&](int lo0, int lo1, int hi0, int hi1) -> int {
-            if (tid == 0) {
-                int next_id = sm.sh[2];
-                for (int j = 0; j < nb; ++j) {
-                    bool need_group = false;
-                    const int id = sm.e[F_ID][j];
-                    if (sm.e[F_FC][j] < 0) {
-                        sm.e[F_FC][j] = next_id;
-                        afc[id] = next_id;
-                        for (int c = 0; c < A; ++c) {
-                            apl[next_id + c] = po_pack_node(id, c); afc[next_id + c] = -1; acrow[next_id + c] = -1;
-                            if (is_row) amax[next_id + c] = PO_NEG_INF;
-                        }
-                        next_id += A;
-                        need_group = true;
-                    } else if (sm.e[F_CROW][j] < 0 || sm.e[F_CROW][j] >= NG || sm.g_owner[sm.e[F_CROW][j]] != id) {
-                        need_group = true;  // its old rows were recycled: every value in them was dead
-                    }
-                    sm.cnew[j] = need_group ? 1 : 0;
-                    if (need_group) {
-                        const int g = alloc_group(id, lo0, lo1, nb);
-                        sm.e[F_CROW][j] = g;
-                        acrow[id] = g;
-                    }
-                    // this step writes up to (hi0, hi1) into the children's rows and the node's own
-                    const int gc = sm.e[F_CROW][j], go = sm.e[F_ROW][j] / PO_A;
-                    sm.g_hi0[gc] = max(sm.g_hi0[gc], hi0); sm.g_hi1[gc] = max(sm.g_hi1[gc], hi1);
-                    sm.g_hi0[go] = max(sm.g_hi0[go], hi0); sm.g_hi1[go] = max(sm.g_hi1[go], hi1);
+            // one lane per beam node (nb <= 25: the first wave).  New node ids are handed out in beam order — a prefix
+            // count over the lanes that need them (ids break score ties); row groups, which only name storage, are
+            // allocated one after the other by lane 0 and marked with this step's window ends at once.
+            if (tid < 64) {
+                const bool bl = tid < nb;
+                bool isnew = false, need_group = false;
+                int id = 0;
+                if (bl) {
+                    id = sm.e[F_ID][tid];
+                    const int cr = sm.e[F_CROW][tid];
+                    if (sm.e[F_FC][tid] < 0) { isnew = true; need_group = true; }
+                    else if (cr < 0 || cr >= NG || sm.g_owner[cr] != id) need_group = true;  // old rows recycled: all dead
                 }
-                sm.sh[2] = next_id;
+                const unsigned long long bn = __ballot(isnew), bg = __ballot(need_group);
+                const int base = sm.sh[2];
+                if (isnew) {
+                    const int fc = base + A * __popcll(bn & ((1ull << tid) - 1ull));
+                    sm.e[F_FC][tid] = fc;
+                    afc[id] = fc;
+                    for (int c = 0; c < A; ++c) {
+                        apl[fc + c] = po_pack_node(id, c); afc[fc + c] = -1; acrow[fc + c] = -1;
+                        if (is_row) amax[fc + c] = PO_NEG_INF;
+                    }
+                }
+                if (bl) sm.cnew[tid] = need_group ? 1 : 0;
+                b2_sync_lds<64>();
+                if (tid == 0) {
+                    sm.sh[2] = base + A * __popcll(bn);
+                    for (unsigned long long m = bg; m != 0; m &= m - 1) {
+                        const int j = __builtin_ctzll(m);
+                        const int idj = sm.e[F_ID][j];
+                        const int g = alloc_group(idj, lo0, lo1, nb);
+                        sm.e[F_CROW][j] = g;
+                        acrow[idj] = g;
+                        sm.g_hi0[g] = hi0; sm.g_hi1[g] = hi1;
+                    }
+                }
+                b2_sync_lds<64>();
+                if (bl) {   // this step writes up to (hi0, hi1) into the children's rows and the node's own
+                    const int gc = sm.e[F_CROW][tid], go = sm.e[F_ROW][tid] / PO_A;
+                    atomicMax(&sm.g_hi0[gc], hi0); atomicMax(&sm.g_hi1[gc], hi1);
+                    atomicMax(&sm.g_hi0[go], hi0); atomicMax(&sm.g_hi1[go], hi1);
+                }
             }
             po_lds_barrier();
             const int ne = nb * (A + 1);
