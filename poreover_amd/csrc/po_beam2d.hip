@@ -126,6 +126,9 @@ struct B2Smem {
     int sh[16];
     double score[NCM];
     double mxs[2][NCP];
+    // incremental main steps: per (read, slot) the maximum of the previous main step's window and its (latest) time
+    double cmx[2][NCP];
+    int cmt[2][NCP];
     double xch[2][2][NCP][K];
     double ybuf[2][B2_YD];  // the y rows of the current step's windows, per read
     unsigned long long nupd;  // profiling: update_prob evaluations of the current pair
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             sm.sh[3] = 1;      // group allocation cursor
             sm.sh[4] = PO_OK;
             sm.sh[8] = INT_MIN; sm.sh[9] = INT_MIN;  // window ends of the previous row_col main step: none yet
+            sm.sh[10] = 0; sm.sh[11] = 0; sm.sh[12] = 0; sm.sh[13] = 0;  // incremental steps: nothing to build on yet
         }
         if (tid < WMAX) sm.stay[tid] = 0;
         if (tid < A) {
@@ -378,13 +382,46 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
         auto scan = [&](bool is_main, bool reuse, int nelem, int skip_lo, int skip_hi, int t00, int len0_, int t01, int len1_) {
             // the window bounds come from (wave-uniform) vector loads: pin them to SGPRs so the iteration
             // loop is a scalar loop
-            const int len0 = __builtin_amdgcn_readfirstlane(len0_), len1 = __builtin_amdgcn_readfirstlane(len1_);
-            const int t0 = r ? t01 : t00, len = r ? len1 : len0;
-            const bool part = (s < nelem) && (len > 0) && !(r == 0 && s >= skip_lo && s < skip_hi);
+            // INCREMENTAL main step (as in beam2d_x2_kernel, restricted to the simplest case): the previous prune left
+            // the beam exactly as it was and nothing is created or re-allocated now, so every element sits in the slot
+            // it had, and over the part of its windows the previous main step covered it would recompute the stored
+            // bits.  Only the times beyond the previous window ends are computed (seeded from the store); the window
+            // maximum of the rest is carried per (read, slot), or re-read from the store when its time has left the
+            // window.  sh[12 + r]: cmx / cmt of read r were written for the current slot layout.
+            const bool steady = is_main && reuse && sm.sh[10] != 0 && sm.sh[11] != 0;
+            int l0 = len0_, l1 = len1_, s0 = t00, s1 = t01;
+            if (steady && sm.sh[12] != 0) { s0 = min(max(sm.sh[8], t00), t00 + len0_); l0 = t00 + len0_ - s0; }
+            if (steady && sm.sh[13] != 0) { s1 = min(max(sm.sh[9], t01), t01 + len1_); l1 = t01 + len1_ - s1; }
+            const int len0 = __builtin_amdgcn_readfirstlane(l0), len1 = __builtin_amdgcn_readfirstlane(l1);
+            const int t0 = r ? s1 : s0, len = r ? len1 : len0;
+            const int t0f = r ? t01 : t00, lenf = r ? len1_ : len0_;   // the full window
+            const bool partf = (s < nelem) && (lenf > 0) && !(r == 0 && s >= skip_lo && s < skip_hi);
+            const bool part = partf && (len > 0);
             const int Lmax = max(len0, len1);
             int pslot = PS_ROOT, sym = 0;
             bool same = false, rootpar = false;
             double self[K], mx = PO_NEG_INF;
+            int mt = -1;
+            if (partf && t0 > t0f) {   // the carried part [t0f, t0) of the window
+                const double pm = sm.cmx[r][s];
+                const int pt = sm.cmt[r][s];
+                if (pm == PO_NEG_INF || (pt >= t0f && pt < t0)) { mx = pm; mt = pt; }
+                else {
+                    const Ent* rp = pool + ((size_t)sm.e[F_ROW][s] * 2 + r) * R;
+                    const unsigned long long tg = make_tag(epoch, sm.e[F_ID][s], 0);
+                    for (int bt = t0f; bt < t0; bt += 4) {
+                        Ent e4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e4[q] = rp[(bt + q) & Rm];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int tq = bt + q;
+                            const double val = (tq < t0 && e4[q].tag == tg + (unsigned)tq) ? e4[q].v[0] : PO_NEG_INF;
+                            if (tq < t0 && val >= mx) { mx = val; mt = tq; }
+                        }
+                    }
+                }
+            }
             Ent* myrow = pool;          // this element's ring row on read r
             const Ent* prow = pool;     // a frozen parent's ring row
             unsigned long long tag0 = 0, ptag0 = 0;
@@ -420,7 +457,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             // parent was a beam node then and kept its row group.  badf marks the others and is pushed down
             // the parent links; everyone else only stores from the previous window end on.
             bool bad = true;
-            if (reuse) {
+            if (steady) bad = false;   // (every element was an element, in this slot, in the previous main step)
+            else if (reuse) {
                 bad = false;
                 if (s < nelem && s >= nb) bad = !(sm.stay[pslot] && !sm.cnew[pslot]);
                 if (r == 0 && s < nelem) sm.badf[s] = bad;
@@ -494,13 +532,15 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
 #endif
 #pragma unroll
                     for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }
-                    if (out[0] > mx) mx = out[0];
+                    if (out[0] >= mx) { mx = out[0]; mt = t; }
                 }
                 b2_sync_lds<nthr>();  // only xch crosses iterations; the stores stay in flight
             }
             TK(is_main ? 5 : 9);  // scan: iterations
             }
             if (s < nelem) sm.mxs[r][s] = mx;
+            if (is_main && partf) { sm.cmx[r][s] = mx; sm.cmt[r][s] = mt; }
+            if (is_main && tid == 0) { if (len0_ > 0) sm.sh[12] = 1; if (len1_ > 0) sm.sh[13] = 1; }
             if (tid == 0) sm.nupd += (unsigned)(nelem * (len0 + len1));  // profiling (skipped slots counted too)
         };
 
@@ -550,6 +590,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 if (bl) sm.cnew[tid] = need_group ? 1 : 0;
                 b2_sync_lds<64>();
                 if (tid == 0) {
+                    sm.sh[11] = (bg == 0) ? 1 : 0;   // nothing created, no row group re-allocated in this step
                     sm.sh[2] = base + A * __popcll(bn);
                     for (unsigned long long m = bg; m != 0; m &= m - 1) {
                         const int j = __builtin_ctzll(m);
@@ -627,7 +668,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                         for (int i = 0; i < ne; ++i) if (sm.e[F_ID][i] == sm.e[F_PAR][j]) ps = i;
                     sm.e[F_PSLOT][j] = ps;
                 }
-                sm.sh[2] = next_id; sm.sh[6] = ne; sm.sh[7] = np;
+                sm.sh[2] = next_id; sm.sh[6] = ne; sm.sh[7] = np; sm.sh[11] = 0;
             }
             po_lds_barrier();
             *nproc = sm.sh[7];
@@ -667,9 +708,11 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             }
             if (same_beam) {
                 if (tid < nb) sm.stay[tid] = 1;
+                if (tid == 0) sm.sh[10] = 1;
                 po_lds_barrier();
                 return;
             }
+            if (tid == 0) { sm.sh[10] = 0; sm.sh[12] = 0; sm.sh[13] = 0; }
             if (tid < ne && !sm.dup[tid]) {
                 const double sc = sm.score[tid];
                 const int id = sm.e[F_ID][tid];
