@@ -678,7 +678,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
         // prune (Beam.h:93-108) + next beam table.  A slot whose node also sits in an earlier slot is
         // the same node pushed twice (std::unique).
         auto prune_and_advance = [&](int ne, bool regular) {
-            if (tid < ne) {
+            // (the duplicate flags only depend on the node ids: unchanged while the table is — see "steady" in scan)
+            const bool dup_valid = regular && sm.sh[10] != 0 && sm.sh[11] != 0;
+            if (tid < ne && !dup_valid) {
                 int d = 0;
                 const int x = sm.e[F_ID][tid];
                 if (regular) {
