@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the pair beam kernels against the CPU oracle (test infrastructure), beyond what
+tests/ pins: python scripts/fuzz_parity.py [--seconds 120] [--seed 1] [--procs 16].  Needs an MI355X.
+Every round draws a configuration (model, method, beam width, envelope style, lengths), decodes a batch on the GPU
+through the C-ABI and the same pairs with the oracle on the host cores, and compares strings and statuses."""
+import argparse
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def jagged(rng, U, V, style, pad):
+    """envelopes unlike the pipeline's: stairs / wobble / bursts around the diagonal (monotone row starts for `row`/`grid`)"""
+    env = np.zeros((U, 2), dtype=np.int64)
+    c = 0.0
+    for u in range(U):
+        if style == "stairs":
+            c = (u // 7) * 7 * V / U
+        elif style == "wobble":
+            c = u * V / U + 3.0 * np.sin(u / 5.0)
+        else:
+            c = u * V / U + (rng.integers(-2, 3) if u % 11 == 0 else 0)
+        w = pad + (rng.integers(0, pad + 1) if style == "bursts" and u % 13 == 0 else 0)
+        env[u] = (max(0, int(c) - w), min(V, int(c) + w + 1))
+    env[:, 0] = np.maximum.accumulate(env[:, 0])
+    env[:, 1] = np.maximum(env[:, 1], env[:, 0] + 1).clip(max=V)
+    return env
+
+
+def _oracle_one(job):
+    from oracle import po_oracle as O
+    y1, y2, env, W, model, method = job
+    try:
+        return O.cpp_beam_search_2d(y1, y2, env, W, model_=model, method_=method), 0
+    except O.OracleError as e:
+        return "", e.code
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--procs", type=int, default=min(32, os.cpu_count() or 1))
+    args = ap.parse_args()
+    from oracle import po_oracle as O
+    O.build()
+    from poreover_amd.synth import synth_pair
+    pool = mp.get_context("fork").Pool(args.procs)   # before the GPU runtime is initialised
+    from poreover_amd import batch
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    rounds = pairs = bad = refused = 0
+    while time.time() < t_end:
+        model, ff = [("ctc", False), ("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)][rng.integers(4)]
+        method = ["row_col", "row_col", "row_col", "row", "grid"][rng.integers(5)]
+        W = int([1, 2, 3, 4, 5, 5, 5, 6, 7, 9, 10, 12, 13, 16, 25][rng.integers(15)])
+        if method == "grid" and model != "ctc":
+            model, ff = "ctc", False     # (the reference's own order is address-dependent there)
+        tmax = 260 if method == "grid" else 1400
+        n = int(rng.integers(4, 40))
+        style = ["pipeline", "diag", "stairs", "wobble", "bursts"][rng.integers(5)]
+        y1s, y2s, envs = [], [], []
+        for i in range(n):
+            T = int(rng.integers(30, tmax))
+            y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=T, flipflop=ff)
+            if rng.random() < 0.15:
+                y2 = y2[: max(2, (2 * len(y2)) // 3)]
+            U, V = len(y1), len(y2)
+            if style == "pipeline":
+                kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
+                try:
+                    env = np.asarray(O.pair_decode(y1, y2, kind, 5, "row_col")["envelope"])
+                except Exception:
+                    env = np.asarray(O.diagonal_envelope(U, V, 12))
+                if env is None or len(env) != U:
+                    env = np.asarray(O.diagonal_envelope(U, V, 12))
+            elif style == "diag":
+                env = np.asarray(O.diagonal_envelope(U, V, int(rng.integers(3, 30))))
+            else:
+                env = jagged(rng, U, V, style, int(rng.integers(2, 14)))
+            y1s.append(y1); y2s.append(y2); envs.append(env)
+        want = pool.map(_oracle_one, [(a, b, e, W, model, method) for a, b, e in zip(y1s, y2s, envs)])
+        got, st = batch.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method=method, return_status=True)
+        for i, ((ws, wc), g, c) in enumerate(zip(want, got, st.tolist())):
+            ok = (c == wc) and (wc != 0 or g == ws)
+            if wc == 0 and (c == -4 or (c == -6 and method != "row_col")):   # capacity / unsupported-envelope refusals
+                ok = True
+                refused += 1
+            if not ok:
+                bad += 1
+                print("MISMATCH", dict(model=model, method=method, W=W, style=style, U=len(y1s[i]), V=len(y2s[i]),
+                                        status=(c, wc), got=g[:40], want=ws[:40]), flush=True)
+        rounds += 1; pairs += n
+    pool.terminate()
+    print("fuzz: %d rounds, %d pairs, %d mismatches, %d refused by the engine (PO_E_NOMEM / PO_E_UNSUPPORTED) where the "
+          "oracle decodes" % (rounds, pairs, bad, refused))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
