@@ -2185,7 +2185,10 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     g.blocks = b2_num_cus() * per_cu;
     if (max_blocks > 0 && g.blocks > max_blocks) g.blocks = max_blocks;
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
-    g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << (g.wclass == 25 ? 21 : 20));  // value store per workgroup
+    // value store per workgroup: 4 / 8 MB (one / three values per entry); four times that for the widest beam class
+    // and for the pass over the pairs the two-pairs-per-wave path handed back (max_blocks > 0: few workgroups, and
+    // those pairs are the ones with windows hundreds of frames wide, whose live rows grow with the window squared)
+    g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << ((g.wclass == 25 || max_blocks > 0) ? 22 : 20));
     const int64_t WM = W > PO_A ? W : PO_A;
     const int64_t steps = (method == PO_METHOD_ROW) ? mr1 : std::min(mr1, mr2);
     g.arena_cap = ((size_t)(1 + PO_A + (int64_t)PO_A * WM * (steps + 1)) + 1) & ~size_t(1);  // even: a double array follows
@@ -2207,7 +2210,7 @@ struct X2Geom {
     size_t pool_bytes, arena_cap;
     size_t off_queue, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
 };
-constexpr int X2_FB_BLOCKS = 256;  // workgroups of the beam2d_kernel pass over deferred pairs
+constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over deferred pairs (16 / 32 MB of store each)
 bool x2_eligible(int n, int W, int model, int method) {
     const bool legacy = getenv("PO_B2_LEGACY") != nullptr;  // A/B and test switch: always use beam2d_kernel
     (void)model; (void)n;  // all three tree models (the 3-value ones run 2 waves per SIMD)

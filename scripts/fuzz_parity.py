@@ -91,6 +91,8 @@ def main():
             if wc == 0 and (c == -4 or (c == -6 and method != "row_col")):   # capacity / unsupported-envelope refusals
                 ok = True
                 refused += 1
+                print("refused", dict(model=model, method=method, W=W, style=style, U=len(y1s[i]), V=len(y2s[i]), status=c,
+                                      widest_row=int((envs[i][:, 1] - envs[i][:, 0]).max())), flush=True)
             if not ok:
                 bad += 1
                 print("MISMATCH", dict(model=model, method=method, W=W, style=style, U=len(y1s[i]), V=len(y2s[i]),
