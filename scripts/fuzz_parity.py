@@ -41,8 +41,67 @@ def _oracle_one(job):
         return "", e.code
 
 
+def _oracle_pipeline(job):
+    from oracle import po_oracle as O
+    y1, y2, kind, W, method = job
+    try:
+        r = O.pair_decode(y1, y2, kind, W, method)
+        return (r["status"], r["seq1"], r["seq2"], r.get("consensus"), None if r.get("envelope") is None else
+                np.asarray(r["envelope"]).tolist(), r.get("sequence_identity"))
+    except O.OracleError as e:
+        return (e.code, None, None, None, None, None)
+
+
+def pipeline_mode(args, pool):
+    """the whole stage chain (Viterbi x2, banded NW, skips, envelope, pair beam) against the oracle's"""
+    from poreover_amd import batch
+    from poreover_amd.synth import synth_pair
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    rounds = pairs = bad = 0
+    while time.time() < t_end:
+        kind = ["poreover", "poreover", "bonito", "flipflop"][rng.integers(4)]
+        method = ["row_col", "row_col", "row"][rng.integers(3)]
+        W = int([3, 5, 5, 5, 8, 10][rng.integers(6)])
+        n = int(rng.integers(4, 48))
+        y1s, y2s = [], []
+        for i in range(n):
+            y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=int(rng.integers(40, 2500)), flipflop=(kind == "flipflop"))
+            if rng.random() < 0.1:
+                y2 = y2[: max(2, len(y2) // 2)]
+            y1s.append(y1); y2s.append(y2)
+        want = pool.map(_oracle_pipeline, [(a, b, kind, W, method) for a, b in zip(y1s, y2s)])
+        from poreover_amd import _lib
+        try:
+            got = batch.pair_decode_batch(y1s, y2s, kind, W, method)
+        except _lib.EngineError:    # some pair is refused (e.g. the reference's frame-map assertion): one by one
+            got = []
+            for a, b in zip(y1s, y2s):
+                try:
+                    got.append(batch.pair_decode_batch([a], [b], kind, W, method)[0])
+                except _lib.EngineError as e:
+                    got.append({"status": e.code, "seq1": None, "seq2": None})
+        for i, (w, g) in enumerate(zip(want, got)):
+            ok = g["status"] == w[0]
+            if ok and w[1] is not None and g["seq1"] is not None:
+                ok = (g["seq1"], g["seq2"]) == (w[1], w[2])
+            if ok and w[0] == 0:
+                ok = g["consensus"] == w[3] and np.asarray(g["envelope"]).tolist() == w[4] and g["sequence_identity"] == w[5]
+            if g["status"] == -4 and w[0] == 0:
+                ok = True
+            if not ok:
+                bad += 1
+                print("MISMATCH", dict(kind=kind, method=method, W=W, U=len(y1s[i]), V=len(y2s[i]), status=(g["status"], w[0])),
+                      flush=True)
+        rounds += 1; pairs += n
+    pool.terminate()
+    print("fuzz pipeline: %d rounds, %d pairs, %d mismatches" % (rounds, pairs, bad))
+    sys.exit(1 if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--pipeline", action="store_true", help="fuzz pair_decode_batch (the whole stage chain) instead")
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--procs", type=int, default=min(32, os.cpu_count() or 1))
@@ -51,6 +110,8 @@ def main():
     O.build()
     from poreover_amd.synth import synth_pair
     pool = mp.get_context("fork").Pool(args.procs)   # before the GPU runtime is initialised
+    if args.pipeline:
+        return pipeline_mode(args, pool)
     from poreover_amd import batch
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
