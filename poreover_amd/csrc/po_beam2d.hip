@@ -2241,6 +2241,7 @@ int x2_blocks_per_cu(int model, int W) {
         int nblk = 0;
         const void* fn = mi == 0 ? x2_fn<PO_MODEL_CTC>(W) : (mi == 1 ? x2_fn<PO_MODEL_MERGE>(W) : x2_fn<PO_MODEL_FLIPFLOP>(W));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, 64, 0) != hipSuccess || nblk <= 0) nblk = 8;
+        if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_x2_kernel model %d W %d: %d resident workgroups per CU\n", model, W, nblk);
         if (const char* e = getenv("PO_X2_PER_CU")) {  // experiment knob: fewer resident workgroups per CU
             const int v = atoi(e);
             if (v > 0 && v < nblk) nblk = v;
