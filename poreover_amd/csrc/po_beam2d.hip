@@ -2212,13 +2212,19 @@ struct X2Geom {
 };
 constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over deferred pairs (16 / 32 MB of store each)
 bool x2_eligible(int n, int W, int model, int method) {
-    const bool legacy = getenv("PO_B2_LEGACY") != nullptr;  // A/B and test switch: always use beam2d_kernel
-    (void)model; (void)n;  // all three tree models (the 3-value ones run 2 waves per SIMD)
-    if (legacy || method != PO_METHOD_ROW_COL) return false;
-    // W <= 6: two pairs per wave.  7 <= W <= 12: one pair per wave with the reads one after the other — since the
-    // incremental steps it beats beam2d_kernel's two waves per pair at every batch size (W = 10: 6.5k vs 3.5k pairs/s
-    // at 256 pairs, 22.9k vs 12.7k at 1024, 36.6k vs 19.6k at 3328, 55k at 13k).
-    return W <= 12;
+    // PO_B2_LEGACY: always beam2d_kernel; PO_X2_FORCE: beam2d_x2_kernel whenever it can run (A/B and test switches)
+    if (getenv("PO_B2_LEGACY") != nullptr || method != PO_METHOD_ROW_COL || W > 12) return false;
+    if (getenv("PO_X2_FORCE") != nullptr) return true;
+    // 7 <= W <= 12: one pair per wave with the reads one after the other — since the incremental steps it beats
+    // beam2d_kernel's two waves per pair at every batch size (W = 10: 6.5k vs 3.5k pairs/s at 256 pairs, 22.9k vs
+    // 12.7k at 1024, 36.6k vs 19.6k at 3328, 55k at 13k; Bonito W = 10: 29.2k vs 24.5k at 10k).
+    if (W > 6) return true;
+    // W <= 6: two pairs per wave is the THROUGHPUT form — a pair takes longer than on a wave of its own (47 vs 31 ms
+    // for a T = 4000 pair), so it pays once the batch exceeds the pairs beam2d_kernel keeps in flight (ctc, W = 5:
+    // 37.3k vs 50.4k pairs/s at 2048 pairs, 50.0k vs 40.5k at 3072, 65.1k vs 51.6k at 4096, 78k vs 60k at 10 000).
+    // The three-value models run it at 2 waves per SIMD and are better off with beam2d_kernel at every size
+    // measured (Bonito W = 5: 7.0k vs 11.8k at 512, 24.2k vs 37.8k at 2048, 39.0k vs 41.7k at 10 000).
+    return model == PO_MODEL_CTC && n > 10 * b2_num_cus();
 }
 void (*g_b2_mark_fwd)(int begin, hipStream_t stream) = nullptr;   // set through po_b2_set_mark
 template <int MODEL>

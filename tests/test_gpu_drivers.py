@@ -9,6 +9,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["default", "x2"])
+def kernel_route(request, monkeypatch):
+    """every test runs twice: with the engine's own choice between beam2d_kernel and beam2d_x2_kernel (small batches
+    of W <= 6 go to the former) and with the two-pairs-per-wave kernel forced wherever it can run (PO_X2_FORCE)"""
+    if request.param == "x2":
+        monkeypatch.setenv("PO_X2_FORCE", "1")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def eng():
     from poreover_amd import _lib
