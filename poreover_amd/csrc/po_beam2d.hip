@@ -756,10 +756,16 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
 
         if (!is_row) {
             // ============================================================ row_col: the diagonal walk
+            // u and v advance by at most one per round: the bounds of row u + 1 and column v + 1 are requested a round
+            // ahead (a round otherwise starts with a dependent global round trip, and most catch-up rounds are no-ops)
             int u = 0, v = 0;
+            const int2* env2 = (const int2*)env;
+            const int2* envt2 = (const int2*)envt;
+            int2 er_c = env2[0], ec_c = envt2[0], er_n = er_c, ec_n = ec_c;
             while (u <= U - 1 && v <= V - 1) {
-                const int ers = env[2 * u], ere = env[2 * u + 1];
-                const int ecs = envt[2 * v], ece = envt[2 * v + 1];
+                er_n = env2[min(u + 1, U - 1)]; ec_n = envt2[min(v + 1, V - 1)];
+                const int ers = er_c.x, ere = er_c.y;
+                const int ecs = ec_c.x, ece = ec_c.y;
                 const bool row_ok = (v >= ers && v < ere);
                 const bool col_ok = (u >= ecs && u < ece);
                 const bool cu_v = (!row_ok && v < ers);                 // catch-up on read 1 (:314-322)
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                         po_lds_barrier();
                     }
                     TKC(11);
-                    if (cu_v) v++; else u++;
+                    if (cu_v) { v++; ec_c = ec_n; } else { u++; er_c = er_n; }
                     continue;
                 }
                 if (!row_ok || !col_ok) { st = PO_E_ENVELOPE; break; }  // uninitialised bounds upstream (:309)
@@ -799,11 +805,15 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 TK(1);
                 u++;
                 v++;
+                er_c = er_n; ec_c = ec_n;
             }
         } else {
             // ============================================================ row: every row of read 0
+            int2 rb_n = env ? ((const int2*)env)[0] : make_int2(0, V);   // (the next row's band is requested a row ahead)
             for (int u = env ? 0 : 1; u < U; ++u) {
-                const int rs = env ? env[2 * u] : 0, re = env ? env[2 * u + 1] : V;
+                const int2 rb = rb_n;
+                if (env) rb_n = ((const int2*)env)[min(u + 1, U - 1)];
+                const int rs = rb.x, re = rb.y;
                 const int wlen = max(0, re - rs);
                 int ne, nproc;
                 const bool regular = (nb == W);
