@@ -210,22 +210,40 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
         int R = 32, NG = 0;
         if (st == PO_OK) {
             int bad = 0, wmax = env ? 0 : V;
-            int unsup = 0;
+            int unsup = 0, nonmono = 0;
             if (env)
                 for (int u = tid; u < U; u += nthr) {
                     const int lo = env[2 * u], hi = env[2 * u + 1];
                     if (lo < hi && (lo < 0 || hi > V)) bad = 1;
+                    if (lo < 0 || hi > V || (u > 0 && (lo < env[2 * u - 2] || hi < env[2 * u - 1]))) nonmono = 1;
                     // row method: a later row reads time rs-1, so row starts must not move backwards
                     // for the ring store to still hold it (every envelope the pipeline builds complies)
                     if (is_row && u > 0 && lo < env[2 * u - 2]) unsup = 1;
                     wmax = max(wmax, hi - lo);
                 }
+            const bool mono = !__syncthreads_or(nonmono);   // row bounds never move backwards (what build_envelope makes)
             if (!is_row)
-                for (int x = tid; x < V; x += nthr) { envt[2 * x] = -1; envt[2 * x + 1] = -1; }
+                for (int x = tid; x < V; x += nthr) { envt[2 * x] = mono ? 0x7fffffff : -1; envt[2 * x + 1] = -1; }
             if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
             if (__syncthreads_or(unsup) && st == PO_OK) st = PO_E_UNSUPPORTED;
             if (st == PO_OK) {
-                if (!is_row) {
+                if (!is_row && mono) {
+                    // the rows covering column x are then the contiguous range [a(x), b(x)]: row u is a(x) for the columns
+                    // between the previous row's end and its own, and b(x) for those between its start and the next
+                    // row's — every column is written once (as in beam2d_prepass_kernel)
+                    for (int u = tid; u < U; u += nthr) {
+                        const int lo = env[2 * u], hi = env[2 * u + 1];
+                        const int hp = (u > 0) ? env[2 * u - 1] : 0, ln = (u + 1 < U) ? env[2 * u + 2] : V;
+                        for (int x = hp; x < hi; ++x) envt[2 * x] = u;
+                        for (int x = lo; x < ln; ++x) envt[2 * x + 1] = u;
+                    }
+                    __syncthreads();
+                    for (int x = tid; x < V; x += nthr) {
+                        const int a_ = envt[2 * x], b_ = envt[2 * x + 1];
+                        if (a_ != 0x7fffffff && b_ >= a_) { envt[2 * x + 1] = b_ + 1; wmax = max(wmax, b_ + 1 - a_); }
+                        else { envt[2 * x] = -1; envt[2 * x + 1] = -1; }
+                    }
+                } else if (!is_row) {
                     // each column x is always visited by thread x % nthr, rows in order: race-free
                     for (int u = 0; u < U; ++u) {
                         const int lo = env[2 * u], hi = env[2 * u + 1];
@@ -262,17 +280,32 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
 
         // blank prefix sums of both reads = the CTC root's alpha (PrefixTree.h:509-515); serial in t so
         // the rounding is the reference's
-        if (MODEL == PO_MODEL_CTC && s == 0) {
-            double* cw = r ? cum1 : cum0;
-            const int Tn = r ? V : U;
-            double acc = 0.0;
-            for (int t0 = 0; t0 < Tn; t0 += 8) {
-                double b[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) b[q] = (t0 + q < Tn) ? yr_[(int64_t)(t0 + q) * C + A] : 0.0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (t0 + q < Tn) { acc += b[q]; cw[t0 + q] = acc; }
+        // (the first 32 / 64 threads of each read load that many frames at a time, coalesced, and add them in lane
+        // order through v_readlane — one wave holds both reads when a read has 32 threads)
+        {
+            constexpr int SL = (NCP < 64) ? NCP : 64;
+            const int Tn = r ? V : U, Tw = (NCP < 64) ? max(U, V) : Tn;   // (wave-uniform trip count)
+            if (MODEL == PO_MODEL_CTC && s < SL) {
+                double* cw = r ? cum1 : cum0;
+                double acc = 0.0;
+                for (int t0 = 0; t0 < Tw; t0 += SL) {
+                    const int t = t0 + s;
+                    const double x = (t < Tn) ? yr_[(int64_t)t * C + A] : 0.0;
+                    double mine = 0.0;
+#pragma unroll 4
+                    for (int j = 0; j < SL; ++j) {   // (not unrolled further: the beam-width classes are register-tight)
+                        double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), j),
+                                                     __builtin_amdgcn_readlane(__double2loint(x), j));
+                        if (NCP < 64) {   // lanes 32.. of the wave belong to read 1
+                            const double xb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), (j + 32) & 63),
+                                                               __builtin_amdgcn_readlane(__double2loint(x), (j + 32) & 63));
+                            xj = r ? xb : xj;
+                        }
+                        if (t0 + j < Tn) acc += xj;
+                        if (s == j) mine = acc;
+                    }
+                    if (t < Tn) cw[t] = mine;
+                }
             }
         }
         for (int g = tid; g < SM::NGL; g += nthr) { sm.g_owner[g] = -1; sm.g_hi0[g] = 0; sm.g_hi1[g] = 0; }
