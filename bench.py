@@ -30,6 +30,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MAIN_KERNEL = "beam2d_kernel<0, 6>"  # the pair beam search kernel this workload runs on (row_col, ctc, W = 5)
 
 
 def _cpu_pair_worker(args):
@@ -232,7 +233,7 @@ def main():
             pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_v12.json")
             with open(pj) as f:
                 pm = json.load(f)
-            kk = [v for k, v in pm["kernels"].items() if k.startswith("beam2d_x2_kernel")][0]
+            kk = [v for k, v in pm["kernels"].items() if k.startswith(MAIN_KERNEL)][0]
             per_pair = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0 / 1250.0
             if T == 4000 and args.beam_width == 5:
                 traffic = per_pair * P
@@ -253,7 +254,7 @@ def main():
                                    "HBM" % (P, T, args.beam_width),
                        "pairs_per_gpu": P, "T": T, "beam_width": args.beam_width, "method": "row_col",
                        "decoded_pairs_rank0": decoded, "parallelism": "shard%d (no collective)" % args.gpus},
-            "roofline": {"bound": "hbm", "kernel": "beam2d_x2_kernel", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": MAIN_KERNEL, "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bk_avg, 3),
                          "launches": bk_n, "stage_ms": round(b2_avg, 3),

@@ -49,6 +49,16 @@
 namespace {
 
 constexpr int B2_YD = 256;   // doubles per read in the y window buffer (51 rows of 5, 32 rows of 8)
+// The W <= 6 class (64 threads per pair) runs at 124 VGPRs, i.e. 4 waves per SIMD — if its LDS lets 16 workgroups
+// share a CU.  The chains of dependent f64 operations in logaddexp leave a wave idle most of the time, so resident
+// waves are what buys throughput here: 96 doubles of y rows per read (19 rows of 5) and 112 row groups bring the
+// workgroup to 10 096 B (16 per CU) and the kernel from 65k to 85k pairs/s at 10 000 pairs.
+#ifndef B2_YD6
+#define B2_YD6 96
+#endif
+#ifndef B2_NGL6
+#define B2_NGL6 112
+#endif
 
 template <int K>
 struct alignas(K == 1 ? 16 : 32) Entry {
@@ -121,7 +131,7 @@ struct B2Smem {
     int badf[NCM];          // element may not skip redundant stores (see scan)
     int dup[NCM];
     // row groups tracked per pair: a step can open up to W new ones and a group lives for about a window
-    static constexpr int NGL = (WMAX > 12) ? 768 : 256;
+    static constexpr int NGL = (WMAX > 12) ? 768 : ((WMAX <= 6) ? B2_NGL6 : 256);
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[16];
     double score[NCM];
@@ -130,8 +140,10 @@ struct B2Smem {
     double cmx[2][NCP];
     int cmt[2][NCP];
     double xch[2][2][NCP][K];
-    double ybuf[2][B2_YD];  // the y rows of the current step's windows, per read
-    unsigned long long nupd;  // profiling: update_prob evaluations of the current pair
+    static constexpr int YD = (WMAX <= 6) ? B2_YD6 : B2_YD;
+    double ybuf[2][YD];     // the y rows of the current step's windows, per read
+    unsigned long long nupd;    // profiling: update_prob evaluations the reference's schedule makes for the current pair
+    unsigned long long nupd_x;  // ... and those this kernel executed (incremental steps, no-op catch-ups)
     PoLaeTables lae;        // tables of the specialised logaddexp (po_device.h)
 };
 
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             if (r == 1) amax[1 + s] = out[0];
         }
         int nb = A;  // beam size
-        if (tid == 0) sm.nupd = 0;  // update_prob evaluations of this pair (profiling only; kept in LDS)
+        if (tid == 0) { sm.nupd = 0; sm.nupd_x = 0; }  // update_prob evaluations of this pair (profiling only; kept in LDS)
         __syncthreads();
         TK(0);  // pre-pass + init
 
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             // iteration index).  With no vector-memory LOAD left in the iteration loop the wave never
             // waits there for the acknowledgement of its value-store writes: vmcnt counts loads and stores
             // in order, so waiting for any load also waits for every store issued before it.
-            const int yrows = B2_YD / C;
+            const int yrows = SM::YD / C;
             for (int k0 = 0; k0 < Lmax; k0 += yrows) {
             {
                 const int nrow = min(len, k0 + yrows) - k0;  // this read's rows in the chunk (<= 0: none)
@@ -574,7 +586,10 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             if (s < nelem) sm.mxs[r][s] = mx;
             if (is_main && partf) { sm.cmx[r][s] = mx; sm.cmt[r][s] = mt; }
             if (is_main && tid == 0) { if (len0_ > 0) sm.sh[12] = 1; if (len1_ > 0) sm.sh[13] = 1; }
-            if (tid == 0) sm.nupd += (unsigned)(nelem * (len0 + len1));  // profiling (skipped slots counted too)
+            if (tid == 0) {   // profiling (skipped slots counted too)
+                sm.nupd += (unsigned)(nelem * (len0_ + len1_));
+                sm.nupd_x += (unsigned)(nelem * (len0 + len1));
+            }
         };
 
         // parent slot of beam slot j: the parent is an element if it is a beam node or a child of a
@@ -821,6 +836,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                         po_lds_barrier();
                     }
                     TKC(11);
+                    if (!need && tid == 0) sm.nupd += (unsigned)nbe;   // (a catch-up the reference computes and this kernel need not)
                     if (cu_v) { v++; ec_c = ec_n; } else { u++; er_c = er_n; }
                     continue;
                 }
@@ -901,7 +917,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             a.seq_len[pi] = nout;
             a.status[pi] = st;
         }
-        if (a.upd_count && tid == 0) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd); }
+        if (a.upd_count && tid == 0) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
         TK(10);  // label walk
     }
 #ifdef PO_B2_TIMING
@@ -2262,12 +2278,11 @@ bool x2_eligible(int n, int W, int model, int method) {
     // beam2d_kernel's two waves per pair at every batch size (W = 10: 6.5k vs 3.5k pairs/s at 256 pairs, 22.9k vs
     // 12.7k at 1024, 36.6k vs 19.6k at 3328, 55k at 13k; Bonito W = 10: 29.2k vs 24.5k at 10k).
     if (W > 6) return true;
-    // W <= 6: two pairs per wave is the THROUGHPUT form — a pair takes longer than on a wave of its own (47 vs 31 ms
-    // for a T = 4000 pair), so it pays once the batch exceeds the pairs beam2d_kernel keeps in flight (ctc, W = 5:
-    // 37.3k vs 50.4k pairs/s at 2048 pairs, 50.0k vs 40.5k at 3072, 65.1k vs 51.6k at 4096, 78k vs 60k at 10 000).
-    // The three-value models run it at 2 waves per SIMD and are better off with beam2d_kernel at every size
-    // measured (Bonito W = 5: 7.0k vs 11.8k at 512, 24.2k vs 37.8k at 2048, 39.0k vs 41.7k at 10 000).
-    return model == PO_MODEL_CTC && n > 10 * b2_num_cus();
+    // W <= 6: beam2d_kernel (one wave per pair, 16 resident per CU) is both the lower-latency and — since it fits 4
+    // waves per SIMD — the higher-throughput form: ctc W = 5 84.8k vs 78.9k pairs/s at 10 000 pairs, 83.8k vs 65.1k at
+    // 4096, 89.7k vs 81.6k at 16 384; Bonito 54.7k vs 39.0k.  The two-pairs-per-wave kernel (168 VGPRs: 3 waves per
+    // SIMD) stays reachable through PO_X2_FORCE and serves 7 <= W <= 12.
+    return false;
 }
 void (*g_b2_mark_fwd)(int begin, hipStream_t stream) = nullptr;   // set through po_b2_set_mark
 template <int MODEL>
