@@ -88,6 +88,7 @@ struct B2Args {
     long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
     const int2* only_meta;             // non-NULL: decode only the pairs the two-pairs-per-wave path deferred (meta.y == -2)
     int* cellb;                        // grid method: two rows of per-cell beams per workgroup (2 * vcap * (1 + 6 W) ints)
+    int retry_nomem;                   // second pass with a larger store: decode only the pairs the first one gave PO_E_NOMEM
     unsigned long long* upd_count;     // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
 };
 
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
         epoch++;
         TK_START();
         if (a.only_meta && a.only_meta[pi].y != X2_DEFERRED) continue;  // done by beam2d_x2_kernel
+        if (a.retry_nomem) {
+            if (a.status[pi] != PO_E_NOMEM) continue;                  // decoded (or refused for good) by the first pass
+        } else
         if (a.use_pre_status && a.status[pi] != PO_OK) {  // skipped upstream (pair_decode.py:372-375,395-398)
             if (tid == 0) a.seq_len[pi] = 0;
             continue;
@@ -2239,6 +2243,9 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     B2Geom g;
     const int K = (model == PO_MODEL_CTC) ? 1 : 3;
     g.wclass = W <= 6 ? 6 : (W <= 12 ? 12 : 25);
+    // the small passes (pairs handed back by the x2 kernel, retries after PO_E_NOMEM) run the W <= 6 class on the
+    // W <= 12 kernel (256 instead of 112 row groups) and the W <= 12 class on the W <= 25 kernel (768)
+    if (max_blocks > 0 && g.wclass < 25) g.wclass = (g.wclass == 6) ? 12 : 25;
     g.threads = g.wclass == 6 ? 64 : (g.wclass == 12 ? 128 : 256);
     const int per_cu = b2_blocks_per_cu(model, g.wclass);
     g.blocks = b2_num_cus() * per_cu;
@@ -2247,7 +2254,9 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     // value store per workgroup: 4 / 8 MB (one / three values per entry); four times that for the widest beam class
     // and for the pass over the pairs the two-pairs-per-wave path handed back (max_blocks > 0: few workgroups, and
     // those pairs are the ones with windows hundreds of frames wide, whose live rows grow with the window squared)
-    g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << ((g.wclass == 25 || max_blocks > 0) ? 22 : 20));
+    // (the W <= 6 class, with 16 workgroups per CU, gets half of that on its direct path: its 112 row groups fit
+    // windows up to 126 frames in it, and a pair that runs out is decoded again by the retry pass below)
+    g.pool_bytes = al256((K == 1 ? (size_t)4 : (size_t)8) << ((g.wclass == 25 || max_blocks > 0) ? 22 : (g.wclass == 6 ? 19 : 20)));
     const int64_t WM = W > PO_A ? W : PO_A;
     const int64_t steps = (method == PO_METHOD_ROW) ? mr1 : std::min(mr1, mr2);
     g.arena_cap = ((size_t)(1 + PO_A + (int64_t)PO_A * WM * (steps + 1)) + 1) & ~size_t(1);  // even: a double array follows
@@ -2401,7 +2410,7 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
     if (method == PO_METHOD_GRID) return grid_geometry(n, mr1, mr2, W, model, true).total;
     if (method == PO_METHOD_GRID_NOENV) return grid_geometry(n, mr1, mr2, W, model, false).total;
     if (x2_eligible(n, W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
-    return b2_geometry(n, mr1, mr2, W, model, method).total;
+    return b2_geometry(n, mr1, mr2, W, model, method).total + b2_geometry(n, mr1, mr2, W, model, method, X2_FB_BLOCKS).total;
 }
 
 namespace {
@@ -2449,9 +2458,15 @@ namespace {
 int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off, const int32_t* env,
                      int n, int C, int A, uint32_t alphabet, int W, int model, int method, int64_t mr1, int64_t mr2,
                      char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status, int use_pre_status, void* ws,
-                     size_t ws_bytes, hipStream_t stream, int max_blocks, const int2* only_meta) {
+                     size_t ws_bytes, hipStream_t stream, int max_blocks, const int2* only_meta, int retry = 0) {
     const B2Geom g = b2_geometry(n, mr1, mr2, W, model, method, max_blocks);
     if (ws_bytes < g.total) return PO_E_CAP;
+    // direct path: a second, small pass (64 workgroups, four times the store) decodes the pairs whose live rows did
+    // not fit the first one's store — windows hundreds of frames wide; an empty pass costs its 1 GB memset
+    if (max_blocks == 0 && !retry) {
+        const size_t rb = b2_geometry(n, mr1, mr2, W, model, method, X2_FB_BLOCKS).total;
+        if (ws_bytes < g.total + rb) return PO_E_CAP;
+    }
     char* w = (char*)ws;
     B2Args a;
     a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
@@ -2466,6 +2481,7 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     a.dbg = nullptr;
     a.only_meta = only_meta;
     a.cellb = nullptr;
+    a.retry_nomem = retry;
     a.upd_count = g_b2_upd_counter;
 #ifdef PO_B2_TIMING
     static long long* dbg_buf = nullptr;
@@ -2475,12 +2491,12 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     // queue counter and the store's tags start from zero on every launch
     if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
     if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
-    if (g_b2_mark && !only_meta) g_b2_mark(1, stream);
+    if (g_b2_mark && !only_meta && !retry) g_b2_mark(1, stream);
     if (model == PO_MODEL_CTC) b2_launch_w<PO_MODEL_CTC>(g, a, stream);
     else if (model == PO_MODEL_MERGE) b2_launch_w<PO_MODEL_MERGE>(g, a, stream);
     else if (model == PO_MODEL_FLIPFLOP) b2_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
     else return PO_E_ARG;
-    if (g_b2_mark && !only_meta) g_b2_mark(0, stream);
+    if (g_b2_mark && !only_meta && !retry) g_b2_mark(0, stream);
 #ifdef PO_B2_TIMING
     {
         long long h[12];
@@ -2493,6 +2509,9 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
         for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-24s %12lld\n", nm[i], h[i]);
     }
 #endif
+    if (max_blocks == 0 && !retry)
+        return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off, seq_len,
+                                status, use_pre_status, (char*)ws + g.total, ws_bytes - g.total, stream, X2_FB_BLOCKS, nullptr, 1);
     return PO_OK;
 }
 }  // namespace
@@ -2523,6 +2542,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.cum = (double*)(w + g.off_cum); a.tcap = (long long)g.tcap;
         a.envt = nullptr; a.vcap = (long long)g.vcap;
         a.cellb = (int*)(w + g.off_cell);
+        a.retry_nomem = 0;
         a.dbg = nullptr; a.only_meta = nullptr;
         a.upd_count = g_b2_upd_counter;
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
