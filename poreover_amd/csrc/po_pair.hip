@@ -160,7 +160,10 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         if (a.mode == 0 && a.st1[pi] != PO_OK) st = a.st1[pi];
         else if (a.mode == 0 && a.st2[pi] != PO_OK) st = a.st2[pi];
         else if (a.mode == 0 && abs(l1 - l2) > 1000) st = PO_SKIP_LENGTH;   // pair_decode.py:372-375
-        else if (a.mode != 1 && (l1 < 1 || l2 < 1)) st = PO_E_ARG;           // empty basecall: IndexError upstream
+        // an empty basecall: global_pair_banded aligns it to gaps only, identity 0.0 -> the pair is skipped like any
+        // other of low identity (pair_decode.py:395-398); two empty ones divide 0 by 0 upstream
+        else if (a.mode == 0 && (l1 < 1) != (l2 < 1)) st = PO_SKIP_IDENTITY;
+        else if (a.mode != 1 && (l1 < 1 || l2 < 1)) st = PO_E_ARG;
         const bool full = a.full_alignment != 0;
         const int nrows = full ? l1 + 1 : l1;
         if (st == PO_OK && a.mode != 2 && (nrows > a.row_cap || (long long)l1 + l2 + 8 > a.aln_cap)) st = PO_E_CAP;

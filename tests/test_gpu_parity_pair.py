@@ -99,6 +99,16 @@ def test_pipeline_full_alignment_and_skips(eng, oracle):
     want = oracle.pair_decode(long_, a)
     assert want["status"] == oracle.SKIP_LENGTH and got["status"] == want["status"]
     assert (got["length1"], got["length2"]) == (want["length1"], want["length2"])
+    # an empty basecall (a read of blanks only, in either position): the reference aligns it to gaps, identity 0.0,
+    # and skips the pair like any other of low identity (found by scripts/fuzz_parity.py --pipeline)
+    e1, e2 = synth_pair(947200141, T=58)
+    e2 = e2[: max(2, len(e2) // 2)]
+    assert oracle.viterbi_decode(e2)[0] == "" and oracle.viterbi_decode(e1)[0] != ""
+    for p, q in ((e1, e2), (e2, e1)):
+        got = eng.pair_decode_batch([p], [q])[0]
+        want = oracle.pair_decode(p, q)
+        assert want["status"] == oracle.SKIP_IDENTITY and got["status"] == want["status"]
+        assert got["sequence_identity"] == 0.0 and (got["length1"], got["length2"]) == (want["length1"], want["length2"])
 
 
 def test_pipeline_full_size(eng, oracle):
