@@ -99,8 +99,57 @@ def pipeline_mode(args, pool):
     sys.exit(1 if bad else 0)
 
 
+def _oracle_oned(job):
+    from oracle import po_oracle as O
+    y, kind, model, W = job
+    seq, path = O.viterbi_decode(y, kind)
+    beam = O.cpp_beam_search(y, W, model_=model)
+    lab = beam[: max(1, min(len(beam), 60))] if beam else "A"
+    fwd = O.cpp_forward(y, lab, model_=model)
+    acc = O.cpp_viterbi_acceptor(y, seq, 1000).tolist() if (kind == "poreover" and seq) else None
+    return seq, [int(x) for x in path], beam, lab, fwd, acc
+
+
+def oned_mode(args, pool):
+    """the 1-D entry points: Viterbi (three kinds), CTC beam search (three models), forward, Viterbi acceptor"""
+    from poreover_amd import batch
+    from poreover_amd.synth import synth_pair
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    rounds = reads = bad = 0
+    while time.time() < t_end:
+        kind, model, ff = [("poreover", "ctc", False), ("bonito", "ctc_merge_repeats", False),
+                           ("flipflop", "ctc_flipflop", True)][rng.integers(3)]
+        W = int([1, 2, 3, 5, 8, 10, 16, 25, 40][rng.integers(9)])
+        n = int(rng.integers(4, 40))
+        ys = []
+        for i in range(n):
+            T = int(rng.integers(1, 40)) if rng.random() < 0.15 else int(rng.integers(40, 3000))
+            y1, _ = synth_pair(int(rng.integers(1 << 30)), T=max(T, 12), flipflop=ff)
+            ys.append(y1[:T])
+        want = pool.map(_oracle_oned, [(y, kind, model, W) for y in ys])
+        seqs, paths = batch.viterbi_batch(ys, kind, return_path=True)
+        beams = batch.beam_search_batch(ys, W, model=model)
+        fwd = batch.forward_batch(ys, [w[3] for w in want], model=model)
+        for i, w in enumerate(want):
+            ok = seqs[i] == w[0] and [int(x) for x in paths[i]] == w[1] and beams[i] == w[2]
+            f, g = w[4], float(fwd[i])
+            ok = ok and ((f == g) or (np.isfinite(f) and abs(f - g) <= 1e-12 * max(1.0, abs(f))) or (np.isinf(f) and np.isinf(g)))
+            if ok and w[5] is not None:
+                ok = batch.viterbi_acceptor_batch([ys[i]], [w[0]], 1000)[0].tolist() == w[5]
+            if not ok:
+                bad += 1
+                print("MISMATCH", dict(kind=kind, model=model, W=W, T=len(ys[i]), seq=(seqs[i][:20], w[0][:20]),
+                                        beam=(beams[i][:20], w[2][:20]), fwd=(g, f)), flush=True)
+        rounds += 1; reads += n
+    pool.terminate()
+    print("fuzz 1-D: %d rounds, %d reads, %d mismatches" % (rounds, reads, bad))
+    sys.exit(1 if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--oned", action="store_true", help="fuzz the 1-D entry points (Viterbi, beam search, forward, acceptor)")
     ap.add_argument("--pipeline", action="store_true", help="fuzz pair_decode_batch (the whole stage chain) instead")
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
@@ -112,6 +161,8 @@ def main():
     pool = mp.get_context("fork").Pool(args.procs)   # before the GPU runtime is initialised
     if args.pipeline:
         return pipeline_mode(args, pool)
+    if args.oned:
+        return oned_mode(args, pool)
     from poreover_amd import batch
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
