@@ -154,9 +154,10 @@ struct B2Smem {
 #define B2_THREADS(WM) ((WM) * (PO_A + 1) <= 32 ? 64 : ((WM) * (PO_A + 1) <= 64 ? 128 : 256))
 
 template <int MODEL, int WMAX>
-// (4 waves per SIMD are what the W <= 6 class lives on — see B2_YD6: the bound keeps an innocent edit from costing a quarter
-// of its throughput; 124 / 128 VGPRs today, so it changes nothing)
-__global__ __launch_bounds__(B2_THREADS(WMAX), (((MODEL == PO_MODEL_CTC && WMAX == 12) || (MODEL != PO_MODEL_FLIPFLOP && WMAX == 6)) ? 4 : 1)) void beam2d_kernel(B2Args a) {
+// (4 waves per SIMD are what the W <= 6 class lives on — see B2_YD6.  It compiles to 124 / 128 VGPRs (ctc / merge
+// repeats); an edit that costs four more registers costs a quarter of the throughput — check with
+// -Rpass-analysis=kernel-resource-usage.  Forcing the bound here makes the allocator's choices 2 % worse today.)
+__global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX == 12) ? 4 : 1)) void beam2d_kernel(B2Args a) {
     using SM = B2Smem<MODEL, WMAX>;
     constexpr int K = SM::K, NCM = SM::NCM, NCP = SM::NCP, nthr = 2 * NCP;
     using Ent = Entry<K>;
