@@ -405,7 +405,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             sm.sh[3] = 1;      // group allocation cursor
             sm.sh[4] = PO_OK;
             sm.sh[8] = INT_MIN; sm.sh[9] = INT_MIN;  // window ends of the previous row_col main step: none yet
-            sm.sh[10] = 0; sm.sh[11] = 0; sm.sh[12] = 0; sm.sh[13] = 0;  // incremental steps: nothing to build on yet
+            sm.sh[10] = 0; sm.sh[11] = 0; sm.sh[12] = 0; sm.sh[13] = 0; sm.sh[14] = 0;  // incremental steps: nothing to build on yet
         }
         if (tid < WMAX) sm.stay[tid] = 0;
         if (tid < A) {
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
         // the same node pushed twice (std::unique).
         auto prune_and_advance = [&](int ne, bool regular) {
             // (the duplicate flags only depend on the node ids: unchanged while the table is — see "steady" in scan)
-            const bool dup_valid = regular && sm.sh[10] != 0 && sm.sh[11] != 0;
+            const bool dup_valid = regular && sm.sh[14] != 0 && sm.sh[11] != 0;
             if (tid < ne && !dup_valid) {
                 int d = 0;
                 const int x = sm.e[F_ID][tid];
@@ -765,11 +765,11 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             }
             if (same_beam) {
                 if (tid < nb) sm.stay[tid] = 1;
-                if (tid == 0) sm.sh[10] = 1;
+                if (tid == 0) { sm.sh[10] = 1; sm.sh[14] = 1; }
                 po_lds_barrier();
                 return;
             }
-            if (tid == 0) { sm.sh[10] = 0; sm.sh[12] = 0; sm.sh[13] = 0; }
+            if (tid == 0) sm.sh[14] = 0;
             if (tid < ne && !sm.dup[tid]) {
                 const double sc = sm.score[tid];
                 const int id = sm.e[F_ID][tid];
@@ -783,6 +783,26 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             po_lds_barrier();
             const int nbn = min(W, sm.sh[5]);
             if (tid < nbn) sm.stay[tid] = (regular && sm.sel[tid] < nb) ? 1 : 0;
+            {
+                // The same beam nodes in another order: every element of the next step was an element of this one, in
+                // the slot the permutation says (beam slot i <- sel[i]; its children follow it), so the carried maxima
+                // move along and the next step can still be incremental.  Anything else ends the run.
+                const bool perm = regular && nbn == nb && !__syncthreads_or(tid < nbn && sm.sel[tid] >= nb);
+                double c0 = 0.0, c1 = 0.0;
+                int t0_ = 0, t1_ = 0;
+                if (perm && tid < ne) {
+                    int src = tid;
+                    if (tid < nb) src = sm.sel[tid];
+                    else { const int j = ((tid - nb) * divA) >> 16; src = nb + A * sm.sel[j] + ((tid - nb) - j * A); }
+                    c0 = sm.cmx[0][src]; c1 = sm.cmx[1][src]; t0_ = sm.cmt[0][src]; t1_ = sm.cmt[1][src];
+                }
+                po_lds_barrier();
+                if (perm && tid < ne) { sm.cmx[0][tid] = c0; sm.cmx[1][tid] = c1; sm.cmt[0][tid] = t0_; sm.cmt[1][tid] = t1_; }
+                if (tid == 0) {
+                    if (perm) sm.sh[10] = 1;
+                    else { sm.sh[10] = 0; sm.sh[12] = 0; sm.sh[13] = 0; }
+                }
+            }
             if (tid < nbn) {
                 const int e = sm.sel[tid];
                 if (e < nb) {
