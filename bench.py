@@ -226,18 +226,18 @@ def main():
         vt_bytes = 8.0 * Cc * (tr1 + tr2) + 5.0 * n1d  # log-probs in; per base one character + one int32 frame index out
         vt_avg = vt_ms / max(vt_n, 1)
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
-        # committed rocprofv3 passes (profiles/r01_pmc_hbm_v14.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # committed rocprofv3 passes (profiles/r01_pmc_hbm_v15.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # 1250 pairs per launch, same T / W) are scaled to this launch's pair count
         traffic, traffic_src = None, None
         try:
-            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_v14.json")
+            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_v15.json")
             with open(pj) as f:
                 pm = json.load(f)
             kk = [v for k, v in pm["kernels"].items() if k.startswith(MAIN_KERNEL)][0]
             per_pair = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0 / 1250.0
             if T == 4000 and args.beam_width == 5:
                 traffic = per_pair * P
-                traffic_src = "profiles/r01_pmc_hbm_v14.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes at 1250 pairs per launch), scaled by pairs"
+                traffic_src = "profiles/r01_pmc_hbm_v15.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes at 1250 pairs per launch), scaled by pairs"
         except Exception:
             pass
         out = {
