@@ -282,6 +282,46 @@ def pair_decode(y1_, y2_, kind="poreover", beam_width=5, method="row_col", paddi
             "sequence_identity": sm.identity, "skipped": sm.skipped, "status": 0 if rc >= 0 else rc}
 
 
+# ----------------------------------------------------------------------------- trace ingest (numpy)
+def load_logits(arr, flatten=True):
+    """decode.load_logits on an array instead of a file (decode.py:34-51): rows that already sum to 1 are
+    probabilities -> log; otherwise (B, W, C) logits -> x - logsumexp(x, axis=2) in the array's own precision
+    (float32 for `poreover call` output).  logsumexp is a third-party function the reference does not pin
+    (requirements.txt names scipy without a version); the parity target is the reference run in this image, i.e.
+    scipy 1.15.3, whose published algorithm (scipy/special/_logsumexp.py::_logsumexp) is restated here: the
+    maximal elements are taken out of the sum (m = how many there are), s = sum(exp(x - max)) over the others,
+    result = log1p(s / m) + log(m) + max."""
+    a = np.asarray(arr)
+    if np.isclose(np.sum(a[0]), 1):
+        out = np.log(a)
+    else:
+        a_max = np.max(a, axis=2, keepdims=True)
+        is_max = (a == a_max)
+        m = np.sum(is_max.astype(a.dtype), axis=2, keepdims=True, dtype=a.dtype)
+        shift = np.where(np.isfinite(a_max), a_max, np.asarray(0, dtype=a.dtype))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            e = np.exp(np.where(is_max, -np.inf, a).astype(a.dtype) - shift)
+            ssum = np.sum(e, axis=2, keepdims=True, dtype=a.dtype)
+            ssum = np.where(ssum == 0, ssum, ssum / m)
+            lse = (np.log1p(ssum) + np.log(m) + a_max).squeeze(axis=2)
+        out = (a.T - lse.T).T
+    if flatten and out.ndim > 2:
+        out = np.concatenate(out)
+    return out
+
+
+def reverse_complement(log_prob, kind="poreover"):
+    """transducer.reverse_complement (transducer.py:68-70 poreover / bonito, :104-106 flip-flop)"""
+    perm = [3, 2, 1, 0, 7, 6, 5, 4] if kind == "flipflop" else [3, 2, 1, 0, 4]
+    return np.ascontiguousarray(np.asarray(log_prob)[::-1, perm])
+
+
+def trace_to_log_prob(trace_u8):
+    """decode.py:89-93,99-103: uint8 flip-flop trace -> log((x + eps) / (255 + eps))"""
+    eps = 0.0000001
+    return np.log((np.asarray(trace_u8) + eps) / (255 + eps))
+
+
 # ------------------------------------------------------------- the reference's own C++ (_ref)
 def ref_beam_search(y_, beam_width_=25, alphabet_="ACGT", model_="ctc"):
     y = _f64(y_)

@@ -3,7 +3,8 @@
 // Replaces, from decoding/decode.py and decoding/transducer.py of the reference:
 //   logit_to_log_likelihood (decode.py:34-39): x - logsumexp(x) per frame.  The reference does this in
 //       the array's own precision (float32 logits stay float32, scipy.special.logsumexp) and only
-//       then widens to float64 (transducer.py:16); so does this kernel.
+//       then widens to float64 (transducer.py:16); so does this kernel, with the arithmetic of the scipy
+//       version the reference runs on in this image (oracle/po_oracle.py::load_logits restates it).
 //   the uint8 flip-flop trace scaling (decode.py:89-93,99-103): log((x + 1e-7) / (255 + 1e-7)) in float64
 //   the Bonito column permutation [1,2,3,4,0] (decode.py:79) and reverse_complement
 //       (transducer.py:68-70,104-106): time reversal + column permutation — folded into the same pass.
@@ -36,11 +37,19 @@ __global__ __launch_bounds__(256) void ingest_kernel(IGArgs a) {
         double v[8];
         if (a.mode == 0) {
             const float* x = (const float*)a.src + srow * C;
+            // scipy.special.logsumexp as shipped in this image (1.15.3, _logsumexp.py): the maximal elements leave
+            // the sum (cnt of them), s = sum of exp(x - max) over the others in index order (numpy adds fewer than
+            // 8 elements sequentially; the maximal ones contribute exp(-inf) = +0), lse = log1p(s / cnt) + log(cnt) + max
             float xv[8], m = x[0];
             for (int c = 0; c < C; ++c) { xv[c] = x[c]; m = fmaxf(m, xv[c]); }
-            float sum = 0.f;  // numpy sums fewer than 8 elements sequentially
-            for (int c = 0; c < C; ++c) sum += expf(xv[c] - m);
-            const float lse = logf(sum) + m;
+            const float shift = isfinite(m) ? m : 0.f;
+            float sum = 0.f, cnt = 0.f;
+            for (int c = 0; c < C; ++c) {
+                if (xv[c] == m) cnt += 1.f;
+                else sum += expf(xv[c] - shift);
+            }
+            if (sum != 0.f) sum = sum / cnt;
+            const float lse = (log1pf(sum) + logf(cnt)) + m;
             for (int c = 0; c < C; ++c) v[c] = (double)(xv[c] - lse);
         } else if (a.mode == 1) {
             const unsigned char* x = (const unsigned char*)a.src + srow * C;

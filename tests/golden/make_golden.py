@@ -365,17 +365,8 @@ def main():
     inputs["revcomp_poreover_in"] = y1[:50]
     inputs["revcomp_poreover_out"] = m.log_prob
 
-    # ---- G8: real-data sanity: hashes only (the data stays in the reference)
-    import hashlib
-    real = {}
-    try:
-        r1 = ref_decode.model_from_trace(os.path.join(REF, "data/reads/read1.npy"), "poreover")
-        s = r1.viterbi_decode()
-        real["read1_viterbi_len"] = len(s)
-        real["read1_viterbi_md5"] = hashlib.md5(s.encode()).hexdigest()[:12]
-    except Exception as e:  # pragma: no cover
-        real["error"] = repr(e)
-    G["real"] = real
+    # (real signal — the reference's data/reads/read1.npy / read2.npy — is pinned by make_golden_real.py, which
+    #  fails loudly instead of recording an exception as an earlier version of this section did)
 
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(G, f, indent=0, sort_keys=True)
