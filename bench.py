@@ -15,6 +15,10 @@ BASELINE 10k-pair job and N GPUs decode N x 10k pairs.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--T 4000]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` (N > 1) outside a torchrun environment starts the N ranks itself (a fresh torch.distributed.run child,
+created before this process has touched torch or HIP) and relays rank 0's line; the reported n_gpus is always the
+number of ranks that ran.
+
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the byte accounting).
 """
 import argparse
@@ -85,6 +89,25 @@ def cpu_baseline(T, sample_pairs):
     }
 
 
+def _self_launch(gpus):
+    """--gpus N without RANK / WORLD_SIZE in the environment: become the launcher.  Nothing in this process has
+    imported torch or initialised HIP; the ranks are children of a fresh torch.distributed.run process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _digest(seq1, seq2, cons):
+    import hashlib
+    return hashlib.md5(("%s|%s|%s" % (seq1, seq2, cons)).encode()).hexdigest()[:10]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,14 +118,17 @@ def main():
     ap.add_argument("--beam_width", type=int, default=5)
     ap.add_argument("--gen_procs", type=int, default=0, help="processes generating the synthetic inputs (0 = auto; use 1 under "
                     "rocprofv3, whose preloaded library initialises the GPU before Python starts, which makes fork unsafe)")
-    ap.add_argument("--cpu_sample", type=int, default=96, help="pairs decoded on the CPU for the baseline (0 = skip)")
+    ap.add_argument("--cpu_sample", type=int, default=512, help="pairs decoded on the CPU for the baseline (0 = skip)")
+    ap.add_argument("--no_secondary", action="store_true", help="skip the secondary configurations (1-D beam, flip-flop, "
+                    "single-pair latency, end-to-end) measured after the timed region at N = 1")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    args.gpus = world   # n_gpus in the report = the ranks that actually run
 
     # ---- everything that forks worker processes happens BEFORE the GPU runtime is initialised
     # (forking a process that holds a HIP context is unsafe, in particular under rocprofv3)
@@ -121,6 +147,17 @@ def main():
     y1, o1, Cc = pack_rows([p[0] for p in pairs])
     y2, o2, _ = pack_rows([p[1] for p in pairs])
     del pairs
+    secondary = rank == 0 and world == 1 and not args.no_secondary
+    ff_reads = None
+    if secondary:   # BASELINE config 5: 1 000 flip-flop reads (T x 8)
+        from poreover_amd.synth import synth_read
+        nff = min(1000, P)
+        if nproc > 1:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(nproc) as pool:
+                ff_reads = pool.starmap(synth_read, [(500000 + i, T, 0, True) for i in range(nff)], chunksize=16)
+        else:
+            ff_reads = [synth_read(500000 + i, T, 0, True) for i in range(nff)]
     cpu_base = None
     if rank == 0 and args.gpus == 1 and world == 1 and args.cpu_sample > 0:
         cpu_base = cpu_baseline(T, args.cpu_sample)
@@ -203,6 +240,94 @@ def main():
     if bad:
         raise SystemExit("bench.py: %d pairs failed with an engine error (first code %d)" % (bad, int(st[(st != 0)][0])))
 
+    # ---- parity of what was just timed: the first pairs of rank 0 against the committed digests of the oracle's
+    # results for the same seeds (tests/golden/batch_digest.json) — strings, not only statuses
+    parity = None
+    if rank == 0 and T == 4000 and args.beam_width == 5:
+        try:
+            with open(os.path.join(REPO, "tests", "golden", "batch_digest.json")) as f:
+                dig = json.load(f)["records"]
+            k = min(P, len(dig))
+            h_seq = d_seq[: int(so[k])].cpu().numpy().tobytes()
+            h_s1 = d_seq1d[: int(s1o[2 * k])].cpu().numpy().tobytes()
+            h_l1, h_l2 = d_l1[:k].cpu().numpy(), d_l2[:k].cpu().numpy()
+            bad_dig = 0
+            for i in range(k):
+                a = h_s1[s1o[2 * i]: s1o[2 * i] + h_l1[i]].decode()
+                b = h_s1[s1o[2 * i + 1]: s1o[2 * i + 1] + h_l2[i]].decode()
+                c = h_seq[so[i]: so[i] + lens[i]].decode() if st[i] == 0 else ""
+                if [int(st[i]), len(a), len(b), len(c), _digest(a, b, c)] != dig[i]:
+                    bad_dig += 1
+            parity = {"pairs_checked": k, "digest_mismatches": bad_dig,
+                      "against": "tests/golden/batch_digest.json (CPU oracle, same seeds)"}
+            if bad_dig > max(1, k // 100):
+                raise SystemExit("bench.py: %d of %d decoded pairs differ from the oracle's digests" % (bad_dig, k))
+        except FileNotFoundError:
+            parity = None
+
+    sec = {}
+    if secondary:
+        def timed(fn, reps=3):
+            ev = [(lib.po_event_create(), lib.po_event_create()) for _ in range(reps)]
+            fn()
+            torch.cuda.synchronize()
+            for a_, b_ in ev:
+                lib.po_event_record(a_, stream); fn(); lib.po_event_record(b_, stream)
+            ms = []
+            for a_, b_ in ev:
+                f = C.c_float()
+                lib.po_event_elapsed_ms(a_, b_, C.byref(f)); ms.append(f.value)
+                lib.po_event_destroy(a_); lib.po_event_destroy(b_)
+            return sorted(ms)[len(ms) // 2]
+
+        def beam1d_config(d_y, d_off, n, Cn, rows, maxrows, model, W):
+            d_so = d_off
+            d_sq = torch.empty(rows, dtype=torch.uint8, device=dev)
+            d_ln = torch.zeros(n, dtype=torch.int32, device=dev)
+            d_stt = torch.zeros(n, dtype=torch.int32, device=dev)
+            wsz = lib.po_beam1d_workspace_bytes(n, rows, maxrows, Cn, W, _lib.MODELS[model])
+            d_w = torch.empty(wsz, dtype=torch.uint8, device=dev)
+            ms = timed(lambda: _lib.check(lib.po_beam1d_batch(d_y.data_ptr(), d_off.data_ptr(), n, Cn, b"ACGT", W, _lib.MODELS[model],
+                                                              d_sq.data_ptr(), d_so.data_ptr(), d_ln.data_ptr(), d_stt.data_ptr(),
+                                                              d_w.data_ptr(), wsz, stream), "po_beam1d_batch"))
+            assert int((d_stt != 0).sum().item()) == 0
+            nb = int(d_ln.sum().item())
+            return {"reads": n, "beam_width": W, "kernel_ms": round(ms, 3), "reads_per_s": round(n / ms * 1e3, 1),
+                    "mbases_per_s": round(nb / ms / 1e3, 3)}
+
+        n2 = min(1000, P)
+        sec["config2_beam1d_1k_reads_W10"] = beam1d_config(d_y1, d_o1, n2, Cc, int(o1[n2]), mr1, "ctc", 10)
+        yff, off_ff, Cff = pack_rows(ff_reads)
+        d_yff, d_off_ff = torch.from_numpy(yff).to(dev), torch.from_numpy(off_ff).to(dev)
+        sec["config5_flipflop_1k_reads_W10"] = beam1d_config(d_yff, d_off_ff, len(ff_reads), Cff, int(off_ff[-1]),
+                                                             int(np.diff(off_ff).max()), "ctc_flipflop", 10)
+        del d_yff, yff
+        # config 3: one pair, latency of the whole chain (median of 5)
+        wsb1 = lib.po_pair_decode_workspace_bytes(1, int(o1[1]), int(o2[1]), int(o1[1]), int(o2[1]), Cc, C.byref(opt))
+        lat = timed(lambda: _lib.check(lib.po_pair_decode_batch(
+            d_y1.data_ptr(), d_o1.data_ptr(), d_y2.data_ptr(), d_o2.data_ptr(), 1, Cc, C.byref(opt), d_seq1d.data_ptr(),
+            d_s1o.data_ptr(), d_l1.data_ptr(), d_l2.data_ptr(), d_id.data_ptr(), d_env.data_ptr(), d_seq.data_ptr(),
+            d_so.data_ptr(), d_len.data_ptr(), d_st.data_ptr(), d_ws.data_ptr(), wsb1, stream), "po_pair_decode_batch"), reps=5)
+        sec["config3_single_pair_latency_ms"] = round(lat, 3)
+        # end to end: host numpy (float32 logits, the form the .npy files hold) in -> Python strings out, through the
+        # pipelined host layer (pack -> H2D -> device ingest -> decode -> D2H, two slots)
+        from poreover_amd import batch as pobatch
+        del d_ws
+        torch.cuda.empty_cache()
+        l1s = [y1[o1[i]:o1[i + 1]].astype(np.float32) for i in range(P)]
+        l2s = [y2[o2[i]:o2[i + 1]].astype(np.float32) for i in range(P)]
+        pobatch.pair_decode_stream(l1s[:256], l2s[:256], "poreover", args.beam_width, "row_col")   # buffers + first-use costs
+        best, stt = None, {}
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res = pobatch.pair_decode_stream(l1s, l2s, "poreover", args.beam_width, "row_col", stats=stt)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        sec["e2e"] = {"pairs_per_s": round(P / best, 1), "seconds": round(best, 4), "pairs": P,
+                      "mbases_per_s": round(sum(len(r["consensus"] or "") for r in res) / best / 1e6, 3),
+                      "input": "list of host float32 logit matrices (T x 5), 80 KB per read over PCIe", "output": "Python strings",
+                      "pipeline": dict(stt)}
+
     # whole-job aggregate: max time over ranks, sum of units
     tmax, (tot_pairs, tot_bases) = podist.job_aggregate(dist, elapsed, [P * args.steps, bases * args.steps], dev)
 
@@ -225,19 +350,26 @@ def main():
         n1d = int(d_l1.sum().item() + d_l2.sum().item())
         vt_bytes = 8.0 * Cc * (tr1 + tr2) + 5.0 * n1d  # log-probs in; per base one character + one int32 frame index out
         vt_avg = vt_ms / max(vt_n, 1)
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
-        # committed rocprofv3 passes (profiles/r01_pmc_hbm_v15.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # 1250 pairs per launch, same T / W) are scaled to this launch's pair count
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so this figure is
+        # NOT measured in this run — it comes from the newest committed rocprofv3 counter passes (profiles/
+        # rNN_pmc_hbm*.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes, same T / W), scaled
+        # from that run's pairs per launch to this launch's
         traffic, traffic_src = None, None
         try:
-            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_v15.json")
-            with open(pj) as f:
-                pm = json.load(f)
-            kk = [v for k, v in pm["kernels"].items() if k.startswith(MAIN_KERNEL)][0]
-            per_pair = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0 / 1250.0
-            if T == 4000 and args.beam_width == 5:
+            import glob
+            pdir = os.path.join(REPO, "profiles")
+            for pj in sorted(glob.glob(os.path.join(pdir, "r*_pmc_hbm*.json")), key=os.path.getmtime, reverse=True):
+                with open(pj) as f:
+                    pm = json.load(f)
+                kks = [v for k, v in pm.get("kernels", {}).items() if k.startswith(MAIN_KERNEL)]
+                if not kks or not (T == 4000 and args.beam_width == 5):
+                    continue
+                per_launch = float(pm.get("pairs_per_launch", 1250))
+                per_pair = (2.0 * kks[0]["FETCH_SIZE_KB_per_launch"] + kks[0]["WRITE_SIZE_KB_per_launch"]) * 1024.0 / per_launch
                 traffic = per_pair * P
-                traffic_src = "profiles/r01_pmc_hbm_v15.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes at 1250 pairs per launch), scaled by pairs"
+                traffic_src = ("NOT measured in this run: %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at %d "
+                               "pairs per launch), scaled by pairs" % (os.path.relpath(pj, REPO), int(per_launch)))
+                break
         except Exception:
             pass
         out = {
@@ -271,20 +403,25 @@ def main():
         }
         # the pair beam search priced against what actually bounds it: one logaddexp per update_prob (ctc)
         lae_rate = n_upd / (bk_ms * 1e-3) if bk_ms > 0 else 0.0   # (kernel time, like `roofline`)
+        exe_rate = n_upd_exec / (bk_ms * 1e-3) if bk_ms > 0 else 0.0
         out["compute_roofline"] = {"bound": "f64 logaddexp stream (VALU)", "unit": "logaddexp/s",
-                                   "achieved": round(lae_rate, 1), "peak": round(lae_peak.value, 1),
-                                   "frac": round(lae_rate / lae_peak.value, 5) if lae_peak.value > 0 else None,
-                                   "updates_per_step": n_upd // max(args.steps, 1),
+                                   "achieved": round(exe_rate, 1), "peak": round(lae_peak.value, 1),
+                                   "frac": round(exe_rate / lae_peak.value, 5) if lae_peak.value > 0 else None,
                                    "executed_per_step": n_upd_exec // max(args.steps, 1),
-                                   "executed_frac": round(n_upd_exec / (bk_ms * 1e-3) / lae_peak.value, 5)
-                                   if lae_peak.value > 0 and bk_ms > 0 else None,
-                                   "note": "achieved = update_prob evaluations of the reference's schedule for this "
-                                           "input (ALGORITHMIC work: every element over its full windows in every "
-                                           "step) / time of the pair beam kernel; the kernels execute only executed_per_step "
-                                           "of them (results of the others are provably already stored; bit-identical "
-                                           "output), executed_frac prices those; peak = po_lae_peak micro-benchmark "
-                                           "on this device (all lanes busy, 4 independent chains per lane, same "
-                                           "table-driven logaddexp)"}
+                                   "reference_schedule_per_step": n_upd // max(args.steps, 1),
+                                   "reference_schedule_frac": round(lae_rate / lae_peak.value, 5) if lae_peak.value > 0 else None,
+                                   "note": "achieved / frac = update_prob evaluations the pair beam kernel EXECUTES / its "
+                                           "time, against the po_lae_peak micro-benchmark on this device (all lanes busy, 4 "
+                                           "independent chains per lane, same table-driven logaddexp); "
+                                           "reference_schedule_* counts what the reference's schedule evaluates for this "
+                                           "input (every element over its full windows in every step) — the kernel skips "
+                                           "the ones whose result is provably already stored (bit-identical output)"}
+        if parity is not None:
+            out["parity_check"] = parity
+        if sec:
+            out["secondary"] = sec
+            if "e2e" in sec:
+                out["e2e_pairs_per_s"] = sec["e2e"]["pairs_per_s"]
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
             out["gpu_over_cpu_all_cores"] = round(out["value"] / cpu_base["value"], 1)

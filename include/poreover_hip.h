@@ -277,6 +277,31 @@ int po_pair_decode_batch_h(const double* y1_h, const int64_t* y1_off_h, const do
                            int32_t* env_out_h, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,
                            int32_t* status_h);
 
+/* ---- host-to-strings pipeline of the pair decoder ---------------------------------------------------
+ * replaces the reference's fan-out of pair_decode_helper over worker processes (pair_decode.py:292-297)
+ * together with the trace loading each worker does: decode.load_logits / logit_to_log_likelihood
+ * (decode.py:34-51), the Bonito column order (decode.py:79), the uint8 trace scaling (decode.py:89-93) and
+ * transducer.reverse_complement of read 2 (transducer.py:68-70,104-106; pair_decode.py:323-329).
+ * Inputs are HOST arrays as the basecaller wrote them: y1_h[i] / y2_h[i] point to C-contiguous (rows1[i], C) /
+ * (rows2[i], C) matrices of float32 logits (in_mode PO_INGEST_LOGITS_F32), uint8 traces (PO_INGEST_TRACE_U8) or
+ * float64 log-probabilities (PO_INGEST_F64); perm1 / perm2 (C ints or NULL): column order of read 1 / read 2
+ * (out[:, c] = in[:, perm[c]]), reverse2: read 2 is time-reversed.  The pairs are decoded in waves of at most
+ * wave_pairs pairs / wave_rows frames through two slots {stream, pinned staging, device buffers, workspace}:
+ * wave k + 1 is packed and uploaded while wave k decodes, device memory is bounded by two waves whatever n is,
+ * and nothing is allocated per call once the buffers have grown to the wave size.
+ * Outputs as po_pair_decode_batch_h (all host); env_out_h may be NULL (rows of pair i at 2 * sum(rows1[:i])).
+ * A pipeline belongs to one host thread and one device.  */
+typedef struct po_pipeline po_pipeline;
+po_pipeline* po_pipeline_create(int device, int wave_pairs, int64_t wave_rows, int host_threads); /* 0 = defaults */
+void po_pipeline_destroy(po_pipeline* p);
+int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64_t* rows1, const void* const* y2_h,
+                            const int64_t* rows2, int n, int C, int in_mode, const int* perm1, const int* perm2,
+                            int reverse2, const po_pair_options* opt, char* seq1d_h, const int64_t* seq1d_off_h,
+                            int32_t* len1_h, int32_t* len2_h, double* identity_h, int32_t* env_out_h, char* seq_h,
+                            const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h);
+/* host milliseconds of the last call: packing, waiting for the device, whole call; number of waves */
+int po_pipeline_stats(po_pipeline* p, double* pack_ms, double* wait_ms, double* total_ms, int* waves);
+
 /* ---- timing aid for bench.py: HIP events on the stream the kernels run on ----------------- */
 void* po_event_create(void);
 int po_event_record(void* ev, void* stream);

@@ -110,6 +110,13 @@ PROTOTYPES = {
     "po_forward_vec_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "po_viterbi_acceptor_cy_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _i32p,
                                               _i32p]),
+    "po_pipeline_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int64, C.c_int]),
+    "po_pipeline_destroy": (None, [C.c_void_p]),
+    "po_pipeline_pair_decode": (C.c_int, [C.c_void_p, _vp, _i64p, _vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int), C.c_int, C.POINTER(PairOptions), _cp, _i64p, _i32p, _i32p, _dp,
+                                          _i32p, _cp, _i64p, _i32p, _i32p]),
+    "po_pipeline_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int)]),
     "po_event_create": (C.c_void_p, []),
     "po_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "po_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

@@ -6,12 +6,13 @@ Host buffers go through the *_h entry points of the C-ABI (which copy to the dev
 and copy back); device-resident callers use the device-pointer forms directly (see bench.py).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _lib as L
 
-__all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pack_rows",
+__all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pair_decode_batch_sharded", "pair_decode_stream", "pack_rows",
            "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "pair_prefix_search_batch", "forward_vec_batch", "align_batch", "envelope_batch", "ingest_batch", "pair_gamma_batch"]
 
 
@@ -179,6 +180,142 @@ def pair_decode_batch(arrays1, arrays2, kind="poreover", beam_width=5, method="r
             "skipped": 0 if code == 0 else 1, "status": code,
             "envelope": env[o1[i]:o1[i + 1]].astype(np.int64) if code == 0 else None})
     return out
+
+
+_PIPELINES = {}
+INGEST_MODES = {np.dtype(np.float32): 0, np.dtype(np.uint8): 1, np.dtype(np.float64): 2}
+
+
+def _pipeline(wave_pairs=0, wave_rows=0, threads=0):
+    """One po_pipeline per (process, device, geometry): its pinned staging buffers, device buffers and workspace
+    are allocated once and reused by every call."""
+    dev = int(os.environ.get("POREOVER_DEVICE", "0") or 0)
+    key = (os.getpid(), dev, int(wave_pairs), int(wave_rows), int(threads))
+    pl = _PIPELINES.get(key)
+    if pl is None:
+        lib = L.load()
+        pl = lib.po_pipeline_create(dev, int(wave_pairs), int(wave_rows), int(threads))
+        if not pl:
+            raise L.EngineError(L.E_HIP, "po_pipeline_create", (lib.po_last_error() or b"").decode())
+        _PIPELINES[key] = pl
+    return pl
+
+
+def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="row_col", padding=5, alignment="banded",
+                       diagonal_envelope=False, diagonal_width=50, perm1=None, perm2=None, reverse2=False,
+                       return_envelope=False, wave_pairs=0, wave_rows=0, threads=0, strict=True, stats=None):
+    """The pair-decode stage chain for a list of pairs, HOST ARRAYS IN -> STRINGS OUT, through the engine's
+    pipelined host layer (po_pipeline_pair_decode): the arrays are uploaded as they are — float32 logits, uint8
+    flip-flop traces or float64 log-probabilities, all of one dtype — in waves, log-softmax / trace scaling /
+    column order (perm1, perm2: out[:, c] = in[:, perm[c]]) / time reversal of read 2 (reverse2; reverse_complement =
+    reverse2 + perm2 [3,2,1,0,4]) run on the device, and wave k + 1 uploads while wave k decodes.
+    Returns the same records as pair_decode_batch (envelope only with return_envelope).  strict=False: a per-pair
+    engine error is left in the record's status instead of raising for the whole batch."""
+    lib = L.load()
+    n = len(arrays1)
+    if n == 0:
+        return []
+    a1 = [np.ascontiguousarray(a) for a in arrays1]
+    a2 = [np.ascontiguousarray(a) for a in arrays2]
+    dt = a1[0].dtype
+    mode = INGEST_MODES.get(np.dtype(dt))
+    if mode is None or any(a.dtype != dt or a.ndim != 2 for a in a1 + a2):
+        raise ValueError("pair_decode_stream takes 2-D float32 logits, uint8 traces or float64 log-probabilities of one dtype")
+    Cc = a1[0].shape[1]
+    if any(a.shape[1] != Cc for a in a1 + a2):
+        raise ValueError("all matrices of a batch must have the same number of columns")
+    model = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}[kind]
+    opt = L.PairOptions(int(beam_width), L.MODELS[model], L.METHODS[method], int(padding),
+                        1 if alignment == "full" else 0, 1 if diagonal_envelope else 0, int(diagonal_width))
+    r1 = np.array([len(a) for a in a1], dtype=np.int64)
+    r2 = np.array([len(a) for a in a2], dtype=np.int64)
+    p1 = (C.c_void_p * n)(*[a.ctypes.data for a in a1])
+    p2 = (C.c_void_p * n)(*[a.ctypes.data for a in a2])
+    s1o = np.zeros(2 * n + 1, dtype=np.int64)
+    caps = np.empty(2 * n, dtype=np.int64)
+    caps[0::2], caps[1::2] = r1, r2
+    np.cumsum(caps, out=s1o[1:])
+    so = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(r1 + r2, out=so[1:])
+    seq1d = np.empty(max(int(s1o[-1]), 1), dtype=np.uint8)
+    seq = np.empty(max(int(so[-1]), 1), dtype=np.uint8)
+    l1, l2, lens, st = (np.zeros(n, dtype=np.int32) for _ in range(4))
+    ident = np.zeros(n, dtype=np.float64)
+    env = np.zeros((max(int(r1.sum()), 1), 2), dtype=np.int32) if return_envelope else None
+    pm1 = (C.c_int * Cc)(*perm1) if perm1 is not None else None
+    pm2 = (C.c_int * Cc)(*perm2) if perm2 is not None else None
+    pl = _pipeline(wave_pairs, wave_rows, threads)
+    L.check(lib.po_pipeline_pair_decode(pl, p1, _ptr(r1), p2, _ptr(r2), n, Cc, mode, pm1, pm2, 1 if reverse2 else 0,
+                                        C.byref(opt), _ptr(seq1d), _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(ident), _ptr(env),
+                                        _ptr(seq), _ptr(so), _ptr(lens), _ptr(st)), "po_pipeline_pair_decode")
+    if stats is not None:
+        pk, wt, tot, wv = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        lib.po_pipeline_stats(pl, C.byref(pk), C.byref(wt), C.byref(tot), C.byref(wv))
+        stats.update(pack_ms=pk.value, wait_ms=wt.value, total_ms=tot.value, waves=wv.value)
+    raw1, raw = seq1d.tobytes(), seq.tobytes()
+    eo = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(r1, out=eo[1:])
+    out = []
+    for i in range(n):
+        code = int(st[i])
+        if strict and code not in (0, L.SKIP_LENGTH, L.SKIP_IDENTITY):
+            raise L.EngineError(code, "pair decode of pair %d" % i)
+        out.append({
+            "seq1": raw1[s1o[2 * i]:s1o[2 * i] + l1[i]].decode("ascii"),
+            "seq2": raw1[s1o[2 * i + 1]:s1o[2 * i + 1] + l2[i]].decode("ascii"),
+            "consensus": raw[so[i]:so[i] + lens[i]].decode("ascii") if code == 0 else None,
+            "length1": int(l1[i]), "length2": int(l2[i]),
+            "sequence_identity": float(ident[i]) if code != L.SKIP_LENGTH else None,
+            "skipped": 0 if code == 0 else 1, "status": code,
+            "envelope": env[eo[i]:eo[i + 1]].astype(np.int64) if (code == 0 and return_envelope) else None})
+    return out
+
+
+def _sharded_pair_worker(items, extra):
+    """One worker of pair_decode_batch_sharded (a spawned process bound to its device by dist.run_sharded): maps the
+    packed inputs the parent left in shared memory and decodes the pairs whose indices it was given."""
+    y1 = np.load(extra["y1"], mmap_mode="r")
+    y2 = np.load(extra["y2"], mmap_mode="r")
+    o1, o2 = extra["o1"], extra["o2"]
+    a = [y1[o1[i]:o1[i + 1]] for i in items]
+    b = [y2[o2[i]:o2[i + 1]] for i in items]
+    res = pair_decode_batch(a, b, **extra["kw"])
+    if not extra["keep_envelope"]:
+        for r in res:
+            r["envelope"] = None
+    return res
+
+
+def pair_decode_batch_sharded(arrays1, arrays2, devices=None, keep_envelope=True, **kw):
+    """pair_decode_batch over several GPUs of one node (BASELINE config 4; the reference's Pool fan-out,
+    pair_decode.py:292-297): pairs are split by cost U + V (greedy longest-first, dist.shard_by_cost), each device
+    gets one spawned worker process that decodes its share through the C-ABI, and the results come back in input
+    order.  Inputs travel through shared memory (one packed copy, mapped by every worker), outputs are small.
+    devices: list of device indices (default: every visible device; an index may repeat); with one device — or one
+    pair — this is pair_decode_batch.  The CALLING process must not have initialised the GPU when more than one
+    worker is spawned (see dist.py)."""
+    from . import dist as podist
+    n = len(arrays1)
+    devs = podist.plan_devices(n, devices)
+    if len(devs) <= 1:
+        if devs and devs[0] != 0:
+            L.check(L.load().po_set_device(devs[0]), "po_set_device")
+        return pair_decode_batch(arrays1, arrays2, **kw)
+    import shutil
+    import tempfile
+    y1, o1, Cc = pack_rows(arrays1)
+    y2, o2, _ = pack_rows(arrays2, Cc)
+    tmp = tempfile.mkdtemp(prefix="poreover_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        f1, f2 = os.path.join(tmp, "y1.npy"), os.path.join(tmp, "y2.npy")
+        np.save(f1, y1)
+        np.save(f2, y2)
+        del y1, y2
+        extra = {"y1": f1, "y2": f2, "o1": o1, "o2": o2, "kw": kw, "keep_envelope": keep_envelope}
+        costs = [int(o1[i + 1] - o1[i] + o2[i + 1] - o2[i]) for i in range(n)]
+        return podist.run_sharded(list(range(n)), costs, _sharded_pair_worker, devs, extra)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _pack_labels(labels):

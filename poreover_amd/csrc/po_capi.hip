@@ -147,13 +147,17 @@ int po_device_count(void) {
 }
 
 int po_set_device(int device) {
+    g_err.clear();
     HIPCHK(hipSetDevice(device));
     return PO_OK;
 }
 
 const char* po_last_error(void) { return g_err.c_str(); }
+// internal: lets the other translation units (po_stream.hip) leave a message for po_last_error
+void po_set_error(const char* msg) { g_err = msg ? msg : ""; }
 
 int po_device_info(int device, char* name, int name_cap, int* cus, int* clock_khz, size_t* total_mem) {
+    g_err.clear();
     hipDeviceProp_t p;
     HIPCHK(hipGetDeviceProperties(&p, device));
     if (name && name_cap > 0) { std::strncpy(name, p.name, name_cap - 1); name[name_cap - 1] = 0; }
@@ -166,6 +170,7 @@ int po_device_info(int device, char* name, int name_cap, int* cus, int* clock_kh
 // -------------------------------------------------------------------------------- ingest
 int po_ingest_batch(const void* src, const int64_t* row_off, int n, int C, int mode, const int* perm_h, int reverse,
                     double* out, void* stream) {
+    g_err.clear();
     if (n < 0 || !src || !row_off || !out) { g_err = "po_ingest_batch: null argument"; return PO_E_ARG; }
     if (n == 0) return PO_OK;
     int64_t ends[2] = {0, 0};
@@ -181,6 +186,7 @@ int po_ingest_batch(const void* src, const int64_t* row_off, int n, int C, int m
 
 // -------------------------------------------------------------------------------- viterbi
 size_t po_viterbi_workspace_bytes(int n, int64_t total_rows, int C, int kind) {
+    g_err.clear();
     if (kind != PO_KIND_FLIPFLOP) return 256;
     return al256((size_t)total_rows * 8) + al256((size_t)total_rows) + 256;  // ptr[T][8] + path[T]
 }
@@ -189,6 +195,7 @@ int po_viterbi_batch(const double* y, const int64_t* y_off, int n, int C, const 
                      int8_t* path, char* seq,
                      const int64_t* seq_off, int32_t* seq_len, int32_t* map, int32_t* status, void* ws,
                      size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !y || !y_off || !seq || !seq_off || !seq_len || !status) { g_err = "po_viterbi_batch: null argument"; return PO_E_ARG; }
     uint32_t ap = 0;
     const int A = pack_alphabet(alphabet, &ap);
@@ -215,6 +222,7 @@ int po_viterbi_batch(const double* y, const int64_t* y_off, int n, int C, const 
 
 // -------------------------------------------------------------------------------- beam 1-D
 size_t po_beam1d_workspace_bytes(int n, int64_t total_rows, int64_t max_rows, int C, int W, int model) {
+    g_err.clear();
     (void)max_rows; (void)C; (void)model;
     return 2 * al256(sizeof(int) * (size_t)po_beam1d_arena_nodes(n, total_rows, W)) + 256;
 }
@@ -226,6 +234,7 @@ int po_beam1d_batch(const double* y, const int64_t* y_off, int n, int C, const c
                     char* seq,
                     const int64_t* seq_off, int32_t* seq_len, int32_t* status, void* ws, size_t ws_bytes,
                     void* stream) {
+    g_err.clear();
     if (n < 0 || !y || !y_off || !seq || !seq_off || !seq_len || !status || !ws) { g_err = "po_beam1d_batch: null argument"; return PO_E_ARG; }
     if (ws_bytes < 512) { g_err = "po_beam1d_batch: workspace too small"; return PO_E_CAP; }
     uint32_t ap = 0;
@@ -250,6 +259,7 @@ int po_beam1d_batch(const double* y, const int64_t* y_off, int n, int C, const c
 // -------------------------------------------------------------------------------- beam 2-D
 size_t po_beam2d_workspace_bytes(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, int W,
                                  int model, int method) {
+    g_err.clear();
     return po_beam2d_ws_bytes_impl(n, tr1, tr2, mr1, mr2, C, W, model, method);
 }
 
@@ -257,6 +267,7 @@ int po_beam2d_batch(const double* y1, const int64_t* y1_off, const double* y2, c
                     const int32_t* env, int n, int C, const char* alphabet, int W, int model, int method,
                     char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status, void* ws,
                     size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !y1 || !y1_off || !y2 || !y2_off || !seq || !seq_off || !seq_len || !status || !ws) { g_err = "po_beam2d_batch: null argument"; return PO_E_ARG; }
     uint32_t ap = 0;
     const int A = pack_alphabet(alphabet, &ap);
@@ -264,7 +275,7 @@ int po_beam2d_batch(const double* y1, const int64_t* y1_off, const double* y2, c
     ProfScope ps(PO_K_BEAM2D, (hipStream_t)stream);
     int rc = po_launch_beam2d(y1, y1_off, y2, y2_off, env, n, C, A, ap, W, model, method, seq, seq_off, seq_len, status,
                               ws, ws_bytes, (hipStream_t)stream);
-    if (rc != PO_OK) { if (g_err.empty()) g_err = "po_beam2d_batch: launch refused"; return rc; }
+    if (rc != PO_OK) { g_err = "po_beam2d_batch: launch refused"; return rc; }
     HIPCHK(hipGetLastError());
     return PO_OK;
 }
@@ -286,11 +297,13 @@ int batch_maxima(const int64_t* y_off, const int64_t* label_off, int n, hipStrea
 }
 }  // namespace
 
-size_t po_forward_workspace_bytes(int n, int64_t max_rows, int model) { return po_lattice_ws_bytes(n, max_rows, 0, model, 0); }
+size_t po_forward_workspace_bytes(int n, int64_t max_rows, int model) {
+    g_err.clear(); return po_lattice_ws_bytes(n, max_rows, 0, model, 0); }
 
 int po_forward_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int model,
                      const char* labels, const int64_t* label_off, double* logp, int32_t* status, void* ws,
                      size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !y || !y_off || !labels || !label_off || !logp || !status || !ws) { g_err = "po_forward_batch: null argument"; return PO_E_ARG; }
     uint32_t ap = 0;
     const int A = pack_alphabet(alphabet, &ap);
@@ -306,12 +319,14 @@ int po_forward_batch(const double* y, const int64_t* y_off, int n, int C, const 
 }
 
 size_t po_viterbi_acceptor_workspace_bytes(int n, int64_t max_rows, int64_t max_label) {
+    g_err.clear();
     return po_lattice_ws_bytes(n, max_rows, max_label, PO_MODEL_CTC, 1);
 }
 
 int po_viterbi_acceptor_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, int band_size,
                               const char* labels, const int64_t* label_off, int32_t* path, int32_t* status, void* ws,
                               size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !y || !y_off || !labels || !label_off || !path || !status || !ws) { g_err = "po_viterbi_acceptor_batch: null argument"; return PO_E_ARG; }
     uint32_t ap = 0;
     const int A = pack_alphabet(alphabet, &ap);
@@ -328,11 +343,13 @@ int po_viterbi_acceptor_batch(const double* y, const int64_t* y_off, int n, int 
 }
 
 // -------------------------------------------------------------------------------- prefix search
-size_t po_prefix_search_workspace_bytes(int n, int64_t max_rows) { return po_prefix_ws_bytes(n, max_rows); }
+size_t po_prefix_search_workspace_bytes(int n, int64_t max_rows) {
+    g_err.clear(); return po_prefix_ws_bytes(n, max_rows); }
 
 int po_prefix_search_batch(const double* y, const int64_t* y_off, int n, int C, const char* alphabet, char* seq,
                            const int64_t* seq_off, int32_t* seq_len, double* logp, int32_t* status, void* ws,
                            size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !y || !y_off || !seq || !seq_off || !seq_len || !logp || !status || !ws) { g_err = "po_prefix_search_batch: null argument"; return PO_E_ARG; }
     uint32_t ap = 0;
     const int A = pack_alphabet(alphabet, &ap);
@@ -351,10 +368,12 @@ int po_prefix_search_batch(const double* y, const int64_t* y_off, int n, int C, 
 }
 
 // -------------------------------------------------------------------------------- align / envelope
-size_t po_align_workspace_bytes(int n, int64_t ml1, int64_t ml2, int band) { return po_align_ws_bytes(n, ml1, ml2, band); }
+size_t po_align_workspace_bytes(int n, int64_t ml1, int64_t ml2, int band) {
+    g_err.clear(); return po_align_ws_bytes(n, ml1, ml2, band); }
 
 int po_align_batch(const char* seqs, const int64_t* seq_off, int n, int band_width, char* aln1, char* aln2,
                    const int64_t* aln_off, int32_t* ncol, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !seqs || !seq_off || !aln1 || !aln2 || !aln_off || !ncol || !status || !ws) { g_err = "po_align_batch: null argument"; return PO_E_ARG; }
     if (n == 0) return PO_OK;
     std::vector<int64_t> h(2 * (size_t)n + 1);
@@ -368,12 +387,14 @@ int po_align_batch(const char* seqs, const int64_t* seq_off, int n, int band_wid
     return PO_OK;
 }
 
-size_t po_envelope_workspace_bytes(int n, int64_t max_ncol) { return po_envelope_ws_bytes(n, max_ncol); }
+size_t po_envelope_workspace_bytes(int n, int64_t max_ncol) {
+    g_err.clear(); return po_envelope_ws_bytes(n, max_ncol); }
 
 int po_envelope_batch(const char* aln1, const char* aln2, const int64_t* aln_off, const int32_t* ncol, int n,
                       const int32_t* map1, const int64_t* map1_off, const int32_t* map2, const int64_t* map2_off,
                       const int32_t* U, const int32_t* V, int padding, int32_t* env, const int64_t* env_off,
                       int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !aln1 || !aln2 || !aln_off || !ncol || !map1 || !map1_off || !map2 || !map2_off || !U || !V || !env ||
         !env_off || !status || !ws) { g_err = "po_envelope_batch: null argument"; return PO_E_ARG; }
     if (n == 0) return PO_OK;
@@ -390,12 +411,14 @@ int po_envelope_batch(const char* aln1, const char* aln2, const int64_t* aln_off
 }
 
 // -------------------------------------------------------------------------------- pair gamma
-size_t po_pair_gamma_workspace_bytes(int n, int64_t max_cells, int64_t mr1, int64_t mr2) { return po_gamma_ws_bytes(n, max_cells, mr1, mr2); }
+size_t po_pair_gamma_workspace_bytes(int n, int64_t max_cells, int64_t mr1, int64_t mr2) {
+    g_err.clear(); return po_gamma_ws_bytes(n, max_cells, mr1, mr2); }
 
 int po_pair_gamma_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
                         const int32_t* env, const int64_t* env_off, int n, int C, int flavor, int64_t max_cells,
                         double* gamma00, double* dense_out, const int64_t* dense_off, int32_t* status, void* ws,
                         size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !y1 || !y1_off || !y2 || !y2_off || !gamma00 || !status || !ws || (env && !env_off) ||
         (dense_out && !dense_off)) { g_err = "po_pair_gamma_batch: null argument"; return PO_E_ARG; }
     if (n == 0) return PO_OK;
@@ -415,6 +438,7 @@ int po_pair_gamma_batch(const double* y1, const int64_t* y1_off, const double* y
 // -------------------------------------------------------------------------------- pair decode
 size_t po_pair_decode_workspace_bytes(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C,
                                       const po_pair_options* opt) {
+    g_err.clear();
     return po_pair_ws_bytes_impl(n, tr1, tr2, mr1, mr2, C, opt);
 }
 
@@ -422,11 +446,12 @@ int po_pair_decode_batch(const double* y1, const int64_t* y1_off, const double* 
                          int C, const po_pair_options* opt, char* seq1d, const int64_t* seq1d_off, int32_t* len1,
                          int32_t* len2, double* identity, int32_t* env_out, char* seq, const int64_t* seq_off,
                          int32_t* seq_len, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+    g_err.clear();
     if (n < 0 || !y1 || !y1_off || !y2 || !y2_off || !opt || !seq1d || !seq1d_off || !len1 || !len2 || !identity ||
         !seq || !seq_off || !seq_len || !status || !ws) { g_err = "po_pair_decode_batch: null argument"; return PO_E_ARG; }
     int rc = po_launch_pair_decode(y1, y1_off, y2, y2_off, n, C, opt, seq1d, seq1d_off, len1, len2, identity,
                                    env_out, seq, seq_off, seq_len, status, ws, ws_bytes, (hipStream_t)stream);
-    if (rc != PO_OK) { if (g_err.empty()) g_err = "po_pair_decode_batch: launch refused"; return rc; }
+    if (rc != PO_OK) { g_err = "po_pair_decode_batch: launch refused"; return rc; }
     HIPCHK(hipGetLastError());
     return PO_OK;
 }
@@ -451,6 +476,7 @@ struct DevBuf {
 
 int po_ingest_batch_h(const void* src_h, const int64_t* row_off_h, int n, int C, int mode, const int* perm_h, int reverse,
                       double* out_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t rows = row_off_h[n];
     const size_t esz = mode == PO_INGEST_LOGITS_F32 ? 4 : (mode == PO_INGEST_TRACE_U8 ? 1 : 8);
@@ -469,6 +495,7 @@ int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, 
                        int8_t* path_h,
                        char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* map_h,
                        int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t rows = y_off_h[n] - y_off_h[0];
     const int64_t seqb = seq_off_h[n];
@@ -501,6 +528,7 @@ int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, 
 int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int W,
                       int model, char* seq_h,
                       const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t rows = y_off_h[n] - y_off_h[0];
     const int64_t seqb = seq_off_h[n];
@@ -530,6 +558,7 @@ int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, c
 int po_pair_gamma_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
                           const int32_t* env_h, const int64_t* env_off_h, int n, int C, int flavor, double* gamma00_h,
                           double* dense_out_h, const int64_t* dense_off_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
     int64_t m1 = 0, m2 = 0, mc = 0;
@@ -570,6 +599,7 @@ int po_pair_gamma_batch_h(const double* y1_h, const int64_t* y1_off_h, const dou
 int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
                                   int n, int C, const char* alphabet, int flavor, char* seq_h, const int64_t* seq_off_h,
                                   int32_t* seq_len_h, double* logp_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     uint32_t ap = 0;
     const int A = pack_alphabet(alphabet, &ap);
@@ -625,6 +655,7 @@ int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, c
 
 int po_forward_vec_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, int s, int i, int flavor,
                            const double* previous_h, double* out_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     if (!y_h || !y_off_h || !out_h) { g_err = "po_forward_vec_batch_h: null argument"; return PO_E_ARG; }
     const int64_t rows = y_off_h[n] - y_off_h[0];
@@ -646,6 +677,7 @@ int po_forward_vec_batch_h(const double* y_h, const int64_t* y_off_h, int n, int
 
 int po_align_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, char* aln1_h, char* aln2_h,
                      const int64_t* aln_off_h, int32_t* ncol_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     int64_t m1 = 0, m2 = 0;
     for (int i = 0; i < n; ++i) {
@@ -677,6 +709,7 @@ int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* a
                         const int32_t* map1_h, const int64_t* map1_off_h, const int32_t* map2_h,
                         const int64_t* map2_off_h, const int32_t* U_h, const int32_t* V_h, int padding, int32_t* env_h,
                         const int64_t* env_off_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     int64_t mc = 0;
     for (int i = 0; i < n; ++i) mc = std::max<int64_t>(mc, ncol_h[i]);
@@ -709,6 +742,7 @@ int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* a
 
 int po_prefix_search_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, char* seq_h,
                              const int64_t* seq_off_h, int32_t* seq_len_h, double* logp_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t rows = y_off_h[n] - y_off_h[0];
     const int64_t seqb = seq_off_h[n];
@@ -739,6 +773,7 @@ int po_prefix_search_batch_h(const double* y_h, const int64_t* y_off_h, int n, i
 
 int po_forward_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int model,
                        const char* labels_h, const int64_t* label_off_h, double* logp_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t rows = y_off_h[n] - y_off_h[0], nl = label_off_h[n] - label_off_h[0];
     int64_t mx = 0;
@@ -767,6 +802,7 @@ int po_forward_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, 
 int po_viterbi_acceptor_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
                                 int band_size, const char* labels_h, const int64_t* label_off_h, int32_t* path_h,
                                 int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t rows = y_off_h[n] - y_off_h[0], nl = label_off_h[n] - label_off_h[0];
     int64_t mx = 0, ml = 0;
@@ -799,6 +835,7 @@ int po_viterbi_acceptor_batch_h(const double* y_h, const int64_t* y_off_h, int n
 int po_viterbi_acceptor_cy_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet,
                                    int band_size, const char* labels_h, const int64_t* label_off_h, int32_t* path_h,
                                    int32_t* status_h) {
+    g_err.clear();
     if (band_size < 0) { g_err = "po_viterbi_acceptor_cy_batch_h: negative band"; return PO_E_ARG; }
     return po_viterbi_acceptor_batch_h(y_h, y_off_h, n, C, alphabet, -(band_size + 1), labels_h, label_off_h, path_h, status_h);
 }
@@ -807,6 +844,7 @@ int po_beam2d_batch_h(const double* y1_h, const int64_t* y1_off_h, const double*
                       const int32_t* env_h, int n, int C, const char* alphabet, int W, int model, int method,
                       char* seq_h,
                       const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
     const int64_t seqb = seq_off_h[n];
@@ -848,6 +886,7 @@ int po_pair_decode_from_1d_batch_h(const double* y1_h, const int64_t* y1_off_h, 
                                    const int64_t* seq1d_off_h, const int32_t* len1_h, const int32_t* len2_h,
                                    const int32_t* map1_h, const int32_t* map2_h, double* identity_h, int32_t* env_out_h,
                                    char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
     const int64_t seqb = seq_off_h[n], s1b = seq1d_off_h[2 * n];
@@ -899,6 +938,7 @@ int po_pair_decode_batch_h(const double* y1_h, const int64_t* y1_off_h, const do
                            const int64_t* seq1d_off_h, int32_t* len1_h, int32_t* len2_h, double* identity_h,
                            int32_t* env_out_h, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h,
                            int32_t* status_h) {
+    g_err.clear();
     if (n <= 0) return PO_OK;
     const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
     const int64_t seqb = seq_off_h[n], s1b = seq1d_off_h[2 * n];
@@ -950,10 +990,12 @@ void* po_event_create(void) {
     return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
 }
 int po_event_record(void* ev, void* stream) {
+    g_err.clear();
     HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
     return PO_OK;
 }
 int po_event_elapsed_ms(void* start, void* stop, float* ms) {
+    g_err.clear();
     HIPCHK(hipEventSynchronize((hipEvent_t)stop));
     HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return PO_OK;
@@ -961,10 +1003,12 @@ int po_event_elapsed_ms(void* start, void* stop, float* ms) {
 void po_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 
 int po_profile_update_counter(uint64_t* device_counter) {
+    g_err.clear();
     po_b2_set_update_counter((unsigned long long*)device_counter);
     return PO_OK;
 }
 int po_lae_peak(int iters, double* lae_per_s, void* stream) {
+    g_err.clear();
     if (iters < 1 || !lae_per_s) { g_err = "po_lae_peak: bad argument"; return PO_E_ARG; }
     int rc = po_launch_lae_peak(iters, lae_per_s, (hipStream_t)stream);
     if (rc != PO_OK) g_err = "po_lae_peak: launch failed";
@@ -981,6 +1025,7 @@ void po_profile_reset(void) {
     std::memset(g_prof_n, 0, sizeof(g_prof_n));
 }
 int po_profile_get(int kernel, double* total_ms, int64_t* launches) {
+    g_err.clear();
     if (kernel < 0 || kernel >= PO_K_COUNT) return PO_E_ARG;
     prof_drain();
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -4,7 +4,7 @@
 //   logit_to_log_likelihood (decode.py:34-39): x - logsumexp(x) per frame.  The reference does this in
 //       the array's own precision (float32 logits stay float32, scipy.special.logsumexp) and only
 //       then widens to float64 (transducer.py:16); so does this kernel, with the arithmetic of the scipy
-//       version the reference runs on in this image (oracle/po_oracle.py::load_logits restates it).
+//       version the reference runs on in this image (1.15.3; the test suite pins it on the reference's sample reads).
 //   the uint8 flip-flop trace scaling (decode.py:89-93,99-103): log((x + 1e-7) / (255 + 1e-7)) in float64
 //   the Bonito column permutation [1,2,3,4,0] (decode.py:79) and reverse_complement
 //       (transducer.py:68-70,104-106): time reversal + column permutation — folded into the same pass.

@@ -71,14 +71,40 @@ def _trace_from_hdf5(path, dataset):
         return np.array(hdf[dataset])
 
 
+def _deferred_logits(file_path):
+    """load_logits(flatten=True) with the log-softmax left to the engine's ingest kernel when the file holds
+    float32 logits of shape (B, W, C) (what `poreover call` and the Bonito patch write); probabilities, other
+    dtypes and the shapes on which the reference raises go through load_logits itself."""
+    arr = np.load(file_path)
+    if arr.ndim == 3 and arr.dtype == np.float32 and not np.isclose(np.sum(arr[0]), 1):
+        return transducer.DeferredTrace(arr.reshape(-1, arr.shape[2]), 0,
+                                        lambda a, _s=arr.shape: np.concatenate(logit_to_log_likelihood(a.reshape(_s))))
+    if np.isclose(np.sum(arr[0]), 1):
+        arr = np.log(arr)
+    else:
+        arr = logit_to_log_likelihood(arr)
+    return np.concatenate(arr) if len(arr.shape) > 2 else arr
+
+
+def _deferred_trace(trace):
+    """uint8 flip-flop trace -> log((x + eps) / (255 + eps)) (decode.py:89-93,99-103), on the device when it can be"""
+    eps = 0.0000001
+    trace = np.asarray(trace)
+    if trace.dtype == np.uint8 and trace.ndim == 2:
+        return transducer.DeferredTrace(trace, 1, lambda a: np.log((a + eps) / (255 + eps)))
+    return np.log((trace + eps) / (255 + eps))
+
+
 def model_from_trace(f, basecaller=""):
-    """decode.py:67-112"""
+    """decode.py:67-112.  float32 logits and uint8 traces stay as they are inside the returned object (deferred
+    ingest: the batched drivers upload them in that form); .log_prob gives the reference's float64 table."""
     _, ext = os.path.splitext(f)
     if ext == '.npy' and basecaller == 'poreover':
-        return transducer.poreover(load_logits(f, flatten=True))
+        return transducer.poreover(_deferred_logits(f))
     if ext == '.npy' and basecaller == 'bonito':
-        trace = load_logits(f, flatten=True)
-        return transducer.bonito(trace[::, [1, 2, 3, 4, 0]])
+        model = transducer.bonito(_deferred_logits(f))
+        model._permute([1, 2, 3, 4, 0])          # trace[::, [1, 2, 3, 4, 0]] (decode.py:79)
+        return model
     if ext == '.csv':
         trace = np.log(np.loadtxt(f, delimiter=',', skiprows=1))
         if trace.shape[1] == 5:
@@ -86,12 +112,9 @@ def model_from_trace(f, basecaller=""):
         if trace.shape[1] == 8:
             return transducer.flipflop(trace)
     if ext == '.hdf5' or basecaller == 'flappie':
-        eps = 0.0000001
-        return transducer.flipflop(np.log((_trace_from_hdf5(f, None) + eps) / (255 + eps)))
+        return transducer.flipflop(_deferred_trace(_trace_from_hdf5(f, None)))
     if ext == '.fast5' or basecaller == 'guppy':
-        eps = 0.0000001
-        trace = _trace_from_hdf5(f, '/Analyses/Basecall_1D_000/BaseCalled_template/Trace')
-        return transducer.flipflop(np.log((trace + eps) / (255 + eps)))
+        return transducer.flipflop(_deferred_trace(_trace_from_hdf5(f, '/Analyses/Basecall_1D_000/BaseCalled_template/Trace')))
     if basecaller == "":
         print("Problem loading the trace probabilities, please specify where they came from with "
               "--basecaller [poreover/guppy/flappie]")
@@ -131,6 +154,37 @@ def decode_models(models, args):
     return out
 
 
+def decode_files_local(in_files, args):
+    """Sequences of a list of trace files, decoded on THIS process's device (one batched engine call per kind)."""
+    return decode_models([model_from_trace(p, args.basecaller) for p in in_files], args)
+
+
+def decode_files(in_files, args, devices=None, decode_fn=None):
+    """decode.py:158-162's Pool fan-out, over GPUs: files are split by size over the node's devices (one spawned
+    worker per device, or the ranks of a torchrun launch) and the sequences come back in input order (None on ranks
+    other than 0 of a torchrun launch)."""
+    from .. import dist as podist
+    fn = decode_fn or decode_files_local
+    rank, local_rank, world = podist.env_rank_world()
+    costs = []
+    for p in in_files:
+        try:
+            costs.append(max(1, os.path.getsize(p)))
+        except OSError:
+            costs.append(1)
+    if world > 1:
+        if decode_fn is None:
+            _lib.check(_lib.load().po_set_device(local_rank), "po_set_device")
+        return podist.decode_distributed(in_files, costs, fn, args)
+    threads = getattr(args, 'threads', 1)
+    devs = podist.plan_devices(len(in_files), devices, threads if threads and threads > 1 else None)
+    if len(devs) <= 1:
+        if devs and devs[0] != 0 and decode_fn is None:
+            _lib.check(_lib.load().po_set_device(devs[0]), "po_set_device")
+        return fn(in_files, args)
+    return podist.run_sharded(in_files, costs, fn, devs, args, bind_device=decode_fn is None)
+
+
 def decode_helper(in_path, args):
     """decode.py:169-192 for one file"""
     model = model_from_trace(in_path, args.basecaller)
@@ -148,8 +202,9 @@ def decode(args):
         in_files = sorted(glob.glob("{}/*{}".format(in_path[0], file_ext)))
     if len(in_files) > 1:
         logger.info("found {} reads to decode".format(len(in_files)))
-        models = [model_from_trace(p, args.basecaller) for p in in_files]
-        seqs = decode_models(models, args)
+        seqs = decode_files(in_files, args)
+        if seqs is None:   # a rank other than 0 of a torchrun launch: rank 0 writes the file
+            return
         with open(args.out + '.fasta', 'w') as out_f:
             for p, s in zip(in_files, seqs):
                 print(fasta_format(Path(p).stem, s), file=out_f)

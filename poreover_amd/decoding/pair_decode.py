@@ -193,9 +193,49 @@ def _decode_pairs_split(in_paths, loaded, args, out):
     return out
 
 
-def decode_pairs(in_paths, args):
-    """pair_decode_helper for a LIST of pairs: returns a list of the reference's return tuples
-    (1-, 2- or 3-tuples, pair_decode.py:375,398,526-529)."""
+def _pair_cost(in_path, args):
+    """Cost proxy of a pair before anything is decoded: bytes of its two trace files (proportional to the frames
+    U + V)."""
+    tot = 0
+    for p in in_path[:2]:
+        q = Path(p)
+        if q.suffix == ".fast5":
+            q = q.with_suffix(".npy")
+        try:
+            tot += os.path.getsize(os.path.join(args.dir, q))
+        except OSError:
+            tot += 1
+    return max(tot, 1)
+
+
+def decode_pairs(in_paths, args, devices=None, decode_fn=None):
+    """pair_decode_helper for a LIST of pairs, spread over the GPUs of the node where the reference spreads them
+    over processes (pair_decode.py:292-297): returns the reference's return tuples in input order.
+      * under torchrun (WORLD_SIZE > 1): this rank decodes its shard on device LOCAL_RANK, rank 0 gets every record,
+        the other ranks None;
+      * otherwise one spawned worker process per visible device (devices=[...] names them; an index may repeat),
+        or this process alone when there is one device or one pair.
+    decode_fn(list_of_pairs, args) -> records replaces the engine call (tests inject a CPU function)."""
+    from .. import dist as podist
+    fn = decode_fn or decode_pairs_local
+    rank, local_rank, world = podist.env_rank_world()
+    costs = [_pair_cost(p, args) for p in in_paths]
+    if world > 1:
+        if decode_fn is None:
+            _lib.check(_lib.load().po_set_device(local_rank), "po_set_device")
+        return podist.decode_distributed(in_paths, costs, fn, args)
+    threads = getattr(args, 'threads', 1)
+    devs = podist.plan_devices(len(in_paths), devices, threads if threads and threads > 1 else None)
+    if len(devs) <= 1:
+        if devs and devs[0] != 0 and decode_fn is None:
+            _lib.check(_lib.load().po_set_device(devs[0]), "po_set_device")
+        return fn(in_paths, args)
+    return podist.run_sharded(in_paths, costs, fn, devs, args, bind_device=decode_fn is None)
+
+
+def decode_pairs_local(in_paths, args):
+    """pair_decode_helper for a list of pairs on THIS process's device: returns a list of the reference's return
+    tuples (1-, 2- or 3-tuples, pair_decode.py:375,398,526-529)."""
     _check_supported(args)
     loaded = [_load_pair(p, args) for p in in_paths]
     out = [None] * len(loaded)
@@ -203,15 +243,35 @@ def decode_pairs(in_paths, args):
         return _decode_pairs_split(in_paths, loaded, args, out)
     if getattr(args, 'skip_matches', False):
         return _decode_pairs_skip_matches(in_paths, loaded, args, out)
-    by_kind = {}
-    for i, (_, _, m1, _) in enumerate(loaded):
-        by_kind.setdefault(m1.kind, []).append(i)
-    for kind, idx in by_kind.items():
-        res = _batch.pair_decode_batch([loaded[i][2].log_prob for i in idx], [loaded[i][3].log_prob for i in idx],
-                                       kind=kind, beam_width=args.beam_width, method=args.beam_search_method,
-                                       padding=args.padding, alignment=args.alignment,
-                                       diagonal_envelope=args.diagonal_envelope,
-                                       diagonal_width=args.diagonal_width, single=getattr(args, 'single', 'viterbi'))
+    # pairs that can share one engine call: same kind, same input form (float32 logits / uint8 trace / float64
+    # log-probabilities) and the same pending column order / reversal — with --reverse_complement on raw logits that
+    # is every pair of the file, and the log-softmax, the permutations and the reversal run on the device
+    groups = {}
+    for i, (_, _, m1, m2) in enumerate(loaded):
+        if getattr(args, 'single', 'viterbi') != 'viterbi' or m1.engine_input()[3]:
+            key = (m1.kind, 'host')          # --single beam works on the float64 tables
+        else:
+            e1, e2 = m1.engine_input(), m2.engine_input()
+            key = (m1.kind, e1[1], tuple(e1[2]), e2[1], tuple(e2[2]), e2[3]) if e1[1] == e2[1] else (m1.kind, 'host')
+        groups.setdefault(key, []).append(i)
+    for key, idx in groups.items():
+        kind = key[0]
+        common = dict(kind=kind, beam_width=args.beam_width, method=args.beam_search_method, padding=args.padding,
+                      alignment=args.alignment, diagonal_envelope=args.diagonal_envelope,
+                      diagonal_width=args.diagonal_width)
+        if key[1] == 'host' and getattr(args, 'single', 'viterbi') != 'viterbi':
+            res = _batch.pair_decode_batch([loaded[i][2].log_prob for i in idx], [loaded[i][3].log_prob for i in idx],
+                                           single=args.single, **common)
+        elif key[1] == 'host':
+            res = _batch.pair_decode_stream([loaded[i][2].log_prob for i in idx], [loaded[i][3].log_prob for i in idx],
+                                            strict=False, **common)
+        else:
+            ident = list(range(len(key[2])))
+            res = _batch.pair_decode_stream([loaded[i][2].engine_input()[0] for i in idx],
+                                            [loaded[i][3].engine_input()[0] for i in idx],
+                                            perm1=None if list(key[2]) == ident else list(key[2]),
+                                            perm2=None if list(key[4]) == ident else list(key[4]), reverse2=key[5],
+                                            strict=False, **common)
         for i, r in zip(idx, res):
             in_path = in_paths[i]
             path1, path2 = loaded[i][0], loaded[i][1]
@@ -221,6 +281,15 @@ def decode_pairs(in_paths, args):
                           {'read1': in_path[0], 'read2': in_path[1]})
                 continue
             summary = {'read1': in_path[0], 'read2': in_path[1], 'length1': r["length1"], 'length2': r["length2"]}
+            if r["status"] not in (0, _lib.SKIP_LENGTH, _lib.SKIP_IDENTITY):
+                # a per-pair engine refusal (capacity, an envelope the reference itself is undefined on): the pair is
+                # reported and skipped, the other pairs of the batch are unaffected
+                logging.getLogger("poreover_amd").warning("pair %s %s not decoded: %s", in_path[0], in_path[1],
+                                                          _lib._CODE_NAMES.get(r["status"], r["status"]))
+                summary['skipped'] = 1
+                summary['error'] = _lib._CODE_NAMES.get(r["status"], str(r["status"]))
+                out[i] = [summary]
+                continue
             if r["status"] == _lib.SKIP_LENGTH:
                 summary['skipped'] = 1
                 out[i] = [summary]
@@ -254,6 +323,8 @@ def pair_decode(args):
             pairs = [line.split() for line in read_pairs if line.split()]
         logger.info("found {} read pairs in {}".format(len(pairs), in_path[0]))
         results = decode_pairs(pairs, args)
+        if results is None:   # a rank other than 0 of a torchrun launch: rank 0 writes the files
+            return
         keys = ["read1", "read2", "length1", "length2", "sequence_identity", "skipped"]
         with open(args.out + '.1d.fasta', 'w') as out_1d_f, open(args.out + '.2d.fasta', 'w') as out_2d_f, \
                 open(args.out + '.log', 'w', 1) as log_f:

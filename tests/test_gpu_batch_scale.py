@@ -1,0 +1,76 @@
+"""GPU parity at BATCH scale (BASELINE config 4's per-GPU job in miniature): the first 1024 pairs of the bench
+workload (synth_pair(seed, T=4000), W = 5, row_col) decoded by ONE po_pair_decode_batch call, compared pair by
+pair with the committed digests of the CPU oracle's results (tests/golden/batch_digest.json, made by
+tests/golden/make_batch_digest.py).  Any pair whose digest differs is decoded again by the oracle and must stay
+inside the stated tolerance: identical Viterbi basecalls, consensus within 0.1 % edit distance over the batch."""
+import json
+import os
+from multiprocessing import get_context
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, REPO
+
+pytestmark = pytest.mark.gpu
+
+NPAIRS = 1024
+
+
+def _gen(seed):
+    from poreover_amd.synth import synth_pair
+    return synth_pair(seed, T=4000)
+
+
+def _digest(seq1, seq2, cons):
+    import hashlib
+    return hashlib.md5(("%s|%s|%s" % (seq1, seq2, cons if cons is not None else "")).encode()).hexdigest()[:10]
+
+
+def levenshtein(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+@pytest.fixture(scope="module")
+def workload():
+    # generated in worker processes started with "spawn" (this pytest process holds a HIP context)
+    with get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
+        pairs = pool.map(_gen, range(NPAIRS), chunksize=16)
+    with open(os.path.join(GOLDEN_DIR, "batch_digest.json")) as f:
+        dig = json.load(f)
+    assert dig["T"] == 4000 and dig["beam_width"] == 5 and dig["method"] == "row_col" and len(dig["records"]) >= NPAIRS
+    return pairs, dig["records"][:NPAIRS]
+
+
+@pytest.mark.parametrize("route", ["default", "x2"])
+def test_batch_1024_pairs_vs_oracle_digest(workload, oracle, route, monkeypatch):
+    from poreover_amd import _lib, batch
+    _lib.load()
+    if route == "x2":
+        monkeypatch.setenv("PO_X2_FORCE", "1")
+    pairs, recs = workload
+    got = batch.pair_decode_batch([p[0] for p in pairs], [p[1] for p in pairs], "poreover", 5, "row_col")
+    assert len(got) == NPAIRS
+    bad = []
+    for i, (g, r) in enumerate(zip(got, recs)):
+        st, l1, l2, lc, dg = r
+        if (g["status"], g["length1"], g["length2"], len(g["consensus"] or "")) != (st, l1, l2, lc) or \
+                _digest(g["seq1"], g["seq2"], g["consensus"]) != dg:
+            bad.append(i)
+    edits = 0
+    for i in bad:   # beam search near-ties may legitimately differ in the last ulp of exp / log: bounded by edit distance
+        want = oracle.pair_decode(pairs[i][0], pairs[i][1], "poreover", 5, "row_col")
+        assert got[i]["status"] == want["status"], i
+        assert (got[i]["seq1"], got[i]["seq2"]) == (want["seq1"], want["seq2"]), i      # Viterbi: bit-exact
+        edits += levenshtein(got[i]["consensus"] or "", want["consensus"] or "")
+    total = sum(r[3] for r in recs)
+    assert edits <= 0.001 * total, "%d pairs differ, %d edits in %d consensus bases" % (len(bad), edits, total)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "batch_scale_%s.json" % route), "w") as f:
+        json.dump({"pairs": NPAIRS, "route": route, "digest_mismatches": len(bad), "edits": edits, "consensus_bases": total}, f)

@@ -58,10 +58,12 @@ def _edit_distance(a, b):
 def test_ingest_real(eng, real):
     g, inp, y1, y2 = real
     got1, got2 = eng.ingest_batch([np.concatenate(inp["read1_logits"]), np.concatenate(inp["read2_logits"])])
-    # float32 arithmetic on both sides (device expf / log1pf vs numpy's): agreement to 2 float32 ulp
+    # float32 arithmetic on both sides (device expf / log1pf vs numpy's): x - lse agrees to 2 float32 ulp of the
+    # subtrahend lse (|lse| < 16 here: ulp 9.5e-7), most values bit for bit
     for got, want in ((got1, y1), (got2, y2)):
         assert got.shape == want.shape and got.dtype == np.float64
-        assert np.allclose(got, want, rtol=2.4e-7, atol=1e-7)
+        assert np.abs(got - want).max() <= 2e-6
+        assert (got == want).mean() > 0.5
         assert np.array_equal(got.astype(np.float32).astype(np.float64), got)      # float32 values, widened
     rc = eng.ingest_batch([np.concatenate(inp["read2_logits"])], perm=[3, 2, 1, 0, 4], reverse=True)[0]
     assert np.array_equal(rc, got2[::-1][:, [3, 2, 1, 0, 4]])
