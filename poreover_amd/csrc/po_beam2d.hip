@@ -112,6 +112,26 @@ __device__ __forceinline__ void b2_sync_lds() {
     }
 }
 
+// Workgroup barrier that also makes earlier GLOBAL stores of the workgroup visible to its later loads.  With one
+// wave per workgroup nothing has to be waited for: a wave's vector memory operations are performed in execution
+// order and its CU's L1 is write-through, so a load issued after a store of the same wave sees it — __syncthreads()
+// would drain every outstanding store (s_waitcnt vmcnt(0)) once per step for nothing.
+template <int NTHR>
+__device__ __forceinline__ void b2_sync_mem() {
+    if constexpr (NTHR == 64) b2_sync_lds<64>();
+    else __syncthreads();
+}
+// barrier + "does any thread of the workgroup say yes"
+template <int NTHR>
+__device__ __forceinline__ bool b2_any(bool p) {
+    if constexpr (NTHR == 64) {
+        b2_sync_lds<64>();
+        return __ballot(p) != 0ull;
+    } else {
+        return __syncthreads_or(p) != 0;
+    }
+}
+
 // element-table field indices
 enum { F_ID, F_ROW, F_PSLOT, F_SYM, F_FC, F_CROW, F_PAR, F_GPAR, F_PROW, F_DEPTH, F_COUNT };
 // F_SYM packs: own symbol (bits 0-2) | parent's symbol (bits 4-6) | parent-is-root (bit 9)
@@ -127,6 +147,7 @@ struct B2Smem {
     int e[F_COUNT][NCM];    // element table: slots [0, nb) are the beam nodes in rank order
     int nx[F_COUNT][WMAX];  // next beam under construction
     int sel[WMAX];
+    int cu_ps[WMAX];        // parent slots of the beam nodes in catch-up scans (parents among the beam nodes only)
     int stay[WMAX];         // beam slot was a beam slot in the previous main step (its children were elements then)
     int cnew[WMAX];         // its children got new rows in this step
     int badf[NCM];          // element may not skip redundant stores (see scan)
@@ -136,10 +157,13 @@ struct B2Smem {
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[16];
     double score[NCM];
-    double mxs[2][NCP];
-    // incremental main steps: per (read, slot) the maximum of the previous main step's window and its (latest) time
+    // (the window maxima of the scan just finished, mxs[r][s], live in xch[0][r][s][0]: the exchange buffer is idle
+    //  between two scans, and xch[1] keeps the seeds of windows that continue)
+    // incremental main steps: per (read, slot) the maximum of the previous main step's window, its time, and the time
+    // from which the values of that window were non-increasing (ctd)
     double cmx[2][NCP];
     int cmt[2][NCP];
+    int ctd[2][NCP];
     double xch[2][2][NCP][K];
     static constexpr int YD = (WMAX <= 6) ? B2_YD6 : B2_YD;
     double ybuf[2][YD];     // the y rows of the current step's windows, per read
@@ -157,7 +181,7 @@ template <int MODEL, int WMAX>
 // (4 waves per SIMD are what the W <= 6 class lives on — see B2_YD6.  It compiles to 124 / 128 VGPRs (ctc / merge
 // repeats); an edit that costs four more registers costs a quarter of the throughput — check with
 // -Rpass-analysis=kernel-resource-usage.  Forcing the bound here makes the allocator's choices 2 % worse today.)
-__global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX == 12) ? 4 : 1)) void beam2d_kernel(B2Args a) {
+__global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <= 12) ? 4 : 1)) void beam2d_kernel(B2Args a) {
     using SM = B2Smem<MODEL, WMAX>;
     constexpr int K = SM::K, NCM = SM::NCM, NCP = SM::NCP, nthr = 2 * NCP;
     using Ent = Entry<K>;
@@ -405,7 +429,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             sm.sh[3] = 1;      // group allocation cursor
             sm.sh[4] = PO_OK;
             sm.sh[8] = INT_MIN; sm.sh[9] = INT_MIN;  // window ends of the previous row_col main step: none yet
-            sm.sh[10] = 0; sm.sh[11] = 0; sm.sh[12] = 0; sm.sh[13] = 0; sm.sh[14] = 0;  // incremental steps: nothing to build on yet
+            sm.sh[10] = 0; sm.sh[11] = 0; sm.sh[12] = 0; sm.sh[13] = 0; sm.sh[14] = 0; sm.sh[15] = 0;  // incremental steps: nothing to build on yet
         }
         if (tid < WMAX) sm.stay[tid] = 0;
         if (tid < A) {
@@ -454,22 +478,42 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             bool same = false, rootpar = false;
             double self[K], mx = PO_NEG_INF;
             int mt = -1;
+            int td = t0f;   // the values of this window are non-increasing from time td on (maintained as they are computed)
             if (partf && t0 > t0f) {   // the carried part [t0f, t0) of the window
                 const double pm = sm.cmx[r][s];
                 const int pt = sm.cmt[r][s];
+                td = sm.ctd[r][s];
+#ifdef PO_ABL_NOREREAD   // timing ablation only (results are wrong)
+                if (true) { mx = pm; mt = pt; }
+#else
                 if (pm == PO_NEG_INF || (pt >= t0f && pt < t0)) { mx = pm; mt = pt; }
+#endif
                 else {
+                    // the carried maximum's time has left the window
                     const Ent* rp = pool + ((size_t)sm.e[F_ROW][s] * 2 + r) * R;
                     const unsigned long long tg = make_tag(epoch, sm.e[F_ID][s], 0);
-                    for (int bt = t0f; bt < t0; bt += 4) {
-                        Ent e4[4];
+                    if (td <= t0f) {
+                        // ... whose carried part is non-increasing (a node past its peak decays frame by frame — the usual
+                        // case): its maximum is its first value, one entry of the element's own ring row
+                        const Ent e = rp[t0f & Rm];
+                        mx = (e.tag == tg + (unsigned)t0f) ? e.v[0] : PO_NEG_INF;
+                        mt = t0f;
+                    } else {
+                        // ... otherwise the stored values of [t0f, t0) are read back
+                        double pv = PO_NEG_INF;
+                        td = t0f;
+                        for (int bt = t0f; bt < t0; bt += 4) {
+                            Ent e4[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) e4[q] = rp[(bt + q) & Rm];
+                            for (int q = 0; q < 4; ++q) e4[q] = rp[(bt + q) & Rm];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int tq = bt + q;
-                            const double val = (tq < t0 && e4[q].tag == tg + (unsigned)tq) ? e4[q].v[0] : PO_NEG_INF;
-                            if (tq < t0 && val >= mx) { mx = val; mt = tq; }
+                            for (int q = 0; q < 4; ++q) {
+                                const int tq = bt + q;
+                                const double val = (tq < t0 && e4[q].tag == tg + (unsigned)tq) ? e4[q].v[0] : PO_NEG_INF;
+                                if (tq < t0 && val >= mx) { mx = val; mt = tq; }
+                                if (tq < t0 && tq > t0f && val > pv) td = tq;
+                                pv = val;
+                            }
                         }
                     }
                 }
@@ -479,24 +523,33 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             unsigned long long tag0 = 0, ptag0 = 0;
             if (part) {
                 const int node = sm.e[F_ID][s];
-                pslot = sm.e[F_PSLOT][s];
+                pslot = is_main ? sm.e[F_PSLOT][s] : sm.cu_ps[s];
                 const int sy = sm.e[F_SYM][s];
                 sym = sym_last(sy); same = (sym_plast(sy) == sym); rootpar = (sy >> 9) & 1;
                 myrow = pool + ((size_t)sm.e[F_ROW][s] * 2 + r) * R;
                 tag0 = make_tag(epoch, node, 0);
-                bool hit = false;
-                if (t0 >= 1) {
-                    const Ent e = myrow[(t0 - 1) & Rm];
-                    hit = (e.tag == tag0 + (unsigned)(t0 - 1));
+                // The value at t0 - 1.  A window that continues the previous main step's (t0 == that step's window end,
+                // same slot layout) starts from the value this lane computed last, which every main scan leaves in
+                // xch[1] (below) — no round trip to the store.  Catch-up scans only touch the slots of the read they
+                // advance, and a read they advance restarts its windows from t0f.
+                if (t0 > t0f) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) self[k] = e.v[k];
+                    for (int k = 0; k < K; ++k) self[k] = sm.xch[1][r][s][k];
+                } else {
+                    bool hit = false;
+                    if (t0 >= 1) {
+                        const Ent e = myrow[(t0 - 1) & Rm];
+                        hit = (e.tag == tag0 + (unsigned)(t0 - 1));
+#pragma unroll
+                        for (int k = 0; k < K; ++k) self[k] = e.v[k];
+                    }
+                    if (!hit) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) self[k] = PO_NEG_INF;
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) sm.xch[1][r][s][k] = self[k];
                 }
-                if (!hit) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) self[k] = PO_NEG_INF;
-                }
-#pragma unroll
-                for (int k = 0; k < K; ++k) sm.xch[1][r][s][k] = self[k];
                 if (pslot == PS_FROZEN) {
                     prow = pool + ((size_t)sm.e[F_PROW][s] * 2 + r) * R;
                     ptag0 = make_tag(epoch, sm.e[F_PAR][s], 0);
@@ -514,13 +567,13 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 bad = false;
                 if (s < nelem && s >= nb) bad = !(sm.stay[pslot] && !sm.cnew[pslot]);
                 if (r == 0 && s < nelem) sm.badf[s] = bad;
-                __syncthreads();
+                b2_sync_lds<nthr>();
                 for (;;) {
                     int changed = 0;
                     if (s < nelem && !bad && pslot >= 0 && sm.badf[pslot]) { bad = true; changed = 1; }
-                    if (!__syncthreads_or(changed)) break;
+                    if (!b2_any<nthr>(changed)) break;
                     if (r == 0 && bad && s < nelem) sm.badf[s] = 1;
-                    __syncthreads();
+                    b2_sync_lds<nthr>();
                 }
             }
             const int sfrom = bad ? INT_MIN : sm.sh[8 + r];  // first time whose value must be written
@@ -547,7 +600,11 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             {
                 const int nrow = min(len, k0 + yrows) - k0;  // this read's rows in the chunk (<= 0: none)
                 const double* src = yr_ + (int64_t)(t0 + k0) * C;
+#ifdef PO_ABL_NOYLOAD     // timing ablation only (results are wrong)
+                if (nrow * C > 1000000) sm.ybuf[r][s] = src[s];
+#else
                 for (int i = s; i < nrow * C; i += NCP) sm.ybuf[r][i] = src[i];
+#endif
             }
             b2_sync_lds<nthr>();  // y rows (and, first time, the seeds in xch[1]) -> visible to the iterations
             TK(is_main ? 3 : 7);  // scan: self read + y rows
@@ -582,6 +639,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                         myrow[t & Rm] = e;
                     }
 #endif
+                    if (out[0] > self[0]) td = t;   // (the first value of a window is compared with the one before it: harmless)
 #pragma unroll
                     for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }
                     if (out[0] >= mx) { mx = out[0]; mt = t; }
@@ -590,10 +648,14 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             }
             TK(is_main ? 5 : 9);  // scan: iterations
             }
-            if (s < nelem) sm.mxs[r][s] = mx;
-            if (is_main && partf) { sm.cmx[r][s] = mx; sm.cmt[r][s] = mt; }
+            if (s < nelem) sm.xch[0][r][s][0] = mx;   // "mxs"
+            if (is_main && partf) { sm.cmx[r][s] = mx; sm.cmt[r][s] = mt; sm.ctd[r][s] = td; }
+            if (is_main && part) {   // the last value of this window: the seed of a window that continues it
+#pragma unroll
+                for (int q = 0; q < K; ++q) sm.xch[1][r][s][q] = self[q];
+            }
             if (is_main && tid == 0) { if (len0_ > 0) sm.sh[12] = 1; if (len1_ > 0) sm.sh[13] = 1; }
-            if (tid == 0) {   // profiling (skipped slots counted too)
+            if (a.upd_count != nullptr && tid == 0) {   // profiling (skipped slots counted too)
                 sm.nupd += (unsigned)(nelem * (len0_ + len1_));
                 sm.nupd_x += (unsigned)(nelem * (len0 + len1));
             }
@@ -618,6 +680,23 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
         // expansion of the processed elements + children slots.  Regular shape: every beam node is
         // processed, child c of beam node j sits at nb + A*j + c.  lo0/lo1: see alloc_group.
         auto build_regular = [&](int lo0, int lo1, int hi0, int hi1) -> int {
+            // STEADY TABLE.  After a prune that left the beam exactly as it was (same nodes, same slots: sh[14]), every
+            // beam node was expanded in the previous main step and its children's row group was marked with that
+            // step's window ends — later than anything a new allocation would have treated as free since — so nothing
+            // is created, nothing re-allocated, and the element table of the previous step IS this step's, entry for
+            // entry (catch-up scans keep their parent slots elsewhere).  Only the window ends written into the row
+            // groups move on.
+            if (sm.sh[14] != 0 && sm.sh[15] != 0) {
+                if (tid < nb) {
+                    const int gc = sm.e[F_CROW][tid], go = sm.e[F_ROW][tid] / PO_A;
+                    atomicMax(&sm.g_hi0[gc], hi0); atomicMax(&sm.g_hi1[gc], hi1);
+                    atomicMax(&sm.g_hi0[go], hi0); atomicMax(&sm.g_hi1[go], hi1);
+                }
+                if (tid < nb) sm.cnew[tid] = 0;
+                if (tid == 0) sm.sh[11] = 1;
+                po_lds_barrier();
+                return nb * (A + 1);
+            }
             // one lane per beam node (nb <= 25: the first wave).  New node ids are handed out in beam order — a prefix
             // count over the lanes that need them (ids break score ties); row groups, which only name storage, are
             // allocated one after the other by lane 0 and marked with this step's window ends at once.
@@ -665,6 +744,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
             }
             po_lds_barrier();
             const int ne = nb * (A + 1);
+            if (tid == 0) sm.sh[15] = 1;   // a regular table now stands in e[]
             if (tid < ne) {
                 if (tid < nb) {
                     sm.e[F_PSLOT][tid] = beam_parent(tid, nb, true);
@@ -723,7 +803,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                         for (int i = 0; i < ne; ++i) if (sm.e[F_ID][i] == sm.e[F_PAR][j]) ps = i;
                     sm.e[F_PSLOT][j] = ps;
                 }
-                sm.sh[2] = next_id; sm.sh[6] = ne; sm.sh[7] = np; sm.sh[11] = 0;
+                sm.sh[2] = next_id; sm.sh[6] = ne; sm.sh[7] = np; sm.sh[11] = 0; sm.sh[15] = 0;
             }
             po_lds_barrier();
             *nproc = sm.sh[7];
@@ -761,7 +841,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                     if (tid >= nb) viol = !po_better(sm.score[nb - 1], sm.e[F_ID][nb - 1], sc, id);
                     else if (tid + 1 < nb) viol = !po_better(sc, id, sm.score[tid + 1], sm.e[F_ID][tid + 1]);
                 }
-                same_beam = !__syncthreads_or(viol);
+                same_beam = !b2_any<nthr>(viol);
             }
             if (same_beam) {
                 if (tid < nb) sm.stay[tid] = 1;
@@ -787,17 +867,25 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 // The same beam nodes in another order: every element of the next step was an element of this one, in
                 // the slot the permutation says (beam slot i <- sel[i]; its children follow it), so the carried maxima
                 // move along and the next step can still be incremental.  Anything else ends the run.
-                const bool perm = regular && nbn == nb && !__syncthreads_or(tid < nbn && sm.sel[tid] >= nb);
-                double c0 = 0.0, c1 = 0.0;
-                int t0_ = 0, t1_ = 0;
+                const bool perm = regular && nbn == nb && !b2_any<nthr>(tid < nbn && sm.sel[tid] >= nb);
+                double c0 = 0.0, c1 = 0.0, sf0[K], sf1[K];
+                int t0_ = 0, t1_ = 0, d0_ = 0, d1_ = 0;
                 if (perm && tid < ne) {
                     int src = tid;
                     if (tid < nb) src = sm.sel[tid];
                     else { const int j = ((tid - nb) * divA) >> 16; src = nb + A * sm.sel[j] + ((tid - nb) - j * A); }
                     c0 = sm.cmx[0][src]; c1 = sm.cmx[1][src]; t0_ = sm.cmt[0][src]; t1_ = sm.cmt[1][src];
+                    d0_ = sm.ctd[0][src]; d1_ = sm.ctd[1][src];
+#pragma unroll
+                    for (int q = 0; q < K; ++q) { sf0[q] = sm.xch[1][0][src][q]; sf1[q] = sm.xch[1][1][src][q]; }
                 }
                 po_lds_barrier();
-                if (perm && tid < ne) { sm.cmx[0][tid] = c0; sm.cmx[1][tid] = c1; sm.cmt[0][tid] = t0_; sm.cmt[1][tid] = t1_; }
+                if (perm && tid < ne) {
+                    sm.cmx[0][tid] = c0; sm.cmx[1][tid] = c1; sm.cmt[0][tid] = t0_; sm.cmt[1][tid] = t1_;
+                    sm.ctd[0][tid] = d0_; sm.ctd[1][tid] = d1_;
+#pragma unroll
+                    for (int q = 0; q < K; ++q) { sm.xch[1][0][tid][q] = sf0[q]; sm.xch[1][1][tid][q] = sf1[q]; }
+                }
                 if (tid == 0) {
                     if (perm) sm.sh[10] = 1;
                     else { sm.sh[10] = 0; sm.sh[12] = 0; sm.sh[13] = 0; }
@@ -852,31 +940,31 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                     const bool need = cu_v ? (v >= sm.sh[9]) : (u >= sm.sh[8]);
                     if (need) {
                         if (tid < nbe) {
-                            sm.e[F_PSLOT][tid] = beam_parent(tid, nbe, false);
+                            sm.cu_ps[tid] = beam_parent(tid, nbe, false);
                             if (cu_v) atomicMax(&sm.g_hi1[sm.e[F_ROW][tid] / PO_A], v + 1);
                             else atomicMax(&sm.g_hi0[sm.e[F_ROW][tid] / PO_A], u + 1);
                         }
-                        __syncthreads();  // store writes of earlier steps -> visible to this scan's reads
+                        b2_sync_mem<nthr>();  // store writes of earlier steps -> visible to this scan's reads
                         TK(6);
                         if (cu_v) scan(false, false, nbe, 0, 0, 0, 0, v, 1);
                         else scan(false, false, nbe, 0, 0, u, 1, 0, 0);
                         po_lds_barrier();
                     }
                     TKC(11);
-                    if (!need && tid == 0) sm.nupd += (unsigned)nbe;   // (a catch-up the reference computes and this kernel need not)
+                    if (!need && a.upd_count != nullptr && tid == 0) sm.nupd += (unsigned)nbe;   // (a catch-up the reference computes and this kernel need not)
                     if (cu_v) { v++; ec_c = ec_n; } else { u++; er_c = er_n; }
                     continue;
                 }
                 if (!row_ok || !col_ok) { st = PO_E_ENVELOPE; break; }  // uninitialised bounds upstream (:309)
                 // ---- MAIN step at (u, v): windows [u, ece) x [v, ere)  (:342-375)
                 const int ne = build_regular(u - 1, v - 1, ece, ere);
-                __syncthreads();  // arena + store writes -> visible to the reads below
+                b2_sync_mem<nthr>();  // arena + store writes -> visible to the reads below
                 if (sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
                 TK(2);
                 scan(true, true, ne, 0, 0, u, ece - u, v, ere - v);
                 po_lds_barrier();
                 if (tid == 0) { sm.sh[8] = ece; sm.sh[9] = ere; }
-                if (tid < ne) sm.score[tid] = sm.mxs[0][tid] + sm.mxs[1][tid];  // node_greater_max_sym
+                if (tid < ne) sm.score[tid] = sm.xch[0][0][tid][0] + sm.xch[0][1][tid][0];  // node_greater_max_sym (window maxima: see B2Smem)
                 prune_and_advance(ne, true);
                 TK(1);
                 u++;
@@ -895,7 +983,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 const bool regular = (nb == W);
                 if (regular) { ne = build_regular(u - 1, rs - 1, u + 1, re); nproc = nb; }
                 else ne = build_growing(u - 1, rs - 1, u + 1, re, &nproc);
-                __syncthreads();
+                b2_sync_mem<nthr>();
                 if (sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
                 TK(2);
                 // every element is updated on read 0 at time u except beam nodes beyond the first W
@@ -908,7 +996,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                 if (tid == 0) { sm.sh[8] = u + 1; sm.sh[9] = (wlen > 0) ? re : sm.sh[9]; }
                 if (tid < ne) {  // node_greater_max: last_prob[0] + max_prob[1]
                     const int id = sm.e[F_ID][tid];
-                    double m0 = sm.mxs[0][tid], m1 = sm.mxs[1][tid];
+                    double m0 = sm.xch[0][0][tid][0], m1 = sm.xch[0][1][tid][0];   // window maxima of the scan (see B2Smem)
                     if (tid >= skip_lo && tid < skip_hi) {  // last_prob[0] is still the seed value at t = 0
                         double tmp[K];
                         st_read(sm.e[F_ROW][tid], 0, 0, id, tmp);
@@ -918,7 +1006,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX =
                     else m1 = amax[id];           // empty band: max_prob[1] keeps its last value
                     sm.score[tid] = m0 + m1;
                 }
-                __syncthreads();
+                b2_sync_mem<nthr>();
                 prune_and_advance(ne, regular);
                 TK(1);
             }
