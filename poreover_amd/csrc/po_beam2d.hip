@@ -90,6 +90,8 @@ struct B2Args {
     int* cellb;                        // grid method: two rows of per-cell beams per workgroup (2 * vcap * (1 + 6 W) ints)
     int retry_nomem;                   // second pass with a larger store: decode only the pairs the first one gave PO_E_NOMEM
     unsigned long long* upd_count;     // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
+    unsigned long long* wgstate;       // per workgroup {magic, epoch counter}: what its slice of the value store was last tagged with
+    unsigned long long magic;          // names this workspace geometry: a slice whose state word differs is cleared before use
 };
 
 // F_PSLOT of an element whose parent does not move in the scan: a frozen parent (its values are read from
@@ -203,7 +205,31 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
     double* cum0 = a.cum + (size_t)blockIdx.x * 2 * a.tcap;
     double* cum1 = cum0 + a.tcap;
     int* envt = a.envt + (size_t)blockIdx.x * 2 * a.vcap;
+    // The store's tags carry a 16-bit epoch that is new for every pair a workgroup decodes, so entries of earlier
+    // pairs never match and nothing has to be cleared between pairs.  The same holds BETWEEN LAUNCHES: the epoch
+    // counter of a workgroup lives in the workspace next to a magic word naming the workspace geometry, a launch
+    // continues where the previous one stopped, and the slice is cleared only when the word is not there (first
+    // use of this memory) or when the 16 bits wrap around (every 65 535 pairs of this workgroup) — instead of a
+    // memset of the whole store (8 GB for 4096 workgroups) before every launch.
     unsigned epoch = 0;
+    auto clear_slice = [&]() {
+        __syncthreads();
+        for (long long i = tid; i < pool_entries; i += nthr) pool[i].tag = 0ull;
+        __syncthreads();
+    };
+    {
+        unsigned long long* stp = a.wgstate + 2 * (size_t)blockIdx.x;
+        if (tid == 0) {
+            const bool ok = (stp[0] == (a.magic ^ (unsigned long long)blockIdx.x));
+            sm.sh[0] = ok ? 1 : 0;
+            sm.sh[1] = ok ? (int)(unsigned)stp[1] : 0;
+        }
+        __syncthreads();
+        const bool ok = sm.sh[0] != 0;
+        epoch = (unsigned)sm.sh[1];
+        __syncthreads();
+        if (!ok) clear_slice();
+    }
 #ifdef PO_LAE_OCML
     const PoLaeOcml lae;
 #else
@@ -229,6 +255,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
         const int pi = sm.sh[0];
         if (pi >= a.n) break;
         epoch++;
+        if ((epoch & 0xffffu) == 0) { clear_slice(); epoch++; }   // (epoch 0 is what a cleared tag reads as)
         TK_START();
         if (a.only_meta && a.only_meta[pi].y != X2_DEFERRED) continue;  // done by beam2d_x2_kernel
         if (a.retry_nomem) {
@@ -1034,6 +1061,11 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
         }
         if (a.upd_count && tid == 0) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
         TK(10);  // label walk
+    }
+    if (tid == 0) {   // the next launch on this workspace continues from here
+        unsigned long long* stp = a.wgstate + 2 * (size_t)blockIdx.x;
+        stp[0] = a.magic ^ (unsigned long long)blockIdx.x;
+        stp[1] = (unsigned long long)epoch;
     }
 #ifdef PO_B2_TIMING
     if (tid == 0 && a.dbg && blockIdx.x == 0)
@@ -2313,7 +2345,8 @@ namespace {
 struct B2Geom {
     int threads, blocks, wclass;
     size_t pool_bytes, arena_cap, tcap, vcap;
-    size_t off_queue, off_pool, off_arena, off_cum, off_envt, total;
+    size_t off_queue, off_state, off_pool, off_arena, off_cum, off_envt, total;
+    unsigned long long magic;
 };
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 
@@ -2375,8 +2408,12 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     g.vcap = (size_t)mr2;
     size_t o = 0;
     g.off_queue = o; o += 256;
+    g.off_state = o; o += al256(sizeof(unsigned long long) * 2 * (size_t)g.blocks);
     g.off_pool = o; o += g.pool_bytes * g.blocks;
     g.off_arena = o; o += al256(sizeof(int) * 5 * g.arena_cap * g.blocks);  // 3 int arrays + 1 double array
+    // the word a workgroup leaves behind in its state slot: any change of the store's geometry changes it
+    g.magic = 0x9e3779b97f4a7c15ull ^ ((unsigned long long)g.pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)g.blocks << 40) ^
+              ((unsigned long long)g.wclass << 32) ^ ((unsigned long long)K << 36);
     g.off_cum = o; o += al256(sizeof(double) * 2 * g.tcap * g.blocks);
     g.off_envt = o; o += al256(sizeof(int) * 2 * g.vcap * g.blocks);
     g.total = o + 256;
@@ -2594,14 +2631,16 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     a.cellb = nullptr;
     a.retry_nomem = retry;
     a.upd_count = g_b2_upd_counter;
+    a.wgstate = (unsigned long long*)(w + g.off_state);
+    a.magic = g.magic;
 #ifdef PO_B2_TIMING
     static long long* dbg_buf = nullptr;
     if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 12 * sizeof(long long));
     a.dbg = dbg_buf;
 #endif
-    // queue counter and the store's tags start from zero on every launch
+    // the queue counter starts from zero on every launch; the value store is NOT cleared: its tags are told apart by
+    // the epoch counters the workgroups keep in the workspace (see beam2d_kernel)
     if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-    if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
     if (g_b2_mark && !only_meta && !retry) g_b2_mark(1, stream);
     if (model == PO_MODEL_CTC) b2_launch_w<PO_MODEL_CTC>(g, a, stream);
     else if (model == PO_MODEL_MERGE) b2_launch_w<PO_MODEL_MERGE>(g, a, stream);
@@ -2656,6 +2695,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.retry_nomem = 0;
         a.dbg = nullptr; a.only_meta = nullptr;
         a.upd_count = g_b2_upd_counter;
+        a.wgstate = nullptr; a.magic = 0;   // (the grid kernel clears its store per launch)
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
         if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
         if (model == PO_MODEL_CTC) grid_launch_w<PO_MODEL_CTC>(g, a, stream);
