@@ -526,20 +526,34 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                         mx = (e.tag == tg + (unsigned)t0f) ? e.v[0] : PO_NEG_INF;
                         mt = t0f;
                     } else {
-                        // ... otherwise the stored values of [t0f, t0) are read back
+                        // ... otherwise stored values are read back — only those of [t0f, td]: from td on the values fall,
+                        // so x[td] is the maximum of the rest.  Eight loads in flight; no tag to compare (every value of
+                        // the carried part is there: this element computed it in the steps since its window was last
+                        // computed from its start, and the ring holds a whole window).
                         double pv = PO_NEG_INF;
+                        const int te = min(td + 1, t0);
                         td = t0f;
-                        for (int bt = t0f; bt < t0; bt += 4) {
-                            Ent e4[4];
+#ifdef PO_RR4
+                        for (int bt = t0f; bt < te; bt += 4) {
+                            double v8[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) e4[q] = rp[(bt + q) & Rm];
+                            for (int q = 0; q < 4; ++q) v8[q] = rp[(bt + q) & Rm].v[0];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
+#else
+                        for (int bt = t0f; bt < te; bt += 8) {
+                            double v8[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v8[q] = rp[(bt + q) & Rm].v[0];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+#endif
                                 const int tq = bt + q;
-                                const double val = (tq < t0 && e4[q].tag == tg + (unsigned)tq) ? e4[q].v[0] : PO_NEG_INF;
-                                if (tq < t0 && val >= mx) { mx = val; mt = tq; }
-                                if (tq < t0 && tq > t0f && val > pv) td = tq;
-                                pv = val;
+                                if (tq < te) {
+                                    if (v8[q] >= mx) { mx = v8[q]; mt = tq; }
+                                    if (tq > t0f && v8[q] > pv) td = tq;
+                                    pv = v8[q];
+                                }
                             }
                         }
                     }
@@ -618,6 +632,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 else if (tp >= 0) pe_n = prow[tp & Rm];
             };
             if (part && pslot < 0) fetch(0);
+            // (wave-uniform: most scans have no such element, and then the iterations skip its handling with one
+            //  scalar branch instead of two masked blocks)
+            const bool any_static = __ballot(part && pslot < 0) != 0ull;
             // The y rows of both windows go through LDS, B2_YD doubles per read at a time (buffer row =
             // iteration index).  With no vector-memory LOAD left in the iteration loop the wave never
             // waits there for the acknowledgement of its value-store writes: vmcnt counts loads and stores
@@ -636,21 +653,26 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             b2_sync_lds<nthr>();  // y rows (and, first time, the seeds in xch[1]) -> visible to the iterations
             TK(is_main ? 3 : 7);  // scan: self read + y rows
             const int kchunk = min(Lmax, k0 + yrows);
+            const double* ypa = sm.ybuf[r] + ca;   // this lane's two y entries of the chunk's first row; one row on per iteration
+            const double* ypb = sm.ybuf[r] + cb;
+            const int xsl = (pslot >= 0) ? pslot : s;
             for (int kv = k0; kv < kchunk; ++kv) {
                 const int k = __builtin_amdgcn_readfirstlane(kv);  // keeps the loop counter and branch scalar
                 if (part && k < len) {
                     const int t = t0 + k;
-                    const double* yrow = sm.ybuf[r] + (k - k0) * C;
-                    const double ya = yrow[ca], yb = yrow[cb];
+                    const double ya = *ypa, yb = *ypb;
+                    ypa += C; ypb += C;
                     double pp[K], out[K];
 #pragma unroll
-                    for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][pslot >= 0 ? pslot : s][q];
-                    if (pslot < 0) {  // rare: the parent does not move in this scan
-                        const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
+                    for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][xsl][q];
+                    if (any_static) {
+                        if (pslot < 0) {  // rare: the parent does not move in this scan
+                            const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
 #pragma unroll
-                        for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
+                            for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
+                        }
+                        if (pslot < 0 && k + 1 < len) fetch(k + 1);
                     }
-                    if (pslot < 0 && k + 1 < len) fetch(k + 1);
                     po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
                     // direct 16-byte store per lane.  (Tried: buffering 8 iterations in LDS and flushing
                     // row-contiguous 128-byte bursts to cut L2 requests — the flush's extra instructions
@@ -869,6 +891,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     else if (tid + 1 < nb) viol = !po_better(sc, id, sm.score[tid + 1], sm.e[F_ID][tid + 1]);
                 }
                 same_beam = !b2_any<nthr>(viol);
+#ifdef PO_ABL_ALWAYSSAME   // timing ablation only (results are wrong): every prune keeps the beam
+                same_beam = true;
+#endif
             }
             if (same_beam) {
                 if (tid < nb) sm.stay[tid] = 1;
