@@ -2375,6 +2375,19 @@ struct B2Geom {
 };
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 
+// device memory a pair-beam workspace may plan with (a fixed share of the board's memory: the size reported by
+// po_*_workspace_bytes and the size a launch expects must agree whatever else is allocated)
+size_t b2_mem_budget() {
+    static size_t tot = 0;
+    if (!tot) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) tot = p.totalGlobalMem;
+        if (!tot) tot = (size_t)288 << 30;
+    }
+    return tot / 4;
+}
+
 int b2_num_cus() {
     static int cus = 0;
     if (!cus) {
@@ -2431,6 +2444,12 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     g.arena_cap = ((size_t)(1 + PO_A + (int64_t)PO_A * WM * (steps + 1)) + 1) & ~size_t(1);  // even: a double array follows
     g.tcap = (size_t)std::max(mr1, mr2);
     g.vcap = (size_t)mr2;
+    {   // long reads: the per-workgroup arena grows with the read length — fewer resident workgroups rather than a
+        // workspace beyond the board's memory (reads of 10^5 frames: ~40 MB each)
+        const size_t per_block = g.pool_bytes + sizeof(int) * 5 * g.arena_cap + sizeof(double) * 2 * g.tcap + sizeof(int) * 2 * g.vcap;
+        const size_t fit = std::max<size_t>(1, b2_mem_budget() / std::max<size_t>(per_block, 1));
+        if ((size_t)g.blocks > fit) g.blocks = (int)fit;
+    }
     size_t o = 0;
     g.off_queue = o; o += 256;
     g.off_state = o; o += al256(sizeof(unsigned long long) * 2 * (size_t)g.blocks);
@@ -2505,6 +2524,11 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.pool_bytes = al256((size_t)(model == PO_MODEL_CTC ? 2 : 4) << (W <= 6 ? 20 : 21));  // 128 (256) row groups of R <= 128 entries
     const int64_t WM = W > PO_A ? W : PO_A;
     g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 1));
+    {   // as in b2_geometry: within the memory budget for long reads
+        const size_t per_block = (g.pool_bytes + sizeof(int) * 3 * g.arena_cap) * npw;
+        const size_t fit = std::max<size_t>(1, b2_mem_budget() / std::max<size_t>(per_block, 1));
+        if ((size_t)g.blocks > fit) g.blocks = (int)fit;
+    }
     size_t o = 0;
     g.off_queue = o; o += 256;
     g.off_meta = o; o += al256(sizeof(int2) * (size_t)(n > 0 ? n : 1));

@@ -40,6 +40,7 @@ struct PPArgs {
     int band;                                       // banded alignment half-width (align.pyx:13: 500)
     long long seq_lds_cap;                          // bytes of dynamic LDS per basecall (0: read them from global memory)
     int mode;                                       // 0: align + skips + envelope; 1: align only; 2: envelope from a given alignment
+    int retry_cap;                                  // second pass with the big DP slices: only the pairs the first one gave PO_E_CAP
     const int32_t* lenU; const int32_t* lenV;       // mode 2: U_i, V_i given explicitly (y*_off unused)
     const int64_t* map1_off; const int64_t* map2_off;  // mode 2: offsets of the frame maps
     char* aln_out1; char* aln_out2; const int64_t* aln_off; int32_t* ncol_out;  // mode 1 out / mode 2 in (forward order)
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         __syncthreads();
         const int pi = sh[0];
         if (pi >= a.n) break;
+        if (a.retry_cap && a.status[pi] != PO_E_CAP) continue;   // decoded (or refused for good) by the first pass
 #ifdef PO_PP_TIMING
         long long tk_[4] = {0, 0, 0, 0}, tl_ = wall_clock64();
 #define PPTK(i) do { const long long n_ = wall_clock64(); tk_[i] += n_ - tl_; tl_ = n_; } while (0)
@@ -443,9 +445,26 @@ inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 struct PPGeom {
     int blocks, one_wave;
     size_t dp_cap, row_cap, aln_cap;
+    // second pass for dense basecalls (more than rows / 4 bases: Bonito's stride, fast flip-flop models): a few
+    // workgroups whose slices hold ANY basecall of these reads (a basecall has at most one base per frame)
+    int big_blocks;
+    size_t big_dp_cap, big_row_cap, big_aln_cap, off_big_dp, off_big_rows, off_big_aln;
     size_t off_queue, off_map1, off_map2, off_st1, off_st2, off_dp, off_rows, off_aln, off_ff, off_env, off_b2, total;
     size_t ff_bytes, b2_bytes;
 };
+
+// device memory the workspaces may plan with: a fixed share of the board's memory, so that the size a caller
+// is told (po_*_workspace_bytes) and the size the launch expects agree whatever else is allocated
+size_t pp_total_mem() {
+    static size_t tot = 0;
+    if (!tot) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) tot = p.totalGlobalMem;
+        if (!tot) tot = (size_t)288 << 30;
+    }
+    return tot;
+}
 
 int pp_num_cus() {
     static int cus = 0;
@@ -464,14 +483,31 @@ PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     // block barriers and three times as many pairs are in flight; full alignment keeps 256 threads
     g.one_wave = opt->full_alignment ? 0 : 1;
     g.blocks = std::min(n > 0 ? n : 1, pp_num_cus() * (g.one_wave ? 16 : 4));
-    // a basecall has at most one base per frame, so lengths are bounded by the row counts; the DP
-    // budget assumes basecalls of at most max_rows / 4 bases (nanopore basecallers emit roughly one
-    // base per 8-10 frames) — longer ones are reported per pair as PO_E_CAP, never overrun
+    // a basecall has at most one base per frame, so lengths are bounded by the row counts; the first pass
+    // budgets for basecalls of at most max_rows / 4 bases (nanopore basecallers emit roughly one base per 8-10
+    // frames); a pair with a longer one gets PO_E_CAP there and is aligned by the second pass, whose slices hold
+    // a base per frame
     const int64_t lmax1 = std::max<int64_t>(64, mr1 / 4 + 8), lmax2 = std::max<int64_t>(64, mr2 / 4 + 8);
     g.row_cap = (size_t)(lmax1 + 1);
     const int64_t width = opt->full_alignment ? (lmax2 + 1) : std::min<int64_t>(lmax2 + 1, 2 * NW_BAND + 1);
     g.dp_cap = (size_t)((lmax1 + 1) * width);
     g.aln_cap = (size_t)(lmax1 + lmax2 + 16);
+    {   // the first pass's slices within 1/16 of the board's memory (very long reads: fewer workgroups)
+        const size_t per_block = sizeof(int) * g.dp_cap + sizeof(int) * 4 * g.row_cap + 2 * g.aln_cap;
+        const size_t fit = std::max<size_t>(1, (pp_total_mem() / 16) / std::max<size_t>(per_block, 1));
+        g.blocks = (int)std::min<size_t>((size_t)g.blocks, fit);
+    }
+    {
+        const int64_t b1 = mr1 + 8, b2 = mr2 + 8;
+        g.big_row_cap = (size_t)(b1 + 1);
+        const int64_t bw = opt->full_alignment ? (b2 + 1) : std::min<int64_t>(b2 + 1, 2 * NW_BAND + 1);
+        g.big_dp_cap = (size_t)((b1 + 1) * bw);
+        g.big_aln_cap = (size_t)(b1 + b2 + 16);
+        const size_t per_block = sizeof(int) * g.big_dp_cap + sizeof(int) * 4 * g.big_row_cap + 2 * g.big_aln_cap;
+        const size_t fit = ((size_t)2 << 30) / std::max<size_t>(per_block, 1);     // 2 GB for the pass; at least one slice
+        g.big_blocks = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(32, fit), (size_t)(n > 0 ? n : 1)));
+        if (per_block > pp_total_mem() / 8) g.big_blocks = 0;   // (--alignment full on reads of 10^5 frames: no second pass)
+    }
     const int kind = opt->model == PO_MODEL_FLIPFLOP ? PO_KIND_FLIPFLOP : PO_KIND_POREOVER;
     g.ff_bytes = (kind == PO_KIND_FLIPFLOP) ? al256((size_t)std::max(tr1, tr2) * 8) + al256((size_t)std::max(tr1, tr2)) : 0;
     g.b2_bytes = po_beam2d_ws_bytes_impl(n, tr1, tr2, mr1, mr2, C, opt->beam_width, opt->model, opt->method);
@@ -484,6 +520,9 @@ PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.off_dp = o; o += al256(sizeof(int) * g.dp_cap * g.blocks);
     g.off_rows = o; o += al256(sizeof(int) * 4 * g.row_cap * g.blocks);
     g.off_aln = o; o += al256(2 * g.aln_cap * g.blocks);
+    g.off_big_dp = o; o += al256(sizeof(int) * g.big_dp_cap * g.big_blocks);
+    g.off_big_rows = o; o += al256(sizeof(int) * 4 * g.big_row_cap * g.big_blocks);
+    g.off_big_aln = o; o += al256(2 * g.big_aln_cap * g.big_blocks);
     g.off_ff = o; o += g.ff_bytes;
     g.off_env = o; o += al256(sizeof(int32_t) * 2 * (size_t)tr1);
     g.off_b2 = o; o += g.b2_bytes;
@@ -550,7 +589,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     a.map1 = map1; a.map2 = map2; a.st1 = st1; a.st2 = st2;
     a.padding = opt->padding; a.full_alignment = opt->full_alignment;
     a.diagonal_envelope = opt->diagonal_envelope; a.diagonal_width = opt->diagonal_width;
-    a.band = NW_BAND; a.mode = 0;
+    a.band = NW_BAND; a.mode = 0; a.retry_cap = 0;
     a.lenU = a.lenV = nullptr; a.map1_off = a.map2_off = nullptr; a.aln_out1 = a.aln_out2 = nullptr;
     a.aln_off = nullptr; a.ncol_out = nullptr; a.env_off = nullptr;
     a.env = env; a.identity = identity; a.status = status;
@@ -561,6 +600,15 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
     po_prof_stage(PO_K_ALIGN, stream, 1, &tok);
     pp_launch(a, g.blocks, g.one_wave, stream);
+    if (g.big_blocks > 0 && !opt->diagonal_envelope) {   // pairs whose basecalls did not fit the first pass's slices (none, usually)
+        PPArgs b = a;
+        b.retry_cap = 1;
+        b.queue = a.queue + 16;
+        b.dp = (int*)(w + g.off_big_dp); b.dp_cap = (long long)g.big_dp_cap;
+        b.rowinfo = (int*)(w + g.off_big_rows); b.row_cap = (long long)g.big_row_cap;
+        b.aln = w + g.off_big_aln; b.aln_cap = (long long)g.big_aln_cap;
+        pp_launch(b, g.big_blocks, g.one_wave, stream);
+    }
     po_prof_stage(PO_K_ALIGN, stream, 0, &tok);
     // (3) the pair beam search inside the envelope (pair_decode.py:166-173,511)
     po_prof_stage(PO_K_BEAM2D, stream, 1, &tok);

@@ -146,3 +146,46 @@ def test_pipeline_grid_method(eng, oracle):
         assert got[i]["status"] == want["status"] == 0, i
         assert np.array_equal(got[i]["envelope"], want["envelope"]), i
         assert got[i]["consensus"] == want["consensus"], i
+
+
+def _dense_read(rng, seq, T):
+    """a read with a base every ~2.3 frames (Bonito's stride / fast flip-flop models): (T, 5) log-probabilities"""
+    from poreover_amd.synth import log_softmax
+    pos = np.sort(rng.choice(T, size=len(seq), replace=False))
+    lab = np.full(T, 4, dtype=np.int64)
+    lab[pos] = seq
+    logits = rng.normal(0, 1, (T, 5)).astype(np.float32)
+    logits[np.arange(T), lab] += 6.0
+    return log_softmax(logits)
+
+
+@pytest.mark.parametrize("kind", ["poreover", "bonito"])
+def test_dense_basecalls_no_capacity_error(eng, oracle, kind):
+    """0.35 - 0.5 bases per frame: more than the rows / 4 the first alignment pass budgets for — the second pass
+    (slices for one base per frame) must decode them, in the same batch as ordinary pairs (PO_E_CAP)"""
+    rng = np.random.default_rng(77)
+    y1s, y2s = [], []
+    for i, dens in enumerate((0.35, 0.45, 0.5, 0.1, 0.42)):
+        T = 900 + 60 * i
+        ref = rng.integers(4, size=int(T * dens))
+        if kind == "bonito":       # no repeated bases next to each other: bonito collapses them
+            ref = ref[np.insert(np.diff(ref) != 0, 0, True)]
+        mut = ref.copy()
+        flip = rng.random(len(mut)) < 0.05
+        mut[flip] = (mut[flip] + 1) % 4
+        if kind == "bonito":
+            mut = mut[np.insert(np.diff(mut) != 0, 0, True)]
+        y1s.append(_dense_read(rng, ref, T)); y2s.append(_dense_read(rng, mut, T + 37))
+    got = eng.pair_decode_batch(y1s, y2s, kind, 5, "row_col")
+    assert max(g["length1"] / len(y) for g, y in zip(got, y1s)) > 0.3
+    for i, (a, b) in enumerate(zip(y1s, y2s)):
+        try:
+            want = oracle.pair_decode(a, b, kind, 5, "row_col")
+        except oracle.OracleError as e:
+            assert got[i]["status"] == e.code
+            continue
+        assert got[i]["status"] == want["status"], i
+        assert (got[i]["seq1"], got[i]["seq2"]) == (want["seq1"], want["seq2"]), i
+        if want["status"] == 0:
+            assert np.array_equal(got[i]["envelope"], want["envelope"]), i
+            assert got[i]["consensus"] == want["consensus"], i

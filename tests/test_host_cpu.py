@@ -62,3 +62,22 @@ def test_pack_rows():
     assert y.shape == (5, 5) and y.dtype == np.float64 and off.tolist() == [0, 3, 5] and C == 5
     with pytest.raises(ValueError):
         pack_rows([np.zeros((3, 5)), np.zeros((3, 8))])
+
+
+def test_workspace_bounded_for_long_reads():
+    """the pair-decode workspace must not grow as resident workgroups x read length without bound —
+    thousands of pairs of the reference's own sample lengths (62 000 / 75 600 frames) must plan within the board's
+    288 GB (fewer resident workgroups instead)."""
+    _ensure_built()
+    import ctypes as C
+    from poreover_amd import _lib
+    lib = _lib.load(require_gpu=False)
+    n = 8192
+    for W, method in ((5, "row_col"), (10, "row_col"), (25, "row"), (5, "row")):
+        opt = _lib.PairOptions(W, _lib.MODELS["ctc"], _lib.METHODS[method], 5, 0, 0, 50)
+        ws = lib.po_pair_decode_workspace_bytes(n, n * 62000, n * 75600, 62000, 75600, 5, C.byref(opt))
+        fixed = 4 * n * (62000 + 75600) + 8 * n * 62000      # frame maps + envelope: proportional to the input itself
+        assert ws - fixed < 150 * 2**30, (W, method, ws / 2**30)
+    opt = _lib.PairOptions(5, _lib.MODELS["ctc"], _lib.METHODS["row_col"], 5, 0, 0, 50)
+    small = lib.po_pair_decode_workspace_bytes(10000, 40000000, 40000000, 4000, 4400, 5, C.byref(opt))
+    assert small < 48 * 2**30      # (the bench configuration keeps its full occupancy: ~16 GB of DP slices + ~15 GB for the pair beam)
