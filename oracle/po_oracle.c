@@ -291,6 +291,90 @@ static int int_cmp(const void* a, const void* b) {
     return (x > y) - (x < y);
 }
 
+/* ---- libstdc++'s std::partial_sort / std::sort, restated (bits/stl_heap.h, bits/stl_algo.h of GCC's libstdc++):
+ * with exact score ties the result of Beam::prune is whatever these algorithms leave, starting from the
+ * pointer-sorted vector.  Nodes are allocated one after the other and never freed during a search, so pointer order
+ * is taken to be creation order (ids).  comp(a, b) = score(a) > score(b), as the reference's comparators. */
+static int g_tie_stl = 1;   /* 1: what libstdc++ leaves (the reference); 0: score desc, then creation order (round-1 rule, kept for A/B) */
+void oracle_set_tie_rule(int stl) { g_tie_stl = stl; }
+#define SCOMP(a, b) ((a).s > (b).s)
+static void stl_push_heap(scored_t* f, long hole, long top, scored_t v) {
+    long parent = (hole - 1) / 2;
+    while (hole > top && SCOMP(f[parent], v)) { f[hole] = f[parent]; hole = parent; parent = (hole - 1) / 2; }
+    f[hole] = v;
+}
+static void stl_adjust_heap(scored_t* f, long hole, long len, scored_t v) {
+    const long top = hole;
+    long second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (SCOMP(f[second], f[second - 1])) second--;
+        f[hole] = f[second]; hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        f[hole] = f[second - 1]; hole = second - 1;
+    }
+    stl_push_heap(f, hole, top, v);
+}
+static void stl_make_heap(scored_t* f, long len) {
+    if (len < 2) return;
+    long parent = (len - 2) / 2;
+    for (;;) { scored_t v = f[parent]; stl_adjust_heap(f, parent, len, v); if (parent == 0) return; parent--; }
+}
+static void stl_pop_heap(scored_t* f, long len, scored_t* result) { scored_t v = *result; *result = f[0]; stl_adjust_heap(f, 0, len, v); }
+static void stl_partial_sort(scored_t* f, long mid, long n) {
+    if (mid == 0) return;
+    stl_make_heap(f, mid);
+    for (long i = mid; i < n; ++i) if (SCOMP(f[i], f[0])) stl_pop_heap(f, mid, &f[i]);
+    long last = mid;
+    while (last > 1) { --last; stl_pop_heap(f, last, &f[last]); }
+}
+static void stl_unguarded_linear_insert(scored_t* f, long last) {
+    scored_t v = f[last];
+    long next = last - 1;
+    while (SCOMP(v, f[next])) { f[last] = f[next]; last = next; --next; }
+    f[last] = v;
+}
+static void stl_insertion_sort(scored_t* f, long first, long last) {
+    if (first == last) return;
+    for (long i = first + 1; i != last; ++i) {
+        if (SCOMP(f[i], f[first])) { scored_t v = f[i]; memmove(&f[first + 1], &f[first], sizeof(scored_t) * (size_t)(i - first)); f[first] = v; }
+        else stl_unguarded_linear_insert(f, i);
+    }
+}
+static void stl_swap(scored_t* a, scored_t* b) { scored_t t = *a; *a = *b; *b = t; }
+static void stl_introsort_loop(scored_t* f, long first, long last, long depth) {
+    while (last - first > 16) {
+        if (depth == 0) { stl_partial_sort(f + first, last - first, last - first); return; }
+        --depth;
+        const long mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+        if (SCOMP(f[a], f[b])) { if (SCOMP(f[b], f[c])) stl_swap(&f[first], &f[b]); else if (SCOMP(f[a], f[c])) stl_swap(&f[first], &f[c]); else stl_swap(&f[first], &f[a]); }
+        else if (SCOMP(f[a], f[c])) stl_swap(&f[first], &f[a]);
+        else if (SCOMP(f[b], f[c])) stl_swap(&f[first], &f[c]);
+        else stl_swap(&f[first], &f[b]);
+        long lo = first + 1, hi = last;
+        for (;;) {
+            while (SCOMP(f[lo], f[first])) ++lo;
+            --hi;
+            while (SCOMP(f[first], f[hi])) --hi;
+            if (!(lo < hi)) break;
+            stl_swap(&f[lo], &f[hi]);
+            ++lo;
+        }
+        stl_introsort_loop(f, lo, last, depth);
+        last = lo;
+    }
+}
+static void stl_sort(scored_t* f, long n) {
+    if (n == 0) return;
+    long lg = 0;
+    for (long k = n; k > 1; k >>= 1) ++lg;
+    stl_introsort_loop(f, 0, n, 2 * lg);
+    if (n > 16) { stl_insertion_sort(f, 0, 16); for (long i = 16; i != n; ++i) stl_unguarded_linear_insert(f, i); }
+    else stl_insertion_sort(f, 0, n);
+}
+
 /* Beam::prune, Beam.h:93-108: dedupe by identity, keep the top `width` by comparator */
 static int beam_prune(beam_t* b, const tree_t* tr, int kind) {
     qsort(b->el, b->n, sizeof(int), int_cmp);
@@ -300,7 +384,12 @@ static int beam_prune(beam_t* b, const tree_t* tr, int kind) {
     scored_t* sc = (scored_t*)malloc(sizeof(scored_t) * (m ? m : 1));
     if (!sc) return -1;
     for (int i = 0; i < m; ++i) { sc[i].id = b->el[i]; sc[i].s = node_score(tr, b->el[i], kind); }
-    qsort(sc, m, sizeof(scored_t), scored_cmp);
+    if (g_tie_stl) {
+        if (m > b->width) stl_partial_sort(sc, b->width, m);
+        else stl_sort(sc, m);
+    } else {
+        qsort(sc, m, sizeof(scored_t), scored_cmp);
+    }
     if (m > b->width) m = b->width;
     for (int i = 0; i < m; ++i) b->el[i] = sc[i].id;
     b->n = m;

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     int* isnew = (int*)carve(p, sizeof(int) * WM);   // beam node expanded in this very step
     int* dup = (int*)carve(p, sizeof(int) * NC);
     int* nsel = (int*)carve(p, sizeof(int) * WM);
+    int* ord = (int*)carve(p, sizeof(int) * NC);     // prune with exact score ties: candidate slots in node-id order
 
     if (T < 1) {
         if (lane == 0) { seq_len[r] = 0; status[r] = PO_E_ARG; }
@@ -248,21 +249,48 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         }
         __syncthreads();
         int kept = 0;
+        bool tie = false;
         for (int s0 = 0; s0 < NCc; s0 += PO_WAVE) {
             const int s = s0 + lane;
             const bool valid = (s < NCc) && !dup[s];
+            bool teq = false;
             if (valid) {
                 const double sc = Q.val[s];
                 const int id = Q.id[s];
-                int rank = 0;
+                int rank = 0, neq = 0;
 #pragma unroll 8
-                for (int o = 0; o < NCc; ++o)
-                    if (!dup[o] && po_better(Q.val[o], Q.id[o], sc, id)) rank++;
+                for (int o = 0; o < NCc; ++o) {
+                    const double so = Q.val[o];
+                    const bool live = !dup[o];
+                    if (live && po_better(so, Q.id[o], sc, id)) rank++;
+                    if (live && so == sc) neq++;
+                }
                 if (rank < W) nsel[rank] = s;
+                teq = (neq > 1) && (rank < W);   // an exact tie that reaches into the beam
             }
+            tie |= (__ballot(teq) != 0ull);
             kept += __popcll(__ballot(valid));
         }
         __syncthreads();
+        if (tie) {
+            // exact ties decide by what libstdc++'s partial_sort / sort leave (po_device.h): candidates in node-id
+            // order (each live candidate's position = live candidates with a smaller id), then one lane replays it
+            for (int s = lane; s < NCc; s += PO_WAVE) {
+                if (!dup[s]) {
+                    const int id = Q.id[s];
+                    int pos = 0;
+                    for (int o = 0; o < NCc; ++o) pos += (!dup[o] && Q.id[o] < id) ? 1 : 0;
+                    ord[pos] = s;
+                }
+            }
+            __syncthreads();
+            if (lane == 0) {
+                const double* val0 = Q.val;
+                po_stl_prune(ord, kept, W, [&](int slot) { return val0[slot]; });
+                for (int j = 0; j < min(W, kept); ++j) nsel[j] = ord[j];
+            }
+            __syncthreads();
+        }
         const int Wn = min(W, kept);
         for (int j = lane; j < Wn; j += PO_WAVE) sel[j] = nsel[j];
         if (MODEL == PO_MODEL_CTC) blank_cum += yr[A];
@@ -299,7 +327,7 @@ extern "C" size_t po_beam1d_lds_bytes(int W, int model) {
     const int WM = W > PO_A ? W : PO_A, NC = WM * (PO_A + 1);
     auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
     size_t per = 3 * al(sizeof(int) * NC) + al(sizeof(double) * K * NC) + 4 * al(sizeof(int) * WM);
-    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + al(sizeof(int) * NC);
+    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + 2 * al(sizeof(int) * NC);
 }
 
 // node-arena entries for a batch: per read root + A children + A * max(W, A) new nodes per frame

@@ -187,6 +187,104 @@ __device__ __forceinline__ bool po_better(double sa, int ia, double sb, int ib) 
     return (sa > sb) || (!(sb > sa) && ia < ib);
 }
 
+// ---- exact score ties: what Beam::prune leaves (Beam.h:93-108) -----------------------------------------------
+// The reference sorts the candidate POINTERS (nodes are allocated one after the other and never freed during a
+// search, so pointer order is creation order, i.e. node id order), removes duplicates, and then calls
+// std::partial_sort(first, first + W, last, greater-by-score) — or std::sort when there are at most W candidates.
+// With distinct scores every correct algorithm returns the same beam; with EXACT ties (quantised uint8 traces,
+// candidates that are all -inf) the beam is whatever libstdc++'s heap-select / sort_heap / introsort leave.  The
+// functions below restate those algorithms (bits/stl_heap.h, bits/stl_algo.h) on an index array `o` (slots in
+// node-id order) with score(slot) given by a functor; one lane runs them, and only when a tie touches the beam.
+template <class S>
+__device__ inline void po_stl_push_heap(int* o, int hole, int top, int v, const S& sc) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && sc(o[parent]) > sc(v)) { o[hole] = o[parent]; hole = parent; parent = (hole - 1) / 2; }
+    o[hole] = v;
+}
+template <class S>
+__device__ inline void po_stl_adjust_heap(int* o, int hole, int len, int v, const S& sc) {
+    const int top = hole;
+    int second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (sc(o[second]) > sc(o[second - 1])) second--;
+        o[hole] = o[second]; hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        o[hole] = o[second - 1]; hole = second - 1;
+    }
+    po_stl_push_heap(o, hole, top, v, sc);
+}
+template <class S>
+__device__ inline void po_stl_partial_sort(int* o, int mid, int n, const S& sc) {
+    if (mid == 0) return;
+    if (mid >= 2)
+        for (int parent = (mid - 2) / 2;; --parent) { const int v = o[parent]; po_stl_adjust_heap(o, parent, mid, v, sc); if (parent == 0) break; }
+    for (int i = mid; i < n; ++i)
+        if (sc(o[i]) > sc(o[0])) { const int v = o[i]; o[i] = o[0]; po_stl_adjust_heap(o, 0, mid, v, sc); }
+    for (int last = mid; last > 1;) { --last; const int v = o[last]; o[last] = o[0]; po_stl_adjust_heap(o, 0, last, v, sc); }
+}
+template <class S>
+__device__ inline void po_stl_unguarded_linear_insert(int* o, int last, const S& sc) {
+    const int v = o[last];
+    int next = last - 1;
+    while (sc(v) > sc(o[next])) { o[last] = o[next]; last = next; --next; }
+    o[last] = v;
+}
+template <class S>
+__device__ inline void po_stl_insertion_sort(int* o, int first, int last, const S& sc) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (sc(o[i]) > sc(o[first])) { const int v = o[i]; for (int k = i; k > first; --k) o[k] = o[k - 1]; o[first] = v; }
+        else po_stl_unguarded_linear_insert(o, i, sc);
+    }
+}
+template <class S>
+__device__ inline void po_stl_sort(int* o, int n, const S& sc) {   // std::sort; n <= 64 here
+    if (n == 0) return;
+    int lg = 0;
+    for (int k = n; k > 1; k >>= 1) ++lg;
+    // __introsort_loop without recursion: an explicit stack of (first, last, depth)
+    int stk[3 * 16], sp = 0;
+    stk[0] = 0; stk[1] = n; stk[2] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+        while (last - first > 16) {
+            if (depth == 0) { po_stl_partial_sort(o + first, last - first, last - first, sc); break; }
+            --depth;
+            const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+            auto sw = [&](int x, int y) { const int t = o[x]; o[x] = o[y]; o[y] = t; };
+            if (sc(o[a]) > sc(o[b])) { if (sc(o[b]) > sc(o[c])) sw(first, b); else if (sc(o[a]) > sc(o[c])) sw(first, c); else sw(first, a); }
+            else if (sc(o[a]) > sc(o[c])) sw(first, a);
+            else if (sc(o[b]) > sc(o[c])) sw(first, c);
+            else sw(first, b);
+            int lo = first + 1, hi = last;
+            for (;;) {
+                while (sc(o[lo]) > sc(o[first])) ++lo;
+                --hi;
+                while (sc(o[first]) > sc(o[hi])) --hi;
+                if (!(lo < hi)) break;
+                sw(lo, hi);
+                ++lo;
+            }
+            // the reference recurses on [lo, last) first and then loops on [first, lo): order does not matter for
+            // the result (the two ranges are disjoint)
+            if (sp < 16) { stk[3 * sp] = lo; stk[3 * sp + 1] = last; stk[3 * sp + 2] = depth; ++sp; }
+            last = lo;
+        }
+    }
+    if (n > 16) { po_stl_insertion_sort(o, 0, 16, sc); for (int i = 16; i != n; ++i) po_stl_unguarded_linear_insert(o, i, sc); }
+    else po_stl_insertion_sort(o, 0, n, sc);
+}
+// the W best of the n candidates o[0..n) (slots in node-id order) exactly as Beam::prune orders them, in o[0..min(W, n))
+template <class S>
+__device__ inline void po_stl_prune(int* o, int n, int W, const S& sc) {
+    if (n > W) po_stl_partial_sort(o, W, n, sc);
+    else po_stl_sort(o, n, sc);
+}
+
 // node arena entry: parent id and last symbol packed as (parent << 3) | last  (last <= 4)
 __device__ __forceinline__ int po_pack_node(int parent, int last) { return (parent << 3) | last; }
 __device__ __forceinline__ int po_node_parent(int packed) { return packed >> 3; }

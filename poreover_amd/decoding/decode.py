@@ -60,11 +60,16 @@ def load_logits(file_path, flatten=False):
 
 
 def _trace_from_hdf5(path, dataset):
+    """decode.py:53-65: the uint8 trace of a Flappie .hdf5 (first read's 'trace') or a Guppy .fast5 (the named
+    dataset).  The reference opens the file with h5py; so does this function when h5py is installed, and otherwise it
+    uses the engine's own reader of the part of the HDF5 format these files use (hdf5_lite)."""
     try:
         import h5py
-    except ImportError as e:  # same dependency as the reference (decode.py:2)
-        raise ImportError("reading %s needs h5py, as in the reference" % path) from e
-    with h5py.File(path, 'r') as hdf:
+        opener = h5py.File
+    except ImportError:
+        from . import hdf5_lite
+        opener = hdf5_lite.File
+    with opener(path, 'r') as hdf:
         if dataset is None:
             read_id = list(hdf)[0]
             return np.array(hdf[read_id]['trace'])

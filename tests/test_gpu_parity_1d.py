@@ -96,6 +96,17 @@ def test_beam1d_full_size_batch(eng, oracle):
     assert got == want
 
 
+def test_beam1d_flipflop_full_size_batch(eng, oracle):
+    """BASELINE config 5 shape: flip-flop (T x 8 state) traces, T = 4000, W = 10, 64 reads; oracle on every read,
+    Viterbi and beam search."""
+    reads = [synth_pair(3500 + i, T=4000, flipflop=True)[0] for i in range(64)]
+    got = eng.beam_search_batch(reads, 10, model="ctc_flipflop")
+    seqs = eng.viterbi_batch(reads, "flipflop")
+    for i, y in enumerate(reads):
+        assert got[i] == oracle.cpp_beam_search(y, 10, model_="ctc_flipflop"), i
+        assert seqs[i] == oracle.viterbi_decode(y, "flipflop")[0], i
+
+
 def test_beam1d_ragged_and_errors(eng):
     from poreover_amd import _lib
     reads = [synth_pair(10, T=t)[0] for t in (5, 64, 65, 300, 2)]
