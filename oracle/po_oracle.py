@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_ORACLE_SO = os.path.join(_HERE, "_build", "libpooracle.so")
+# PO_ORACLE_SO selects another build of the same restatement (the sanitizer build: `make -C oracle asan`)
+_ORACLE_SO = os.environ.get("PO_ORACLE_SO") or os.path.join(_HERE, "_build", "libpooracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libporef.so")
 
 MODELS = {"ctc": 0, "ctc_merge_repeats": 1, "ctc_flipflop": 2}

@@ -157,7 +157,7 @@ struct B2Smem {
     // row groups tracked per pair: a step can open up to W new ones and a group lives for about a window
     static constexpr int NGL = (WMAX > 12) ? 768 : ((WMAX <= 6) ? B2_NGL6 : 256);
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
-    int sh[16];
+    int sh[20];
     double score[NCM];
     // (the window maxima of the scan just finished, mxs[r][s], live in xch[0][r][s][0]: the exchange buffer is idle
     //  between two scans, and xch[1] keeps the seeds of windows that continue)
@@ -457,6 +457,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             sm.sh[4] = PO_OK;
             sm.sh[8] = INT_MIN; sm.sh[9] = INT_MIN;  // window ends of the previous row_col main step: none yet
             sm.sh[10] = 0; sm.sh[11] = 0; sm.sh[12] = 0; sm.sh[13] = 0; sm.sh[14] = 0; sm.sh[15] = 0;  // incremental steps: nothing to build on yet
+            sm.sh[16] = INT_MIN; sm.sh[17] = INT_MIN;
         }
         if (tid < WMAX) sm.stay[tid] = 0;
         if (tid < A) {
@@ -569,11 +570,13 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 sym = sym_last(sy); same = (sym_plast(sy) == sym); rootpar = (sy >> 9) & 1;
                 myrow = pool + ((size_t)sm.e[F_ROW][s] * 2 + r) * R;
                 tag0 = make_tag(epoch, node, 0);
-                // The value at t0 - 1.  A window that continues the previous main step's (t0 == that step's window end,
-                // same slot layout) starts from the value this lane computed last, which every main scan leaves in
-                // xch[1] (below) — no round trip to the store.  Catch-up scans only touch the slots of the read they
-                // advance, and a read they advance restarts its windows from t0f.
-                if (t0 > t0f) {
+                // The value at t0 - 1.  A window that continues where this read's elements last computed (same slot
+                // layout; sh[16 + r] = the time after the last value a main scan computed on read r) starts from the
+                // value this lane computed last, which every main scan leaves in xch[1] (below) — no round trip to the
+                // store.  (Window ends can move backwards — envelopes with a wide row now and then: the continuation
+                // then starts before the last computed time, and the seed comes from the store.)  Catch-up scans only
+                // touch the slots of the read they advance, and a read they advance restarts its windows from t0f.
+                if (t0 > t0f && t0 == sm.sh[16 + r]) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) self[k] = sm.xch[1][r][s][k];
                 } else {
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                         myrow[t & Rm] = e;
                     }
 #endif
-                    if (out[0] > self[0]) td = t;   // (the first value of a window is compared with the one before it: harmless)
+                    if (out[0] > self[0] && t > td) td = t;   // (times may be computed again after a window end moved back: td never decreases)
 #pragma unroll
                     for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }
                     if (out[0] >= mx) { mx = out[0]; mt = t; }
@@ -703,7 +706,12 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #pragma unroll
                 for (int q = 0; q < K; ++q) sm.xch[1][r][s][q] = self[q];
             }
-            if (is_main && tid == 0) { if (len0_ > 0) sm.sh[12] = 1; if (len1_ > 0) sm.sh[13] = 1; }
+            if (is_main && tid == 0) {
+                if (len0_ > 0) sm.sh[12] = 1;
+                if (len1_ > 0) sm.sh[13] = 1;
+                if (len0 > 0) sm.sh[16] = s0 + len0;   // xch[1] of read 0 / read 1 now holds the values at these times - 1
+                if (len1 > 0) sm.sh[17] = s1 + len1;
+            }
             if (a.upd_count != nullptr && tid == 0) {   // profiling (skipped slots counted too)
                 sm.nupd += (unsigned)(nelem * (len0_ + len1_));
                 sm.nupd_x += (unsigned)(nelem * (len0 + len1));

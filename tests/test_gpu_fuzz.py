@@ -1,0 +1,155 @@
+"""GPU: the round's differential evidence under the driver — seeded, bounded slices of the randomised comparisons
+against the oracle (scripts/fuzz_parity.py runs the open-ended version) and the accuracy harness with its
+identity table (north-star budget: <= 0.1 % edits between engine and reference)."""
+import json
+import os
+from multiprocessing import get_context
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from poreover_amd.synth import synth_pair, synth_truth
+
+pytestmark = pytest.mark.gpu
+
+MODELS = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from poreover_amd import _lib, batch
+    _lib.load()
+    return batch
+
+
+def _band_env(rng, U, V, style, pad):
+    env = np.zeros((U, 2), dtype=np.int64)
+    for u in range(U):
+        c = (u // 7) * 7 * V / U if style == "stairs" else (u * V / U + 3.0 * np.sin(u / 5.0) if style == "wobble" else u * V / U)
+        w = pad + (int(rng.integers(0, pad + 1)) if style == "bursts" and u % 13 == 0 else 0)
+        env[u] = (max(0, int(c) - w), min(V, int(c) + w + 1))
+    env[:, 0] = np.maximum.accumulate(env[:, 0])
+    env[:, 1] = np.maximum(env[:, 1], env[:, 0] + 1).clip(max=V)
+    return env
+
+
+def test_fuzz_pair_beam_kernels(eng, oracle):
+    """random (model, method, W, envelope style, lengths): every pair beam kernel route vs the oracle"""
+    from poreover_amd import _lib
+    rng = np.random.default_rng(20260201)
+    pairs = bad = 0
+    for rnd in range(14):
+        kind = ["poreover", "poreover", "bonito", "flipflop"][rng.integers(4)]
+        method = ["row_col", "row_col", "row"][rng.integers(3)]
+        W = int([1, 3, 5, 5, 6, 8, 10, 12, 16, 25][rng.integers(10)])
+        style = ["diag", "stairs", "wobble", "bursts"][rng.integers(4)]
+        pad = int(rng.integers(4, 18))
+        y1s, y2s, envs = [], [], []
+        for i in range(int(rng.integers(6, 14))):
+            y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=int(rng.integers(30, 900)), flipflop=(kind == "flipflop"))
+            y1s.append(y1); y2s.append(y2); envs.append(_band_env(rng, len(y1), len(y2), style, pad))
+        got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=MODELS[kind], method=method, return_status=True)
+        for i in range(len(y1s)):
+            try:
+                want, code = oracle.cpp_beam_search_2d(y1s[i], y2s[i], envs[i], W, model_=MODELS[kind], method_=method), 0
+            except oracle.OracleError as e:
+                want, code = "", e.code
+            pairs += 1
+            if st[i] == _lib.E_NOMEM and code == 0:      # a capacity refusal is not a wrong answer (none expected at these sizes)
+                bad += 1
+            elif st[i] != code or (code == 0 and got[i] != want):
+                bad += 1
+    assert pairs > 100 and bad == 0, "%d of %d random pairs differ from the oracle" % (bad, pairs)
+
+
+def test_fuzz_pipeline(eng, oracle):
+    """random kinds / methods / widths through the whole stage chain: statuses, basecalls, envelopes, consensus"""
+    rng = np.random.default_rng(20260202)
+    pairs = bad = 0
+    for rnd in range(8):
+        kind = ["poreover", "poreover", "bonito", "flipflop"][rng.integers(4)]
+        method = ["row_col", "row_col", "row"][rng.integers(3)]
+        W = int([3, 5, 5, 5, 8, 10][rng.integers(6)])
+        y1s, y2s = [], []
+        for i in range(int(rng.integers(6, 16))):
+            y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=int(rng.integers(40, 1600)), flipflop=(kind == "flipflop"))
+            if rng.random() < 0.1:
+                y2 = y2[: max(2, len(y2) // 2)]
+            y1s.append(y1); y2s.append(y2)
+        got = eng.pair_decode_stream(y1s, y2s, kind, W, method, return_envelope=True, strict=False, wave_pairs=5)
+        for i in range(len(y1s)):
+            pairs += 1
+            try:
+                w = oracle.pair_decode(y1s[i], y2s[i], kind, W, method)
+            except oracle.OracleError as e:
+                bad += (got[i]["status"] != e.code)
+                continue
+            ok = got[i]["status"] == w["status"] and (got[i]["seq1"], got[i]["seq2"]) == (w["seq1"], w["seq2"])
+            if ok and w["status"] == 0:
+                ok = got[i]["consensus"] == w["consensus"] and np.array_equal(got[i]["envelope"], w["envelope"]) and \
+                    got[i]["sequence_identity"] == w["sequence_identity"]
+            bad += (not ok)
+    assert pairs > 60 and bad == 0, "%d of %d random pairs differ from the oracle" % (bad, pairs)
+
+
+def test_fuzz_one_dimensional(eng, oracle):
+    """Viterbi (three kinds), beam search (three models, W from 1 to 40), forward, Viterbi acceptor"""
+    rng = np.random.default_rng(20260203)
+    reads = bad = 0
+    for rnd in range(8):
+        kind = ["poreover", "bonito", "flipflop"][rng.integers(3)]
+        W = int([1, 2, 5, 10, 25, 40][rng.integers(6)])
+        ys = [synth_pair(int(rng.integers(1 << 30)), T=int(rng.integers(1, 1500)), flipflop=(kind == "flipflop"))[0]
+              for _ in range(int(rng.integers(8, 24)))]
+        seqs, paths = eng.viterbi_batch(ys, kind, return_path=True)
+        beams = eng.beam_search_batch(ys, W, model=MODELS[kind])
+        labs = [b[: max(1, min(len(b), 60))] if b else "A" for b in beams]
+        fwd = eng.forward_batch(ys, labs, model=MODELS[kind])
+        for i, y in enumerate(ys):
+            reads += 1
+            s, p = oracle.viterbi_decode(y, kind)
+            ok = seqs[i] == s and np.array_equal(paths[i], p) and beams[i] == oracle.cpp_beam_search(y, W, model_=MODELS[kind])
+            ok = ok and np.isclose(fwd[i], oracle.cpp_forward(y, labs[i], model_=MODELS[kind]), rtol=1e-12, atol=0)
+            bad += (not ok)
+    assert reads > 60 and bad == 0, "%d of %d random reads differ from the oracle" % (bad, reads)
+
+
+def _cpu_one(seed):
+    from oracle import po_oracle as O
+    y1, y2 = synth_pair(seed, T=4000)
+    r = O.pair_decode(y1, y2, "poreover", 5, "row_col")
+    return r["seq1"], r["seq2"], r["consensus"] if r["status"] == 0 else None
+
+
+def test_accuracy_harness_identity_table(eng, oracle):
+    """256 pairs of the bench shape: engine vs oracle (edit budget 0.1 %, expected 0) and the identity table of
+    read 1 / read 2 / consensus against the synthetic truth — the per-record columns of `poreover benchmark`."""
+    from poreover_amd import accuracy
+    seeds = [100000 + i for i in range(256)]
+    with get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
+        cpu = pool.map(_cpu_one, seeds, chunksize=8)
+    pairs = [synth_pair(s, T=4000) for s in seeds]
+    gpu = eng.pair_decode_stream([p[0] for p in pairs], [p[1] for p in pairs], "poreover", 5, "row_col")
+    edits = bases = 0
+    recs = []
+    for s, c, g in zip(seeds, cpu, gpu):
+        assert (g["seq1"], g["seq2"]) == (c[0], c[1])                      # Viterbi: bit-exact
+        assert (g["consensus"] is None) == (c[2] is None)
+        if c[2] is not None:
+            bases += len(c[2])
+            if g["consensus"] != c[2]:
+                edits += accuracy.alignment_summary(g["consensus"], c[2])["edit_distance"]
+        recs.append(("pair%d" % s, {"read1": g["seq1"], "read2": g["seq2"], "consensus": g["consensus"]}, synth_truth(s, 4000)))
+    assert edits <= 0.001 * bases
+    rows, summary = accuracy.identity_table(recs)
+    assert len(rows) >= 3 * 250 and set(summary) == {"read1", "read2", "consensus"}
+    for k in summary:
+        assert 0.8 < summary[k]["identity"] <= 1.0
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "accuracy_256pairs.json"), "w") as f:
+        json.dump({"pairs": len(seeds), "T": 4000, "beam_width": 5, "method": "row_col", "engine_vs_oracle_edits": edits,
+                   "oracle_consensus_bases": bases, "identity_vs_truth": summary}, f, indent=1)
+    with open(os.path.join(out, "accuracy_256pairs_identity_table.csv"), "w") as f:
+        f.write(accuracy.table_to_csv(rows))
