@@ -173,8 +173,9 @@ int po_envelope_batch(const char* aln1, const char* aln2, const int64_t* aln_off
  * decoding_cy.pair_gamma_log (decoding_cy.pyx:177-220): gamma(0,0) = log P(both reads emit the same
  * label).  env: (U_i + 1) rows per pair with INCLUSIVE column ends (Gamma.h:26-30), rows of pair i at
  * env + 2 * env_off[i]; env == NULL: dense.  flavor 0 = Gamma.h arithmetic (logaddexp, -inf),
- * 1 = decoding_cy arithmetic (log(exp+exp), LOG_0 = -9999).  dense_out (optional, dense only): the full
- * (U+1) x (V+1) gamma matrices at dense_out + dense_off[i].  max_cells = largest per-pair number of
+ * 1 = decoding_cy arithmetic (log(exp+exp), LOG_0 = -9999), 2 = decoding_cy.pair_gamma_log_envelope
+ * (decoding_cy.pyx:224-271; envelope only: log(exp+exp), -inf defaults, cells [start, min(end, V-1)] computed).
+ * dense_out (optional): the full (U+1) x (V+1) gamma matrices at dense_out + dense_off[i] (-inf outside an envelope).  max_cells = largest per-pair number of
  * stored cells (sum over rows of end - start + 1), as used to size the workspace. */
 size_t po_pair_gamma_workspace_bytes(int n, int64_t max_cells, int64_t max_rows1, int64_t max_rows2);
 int po_pair_gamma_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
@@ -238,6 +239,10 @@ int po_prefix_search_batch_h(const double* y_h, const int64_t* y_off_h, int n, i
                              int32_t* status_h);
 int po_align_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, char* aln1_h, char* aln2_h,
                      const int64_t* aln_off_h, int32_t* ncol_h, int32_t* status_h);
+/* the same with the reference's score arguments (align.pyx:29,100: match, mismatch, gap_cost) */
+int po_align_scores_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, int match, int mismatch,
+                            int gap_cost, char* aln1_h, char* aln2_h, const int64_t* aln_off_h, int32_t* ncol_h,
+                            int32_t* status_h);
 int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* aln_off_h, const int32_t* ncol_h, int n,
                         const int32_t* map1_h, const int64_t* map1_off_h, const int32_t* map2_h,
                         const int64_t* map2_off_h, const int32_t* U_h, const int32_t* V_h, int padding,
@@ -249,6 +254,15 @@ int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* a
 int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
                                   int n, int C, const char* alphabet, int flavor, char* seq_h, const int64_t* seq_off_h,
                                   int32_t* seq_len_h, double* logp_h, int32_t* status_h);
+/* The pair prefix search WITH AN ENVELOPE — the working form of decoding_cpp.cpp_pair_prefix_search_log
+ * (decoding_cpp.pyx:143-164 -> pair_prefix_search_log, PairPrefixSearch.cpp:79-229; upstream passes its gamma matrices by
+ * value and crashes): gamma from the envelope DP of Gamma.h:15-98 (env_h: U_i + 1 rows with INCLUSIVE column ends, rows of
+ * pair i at env_h + 2 * env_off_h[i]; -inf outside the stored ranges), the search itself as in the Python paths
+ * (prefix_search.py:247-385; flavor selects the arithmetic of the forward rows).  env_h == NULL: the dense search above. */
+int po_pair_prefix_search_env_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                                      const int32_t* env_h, const int64_t* env_off_h, int n, int C, const char* alphabet,
+                                      int flavor, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, double* logp_h,
+                                      int32_t* status_h);
 /* decoding_cy.forward_vec_log (decoding_cy.pyx:127-156; flavor 1) / prefix_search.forward_vec_log
  * (prefix_search.py:81-96; flavor 0): one row of the CTC forward matrix for symbol s (-1: blank) and label
  * length i, for every item; previous_h (same layout as out_h: one double per frame, items back to back) is the row

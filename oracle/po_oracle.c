@@ -871,7 +871,7 @@ done:
 /* =====================================================================================
  * Gamma DP                      (Gamma.h:15-98; decoding_cy.pyx:177-220; prefix_search.py:35-65)
  * ===================================================================================== */
-double oracle_pair_gamma_envelope(const double* y1, const double* y2, const int* env, int U, int V, int C) {
+static double pair_gamma_envelope_impl(const double* y1, const double* y2, const int* env, int U, int V, int C, double* dense) {
     /* env: U+1 rows, inclusive [start, end] (SparseMatrix.h:35-57); default -inf outside */
     size_t* off = (size_t*)malloc(sizeof(size_t) * (U + 2));
     if (!off) return NAN;
@@ -916,8 +916,14 @@ double oracle_pair_gamma_envelope(const double* y1, const double* y2, const int*
         }
     }
     double res = GGET(g, 0, 0);
+    if (dense) /* the (U+1) x (V+1) matrix with -inf outside the stored ranges (what SparseMatrix::get returns there) */
+        for (int u = 0; u <= U; ++u)
+            for (int v = 0; v <= V; ++v) dense[(size_t)u * (V + 1) + v] = GGET(g, u, v);
     free(off); free(g); free(ga);
     return res;
+}
+double oracle_pair_gamma_envelope(const double* y1, const double* y2, const int* env, int U, int V, int C) {
+    return pair_gamma_envelope_impl(y1, y2, env, U, V, C, NULL);
 }
 
 static double seq_logsumexp_shift(const double* a, int n, int stride) {
@@ -1052,8 +1058,13 @@ done:
 }
 
 /* pair_prefix_search_log / _cy, prefix_search.py:247-385 (dense gamma, no envelope) */
-int oracle_pair_prefix_search_log(const double* y1, int U, const double* y2, int V, int C,
-                                  int flavor, char* label, int cap, double* logp) {
+/* Pair prefix search (prefix_search.py:247-385).  env == NULL: the dense gamma of the Python paths.  env != NULL
+ * (U + 1 rows, inclusive column ranges): gamma from the envelope DP of Gamma.h:15-98, -inf outside the stored
+ * ranges — the WORKING form of PairPrefixSearch.cpp:79-229, whose upstream version passes its gamma matrices by
+ * value to pair_gamma_log_envelope_inplace (so they stay empty) and reads alpha_ast1[U] out of bounds; the prefix
+ * probability is the sum over the cells (u, v), u < U, v < V, as in the Python paths. */
+static int pair_prefix_search_impl(const double* y1, int U, const double* y2, int V, int C,
+                                   int flavor, const int* env, char* label, int cap, double* logp) {
     static const char dna[] = "ACGT";
     const int A = C - 1;
     if (U < 1 || V < 1 || A < 1 || A > 4) return PO_E_ARG;
@@ -1075,7 +1086,8 @@ int oracle_pair_prefix_search_log(const double* y1, int U, const double* y2, int
     double* lab_p = (double*)malloc(sizeof(double) * caplab);
     char** lab_s = (char**)malloc(sizeof(char*) * caplab);
     if (!gm || !a1p || !a2p || !a1s || !a2s || !ast1 || !ast2 || !flat || !curr || !lab_p || !lab_s) goto done;
-    if (oracle_pair_gamma_dense(y1, U, y2, V, C, flavor, gm)) goto done;
+    if (env) { (void)pair_gamma_envelope_impl(y1, y2, env, U, V, C, gm); }
+    else if (oracle_pair_gamma_dense(y1, U, y2, V, C, flavor, gm)) goto done;
     {
         double g = 0;
         for (int t = 0; t < U; ++t) g += y1[(size_t)t * C + A];
@@ -1142,13 +1154,24 @@ done:
     free(gm); free(a1p); free(a2p); free(a1s); free(a2s); free(ast1); free(ast2); free(flat); free(curr);
     return rc;
 }
+int oracle_pair_prefix_search_log(const double* y1, int U, const double* y2, int V, int C,
+                                  int flavor, char* label, int cap, double* logp) {
+    return pair_prefix_search_impl(y1, U, y2, V, C, flavor, NULL, label, cap, logp);
+}
+int oracle_pair_prefix_search_log_env(const double* y1, int U, const double* y2, int V, int C, int flavor,
+                                      const int* env, char* label, int cap, double* logp) {
+    return pair_prefix_search_impl(y1, U, y2, V, C, flavor, env, label, cap, logp);
+}
 
 /* =====================================================================================
  * Needleman-Wunsch                                                  (align/align.pyx:29-178)
  * ===================================================================================== */
-#define NW_MATCH 2
-#define NW_MISMATCH (-1)
-#define NW_GAP (-1)
+/* align.pyx:9-11 defaults; the functions take match / mismatch / gap_cost arguments upstream (align.pyx:29,100) */
+static int g_nw_match = 2, g_nw_mismatch = -1, g_nw_gap = -1;
+void oracle_set_nw_scores(int match, int mismatch, int gap_cost) { g_nw_match = match; g_nw_mismatch = mismatch; g_nw_gap = gap_cost; }
+#define NW_MATCH g_nw_match
+#define NW_MISMATCH g_nw_mismatch
+#define NW_GAP g_nw_gap
 
 static char py_index(const char* s, int len, int i, int* err) { /* python str[i] with wraparound */
     if (i < 0) i += len;
@@ -1164,7 +1187,9 @@ static int nw_traceback(const void* ctx, dp_get_fn get, const char* s1, int l1, 
     int i = l1, j = l2, n = 0, err = 0;
 #define EMIT(c1_, c2_) do { if (n + 1 >= cap) return PO_E_CAP; a1[n] = (c1_); a2[n] = (c2_); n++; } while (0)
     while (i > 0 && j > 0) {
-        int sc = (py_index(s1, l1, i - 1, &err) == py_index(s2, l2, j - 1, &err)) ? NW_MATCH : NW_MISMATCH;
+        /* the trace-back calls scoring_function WITHOUT its match / mismatch arguments (align.pyx:66,143): the defaults
+         * 2 / -1 whatever the fill used; gap_cost is the caller's */
+        int sc = (py_index(s1, l1, i - 1, &err) == py_index(s2, l2, j - 1, &err)) ? 2 : -1;
         int cells[3] = {get(ctx, i - 1, j - 1) + sc, get(ctx, i - 1, j) + NW_GAP, get(ctx, i, j - 1) + NW_GAP};
         int mx = cells[0];
         if (cells[1] > mx) mx = cells[1];

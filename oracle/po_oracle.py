@@ -205,14 +205,23 @@ def prefix_search_log(y_, flavor="py"):
     return out.raw[:n].decode(), lp.value
 
 
-def pair_prefix_search_log(y1_, y2_, flavor="py"):
+def pair_prefix_search_log(y1_, y2_, flavor="py", envelope_inclusive=None):
+    """prefix_search.pair_prefix_search_log (flavor "py") / _cy ("cy"); with envelope_inclusive ((U + 1, 2) inclusive
+    column ranges) gamma comes from the envelope DP of Gamma.h — the working form of PairPrefixSearch.cpp:79-229"""
     y1, y2 = _f64(y1_), _f64(y2_)
     cap = max(y1.shape[0], y2.shape[0]) + 8
     out = C.create_string_buffer(cap)
     lp = C.c_double()
-    n = _chk(oracle_lib().oracle_pair_prefix_search_log(
-        y1.ctypes.data_as(_dp), y1.shape[0], y2.ctypes.data_as(_dp), y2.shape[0], y1.shape[1],
-        0 if flavor == "py" else 1, out, cap, C.byref(lp)), "pair_prefix_search_log")
+    if envelope_inclusive is None:
+        n = _chk(oracle_lib().oracle_pair_prefix_search_log(
+            y1.ctypes.data_as(_dp), y1.shape[0], y2.ctypes.data_as(_dp), y2.shape[0], y1.shape[1],
+            0 if flavor == "py" else 1, out, cap, C.byref(lp)), "pair_prefix_search_log")
+    else:
+        env = np.ascontiguousarray(envelope_inclusive, dtype=np.intc)
+        assert env.shape == (y1.shape[0] + 1, 2)
+        n = _chk(oracle_lib().oracle_pair_prefix_search_log_env(
+            y1.ctypes.data_as(_dp), y1.shape[0], y2.ctypes.data_as(_dp), y2.shape[0], y1.shape[1],
+            0 if flavor == "py" else 1, env.ctypes.data_as(_ip), out, cap, C.byref(lp)), "pair_prefix_search_log_env")
     return out.raw[:n].decode(), lp.value
 
 
@@ -223,11 +232,24 @@ def _align(fn, seq1, seq2, *extra):
     return list(a1.raw[:n].decode()), list(a2.raw[:n].decode())
 
 
-def global_pair(seq1, seq2):
+def _with_scores(fn, match, mismatch, gap_cost):
+    L = oracle_lib()
+    L.oracle_set_nw_scores(int(match), int(mismatch), int(gap_cost))
+    try:
+        return fn()
+    finally:
+        L.oracle_set_nw_scores(2, -1, -1)
+
+
+def global_pair(seq1, seq2, match=2, mismatch=-1, gap_cost=-1):
+    if (match, mismatch, gap_cost) != (2, -1, -1):
+        return _with_scores(lambda: global_pair(seq1, seq2), match, mismatch, gap_cost)
     return _align(oracle_lib().oracle_global_pair, seq1, seq2)
 
 
-def global_pair_banded(seq1, seq2, band_width=500):
+def global_pair_banded(seq1, seq2, band_width=500, match=2, mismatch=-1, gap_cost=-1):
+    if (match, mismatch, gap_cost) != (2, -1, -1):
+        return _with_scores(lambda: global_pair_banded(seq1, seq2, band_width), match, mismatch, gap_cost)
     return _align(oracle_lib().oracle_global_pair_banded, seq1, seq2, int(band_width))
 
 

@@ -78,6 +78,7 @@ PROTOTYPES = {
     "po_align_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64, C.c_int]),
     "po_align_batch": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, _cp, _cp, _i64p, _i32p, _i32p, _vp, C.c_size_t, _vp]),
     "po_align_batch_h": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, _cp, _cp, _i64p, _i32p, _i32p]),
+    "po_align_scores_batch_h": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _cp, _cp, _i64p, _i32p, _i32p]),
     "po_envelope_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "po_envelope_batch": (C.c_int, [_cp, _cp, _i64p, _i32p, C.c_int, _i32p, _i64p, _i32p, _i64p, _i32p, _i32p, C.c_int,
                                     _i32p, _i64p, _i32p, _vp, C.c_size_t, _vp]),
@@ -107,6 +108,8 @@ PROTOTYPES = {
     "po_lae_peak": (C.c_int, [C.c_int, _dp, C.c_void_p]),
     "po_pair_prefix_search_batch_h": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _i32p,
                                                 _dp, _i32p]),
+    "po_pair_prefix_search_env_batch_h": (C.c_int, [_dp, _i64p, _dp, _i64p, _i32p, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp,
+                                                    _i64p, _i32p, _dp, _i32p]),
     "po_forward_vec_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "po_viterbi_acceptor_cy_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _cp, _i64p, _i32p,
                                               _i32p]),

@@ -4,25 +4,17 @@ from .. import batch as _batch
 MATCH_DEFAULT, MISMATCH_DEFAULT, GAP_DEFAULT, BAND_DEFAULT = 2, -1, -1, 500
 
 
-def _check_scores(match, mismatch, gap_cost):
-    if (match, mismatch, gap_cost) != (MATCH_DEFAULT, MISMATCH_DEFAULT, GAP_DEFAULT):
-        raise NotImplementedError("the engine implements the reference's default scores (match 2, mismatch -1, gap -1), "
-                                  "the only ones its drivers use")
-
-
 def global_pair(seq1, seq2, match=MATCH_DEFAULT, mismatch=MISMATCH_DEFAULT, gap_cost=GAP_DEFAULT):
     """Needleman-Wunsch (align.pyx:29-98).  Returns (align1, align2, None): two lists of characters; the
     reference's third item, the dense DP matrix, stays on the device and is not returned."""
-    _check_scores(match, mismatch, gap_cost)
-    a1, a2 = _batch.align_batch([(seq1, seq2)], band_width=0)[0]
+    a1, a2 = _batch.align_batch([(seq1, seq2)], 0, match, mismatch, gap_cost)[0]
     return list(a1), list(a2), None
 
 
 def global_pair_banded(seq1, seq2, band_width=BAND_DEFAULT, match=MATCH_DEFAULT, mismatch=MISMATCH_DEFAULT,
                        gap_cost=GAP_DEFAULT):
     """Banded Needleman-Wunsch exactly as written upstream (align.pyx:100-178)."""
-    _check_scores(match, mismatch, gap_cost)
     if band_width <= 0:
         raise ValueError("band_width must be positive")
-    a1, a2 = _batch.align_batch([(seq1, seq2)], band_width=band_width)[0]
+    a1, a2 = _batch.align_batch([(seq1, seq2)], band_width, match, mismatch, gap_cost)[0]
     return list(a1), list(a2)

@@ -395,29 +395,40 @@ def forward_vec_batch(arrays, s, i, previous=None, flavor="cy"):
     return [out[off[k]:off[k + 1]].copy() for k in range(n)]
 
 
-def pair_prefix_search_batch(arrays1, arrays2, alphabet="ACGT", flavor="cy"):
+def pair_prefix_search_batch(arrays1, arrays2, alphabet="ACGT", flavor="cy", envelopes=None):
     """prefix_search.pair_prefix_search_log_cy (flavor "cy") / pair_prefix_search_log ("py") for a batch of
-    small boxes (dense gamma on the device).  Returns [(label, log-probability), ...]."""
+    small boxes (dense gamma on the device).  envelopes: list of (U_i + 1, 2) arrays with INCLUSIVE column ends
+    (Gamma.h) — gamma then comes from the envelope DP, the working form of decoding_cpp.cpp_pair_prefix_search_log
+    (PairPrefixSearch.cpp:79-229).  Returns [(label, log-probability), ...]."""
     lib = L.load()
     y1, o1, Cc = pack_rows(arrays1)
     y2, o2, _ = pack_rows(arrays2, Cc)
     n = len(arrays1)
+    env = eo = None
+    if envelopes is not None:
+        es = [np.ascontiguousarray(e, dtype=np.int32) for e in envelopes]
+        for e, a in zip(es, arrays1):
+            if e.ndim != 2 or e.shape[1] != 2 or e.shape[0] < len(a) + 1:
+                raise ValueError("gamma envelopes need U + 1 rows")
+        env = np.ascontiguousarray(np.concatenate([e[:len(a) + 1] for e, a in zip(es, arrays1)], axis=0))
+        eo = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(a) + 1 for a in arrays1], out=eo[1:])
     so = np.zeros(n + 1, dtype=np.int64)
     np.cumsum([max(len(a), len(b)) + 2 for a, b in zip(arrays1, arrays2)], out=so[1:])
     seq = np.zeros(max(int(so[-1]), 1), dtype=np.uint8)
     lens = np.zeros(max(n, 1), dtype=np.int32)
     st = np.zeros(max(n, 1), dtype=np.int32)
     lp = np.zeros(max(n, 1), dtype=np.float64)
-    L.check(lib.po_pair_prefix_search_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), n, Cc, alphabet.encode(),
-                                              {"py": 0, "cy": 1}[flavor], _ptr(seq), _ptr(so), _ptr(lens), _ptr(lp),
-                                              _ptr(st)), "po_pair_prefix_search_batch_h")
+    L.check(lib.po_pair_prefix_search_env_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), _ptr(env), _ptr(eo), n, Cc,
+                                                  alphabet.encode(), {"py": 0, "cy": 1}[flavor], _ptr(seq), _ptr(so),
+                                                  _ptr(lens), _ptr(lp), _ptr(st)), "po_pair_prefix_search_env_batch_h")
     for i in range(n):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "pair prefix search of box %d" % i)
     return list(zip(_strings(seq, so, lens), [float(x) for x in lp[:n]]))
 
 
-def align_batch(pairs, band_width=500):
+def align_batch(pairs, band_width=500, match=2, mismatch=-1, gap_cost=-1):
     """align.global_pair_banded (band_width > 0) / align.global_pair (band_width <= 0) for a batch of
     (seq1, seq2) string pairs.  Returns [(align1, align2), ...] as strings of equal length."""
     lib = L.load()
@@ -434,8 +445,8 @@ def align_batch(pairs, band_width=500):
     a2 = np.zeros(max(int(ao[-1]), 1), dtype=np.uint8)
     nc = np.zeros(max(n, 1), dtype=np.int32)
     st = np.zeros(max(n, 1), dtype=np.int32)
-    L.check(lib.po_align_batch_h(_ptr(buf), _ptr(so), n, int(band_width), _ptr(a1), _ptr(a2), _ptr(ao), _ptr(nc),
-                                 _ptr(st)), "po_align_batch_h")
+    L.check(lib.po_align_scores_batch_h(_ptr(buf), _ptr(so), n, int(band_width), int(match), int(mismatch), int(gap_cost),
+                                        _ptr(a1), _ptr(a2), _ptr(ao), _ptr(nc), _ptr(st)), "po_align_scores_batch_h")
     for i in range(n):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "alignment of pair %d" % i)
@@ -495,8 +506,9 @@ def ingest_batch(arrays, perm=None, reverse=False):
 def pair_gamma_batch(arrays1, arrays2, envelopes=None, flavor="cpp", return_matrix=False):
     """gamma(0,0) = log P(both reads emit the same label) for a batch of pairs.
     envelopes: list of (U_i + 1, 2) arrays with INCLUSIVE ends (Gamma.h), or None for the dense DP.
-    flavor "cpp" = Gamma.h arithmetic, "cy" = decoding_cy.pair_gamma_log arithmetic.
-    return_matrix (dense only): also return the (U+1, V+1) gamma matrices."""
+    flavor "cpp" = Gamma.h arithmetic, "cy" = decoding_cy.pair_gamma_log arithmetic (dense), "cy_env" =
+    decoding_cy.pair_gamma_log_envelope (log(exp + exp), -inf defaults, every envelope cell with u < U, v < V computed).
+    return_matrix: return the (U+1, V+1) gamma matrices instead of gamma(0,0) (-inf outside an envelope)."""
     lib = L.load()
     y1, o1, Cc = pack_rows(arrays1)
     y2, o2, _ = pack_rows(arrays2, Cc)
@@ -513,14 +525,12 @@ def pair_gamma_batch(arrays1, arrays2, envelopes=None, flavor="cpp", return_matr
     g0 = np.zeros(max(n, 1), dtype=np.float64)
     st = np.zeros(max(n, 1), dtype=np.int32)
     dn = dof = None
-    if return_matrix:
-        if envelopes is not None:
-            raise ValueError("return_matrix needs the dense DP")
+    if return_matrix:   # (with an envelope: -inf outside the stored ranges)
         dof = np.zeros(n + 1, dtype=np.int64)
         np.cumsum([(len(a) + 1) * (len(b) + 1) for a, b in zip(arrays1, arrays2)], out=dof[1:])
         dn = np.zeros(max(int(dof[-1]), 1), dtype=np.float64)
     L.check(lib.po_pair_gamma_batch_h(_ptr(y1), _ptr(o1), _ptr(y2), _ptr(o2), _ptr(env), _ptr(eo), n, Cc,
-                                      0 if flavor == "cpp" else 1, _ptr(g0), _ptr(dn), _ptr(dof), _ptr(st)),
+                                      {"cpp": 0, "cy": 1, "cy_env": 2}[flavor], _ptr(g0), _ptr(dn), _ptr(dof), _ptr(st)),
             "po_pair_gamma_batch_h")
     for i in range(n):
         if st[i] != 0:

@@ -41,6 +41,8 @@ int po_launch_ingest(const void*, const int64_t*, int, int, int, const int*, int
 size_t po_align_ws_bytes(int, int64_t, int64_t, int);
 int po_launch_align(const char*, const int64_t*, int, int, int64_t, int64_t, char*, char*, const int64_t*, int32_t*, int32_t*,
                     void*, size_t, hipStream_t);
+int po_launch_align_scores(const char*, const int64_t*, int, int, int, int, int, int64_t, int64_t, char*, char*, const int64_t*,
+                           int32_t*, int32_t*, void*, size_t, hipStream_t);
 size_t po_envelope_ws_bytes(int, int64_t);
 int po_launch_envelope(const char*, const char*, const int64_t*, const int32_t*, int, const int32_t*, const int64_t*,
                        const int32_t*, const int64_t*, const int32_t*, const int32_t*, int, int64_t, int32_t*,
@@ -596,24 +598,31 @@ int po_pair_gamma_batch_h(const double* y1_h, const int64_t* y1_off_h, const dou
     return PO_OK;
 }
 
-int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
-                                  int n, int C, const char* alphabet, int flavor, char* seq_h, const int64_t* seq_off_h,
-                                  int32_t* seq_len_h, double* logp_h, int32_t* status_h) {
+int po_pair_prefix_search_env_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                                      const int32_t* env_h, const int64_t* env_off_h, int n, int C, const char* alphabet,
+                                      int flavor, char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, double* logp_h,
+                                      int32_t* status_h) {
     g_err.clear();
     if (n <= 0) return PO_OK;
     uint32_t ap = 0;
     const int A = pack_alphabet(alphabet, &ap);
-    if (A < 0) { g_err = "po_pair_prefix_search_batch_h: alphabet must have 1..4 symbols"; return PO_E_ARG; }
+    if (A < 0) { g_err = "po_pair_prefix_search_env_batch_h: alphabet must have 1..4 symbols"; return PO_E_ARG; }
     const int64_t r1 = y1_off_h[n] - y1_off_h[0], r2 = y2_off_h[n] - y2_off_h[0];
     int64_t m1 = 0, m2 = 0, mc = 0;
     std::vector<int64_t> dof((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) {
         const int64_t U = y1_off_h[i + 1] - y1_off_h[i], V = y2_off_h[i + 1] - y2_off_h[i];
         m1 = std::max(m1, U); m2 = std::max(m2, V);
-        mc = std::max(mc, (U + 1) * (V + 1));
+        int64_t cells = (U + 1) * (V + 1);
+        if (env_h) {   // stored cells of the envelope DP: sum over rows of end - start + 1
+            cells = 0;
+            for (int64_t u = 0; u <= U; ++u) { const int64_t w = (int64_t)env_h[2 * (env_off_h[i] + u) + 1] - env_h[2 * (env_off_h[i] + u)] + 1; cells += w > 0 ? w : 0; }
+        }
+        mc = std::max(mc, cells);
         dof[i + 1] = dof[i] + (U + 1) * (V + 1);
     }
-    DevBuf a, ao, b, bo, g0, dn, dfo, st, st2, ws, so, sq, sl, lp, ws2;
+    DevBuf a, ao, b, bo, g0, dn, dfo, st, st2, ws, so, sq, sl, lp, ws2, ev, eo;
+    if (env_h) { UP(ev, env_h, sizeof(int32_t) * 2 * (size_t)env_off_h[n]); UP(eo, env_off_h, sizeof(int64_t) * (n + 1)); }
     UP(a, y1_h + y1_off_h[0] * C, sizeof(double) * r1 * C);
     UP(b, y2_h + y2_off_h[0] * C, sizeof(double) * r2 * C);
     std::vector<int64_t> o1(y1_off_h, y1_off_h + n + 1), o2(y2_off_h, y2_off_h + n + 1);
@@ -627,8 +636,11 @@ int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, c
     UP(st, nullptr, sizeof(int32_t) * n);
     const size_t wsb = po_pair_gamma_workspace_bytes(n, mc, m1, m2);
     UP(ws, nullptr, wsb);
-    int rc = po_pair_gamma_batch((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p, nullptr,
-                                 nullptr, n, C, flavor, mc, (double*)g0.p, (double*)dn.p, (const int64_t*)dfo.p,
+    // gamma: dense (the Python paths' flavour), or the envelope DP of Gamma.h (its own arithmetic: logaddexp, -inf)
+    // written out as a full matrix with -inf outside the stored ranges
+    int rc = po_pair_gamma_batch((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p,
+                                 env_h ? (const int32_t*)ev.p : nullptr, env_h ? (const int64_t*)eo.p : nullptr, n, C,
+                                 env_h ? 0 : flavor, mc, (double*)g0.p, (double*)dn.p, (const int64_t*)dfo.p,
                                  (int32_t*)st.p, ws.p, wsb, nullptr);
     if (rc != PO_OK) return rc;
     const int64_t seqb = seq_off_h[n];
@@ -643,7 +655,7 @@ int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, c
     rc = po_launch_pair_prefix_search((const double*)a.p, (const int64_t*)ao.p, (const double*)b.p, (const int64_t*)bo.p,
                                       (const double*)dn.p, (const int64_t*)dfo.p, n, C, A, ap, flavor, mr, (char*)sq.p,
                                       (const int64_t*)so.p, (int32_t*)sl.p, (double*)lp.p, (int32_t*)st2.p, ws2.p, wsb2, nullptr);
-    if (rc != PO_OK) { g_err = "po_pair_prefix_search_batch_h: box too long for the LDS rows, or bad C"; return rc; }
+    if (rc != PO_OK) { g_err = "po_pair_prefix_search_env_batch_h: box too long for the LDS rows, or bad C"; return rc; }
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     DOWN(seq_h, sq, (size_t)seqb);
@@ -651,6 +663,13 @@ int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, c
     DOWN(logp_h, lp, sizeof(double) * n);
     DOWN(status_h, st2, sizeof(int32_t) * n);
     return PO_OK;
+}
+
+int po_pair_prefix_search_batch_h(const double* y1_h, const int64_t* y1_off_h, const double* y2_h, const int64_t* y2_off_h,
+                                  int n, int C, const char* alphabet, int flavor, char* seq_h, const int64_t* seq_off_h,
+                                  int32_t* seq_len_h, double* logp_h, int32_t* status_h) {
+    return po_pair_prefix_search_env_batch_h(y1_h, y1_off_h, y2_h, y2_off_h, nullptr, nullptr, n, C, alphabet, flavor, seq_h,
+                                             seq_off_h, seq_len_h, logp_h, status_h);
 }
 
 int po_forward_vec_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, int s, int i, int flavor,
@@ -675,8 +694,9 @@ int po_forward_vec_batch_h(const double* y_h, const int64_t* y_off_h, int n, int
     return PO_OK;
 }
 
-int po_align_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, char* aln1_h, char* aln2_h,
-                     const int64_t* aln_off_h, int32_t* ncol_h, int32_t* status_h) {
+int po_align_scores_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, int match, int mismatch,
+                            int gap_cost, char* aln1_h, char* aln2_h, const int64_t* aln_off_h, int32_t* ncol_h,
+                            int32_t* status_h) {
     g_err.clear();
     if (n <= 0) return PO_OK;
     int64_t m1 = 0, m2 = 0;
@@ -694,15 +714,22 @@ int po_align_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int ba
     UP(st, nullptr, sizeof(int32_t) * n);
     const size_t wsb = po_align_workspace_bytes(n, m1, m2, band_width);
     UP(ws, nullptr, wsb);
-    int rc = po_align_batch((const char*)sq.p, (const int64_t*)so.p, n, band_width, (char*)a1.p, (char*)a2.p,
-                            (const int64_t*)ao.p, (int32_t*)nc.p, (int32_t*)st.p, ws.p, wsb, nullptr);
-    if (rc != PO_OK) return rc;
+    int rc = po_launch_align_scores((const char*)sq.p, (const int64_t*)so.p, n, band_width, match, mismatch, gap_cost, m1, m2,
+                                    (char*)a1.p, (char*)a2.p, (const int64_t*)ao.p, (int32_t*)nc.p, (int32_t*)st.p, ws.p, wsb,
+                                    nullptr);
+    if (rc != PO_OK) { g_err = "po_align_scores_batch_h: workspace too small"; return rc; }
+    HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     DOWN(aln1_h, a1, (size_t)aln_off_h[n]);
     DOWN(aln2_h, a2, (size_t)aln_off_h[n]);
     DOWN(ncol_h, nc, sizeof(int32_t) * n);
     DOWN(status_h, st, sizeof(int32_t) * n);
     return PO_OK;
+}
+
+int po_align_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, char* aln1_h, char* aln2_h,
+                     const int64_t* aln_off_h, int32_t* ncol_h, int32_t* status_h) {
+    return po_align_scores_batch_h(seqs_h, seq_off_h, n, band_width, 2, -1, -1, aln1_h, aln2_h, aln_off_h, ncol_h, status_h);
 }
 
 int po_envelope_batch_h(const char* aln1_h, const char* aln2_h, const int64_t* aln_off_h, const int32_t* ncol_h, int n,

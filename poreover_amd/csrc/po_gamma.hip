@@ -45,7 +45,9 @@ __global__ __launch_bounds__(GM_THREADS) void pair_gamma_kernel(GMArgs a) {
     const double* y2 = a.y2 + o2 * C;
     const bool dense = (a.env == nullptr);
     const int32_t* env = dense ? nullptr : a.env + 2 * a.env_off[pi];
-    const double LOG0 = a.flavor ? -9999.0 : PO_NEG_INF;
+    // flavor 0: Gamma.h; 1: decoding_cy.pair_gamma_log (dense, LOG_0 = -9999); 2: decoding_cy.pair_gamma_log_envelope
+    // (decoding_cy.pyx:224-271: log(exp + exp), -inf defaults, every envelope cell with u < U and v < V is computed)
+    const double LOG0 = (a.flavor == 1) ? -9999.0 : PO_NEG_INF;
     double* g = a.mat + (size_t)blockIdx.x * 2 * a.mat_cap;
     double* ga = g + a.mat_cap;
     long long* roff = a.roff + (size_t)blockIdx.x * a.row_cap;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(GM_THREADS) void pair_gamma_kernel(GMArgs a) {
     for (int d = U + V - 2; d >= 0; --d) {
         for (int u = min(U - 1, d) - tid; u >= 0 && u >= d - (V - 1); u -= GM_THREADS) {
             const int v = d - u;
-            if (v < rs(u) || v > re(u) - 1) continue;   // cells [start, end-1] only (Gamma.h:61-64)
+            if (v < rs(u) || v > ((a.flavor == 2) ? min(re(u), V - 1) : re(u) - 1)) continue;   // cells [start, end-1] only (Gamma.h:61-64)
             const double* r1 = y1 + (int64_t)u * C;
             const double* r2 = y2 + (int64_t)v * C;
             const double gamma_eps = G(g, u + 1, v) + r1[b];
@@ -122,6 +124,14 @@ __global__ __launch_bounds__(GM_THREADS) void pair_gamma_kernel(GMArgs a) {
     if (a.dense_out && dense) {
         double* dst = a.dense_out + a.dense_off[pi];
         for (long long i = tid; i < (long long)(U + 1) * (V + 1); i += GM_THREADS) dst[i] = g[i];
+    } else if (a.dense_out) {
+        // envelope: the (U+1) x (V+1) matrix as SparseMatrix::get shows it — -inf outside the stored ranges
+        // (input of the pair prefix search with an envelope, PairPrefixSearch.cpp:79-229)
+        double* dst = a.dense_out + a.dense_off[pi];
+        for (long long i = tid; i < (long long)(U + 1) * (V + 1); i += GM_THREADS) {
+            const int u = (int)(i / (V + 1)), v = (int)(i - (long long)u * (V + 1));
+            dst[i] = G(g, u, v);
+        }
     }
 }
 

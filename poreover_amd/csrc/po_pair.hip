@@ -38,6 +38,7 @@ struct PPArgs {
     const int32_t* st1; const int32_t* st2;         // status of the two 1-D decodes
     int padding, full_alignment, diagonal_envelope, diagonal_width;
     int band;                                       // banded alignment half-width (align.pyx:13: 500)
+    int match, mismatch, gap;                       // Needleman-Wunsch scores (align.pyx:9-11: 2, -1, -1)
     long long seq_lds_cap;                          // bytes of dynamic LDS per basecall (0: read them from global memory)
     int mode;                                       // 0: align + skips + envelope; 1: align only; 2: envelope from a given alignment
     int retry_cap;                                  // second pass with the big DP slices: only the pairs the first one gave PO_E_CAP
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
                     __syncthreads();
                     break;
                 }
-                for (int j = tid; j < w; j += NT) { row[j] = NW_GAP * j; cur[j] = NW_GAP * j; }
+                for (int j = tid; j < w; j += NT) { row[j] = a.gap * j; cur[j] = a.gap * j; }
                 __syncthreads();
                 ps = js; pe = je;
                 continue;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             //   banded: cell(i, js-1) reads 0 (out of range); seq1[i-1] wraps at i == 0
             //   full:   cell(i, 0) = gap * i, filled cells start at j = 1; seq1[i-1]
             const int jfirst = full ? 1 : js;
-            const int left0 = full ? NW_GAP * i : 0;
+            const int left0 = full ? a.gap * i : 0;
             const char c1 = s1[py_idx(i - 1, l1)];
             if (full && tid == 0) { row[0] = left0; cur[0] = left0; }
             const int cnt = je - jfirst;
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
                 __syncthreads();
                 break;
             }
-            // local running max of c(k) + k over this thread's columns ...
+            // local running max of c(k) + G k over this thread's columns (G = -gap: cell(j) = max(c(j), cell(j-1) + gap)
+            // <=> cell(j) + G j = prefix max of c(k) + G k) ...
             const int j0 = jfirst + tid * per;
             int loc[PERMAX];
             int m = INT_MIN;
@@ -263,9 +265,9 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
                 int val = INT_MIN;
                 if (q < per && j < je) {
                     const char c2 = s2[py_idx(j - 1, l2)];
-                    const int diag = getp(j - 1) + (c1 == c2 ? NW_MATCH : NW_MISMATCH);
-                    const int up = getp(j) + NW_GAP;
-                    val = max(diag, up) + j;
+                    const int diag = getp(j - 1) + (c1 == c2 ? a.match : a.mismatch);
+                    const int up = getp(j) + a.gap;
+                    val = max(diag, up) - a.gap * j;
                 }
                 m = max(m, val);
                 loc[q] = m;
@@ -275,11 +277,11 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             const int incl = block_prefix_max(m);
             pm[tid] = incl;
             __syncthreads();
-            const int excl = max(left0 + (jfirst - 1), tid > 0 ? pm[tid - 1] : INT_MIN);
+            const int excl = max(left0 - a.gap * (jfirst - 1), tid > 0 ? pm[tid - 1] : INT_MIN);
 #pragma unroll
             for (int q = 0; q < PERMAX; ++q) {
                 const int j = j0 + q;
-                if (q < per && j < je) { const int cell = max(loc[q], excl) - j; row[j - js] = cell; cur[j - js] = cell; }
+                if (q < per && j < je) { const int cell = max(loc[q], excl) + a.gap * j; row[j - js] = cell; cur[j - js] = cell; }
             }
             __syncthreads();
             ps = js; pe = je;
@@ -304,8 +306,10 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
                 const int ii = i - lane, jj = j - lane;
                 int c0 = 0, c1v = 0, c2v = 0;
                 if (ii > 0 && jj > 0) {
+                    // (the reference's trace-back calls scoring_function without its match / mismatch arguments,
+                    //  align.pyx:66,143: the default 2 / -1 whatever the fill used; gap_cost is the caller's)
                     const int sc = (s1[py_idx(ii - 1, l1)] == s2[py_idx(jj - 1, l2)]) ? NW_MATCH : NW_MISMATCH;
-                    c0 = get(ii - 1, jj - 1) + sc; c1v = get(ii - 1, jj) + NW_GAP; c2v = get(ii, jj - 1) + NW_GAP;
+                    c0 = get(ii - 1, jj - 1) + sc; c1v = get(ii - 1, jj) + a.gap; c2v = get(ii, jj - 1) + a.gap;
                 }
                 for (int qv = 0; qv < PO_WAVE; ++qv) {
                     const int q = __builtin_amdgcn_readfirstlane(qv);
@@ -590,6 +594,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     a.padding = opt->padding; a.full_alignment = opt->full_alignment;
     a.diagonal_envelope = opt->diagonal_envelope; a.diagonal_width = opt->diagonal_width;
     a.band = NW_BAND; a.mode = 0; a.retry_cap = 0;
+    a.match = NW_MATCH; a.mismatch = NW_MISMATCH; a.gap = NW_GAP;
     a.lenU = a.lenV = nullptr; a.map1_off = a.map2_off = nullptr; a.aln_out1 = a.aln_out2 = nullptr;
     a.aln_off = nullptr; a.ncol_out = nullptr; a.env_off = nullptr;
     a.env = env; a.identity = identity; a.status = status;
@@ -655,9 +660,20 @@ extern "C" size_t po_align_ws_bytes(int n, int64_t max_len1, int64_t max_len2, i
            al256(2 * (size_t)(max_len1 + max_len2 + 16) * blocks) + 256;
 }
 
+extern "C" int po_launch_align_scores(const char* seqs, const int64_t* seq_off, int n, int band, int match, int mismatch,
+                                      int gap, int64_t max_len1, int64_t max_len2, char* aln1, char* aln2,
+                                      const int64_t* aln_off, int32_t* ncol, int32_t* status, void* ws, size_t ws_bytes,
+                                      hipStream_t stream);
 extern "C" int po_launch_align(const char* seqs, const int64_t* seq_off, int n, int band, int64_t max_len1,
                                int64_t max_len2, char* aln1, char* aln2, const int64_t* aln_off, int32_t* ncol,
                                int32_t* status, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return po_launch_align_scores(seqs, seq_off, n, band, NW_MATCH, NW_MISMATCH, NW_GAP, max_len1, max_len2, aln1, aln2, aln_off,
+                                  ncol, status, ws, ws_bytes, stream);
+}
+extern "C" int po_launch_align_scores(const char* seqs, const int64_t* seq_off, int n, int band, int match, int mismatch,
+                                      int gap, int64_t max_len1, int64_t max_len2, char* aln1, char* aln2,
+                                      const int64_t* aln_off, int32_t* ncol, int32_t* status, void* ws, size_t ws_bytes,
+                                      hipStream_t stream) {
     if (n <= 0) return PO_OK;
     if (ws_bytes < po_align_ws_bytes(n, max_len1, max_len2, band)) return PO_E_CAP;
     const int blocks = std::min(n, pp_num_cus() * 4);
@@ -667,6 +683,7 @@ extern "C" int po_launch_align(const char* seqs, const int64_t* seq_off, int n, 
     PPArgs a = {};
     a.n = n; a.seq1d = seqs; a.seq1d_off = seq_off; a.mode = 1;
     a.full_alignment = band > 0 ? 0 : 1; a.band = band > 0 ? band : 0;
+    a.match = match; a.mismatch = mismatch; a.gap = gap;
     a.aln_out1 = aln1; a.aln_out2 = aln2; a.aln_off = aln_off; a.ncol_out = ncol; a.status = status;
     size_t o = 0;
     a.queue = (int*)(w + o); o += 256;
@@ -695,6 +712,7 @@ extern "C" int po_launch_envelope(const char* aln1, const char* aln2, const int6
     const int one_wave = 0;
     PPArgs a = {};
     a.n = n; a.mode = 2; a.padding = padding;
+    a.match = NW_MATCH; a.mismatch = NW_MISMATCH; a.gap = NW_GAP;
     a.aln_out1 = const_cast<char*>(aln1); a.aln_out2 = const_cast<char*>(aln2); a.aln_off = aln_off;
     a.ncol_out = const_cast<int32_t*>(ncol);
     a.map1 = map1; a.map1_off = map1_off; a.map2 = map2; a.map2_off = map2_off; a.lenU = U; a.lenV = V;

@@ -41,3 +41,12 @@ def cpp_pair_gamma_log_envelope(y1_, y2_, envelope_ranges_):
     """decoding_cpp.pyx:168-188: prints gamma(0,0) and returns None, as upstream.  envelope_ranges_: (U + 1, 2)
     with INCLUSIVE column ends (Gamma.h:26-30).  (batch.pair_gamma_batch returns the values.)"""
     print(float(_batch.pair_gamma_batch([_as2d(y1_)], [_as2d(y2_)], [np.asarray(envelope_ranges_, dtype=np.intc)])[0]))
+
+
+def cpp_pair_prefix_search_log(y1_, y2_, envelope_ranges_, alphabet_="ACGT"):
+    """decoding_cpp.pyx:143-164 -> pair_prefix_search_log (PairPrefixSearch.cpp:79-229): the pair prefix search with
+    gamma restricted to an envelope ((U + 1, 2) inclusive column ranges); returns the label.  Upstream's version passes
+    its gamma matrices by value (they stay empty) and reads past its forward rows; this is the working form: the
+    search of the Python paths (prefix_search.py:247-314) on the envelope's gamma."""
+    return _batch.pair_prefix_search_batch([_as2d(y1_)], [_as2d(y2_)], alphabet_, "py",
+                                           [np.asarray(envelope_ranges_, dtype=np.intc)])[0][0]

@@ -21,25 +21,44 @@ def greedy_search(logits, alphabet=['A', 'C', 'G', 'T', '-']):
 
 
 def prefix_search_log_cy(y_, alphabet=DNA_alphabet, return_forward=False):
-    """prefix_search.py:176-238 -> (label, log-probability of the label)"""
-    if return_forward:
-        raise NotImplementedError("return_forward is only used by the reference's deprecated box methods")
+    """prefix_search.py:176-238 -> (label, log-probability of the label), or with return_forward (label, matrix):
+    the transposed rows [0, len(label)) of upstream's per-symbol table prefix_forward[last symbol] — row j is the
+    forward row of label[:j] + label[-1] (the row written for that symbol at search level j + 1)."""
     y = np.asarray(y_, dtype=np.float64)
     sym = "".join(alphabet.keys())
-    return _batch.prefix_search_batch(y, [0, len(y)], sym)[0]
+    label, logp = _batch.prefix_search_batch(y, [0, len(y)], sym)[0]
+    if not return_forward:
+        return label, logp
+    if not label:
+        return label, np.array([]).T
+    last = alphabet[label[-1]]
+    prev = _batch.forward_vec_batch([y], -1, 0, None, "cy")[0]
+    rows = []
+    for j in range(len(label)):
+        rows.append(_batch.forward_vec_batch([y], last, j + 1, [prev], "cy")[0])
+        if j + 1 < len(label):
+            prev = _batch.forward_vec_batch([y], alphabet[label[j]], j + 1, [prev], "cy")[0]
+    return label, np.array(rows).T
 
 
-def pair_prefix_search_log_cy(y1_, y2_, alphabet=DNA_alphabet):
-    """prefix_search.py:316-385 -> (label, log-probability): pair prefix search over the dense gamma matrix
-    of two small boxes (decoding_cy arithmetic)"""
+def _env_arg(envelope_ranges):
+    return None if envelope_ranges is None else [np.asarray(envelope_ranges, dtype=np.int32)]
+
+
+def pair_prefix_search_log_cy(y1_, y2_, alphabet=DNA_alphabet, envelope_ranges=None):
+    """prefix_search.py:316-385 -> (label, log-probability): pair prefix search over the gamma matrix of two small
+    boxes (decoding_cy arithmetic).  envelope_ranges ((U + 1, 2), inclusive column ends): gamma restricted to the
+    envelope (Gamma.h:15-98) — what PairPrefixSearch.cpp:79-229 set out to do."""
     sym = "".join(alphabet.keys())
-    return _batch.pair_prefix_search_batch([np.asarray(y1_, dtype=np.float64)], [np.asarray(y2_, dtype=np.float64)], sym, "cy")[0]
+    return _batch.pair_prefix_search_batch([np.asarray(y1_, dtype=np.float64)], [np.asarray(y2_, dtype=np.float64)], sym, "cy",
+                                           _env_arg(envelope_ranges))[0]
 
 
-def pair_prefix_search_log(y1_, y2_, alphabet=DNA_alphabet):
-    """prefix_search.py:247-314: the numpy twin (-inf instead of LOG_0, np.logaddexp)"""
+def pair_prefix_search_log(y1_, y2_, alphabet=DNA_alphabet, envelope_ranges=None):
+    """prefix_search.py:247-314: the numpy twin (-inf instead of LOG_0, np.logaddexp); envelope_ranges as above"""
     sym = "".join(alphabet.keys())
-    return _batch.pair_prefix_search_batch([np.asarray(y1_, dtype=np.float64)], [np.asarray(y2_, dtype=np.float64)], sym, "py")[0]
+    return _batch.pair_prefix_search_batch([np.asarray(y1_, dtype=np.float64)], [np.asarray(y2_, dtype=np.float64)], sym, "py",
+                                           _env_arg(envelope_ranges))[0]
 
 
 prefix_search_log = prefix_search_log_cy   # the pure-python twin computes the same quantity (prefix_search.py:115)

@@ -29,8 +29,8 @@ def test_alignments_golden(eng, golden):
     assert ("".join(a1), "".join(a2)) == ("ACGTACGTTT-", "ACGT-CGTTTA") and mat is None
     b1, b2 = align.global_pair_banded("ACGTACGTTT", "ACGTCGTTTA")
     assert ("".join(b1), "".join(b2)) == ("-ACGTACG-T-TT", "AACGT-CGTTT-A")     # the reference's banded quirk
-    with pytest.raises(NotImplementedError):
-        align.global_pair("AC", "AC", match=5)
+    a1, a2, _ = align.global_pair("AC", "AC", match=5)        # score arguments as upstream (golden: test_gpu_prefix.py)
+    assert ("".join(a1), "".join(a2)) == ("AC", "AC")
 
 
 def test_envelope_golden(eng, golden, golden_inputs):

@@ -55,4 +55,4 @@ def test_gamma_dense_golden(eng, golden, golden_inputs):
             a, b = k.split("_")
             g00 = decoding_cy.pair_gamma_log(np.log(np.array(pm[a])), np.log(np.array(pm[b])))[0, 0]
             assert np.isclose(g00, hexf(rec["gamma00_cy"]), rtol=1e-12)
-    assert decoding_cy.diagonal_band_envelope(10, 20, 3).tolist()[:3] == [[0, 3], [0, 5], [1, 7]]
+    assert decoding_cy.diagonal_band_envelope(10, 20, 3)[1].tolist()[:3] == [[0, 3], [0, 5], [1, 7]]

@@ -118,3 +118,121 @@ def test_forward_vec_log(oracle, golden_inputs):
         w0 = oracle.forward_vec_log(-1, 0, yk, None, "cy")
         assert np.allclose(p0[k], w0, rtol=1e-13, atol=0)
         assert np.allclose(p1[k], oracle.forward_vec_log(3, 1, yk, w0, "cy"), rtol=1e-13, atol=0)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from poreover_amd import _lib, batch
+    _lib.load()
+    return batch
+
+
+@pytest.fixture(scope="module")
+def oracle_(oracle):
+    return oracle
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: pair prefix search WITH an envelope (PairPrefixSearch.cpp:79-229 made to work), return_forward, and the
+# remaining decoding_cy / align signatures
+def _band(U, V, w):
+    return np.array([(max(0, int(u * V / U) - w), min(V, int(u * V / U) + w)) for u in range(U + 1)])
+
+
+@pytest.mark.parametrize("flavor", ["py", "cy"])
+def test_pair_prefix_search_with_envelope_vs_oracle(eng, oracle, flavor):
+    rng = np.random.default_rng(17)
+    a1, a2, envs = [], [], []
+    for i in range(10):
+        y1, y2 = synth_pair(7100 + i, T=int(rng.integers(18, 70)))
+        a1.append(y1); a2.append(y2); envs.append(_band(len(y1), len(y2), int(rng.integers(5, 14))))
+    got = eng.pair_prefix_search_batch(a1, a2, "ACGT", flavor, envs)
+    for i in range(len(a1)):
+        lab, lp = oracle.pair_prefix_search_log(a1[i], a2[i], flavor, envs[i])
+        assert got[i][0] == lab, i
+        assert np.isclose(got[i][1], lp, rtol=1e-10, atol=1e-12), i
+    # an envelope that covers every cell is the dense search
+    full = [np.array([(0, len(b))] * (len(a) + 1)) for a, b in zip(a1, a2)]
+    dense = eng.pair_prefix_search_batch(a1, a2, "ACGT", "py")
+    for g, d in zip(eng.pair_prefix_search_batch(a1, a2, "ACGT", "py", full), dense):
+        assert g[0] == d[0] and np.isclose(g[1], d[1], rtol=1e-10)
+
+
+def test_pair_prefix_search_envelope_reference_toys(eng, golden):
+    """the reference's toy pairs (tests/test_prefix.py:106-162) through the envelope entry points with the whole box
+    as envelope: the labels and probabilities of its dense Python path"""
+    from poreover_amd.decoding import decoding_cpp, prefix_search
+    from collections import OrderedDict
+    toy_alpha = OrderedDict([("A", 0), ("B", 1)])
+    with np.errstate(divide="ignore"):
+        for key, rec in golden["pair_prefix_toy"].items():
+            a, b = key.split("_")
+            ya, yb = np.log(np.array(golden["prefix_prob"][a])), np.log(np.array(golden["prefix_prob"][b]))
+            full = np.array([(0, len(yb))] * (len(ya) + 1))
+            lab, lp = prefix_search.pair_prefix_search_log(ya, yb, toy_alpha, envelope_ranges=full)
+            assert lab == rec["py"][0] and np.isclose(lp, hexf(rec["py"][1]), rtol=1e-9)
+            assert decoding_cpp.cpp_pair_prefix_search_log(ya, yb, full, "AB") == rec["py"][0]
+
+
+def test_prefix_search_return_forward(eng):
+    import json, os
+    from conftest import GOLDEN_DIR
+    from poreover_amd.decoding import prefix_search
+    with open(os.path.join(GOLDEN_DIR, "extra_golden.json")) as f:
+        ex = json.load(f)
+    y1, _ = synth_pair(40, T=400)
+    for key, rec in ex["prefix_return_forward"].items():
+        lo, hi = (int(x) for x in key.split("_"))
+        lab, mat = prefix_search.prefix_search_log_cy(y1[lo:hi], return_forward=True)
+        want = np.array([[hexf(x) for x in row] for row in rec["matrix"]])
+        assert lab == rec["label"] and list(mat.shape) == rec["shape"]
+        assert np.allclose(mat, want, rtol=1e-12, atol=0)
+
+
+def test_alignment_with_score_arguments(eng):
+    import json, os
+    from conftest import GOLDEN_DIR
+    from poreover_amd.align import align
+    with open(os.path.join(GOLDEN_DIR, "extra_golden.json")) as f:
+        ex = json.load(f)
+    for c in ex["align_scores"]:
+        m, mm, g = c["scores"]
+        f1, f2, _ = align.global_pair(c["s1"], c["s2"], m, mm, g)
+        assert ["".join(f1), "".join(f2)] == c["full"], c["scores"]
+        b1, b2 = align.global_pair_banded(c["s1"], c["s2"], 25, m, mm, g)
+        assert ["".join(b1), "".join(b2)] == c["banded25"], c["scores"]
+
+
+def test_decoding_cy_pair_gamma_log_envelope(eng):
+    """decoding_cy.pyx:224-271 on a small banded pair vs the function as written (python loops, in this test)"""
+    from poreover_amd.decoding import decoding_cy as cy
+    y1, y2 = synth_pair(7300, T=40)
+    y1, y2 = y1[:14], y2[:11]
+    U, V = len(y1), len(y2)
+    rows = [(max(0, int(u * V / U) - 3), min(V, int(u * V / U) + 3)) for u in range(U + 1)]
+
+    def fresh():
+        m = cy.PySparseMatrix()
+        for s, e in rows:
+            m.push_row(s, e)
+        return m
+    got = cy.pair_gamma_log_envelope(y1, y2, fresh(), None, fresh(), fresh())
+    g, ga = fresh(), fresh()
+    g.set(U, V, 0.0); ga.set(U, V, 0.0)
+    for v in range(V):
+        g.set(U, v, float(sum(y2[v:, 4])))
+    for u in range(U):
+        g.set(u, V, float(sum(y1[u:, 4])))
+    cells = [(u, v) for u in range(U + 1) for v in range(rows[u][0], rows[u][1] + 1)]
+    with np.errstate(divide="ignore"):
+        for u, v in reversed(cells):
+            if u < U and v < V:
+                ge = g.get(u + 1, v) + y1[u, 4]
+                gae = ga.get(u, v + 1) + y2[v, 4]
+                tot = sum(np.exp(y1[u, t] + y2[v, t]) for t in range(4))
+                gaa = g.get(u + 1, v + 1) + np.log(tot)
+                ga.set(u, v, np.log(np.exp(gae) + np.exp(gaa)))
+                g.set(u, v, np.log(np.exp(ge) + np.exp(ga.get(u, v))))
+    for u, v in cells:
+        a, b = got.get(u, v), g.get(u, v)
+        assert (np.isneginf(a) and np.isneginf(b)) or np.isclose(a, b, rtol=1e-12), (u, v, a, b)
