@@ -69,6 +69,15 @@ const char* po_last_error(void);
 int po_device_info(int device, char* name, int name_cap, int* compute_units, int* clock_khz,
                    size_t* total_mem);
 
+/* test / tuning hook: which kernel serves the pair beam search.  PO_ROUTE_AUTO = the engine's choice;
+ * PO_ROUTE_X2 = the two-pairs-per-wave kernel wherever it can run; PO_ROUTE_LEGACY = always beam2d_kernel;
+ * defer_odd != 0: the x2 path hands every odd pair to beam2d_kernel (exercises the hand-over).  Process-wide; results
+ * are identical on every route. */
+#define PO_ROUTE_AUTO 0
+#define PO_ROUTE_X2 1
+#define PO_ROUTE_LEGACY 2
+int po_set_pair_route(int route, int defer_odd);
+
 /* ---- trace ingest ------------------------------------------------------------------------------
  * replaces decode.logit_to_log_likelihood (decode.py:34-39), the uint8 trace scaling of
  * model_from_trace (decode.py:89-93,99-103), the Bonito column order (decode.py:79) and

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             __syncthreads();
             if (lane == 0) {
                 const double* val0 = Q.val;
-                po_stl_prune(ord, kept, W, [&](int slot) { return val0[slot]; });
+                po_stl_prune<64>(ord, kept, W, [&](int slot) { return val0[slot]; });
                 for (int j = 0; j < min(W, kept); ++j) nsel[j] = ord[j];
             }
             __syncthreads();

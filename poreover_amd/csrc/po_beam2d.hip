@@ -895,8 +895,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 if (tid < ne && !sm.dup[tid]) {
                     const double sc = sm.score[tid];
                     const int id = sm.e[F_ID][tid];
-                    if (tid >= nb) viol = !po_better(sm.score[nb - 1], sm.e[F_ID][nb - 1], sc, id);
-                    else if (tid + 1 < nb) viol = !po_better(sc, id, sm.score[tid + 1], sm.e[F_ID][tid + 1]);
+                    // (strictly: an exact tie is resolved by the full path below, as the reference's partial_sort does)
+                    if (tid >= nb) viol = !(sm.score[nb - 1] > sc);
+                    else if (tid + 1 < nb) viol = !(sc > sm.score[tid + 1]);
                 }
                 same_beam = !b2_any<nthr>(viol);
 #ifdef PO_ABL_ALWAYSSAME   // timing ablation only (results are wrong): every prune keeps the beam
@@ -910,15 +911,40 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 return;
             }
             if (tid == 0) sm.sh[14] = 0;
+            bool teq = false;
             if (tid < ne && !sm.dup[tid]) {
                 const double sc = sm.score[tid];
                 const int id = sm.e[F_ID][tid];
-                int rank = 0;
+                int rank = 0, neq = 0;
 #pragma unroll 8
-                for (int o = 0; o < ne; ++o)
-                    if (!sm.dup[o] && po_better(sm.score[o], sm.e[F_ID][o], sc, id)) rank++;
+                for (int o = 0; o < ne; ++o) {
+                    const double so = sm.score[o];
+                    const bool live = !sm.dup[o];
+                    if (live && po_better(so, sm.e[F_ID][o], sc, id)) rank++;
+                    if (live && so == sc) neq++;
+                }
                 if (rank < W) sm.sel[rank] = tid;
+                teq = (neq > 1) && (rank < W);   // an exact score tie that reaches into the beam
                 atomicAdd(&sm.sh[5], 1);
+            }
+            if (b2_any<nthr>(teq)) {
+                // Exact ties (candidates that are all -inf, quantised inputs): the beam is what libstdc++'s partial_sort /
+                // sort leave on the candidates in pointer = creation order (po_device.h).  Candidate slots in node-id
+                // order (badf is free between scans), then one thread replays the algorithm.
+                int* ord = sm.badf;
+                if (tid < ne && !sm.dup[tid]) {
+                    const int id = sm.e[F_ID][tid];
+                    int pos = 0;
+                    for (int o = 0; o < ne; ++o) pos += (!sm.dup[o] && sm.e[F_ID][o] < id) ? 1 : 0;
+                    ord[pos] = tid;
+                }
+                po_lds_barrier();
+                if (tid == 0) {
+                    const int m = sm.sh[5];
+                    const double* scp = sm.score;
+                    po_stl_prune<WMAX>(ord, m, W, [&](int slot) { return scp[slot]; });
+                    for (int j = 0; j < min(W, m); ++j) sm.sel[j] = ord[j];
+                }
             }
             po_lds_barrier();
             const int nbn = min(W, sm.sh[5]);
@@ -1168,6 +1194,7 @@ struct X2Half {
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[8];
     X2Cand cand[SG];         // prune candidates: score, node id, duplicate flag — one 16-byte read per comparison
+    int ord[SG];             // prune with exact score ties: candidate slots in node-id order (po_stl_prune)
     double xch[2][SG][K];
     // doubles in the y window buffer: 192 (38 rows of 5) for the two-pairs-per-wave one-value kernel, so that 12
     // workgroups fit a CU's LDS; 256 (32 rows of 8) elsewhere (those kernels are register-bound anyway)
@@ -1962,25 +1989,47 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
             // last of them still beats every child — two comparisons per lane instead of a full ranking.
             bool viol = false;
             if (dmm && nb != W) viol = true;
-            else if (live) {
+            else if (live) {   // (strictly: an exact tie is resolved by the full path, as the reference's partial_sort does)
                 const X2Cand me = h.cand[s];
-                if (s >= nb) { const X2Cand lb = h.cand[nb - 1]; viol = !po_better(lb.sc, lb.id, me.sc, me.id); }
-                else if (s + 1 < nb) { const X2Cand nx = h.cand[s + 1]; viol = !po_better(me.sc, me.id, nx.sc, nx.id); }
+                if (s >= nb) { const X2Cand lb = h.cand[nb - 1]; viol = !(lb.sc > me.sc); }
+                else if (s + 1 < nb) { const X2Cand nx = h.cand[s + 1]; viol = !(me.sc > nx.sc); }
             }
+            const unsigned long long cand = __ballot(live);
+            const int ncand = (SG == 64) ? __popcll(cand) : __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
+            bool teq = false;
             if (__ballot(viol) == 0) {
                 if (dmm && s < nb) h.sel[s] = s;
             } else if (live) {
-                int rank = 0;
+                int rank = 0, neq = 0;
                 const X2Cand me = h.cand[s];
 #pragma unroll 8
                 for (int o = 0; o < SG; ++o) {
                     const X2Cand c = h.cand[o];
                     if (!c.dup && po_better(c.sc, c.id, me.sc, me.id)) rank++;
+                    if (!c.dup && c.sc == me.sc) neq++;
                 }
                 if (rank < W) h.sel[rank] = s;
+                teq = (neq > 1) && (rank < W);   // an exact score tie that reaches into the beam
             }
-            const unsigned long long cand = __ballot(live);
-            const int ncand = (SG == 64) ? __popcll(cand) : __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
+            {   // exact ties: the beam libstdc++'s partial_sort / sort leave on the creation-ordered candidates (po_device.h)
+                const unsigned long long tb = __ballot(teq);
+                if (tb != 0ull) {
+                    const bool tieH = ((SG == 64) ? tb : (g ? (tb >> 32) : (tb & 0xffffffffull))) != 0ull;
+                    x2_sync();
+                    if (tieH && live) {
+                        const X2Cand me = h.cand[s];
+                        int pos = 0;
+                        for (int o = 0; o < SG; ++o) { const X2Cand c = h.cand[o]; pos += (!c.dup && c.id < me.id) ? 1 : 0; }
+                        h.ord[pos] = s;
+                    }
+                    x2_sync();
+                    if (tieH && s == 0) {
+                        const X2Cand* cp = h.cand;
+                        po_stl_prune<WB>(h.ord, ncand, W, [&](int slot) { return cp[slot].sc; });
+                        for (int j = 0; j < min(W, ncand); ++j) h.sel[j] = h.ord[j];
+                    }
+                }
+            }
             x2_sync();
             const int nbn = dmm ? min(W, ncand) : 0;
             // the beam comes out as it went in (same nodes, same slots): nothing to move
@@ -2479,10 +2528,27 @@ struct X2Geom {
     size_t off_queue, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
 };
 constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over deferred pairs (16 / 32 MB of store each)
+// Kernel routing is a process-wide setting of the library (po_set_pair_route), not something a launch looks up in the
+// environment: PO_ROUTE_AUTO (the engine's choice, below), PO_ROUTE_X2 (beam2d_x2_kernel whenever it can run),
+// PO_ROUTE_LEGACY (always beam2d_kernel) — the last two exist for the tests, which run the pair path on both kernels,
+// and for A/B timing.  The environment variables PO_X2_FORCE / PO_B2_LEGACY / PO_X2_DEFER_ODD only give the INITIAL
+// value, read once when the library is first used, so that a workspace size and the launch that follows always agree.
+struct B2Route { int route, defer_odd, x2_per_cu, debug_occ; };
+B2Route& b2_route() {
+    static B2Route r = [] {
+        B2Route x;
+        x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_X2_FORCE") ? PO_ROUTE_X2 : PO_ROUTE_AUTO);
+        x.defer_odd = getenv("PO_X2_DEFER_ODD") ? 1 : 0;
+        x.debug_occ = getenv("PO_DEBUG_OCC") ? 1 : 0;
+        const char* e = getenv("PO_X2_PER_CU");
+        x.x2_per_cu = e ? atoi(e) : 0;
+        return x;
+    }();
+    return r;
+}
 bool x2_eligible(int n, int W, int model, int method) {
-    // PO_B2_LEGACY: always beam2d_kernel; PO_X2_FORCE: beam2d_x2_kernel whenever it can run (A/B and test switches)
-    if (getenv("PO_B2_LEGACY") != nullptr || method != PO_METHOD_ROW_COL || W > 12) return false;
-    if (getenv("PO_X2_FORCE") != nullptr) return true;
+    if (b2_route().route == PO_ROUTE_LEGACY || method != PO_METHOD_ROW_COL || W > 12) return false;
+    if (b2_route().route == PO_ROUTE_X2) return true;
     // 7 <= W <= 12: one pair per wave with the reads one after the other — since the incremental steps it beats
     // beam2d_kernel's two waves per pair at every batch size (W = 10: 6.5k vs 3.5k pairs/s at 256 pairs, 22.9k vs
     // 12.7k at 1024, 36.6k vs 19.6k at 3328, 55k at 13k; Bonito W = 10: 29.2k vs 24.5k at 10k).
@@ -2514,11 +2580,8 @@ int x2_blocks_per_cu(int model, int W) {
         int nblk = 0;
         const void* fn = mi == 0 ? x2_fn<PO_MODEL_CTC>(W) : (mi == 1 ? x2_fn<PO_MODEL_MERGE>(W) : x2_fn<PO_MODEL_FLIPFLOP>(W));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, 64, 0) != hipSuccess || nblk <= 0) nblk = 8;
-        if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_x2_kernel model %d W %d: %d resident workgroups per CU\n", model, W, nblk);
-        if (const char* e = getenv("PO_X2_PER_CU")) {  // experiment knob: fewer resident workgroups per CU
-            const int v = atoi(e);
-            if (v > 0 && v < nblk) nblk = v;
-        }
+        if (b2_route().debug_occ) fprintf(stderr, "[po] beam2d_x2_kernel model %d W %d: %d resident workgroups per CU\n", model, W, nblk);
+        if (b2_route().x2_per_cu > 0 && b2_route().x2_per_cu < nblk) nblk = b2_route().x2_per_cu;  // experiment knob
         per_cu[mi][wi] = nblk;
     }
     return per_cu[mi][wi];
@@ -2623,6 +2686,12 @@ unsigned long long* g_b2_upd_counter = nullptr;
 void (*g_b2_mark)(int begin, hipStream_t stream) = nullptr;   // profiling: brackets the main pair beam kernel
 }
 extern "C" void po_b2_set_mark(void (*f)(int, hipStream_t)) { g_b2_mark = f; g_b2_mark_fwd = f; }
+extern "C" int po_set_pair_route(int route, int defer_odd) {
+    if (route != PO_ROUTE_AUTO && route != PO_ROUTE_X2 && route != PO_ROUTE_LEGACY) return PO_E_ARG;
+    b2_route().route = route;
+    b2_route().defer_odd = defer_odd ? 1 : 0;
+    return PO_OK;
+}
 // profiling: a device counter that the pair beam kernels add their number of update_prob evaluations to
 extern "C" void po_b2_set_update_counter(unsigned long long* dev_counter) { g_b2_upd_counter = dev_counter; }
 
@@ -2778,7 +2847,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
         a.dbg = nullptr;
         a.upd_count = g_b2_upd_counter;
-        a.defer_odd = getenv("PO_X2_DEFER_ODD") != nullptr;
+        a.defer_odd = b2_route().defer_odd;
 #ifdef PO_B2_TIMING
         static long long* dbg_x2 = nullptr;
         if (!dbg_x2) (void)hipMalloc((void**)&dbg_x2, 12 * sizeof(long long));

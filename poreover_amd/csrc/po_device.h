@@ -240,9 +240,13 @@ __device__ inline void po_stl_insertion_sort(int* o, int first, int last, const 
         else po_stl_unguarded_linear_insert(o, i, sc);
     }
 }
-template <class S>
-__device__ inline void po_stl_sort(int* o, int n, const S& sc) {   // std::sort; n <= 64 here
+template <int MAXN, class S>
+__device__ inline void po_stl_sort(int* o, int n, const S& sc) {   // std::sort of n <= MAXN <= 64 elements
     if (n == 0) return;
+    if (MAXN <= 16) {   // (introsort leaves ranges of <= 16 elements to the final insertion sort)
+        po_stl_insertion_sort(o, 0, n, sc);
+        return;
+    }
     int lg = 0;
     for (int k = n; k > 1; k >>= 1) ++lg;
     // __introsort_loop without recursion: an explicit stack of (first, last, depth)
@@ -279,10 +283,10 @@ __device__ inline void po_stl_sort(int* o, int n, const S& sc) {   // std::sort;
     else po_stl_insertion_sort(o, 0, n, sc);
 }
 // the W best of the n candidates o[0..n) (slots in node-id order) exactly as Beam::prune orders them, in o[0..min(W, n))
-template <class S>
-__device__ inline void po_stl_prune(int* o, int n, int W, const S& sc) {
+template <int WMAX, class S>
+__device__ inline void po_stl_prune(int* o, int n, int W, const S& sc) {   // W <= WMAX
     if (n > W) po_stl_partial_sort(o, W, n, sc);
-    else po_stl_sort(o, n, sc);
+    else po_stl_sort<WMAX>(o, n, sc);
 }
 
 // node arena entry: parent id and last symbol packed as (parent << 3) | last  (last <= 4)

@@ -52,10 +52,12 @@ def workload():
 def test_batch_1024_pairs_vs_oracle_digest(workload, oracle, route, monkeypatch):
     from poreover_amd import _lib, batch
     _lib.load()
-    if route == "x2":
-        monkeypatch.setenv("PO_X2_FORCE", "1")
+    _lib.set_pair_route("x2" if route == "x2" else "auto")
     pairs, recs = workload
-    got = batch.pair_decode_batch([p[0] for p in pairs], [p[1] for p in pairs], "poreover", 5, "row_col")
+    try:
+        got = batch.pair_decode_batch([p[0] for p in pairs], [p[1] for p in pairs], "poreover", 5, "row_col")
+    finally:
+        _lib.set_pair_route("auto")
     assert len(got) == NPAIRS
     bad = []
     for i, (g, r) in enumerate(zip(got, recs)):

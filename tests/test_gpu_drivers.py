@@ -12,10 +12,11 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["default", "x2"])
 def kernel_route(request, monkeypatch):
     """every test runs twice: with the engine's own choice between beam2d_kernel and beam2d_x2_kernel (small batches
-    of W <= 6 go to the former) and with the two-pairs-per-wave kernel forced wherever it can run (PO_X2_FORCE)"""
-    if request.param == "x2":
-        monkeypatch.setenv("PO_X2_FORCE", "1")
-    return request.param
+    of W <= 6 go to the former) and with the two-pairs-per-wave kernel forced wherever it can run (_lib.set_pair_route)"""
+    from poreover_amd import _lib
+    _lib.set_pair_route("x2" if request.param == "x2" else "auto")
+    yield request.param
+    _lib.set_pair_route("auto")
 
 
 @pytest.fixture(scope="module")

@@ -11,10 +11,20 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["default", "x2"])
 def kernel_route(request, monkeypatch):
     """every test runs twice: with the engine's own choice between beam2d_kernel and beam2d_x2_kernel (small batches
-    of W <= 6 go to the former) and with the two-pairs-per-wave kernel forced wherever it can run (PO_X2_FORCE)"""
-    if request.param == "x2":
-        monkeypatch.setenv("PO_X2_FORCE", "1")
-    return request.param
+    of W <= 6 go to the former) and with the two-pairs-per-wave kernel forced wherever it can run (_lib.set_pair_route)"""
+    from poreover_amd import _lib
+    _lib.set_pair_route("x2" if request.param == "x2" else "auto")
+    _ROUTE[0] = request.param
+    yield request.param
+    _lib.set_pair_route("auto")
+    _ROUTE[0] = "default"
+
+
+_ROUTE = ["default"]
+
+
+def kernel_route_name():
+    return _ROUTE[0]
 
 MODEL_OF_KIND = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}
 
@@ -72,9 +82,11 @@ def test_rowcol_matches_oracle_batch(eng, oracle, model, ff, W):
 
 def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
     """row_col / W <= 6 / ctc runs two pairs per wave (beam2d_x2_kernel); pairs that kernel defers are
-    decoded by beam2d_kernel in the same call.  PO_X2_DEFER_ODD sends every odd pair down the second
+    decoded by beam2d_kernel in the same call.  set_pair_route(defer_odd=True) sends every odd pair down the second
     path: one batch, both kernels, every string equal to the oracle's."""
-    monkeypatch.setenv("PO_X2_DEFER_ODD", "1")
+    from poreover_amd import _lib
+    route = "x2" if kernel_route_name() == "x2" else "auto"
+    _lib.set_pair_route(route, defer_odd=True)
     y1s, y2s, envs, want = [], [], [], []
     for i in range(9):
         y1, y2 = synth_pair(4200 + i, T=250 + 60 * i)
@@ -82,7 +94,7 @@ def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
         y1s.append(y1); y2s.append(y2); envs.append(env)
         want.append(oracle.cpp_beam_search_2d(y1, y2, env, 5, method_="row_col"))
     assert eng.beam_search_2d_batch(y1s, y2s, envs, 5, method="row_col") == want
-    monkeypatch.delenv("PO_X2_DEFER_ODD")
+    _lib.set_pair_route(route, defer_odd=False)
     assert eng.beam_search_2d_batch(y1s, y2s, envs, 5, method="row_col") == want
     # wide windows: fewer row groups fit the store; a pair whose groups run out there is deferred too
     y1, y2 = synth_pair(4300, T=700)
@@ -93,7 +105,7 @@ def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
 
 @pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
 def test_rowcol_wide_beam_one_pair_per_wave(eng, oracle, monkeypatch, model, ff):
-    """7 <= W <= 12 runs beam2d_x2_kernel with one pair per wave (PO_B2_LEGACY forces beam2d_kernel): same strings
+    """7 <= W <= 12 runs beam2d_x2_kernel with one pair per wave (route "legacy" forces beam2d_kernel): same strings
     as the oracle from both"""
     kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
     y1s, y2s, envs = [], [], []
@@ -104,9 +116,12 @@ def test_rowcol_wide_beam_one_pair_per_wave(eng, oracle, monkeypatch, model, ff)
     for W in (7, 10, 12):
         want = [oracle.cpp_beam_search_2d(a, b, e, W, model_=model, method_="row_col") for a, b, e in zip(y1s, y2s, envs)]
         assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want
-        monkeypatch.setenv("PO_B2_LEGACY", "1")
-        assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want, W
-        monkeypatch.delenv("PO_B2_LEGACY")
+        from poreover_amd import _lib
+        _lib.set_pair_route("legacy")
+        try:
+            assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want, W
+        finally:
+            _lib.set_pair_route("x2" if kernel_route_name() == "x2" else "auto")
 
 
 def test_rowcol_full_size(eng, oracle):
@@ -365,3 +380,37 @@ def test_grid_limits(eng, oracle):
     gap = env.copy(); gap[120] = (gap[120][0], gap[120][0])
     assert eng.beam_search_2d_batch([y1], [y2], [gap], 5, method="grid")[0] == \
         oracle.cpp_beam_search_2d(y1, y2, gap, 5, method_="grid")
+
+
+def _quantised(y):
+    """log-probabilities as a uint8 trace would give them (decode.py:92): exact score ties become common"""
+    return np.log((np.clip(np.rint(np.exp(y) * 255), 0, 255) + 1e-7) / (255 + 1e-7))
+
+
+def test_exact_ties_follow_the_reference(eng, oracle):
+    """Beam::prune with exact score ties = libstdc++'s partial_sort on the creation-ordered candidates.  Seed 20127
+    (bonito model, row, W = 8) is a pair on which score-then-creation-order gives a different string than the
+    reference's own C++ does; plus a sweep of quantised pairs, every one against the oracle (which replays libstdc++
+    and is pinned to the compiled reference on such inputs by tests/test_oracle_vs_ref.py)."""
+    y1, y2 = synth_pair(20127, T=200, flipflop=False)
+    rng = np.random.default_rng(5)
+    Ts = [int(rng.integers(40, 200)) for _ in range(128)]      # the draw sequence that found the pair
+    y1, y2 = synth_pair(20127, T=Ts[127])
+    y1, y2 = _quantised(y1), _quantised(y2)
+    U, V = len(y1), len(y2)
+    env = np.array([(max(0, int(u * V / U) - 8), min(V, int(u * V / U) + 9)) for u in range(U)])
+    want = oracle.cpp_beam_search_2d(y1, y2, env, 8, model_="ctc_merge_repeats", method_="row")
+    if oracle.have_ref():
+        assert want == oracle.ref_beam_search_2d(y1, y2, env, 8, model_="ctc_merge_repeats", method_="row")
+    assert eng.beam_search_2d_batch([y1], [y2], [env], 8, model="ctc_merge_repeats", method="row") == [want]
+    for kind, model in (("poreover", "ctc"), ("bonito", "ctc_merge_repeats"), ("flipflop", "ctc_flipflop")):
+        a, b, envs = [], [], []
+        for i in range(14):
+            p, q = synth_pair(21000 + i, T=60 + 9 * i, flipflop=(kind == "flipflop"))
+            p, q = _quantised(p), _quantised(q)
+            a.append(p); b.append(q)
+            envs.append(np.array([(max(0, int(u * len(q) / len(p)) - 6), min(len(q), int(u * len(q) / len(p)) + 7)) for u in range(len(p))]))
+        for method, W in (("row_col", 3), ("row_col", 5), ("row", 5), ("row_col", 16), ("row", 8)):
+            got = eng.beam_search_2d_batch(a, b, envs, W, model=model, method=method)
+            for i in range(len(a)):
+                assert got[i] == oracle.cpp_beam_search_2d(a[i], b[i], envs[i], W, model_=model, method_=method), (kind, method, W, i)
