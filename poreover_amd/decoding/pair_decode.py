@@ -233,6 +233,24 @@ def decode_pairs(in_paths, args, devices=None, decode_fn=None):
     return podist.run_sharded(in_paths, costs, fn, devs, args, bind_device=decode_fn is None)
 
 
+def _write_debug_pickle(pair, rec, args):
+    """--debug (pair_decode.py:482-490): debug.p with the alignment, the per-base frame maps and the alignment-column ->
+    base-count table of the (last) pair, rebuilt from the engine's stage outputs"""
+    import pickle
+    import numpy as np
+    _, _, m1, m2 = pair
+    (s1, s2), _paths, maps, _st = _batch.viterbi_batch([m1.log_prob, m2.log_prob], m1.kind, return_path=True, return_map=True)
+    a1, a2 = _batch.align_batch([(s1, s2)], 0 if args.alignment == "full" else 500)[0]
+    alignment = np.array([list(a1), list(a2)])
+    a2s = np.zeros(shape=alignment.shape, dtype=int)
+    for i, col in enumerate(alignment.T):      # (column 0 looks at column -1, still zero: pair_decode.py:403-410)
+        for r in range(2):
+            a2s[r, i] = a2s[r, i - 1] if col[r] == '-' else a2s[r, i - 1] + 1
+    with open("debug.p", "wb") as pfile:
+        pickle.dump({'alignment_to_sequence': a2s, 'sequence_to_signal1': [int(x) for x in maps[0]],
+                     'sequence_to_signal2': [int(x) for x in maps[1]], 'alignment': alignment}, pfile)
+
+
 def decode_pairs_local(in_paths, args):
     """pair_decode_helper for a list of pairs on THIS process's device: returns a list of the reference's return
     tuples (1-, 2- or 3-tuples, pair_decode.py:375,398,526-529)."""
@@ -259,22 +277,35 @@ def decode_pairs_local(in_paths, args):
         common = dict(kind=kind, beam_width=args.beam_width, method=args.beam_search_method, padding=args.padding,
                       alignment=args.alignment, diagonal_envelope=args.diagonal_envelope,
                       diagonal_width=args.diagonal_width)
+        want_env = bool(getattr(args, 'debug_envelope', False))
         if key[1] == 'host' and getattr(args, 'single', 'viterbi') != 'viterbi':
             res = _batch.pair_decode_batch([loaded[i][2].log_prob for i in idx], [loaded[i][3].log_prob for i in idx],
                                            single=args.single, **common)
         elif key[1] == 'host':
             res = _batch.pair_decode_stream([loaded[i][2].log_prob for i in idx], [loaded[i][3].log_prob for i in idx],
-                                            strict=False, **common)
+                                            strict=False, return_envelope=want_env, **common)
         else:
             ident = list(range(len(key[2])))
             res = _batch.pair_decode_stream([loaded[i][2].engine_input()[0] for i in idx],
                                             [loaded[i][3].engine_input()[0] for i in idx],
                                             perm1=None if list(key[2]) == ident else list(key[2]),
                                             perm2=None if list(key[4]) == ident else list(key[4]), reverse2=key[5],
-                                            strict=False, **common)
+                                            strict=False, return_envelope=want_env, **common)
+        if getattr(args, 'debug', False) and not args.diagonal_envelope:
+            _write_debug_pickle(loaded[idx[-1]], res[-1], args)
         for i, r in zip(idx, res):
             in_path = in_paths[i]
             path1, path2 = loaded[i][0], loaded[i][1]
+            if getattr(args, 'debug_envelope', False) and r["status"] == 0:
+                # pair_decode.py:503-507: band statistics of the envelope instead of a consensus
+                import numpy as np
+                env = np.asarray(r["envelope"])
+                size = env[:, 1] - env[:, 0]
+                U, V = loaded[i][2].t_max, loaded[i][3].t_max
+                print(path1.stem, path2.stem, r["length1"], r["length2"], U, V, np.mean(size), np.std(size), np.median(size),
+                      np.min(size), np.max(size))
+                out[i] = [{"skipped": 1}]
+                continue
             if args.diagonal_envelope:
                 # no 1-D decoding to return; the header quirk of pair_decode.py:527 is kept
                 out[i] = (fasta_format('consensus;{};{}'.format(args.method, path1.stem, path2.stem), r["consensus"]),

@@ -196,3 +196,33 @@ def test_pair_decode_split_method(eng, monkeypatch, golden, golden_inputs):
         assert want["n_out"] == 2 and len(got) == 2
         assert got[0].startswith(">consensus;split;p%d_a\n" % r["index"])
         assert got[0].split("\n", 1)[1] == want["fasta_2d"].split("\n", 1)[1], r["index"]
+
+
+def test_debug_routes(eng, tmp_path, golden, golden_inputs, capsys, monkeypatch):
+    """--debug_envelope (pair_decode.py:503-507: band statistics line, pair reported as skipped) and --debug
+    (pair_decode.py:482-490: debug.p) against what the reference's helper computed for the same pair"""
+    import pickle
+    from poreover_amd.decoding import pair_decode
+    rec = [r for r in golden["pairs"] if r["kind"] == "poreover"][0]
+    run = rec["runs"]["row_col_w5_banded"]
+    for k in ("y1", "y2"):
+        np.save(tmp_path / ("d_%s.npy" % k), np.exp(golden_inputs["pair%d_%s" % (rec["index"], k)]))
+    monkeypatch.chdir(tmp_path)
+    a = _pair_args(dir=str(tmp_path), out=str(tmp_path / "dbg"), debug_envelope=True)
+    setattr(a, "in", ["d_y1.npy", "d_y2.npy"])
+    out = pair_decode.pair_decode_helper(a)
+    assert out == [{"skipped": 1}]
+    fields = capsys.readouterr().out.strip().split()
+    env = np.array(run["envelope"])
+    size = env[:, 1] - env[:, 0]
+    assert fields[:2] == ["d_y1", "d_y2"] and [int(x) for x in fields[2:5]] == [len(rec["viterbi1"]), len(rec["viterbi2"]), len(env)]
+    assert np.allclose([float(x) for x in fields[6:]], [np.mean(size), np.std(size), np.median(size), np.min(size), np.max(size)])
+    a = _pair_args(dir=str(tmp_path), out=str(tmp_path / "dbg2"), debug=True)
+    setattr(a, "in", ["d_y1.npy", "d_y2.npy"])
+    res = pair_decode.pair_decode_helper(a)
+    assert len(res) == 3
+    with open(tmp_path / "debug.p", "rb") as f:
+        d = pickle.load(f)
+    assert ["".join(d["alignment"][0]), "".join(d["alignment"][1])] == run["alignment"]
+    assert d["sequence_to_signal1"] == rec["map1"] and d["sequence_to_signal2"] == rec["map2"]
+    assert d["alignment_to_sequence"][0, -1] == len(rec["viterbi1"]) and d["alignment_to_sequence"][1, -1] == len(rec["viterbi2"])

@@ -392,7 +392,6 @@ def test_exact_ties_follow_the_reference(eng, oracle):
     (bonito model, row, W = 8) is a pair on which score-then-creation-order gives a different string than the
     reference's own C++ does; plus a sweep of quantised pairs, every one against the oracle (which replays libstdc++
     and is pinned to the compiled reference on such inputs by tests/test_oracle_vs_ref.py)."""
-    y1, y2 = synth_pair(20127, T=200, flipflop=False)
     rng = np.random.default_rng(5)
     Ts = [int(rng.integers(40, 200)) for _ in range(128)]      # the draw sequence that found the pair
     y1, y2 = synth_pair(20127, T=Ts[127])
