@@ -224,6 +224,13 @@ int po_pair_decode_batch(const double* y1, const int64_t* y1_off, const double* 
  * Same semantics as the device-pointer forms with every pointer a HOST pointer; synchronous. */
 int po_ingest_batch_h(const void* src_h, const int64_t* row_off_h, int n, int C, int mode, const int* perm_h,
                       int reverse, double* out_h);
+/* `poreover decode` for a batch of traces in one call (decode.py:114-192: model_from_trace + viterbi_decode /
+ * cpp_beam_search): src_h = the basecaller's own output (float32 logits, uint8 trace or float64 log-probabilities, rows of
+ * all reads back to back, row_off_h[0] == 0), ingest on the device as po_ingest_batch, then Viterbi (beam_width <= 0,
+ * `kind`) or the 1-D beam search (`model`, beam_width) — no host log-softmax, 4 or 1 bytes per value over PCIe. */
+int po_decode_1d_batch_h(const void* src_h, const int64_t* row_off_h, int n, int C, int in_mode, const int* perm_h, int reverse,
+                         const char* alphabet, int kind, int beam_width, int model, char* seq_h, const int64_t* seq_off_h,
+                         int32_t* seq_len_h, int32_t* status_h);
 int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int kind,
                        int8_t* path_h,
                        char* seq_h, const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* map_h,

@@ -95,6 +95,8 @@ PROTOTYPES = {
     "po_pair_decode_batch": (C.c_int, [_dp, _i64p, _dp, _i64p, C.c_int, C.c_int, C.POINTER(PairOptions), _cp,
                                        _i64p, _i32p, _i32p, _dp, _i32p, _cp, _i64p, _i32p, _i32p, _vp,
                                        C.c_size_t, _vp]),
+    "po_decode_1d_batch_h": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int,
+                                       C.c_int, C.c_int, _cp, _i64p, _i32p, _i32p]),
     "po_viterbi_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, _vp, _cp, _i64p, _i32p,
                                      _i32p, _i32p]),
     "po_beam1d_batch_h": (C.c_int, [_dp, _i64p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, _cp, _i64p,

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib as L
 
-__all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pair_decode_batch_sharded", "pair_decode_stream", "pack_rows",
+__all__ = ["viterbi_batch", "beam_search_batch", "beam_search_2d_batch", "pair_decode_batch", "pair_decode_batch_sharded", "pair_decode_stream", "decode_1d_batch", "pack_rows",
            "forward_batch", "viterbi_acceptor_batch", "prefix_search_batch", "pair_prefix_search_batch", "forward_vec_batch", "align_batch", "envelope_batch", "ingest_batch", "pair_gamma_batch"]
 
 
@@ -78,6 +78,38 @@ def beam_search_batch(arrays, beam_width=25, alphabet="ACGT", model="ctc"):
     for i in range(n):
         if st[i] != 0:
             raise L.EngineError(int(st[i]), "beam search of read %d" % i)
+    return _strings(seq, off, lens)
+
+
+def decode_1d_batch(arrays, kind="poreover", algorithm="viterbi", beam_width=25, alphabet="ACGT", perm=None, reverse=False):
+    """`poreover decode` for a batch of reads in ONE engine call (po_decode_1d_batch_h): the arrays are the basecaller's
+    own output — float32 logits, uint8 flip-flop traces or float64 log-probabilities, all of one dtype — and are
+    uploaded as they are; log-softmax / trace scaling / column order run on the device, then Viterbi or the 1-D beam
+    search.  Returns the sequences."""
+    lib = L.load()
+    n = len(arrays)
+    if n == 0:
+        return []
+    arrs = [np.ascontiguousarray(a) for a in arrays]
+    dt = arrs[0].dtype
+    mode = INGEST_MODES.get(np.dtype(dt))
+    if mode is None or any(a.dtype != dt or a.ndim != 2 for a in arrs):
+        raise ValueError("decode_1d_batch takes 2-D float32 logits, uint8 traces or float64 log-probabilities of one dtype")
+    Cc = arrs[0].shape[1]
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(a) for a in arrs], out=off[1:])
+    src = np.ascontiguousarray(np.concatenate(arrs, axis=0))
+    seq = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    st = np.zeros(n, dtype=np.int32)
+    model = {"poreover": "ctc", "bonito": "ctc_merge_repeats", "flipflop": "ctc_flipflop"}[kind]
+    pm = (C.c_int * Cc)(*perm) if perm is not None else None
+    L.check(lib.po_decode_1d_batch_h(_ptr(src), _ptr(off), n, Cc, mode, pm, 1 if reverse else 0, alphabet.encode(), L.KINDS[kind],
+                                     int(beam_width) if algorithm == "beam" else 0, L.MODELS[model], _ptr(seq), _ptr(off),
+                                     _ptr(lens), _ptr(st)), "po_decode_1d_batch_h")
+    for i in range(n):
+        if st[i] != 0:
+            raise L.EngineError(int(st[i]), "decode of read %d" % i)
     return _strings(seq, off, lens)
 
 

@@ -527,6 +527,48 @@ int po_viterbi_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, 
     return PO_OK;
 }
 
+// decode driver in one call: raw basecaller output up, ingest on the device, Viterbi (beam_width <= 0) or 1-D beam
+// search, strings down — `poreover decode` for a batch of files without a host-side log-softmax or a float64 upload
+int po_decode_1d_batch_h(const void* src_h, const int64_t* row_off_h, int n, int C, int in_mode, const int* perm_h, int reverse,
+                         const char* alphabet, int kind, int beam_width, int model, char* seq_h, const int64_t* seq_off_h,
+                         int32_t* seq_len_h, int32_t* status_h) {
+    g_err.clear();
+    if (n <= 0) return PO_OK;
+    if (!src_h || !row_off_h || !seq_h || !seq_off_h || !seq_len_h || !status_h) { g_err = "po_decode_1d_batch_h: null argument"; return PO_E_ARG; }
+    if (in_mode < 0 || in_mode > 2 || row_off_h[0] != 0) { g_err = "po_decode_1d_batch_h: bad input mode / offsets"; return PO_E_ARG; }
+    const int64_t rows = row_off_h[n];
+    const size_t esz = in_mode == PO_INGEST_LOGITS_F32 ? 4 : (in_mode == PO_INGEST_TRACE_U8 ? 1 : 8);
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) mx = std::max<int64_t>(mx, row_off_h[i + 1] - row_off_h[i]);
+    DevBuf src, ro, y, so, sq, sl, st, ws;
+    UP(src, src_h, esz * (size_t)rows * C);
+    UP(ro, row_off_h, sizeof(int64_t) * (n + 1));
+    UP(y, nullptr, sizeof(double) * (size_t)rows * C);
+    UP(so, seq_off_h, sizeof(int64_t) * (n + 1));
+    UP(sq, nullptr, (size_t)seq_off_h[n]);
+    UP(sl, nullptr, sizeof(int32_t) * n);
+    UP(st, nullptr, sizeof(int32_t) * n);
+    int rc = po_launch_ingest(src.p, (const int64_t*)ro.p, n, C, in_mode, perm_h, reverse, rows, (double*)y.p, nullptr);
+    if (rc != PO_OK) { g_err = "po_decode_1d_batch_h: bad C / mode / permutation"; return rc; }
+    if (beam_width <= 0) {
+        const size_t wsb = po_viterbi_workspace_bytes(n, rows, C, kind);
+        UP(ws, nullptr, wsb);
+        rc = po_viterbi_batch((const double*)y.p, (const int64_t*)ro.p, n, C, alphabet, kind, nullptr, (char*)sq.p,
+                              (const int64_t*)so.p, (int32_t*)sl.p, nullptr, (int32_t*)st.p, ws.p, wsb, nullptr);
+    } else {
+        const size_t wsb = po_beam1d_workspace_bytes(n, rows, mx, C, beam_width, model);
+        UP(ws, nullptr, wsb);
+        rc = po_beam1d_batch((const double*)y.p, (const int64_t*)ro.p, n, C, alphabet, beam_width, model, (char*)sq.p,
+                             (const int64_t*)so.p, (int32_t*)sl.p, (int32_t*)st.p, ws.p, wsb, nullptr);
+    }
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(seq_h, sq, (size_t)seq_off_h[n]);
+    DOWN(seq_len_h, sl, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
 int po_beam1d_batch_h(const double* y_h, const int64_t* y_off_h, int n, int C, const char* alphabet, int W,
                       int model, char* seq_h,
                       const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {

@@ -134,13 +134,22 @@ def decode_models(models, args):
     by_kind = {}
     for i, m in enumerate(models):
         by_kind.setdefault(m.kind, []).append(i)
-    for kind, idx in by_kind.items():
+    groups = {}
+    for kind, idx in by_kind.items():      # reads that can share an engine call: same kind, input form, pending permutation
+        for i in idx:
+            e = models[i].engine_input()
+            groups.setdefault((kind, e[1], tuple(e[2]), e[3]), []).append(i)
+    for (kind, mode, perm, rev), idx in groups.items():
+        if args.algorithm in ('viterbi', 'beam'):
+            # the traces go up as the basecaller wrote them (deferred ingest: log-softmax / scaling on the device)
+            ident = list(range(len(perm)))
+            seqs = _batch.decode_1d_batch([models[i].engine_input()[0] for i in idx], kind, args.algorithm, args.beam_width,
+                                          "ACGT", None if list(perm) == ident else list(perm), rev)
+            for i, s in zip(idx, seqs):
+                out[i] = s
+            continue
         ys = [models[i].log_prob for i in idx]
-        if args.algorithm == 'viterbi':
-            seqs = _batch.viterbi_batch(ys, kind)
-        elif args.algorithm == 'beam':
-            seqs = _batch.beam_search_batch(ys, args.beam_width, "ACGT", MODEL_TYPE[kind])
-        elif args.algorithm == 'prefix':
+        if args.algorithm == 'prefix':
             assert kind == "poreover"
             seqs = []
             for yy in ys:   # consecutive windows of args.window frames (decode.py:182-188): offsets, no copies

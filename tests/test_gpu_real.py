@@ -137,3 +137,19 @@ def test_real_segments_batch(eng, oracle, real):
         if want["status"] == 0:
             assert np.array_equal(got[i]["envelope"], want["envelope"]), i
             assert got[i]["consensus"] == want["consensus"], i
+
+
+def test_decode_driver_real_logits_file(eng, real, tmp_path):
+    """`decode` on the reference's sample read as its .npy holds it (float32 logits): uploaded as float32, log-softmax
+    on the device, one engine call — the reference's Viterbi basecall (0 edits expected) and beam search (<= 0.1 %)"""
+    import argparse
+    from poreover_amd.decoding import decode
+    g, inp, y1, y2 = real
+    np.save(tmp_path / "read1.npy", inp["read1_logits"])
+    for algo, want in (("viterbi", g["viterbi1"]), ("beam", g["beam1d_read1"]["25"])):
+        a = argparse.Namespace(out=str(tmp_path / algo), basecaller="poreover", algorithm=algo, window=400, beam_width=25, threads=1)
+        setattr(a, "in", [str(tmp_path / "read1.npy")])
+        decode.decode(a)
+        got = "".join(open(str(tmp_path / algo) + ".fasta").read().split("\n")[1:])
+        if got != want:
+            assert _edit_distance(got, want) <= 0.001 * len(want), algo
