@@ -358,7 +358,7 @@ def main():
         try:
             import glob
             pdir = os.path.join(REPO, "profiles")
-            for pj in sorted(glob.glob(os.path.join(pdir, "r*_pmc_hbm*.json")), key=os.path.getmtime, reverse=True):
+            for pj in sorted(glob.glob(os.path.join(pdir, "r*_pmc_hbm*.json")), key=os.path.basename, reverse=True):   # newest round first
                 with open(pj) as f:
                     pm = json.load(f)
                 kks = [v for k, v in pm.get("kernels", {}).items() if k.startswith(MAIN_KERNEL)]
