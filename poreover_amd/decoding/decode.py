@@ -1,6 +1,9 @@
-"""Mirror of poreover.decoding.decode (reference decode.py:20-192): trace loading, FASTA formatting
-and the `decode` driver.  Where the reference starts one process per file (decode.py:158-162) this
-driver loads every trace and makes ONE batched engine call."""
+"""poreover.decoding.decode (reference decode.py:20-192) behind the same names: trace loading, FASTA formatting and
+the `decode` driver.  Where the reference starts one process per file (decode.py:158-162) this driver loads every
+trace and makes ONE batched engine call per input form (spread over the node's GPUs when there are several).
+fasta_format, softmax, logit_to_log_likelihood and load_logits are short host helpers that restate the reference's
+Python line for line — the output format and the host arithmetic are the interface (the batched drivers do the
+log-softmax on the device instead; load_logits serves `.log_prob` and probability-valued files)."""
 import glob
 import logging
 import os

@@ -1,5 +1,7 @@
-"""Mirror of poreover.decoding.envelope (reference envelope.py:5-103).  build_envelope runs on the GPU
-engine; the small index helpers are plain numpy, as upstream."""
+"""poreover.decoding.envelope (reference envelope.py:5-103) behind the same names.  build_envelope runs on the GPU
+engine.  The small host helpers add_block, check_envelope, offset_envelope and pad_envelope are a few lines each and ARE
+the reference's Python restated line for line (their behaviour — in-place edits, clamping, return values — is the
+interface); none of them is on the decode path."""
 import numpy as np
 
 from .. import batch as _batch

@@ -1,5 +1,7 @@
-"""Mirror of poreover.decoding.transducer (reference transducer.py:11-106): containers for a (T, C)
-table of log-probabilities with argmax / Viterbi decoding — decoding runs on the GPU engine."""
+"""poreover.decoding.transducer (reference transducer.py:11-106) behind the same names: containers for a (T, C)
+table of log-probabilities with argmax / Viterbi decoding — decoding runs on the GPU engine, and a container may hold
+the basecaller's raw output (float32 logits, uint8 trace) for the device ingest instead of the float64 table.
+remove_repeated is the reference's five-line helper restated as it is."""
 import numpy as np
 
 from .. import batch as _batch
