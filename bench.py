@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--gen_procs", type=int, default=0, help="processes generating the synthetic inputs (0 = auto; use 1 under "
                     "rocprofv3, whose preloaded library initialises the GPU before Python starts, which makes fork unsafe)")
     ap.add_argument("--cpu_sample", type=int, default=512, help="pairs decoded on the CPU for the baseline (0 = skip)")
+    ap.add_argument("--e2e_wave_pairs", type=int, default=0, help="pairs per wave of the end-to-end pipeline leg (0 = the library's default)")
     ap.add_argument("--no_secondary", action="store_true", help="skip the secondary configurations (1-D beam, flip-flop, "
                     "single-pair latency, end-to-end) measured after the timed region at N = 1")
     args = ap.parse_args()
@@ -316,11 +317,12 @@ def main():
         torch.cuda.empty_cache()
         l1s = [y1[o1[i]:o1[i + 1]].astype(np.float32) for i in range(P)]
         l2s = [y2[o2[i]:o2[i + 1]].astype(np.float32) for i in range(P)]
-        pobatch.pair_decode_stream(l1s[:256], l2s[:256], "poreover", args.beam_width, "row_col")   # buffers + first-use costs
+        wp = args.e2e_wave_pairs
+        pobatch.pair_decode_stream(l1s[:min(P, max(256, wp))], l2s[:min(P, max(256, wp))], "poreover", args.beam_width, "row_col", wave_pairs=wp)   # buffers + first-use costs
         best, stt = None, {}
         for _ in range(2):
             t0 = time.perf_counter()
-            res = pobatch.pair_decode_stream(l1s, l2s, "poreover", args.beam_width, "row_col", stats=stt)
+            res = pobatch.pair_decode_stream(l1s, l2s, "poreover", args.beam_width, "row_col", stats=stt, wave_pairs=wp)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         sec["e2e"] = {"pairs_per_s": round(P / best, 1), "seconds": round(best, 4), "pairs": P,
