@@ -12,8 +12,16 @@
  *
  * Conventions
  *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in _h
- *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream); no call allocates or frees device memory: scratch comes from `ws`
+ *   - the device-pointer calls enqueue their kernels on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and return without waiting for them; none allocates or frees device memory: scratch comes from `ws`.
+ *     The calls whose geometry depends on batch maxima they are not given (po_pair_decode_batch, po_beam2d_batch,
+ *     po_beam1d_batch, the lattice / alignment calls) first read the offset tables back (one small D2H copy and a
+ *     stream synchronise) — enqueue the inputs before calling; po_viterbi_batch (CTC kinds) and po_ingest_batch do
+ *     not.  The *_h forms and po_pipeline_pair_decode are synchronous.
+ *   - a workspace may be reused from call to call and its contents need not be preserved; the pair beam search
+ *     keeps per-workgroup epoch counters in it and clears what it finds untagged (first use)
+ *   - po_last_error() is per host thread and refers to the last failing call of that thread; the profiling aid at
+ *     the end of this header (po_profile_*) is process-wide and meant for one measuring thread
  *   - y:       concatenated C-contiguous (T_i, C) float64 natural-log probabilities
  *     y_off:   int64[n+1] ROW offsets into y (read i owns rows [y_off[i], y_off[i+1]))
  *   - env:     concatenated (U_i, 2) int32 half-open column ranges, row-aligned with y1
