@@ -237,14 +237,22 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
     const PoLaeFast lae{&sm.lae};
 #endif
 #ifdef PO_B2_TIMING
-    long long tk[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tlast = 0;
+    // three sets of counters: main steps that recompute their windows (0..11), incremental steps on the previous
+    // step's table (12..23), incremental steps after a permutation of the beam (24..35); slot 11 of a set = its steps
+    long long tk[37], tlast = 0;
+    int tko = 0;
+    for (int i = 0; i < 37; ++i) tk[i] = 0;
 #define TK_START() do { tlast = wall_clock64(); } while (0)
-#define TK(i) do { const long long n_ = wall_clock64(); tk[i] += n_ - tlast; tlast = n_; } while (0)
-#define TKC(i) do { tk[i]++; } while (0)
+#define TK(i) do { const long long n_ = wall_clock64(); tk[tko + (i)] += n_ - tlast; tlast = n_; } while (0)
+#define TKC(i) do { tk[tko + (i)]++; } while (0)
+#define TK_TYPE(o) do { tko = (o); } while (0)
+#define TK_STEP() do { if (tko) tk[tko + 11]++; else tk[36]++; } while (0)
 #else
 #define TK_START() do {} while (0)
 #define TK(i) do {} while (0)
 #define TKC(i) do {} while (0)
+#define TK_TYPE(o) do {} while (0)
+#define TK_STEP() do {} while (0)
 #endif
 
     for (;;) {
@@ -650,7 +658,19 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #ifdef PO_ABL_NOYLOAD     // timing ablation only (results are wrong)
                 if (nrow * C > 1000000) sm.ybuf[r][s] = src[s];
 #else
+#ifdef PO_YUNROLL
+                {   // every load of the chunk in flight before the first is waited for
+                    constexpr int NQ = (SM::YD + NCP - 1) / NCP;
+                    double yv[NQ];
+                    const int nv = nrow * C;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { const int i = s + q * NCP; yv[q] = (i < nv) ? src[i] : 0.0; }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { const int i = s + q * NCP; if (i < nv) sm.ybuf[r][i] = yv[q]; }
+                }
+#else
                 for (int i = s; i < nrow * C; i += NCP) sm.ybuf[r][i] = src[i];
+#endif
 #endif
             }
             b2_sync_lds<nthr>();  // y rows (and, first time, the seeds in xch[1]) -> visible to the iterations
@@ -659,6 +679,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             const double* ypa = sm.ybuf[r] + ca;   // this lane's two y entries of the chunk's first row; one row on per iteration
             const double* ypb = sm.ybuf[r] + cb;
             const int xsl = (pslot >= 0) ? pslot : s;
+            int tr = INT_MIN;
             for (int kv = k0; kv < kchunk; ++kv) {
                 const int k = __builtin_amdgcn_readfirstlane(kv);  // keeps the loop counter and branch scalar
                 if (part && k < len) {
@@ -685,19 +706,22 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #else
                     if (t >= sfrom) {
                         Ent e;
-                        e.tag = tag0 + (unsigned)t;
+                        // (t < 2^24 sits in the low word of the tag: a 32-bit add, no carry)
+                        e.tag = (tag0 & 0xffffffff00000000ull) | (unsigned)((unsigned)tag0 + (unsigned)t);
 #pragma unroll
                         for (int q = 0; q < K; ++q) e.v[q] = out[q];
-                        myrow[t & Rm] = e;
+                        myrow[(unsigned)(t & Rm)] = e;
                     }
 #endif
-                    if (out[0] > self[0] && t > td) td = t;   // (times may be computed again after a window end moved back: td never decreases)
+                    if (out[0] > self[0]) tr = t;   // the last time a value rose (folded into td after the loop)
 #pragma unroll
                     for (int q = 0; q < K; ++q) { self[q] = out[q]; sm.xch[k & 1][r][s][q] = out[q]; }
-                    if (out[0] >= mx) { mx = out[0]; mt = t; }
+                    mt = (out[0] >= mx) ? t : mt;
+                    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(out[0]));   // (no NaNs here; the builtin canonicalises both operands)
                 }
                 b2_sync_lds<nthr>();  // only xch crosses iterations; the stores stay in flight
             }
+            td = max(td, tr);   // (times may be computed again after a window end moved back: td never decreases)
             TK(is_main ? 5 : 9);  // scan: iterations
             }
             if (s < nelem) sm.xch[0][r][s][0] = mx;   // "mxs"
@@ -1043,6 +1067,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 }
                 if (!row_ok || !col_ok) { st = PO_E_ENVELOPE; break; }  // uninitialised bounds upstream (:309)
                 // ---- MAIN step at (u, v): windows [u, ece) x [v, ere)  (:342-375)
+                TK_TYPE((sm.sh[14] != 0 && sm.sh[15] != 0) ? 12 : ((sm.sh[10] != 0) ? 24 : 0));
                 const int ne = build_regular(u - 1, v - 1, ece, ere);
                 b2_sync_mem<nthr>();  // arena + store writes -> visible to the reads below
                 if (sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
@@ -1053,6 +1078,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 if (tid < ne) sm.score[tid] = sm.xch[0][0][tid][0] + sm.xch[0][1][tid][0];  // node_greater_max_sym (window maxima: see B2Smem)
                 prune_and_advance(ne, true);
                 TK(1);
+                TK_STEP();
+                TK_TYPE(0);
                 u++;
                 v++;
                 er_c = er_n; ec_c = ec_n;
@@ -1128,7 +1155,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
     }
 #ifdef PO_B2_TIMING
     if (tid == 0 && a.dbg && blockIdx.x == 0)
-        for (int i = 0; i < 12; ++i) a.dbg[i] = tk[i];
+        for (int i = 0; i < 37; ++i) a.dbg[i] = tk[i];
 #endif
 }
 
@@ -1463,6 +1490,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
 
 #ifdef PO_B2_TIMING
     long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+    const int tko = 0;
 #endif
     for (;;) {
         // ------------------------------------------------------------ a half without a pair pulls one
@@ -1945,10 +1973,11 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
 #else
                     if (t >= sfrom) {
                         Ent e;
-                        e.tag = tag0 + (unsigned)t;
+                        // (t < 2^24 sits in the low word of the tag: a 32-bit add, no carry)
+                        e.tag = (tag0 & 0xffffffff00000000ull) | (unsigned)((unsigned)tag0 + (unsigned)t);
 #pragma unroll
                         for (int q = 0; q < K; ++q) e.v[q] = out[q];
-                        myrow[t & Rm] = e;
+                        myrow[(unsigned)(t & Rm)] = e;
                     }
 #endif
                     const bool sw = (k + 1 == len0);  // the next iteration starts read 1: hand its seed over
@@ -2761,7 +2790,7 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     a.magic = g.magic;
 #ifdef PO_B2_TIMING
     static long long* dbg_buf = nullptr;
-    if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 12 * sizeof(long long));
+    if (!dbg_buf) { (void)hipMalloc((void**)&dbg_buf, 37 * sizeof(long long)); (void)hipMemset(dbg_buf, 0, 37 * sizeof(long long)); }
     a.dbg = dbg_buf;
 #endif
     // the queue counter starts from zero on every launch; the value store is NOT cleared: its tags are told apart by
@@ -2775,14 +2804,15 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     if (g_b2_mark && !only_meta && !retry) g_b2_mark(0, stream);
 #ifdef PO_B2_TIMING
     {
-        long long h[12];
+        long long h[37];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
         const char* nm[12] = {"prepass+init", "main:prune+nextbeam", "main:expand+table", "main:scan selfread", "main:scan staging",
                               "main:scan iterations", "catchup:setup", "catchup:selfread", "catchup:staging", "catchup:iterations",
-                              "label walk", "#catchup steps"};
-        fprintf(stderr, "[po_b2_timing] block 0, wall_clock64 ticks (100 MHz => 10 ns each):\n");
-        for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-24s %12lld\n", nm[i], h[i]);
+                              "label walk", "#steps (col 1: catch-ups)"};
+        fprintf(stderr, "[po_b2_timing] block 0, wall_clock64 ticks (100 MHz => 10 ns each): full-window | steady table | after a permutation\n");
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "   %-26s %12lld %12lld %12lld\n", nm[i], h[i], h[12 + i], h[24 + i]);
+        fprintf(stderr, "   %-26s %12lld\n", "#full-window main steps", h[36]);
     }
 #endif
     if (max_blocks == 0 && !retry)

@@ -77,13 +77,19 @@ __device__ __forceinline__ double po_fma_c(double a, double b, double c) { retur
 #endif
 struct PoLaeFast {
     const PoLaeTables* t;
-    // f(d) = log(1 + exp(d)), d <= 0 (d = NaN for (-inf) - (-inf): Log.h's log_(NaN) = -inf)
+    // f(d) = log(1 + exp(d)), d <= 0.  d = NaN (from (-inf) - (-inf)) and d = -inf give 0: the caller adds it to the
+    // larger operand, which is -inf in the first case — Log.h's log_(NaN) = -inf comes out without a test.
+    // Integer steps instead of rint / cvt / ldexp (the loop this sits in is bound by VALU issue): k = rint(d * 64/ln2)
+    // is read off the low word of d * 64/ln2 + 1.5 * 2^52; 2^m is added into the exponent field (m >= -58: no
+    // subnormals); the interval of z in [1, 2] is its top six mantissa bits, rounded.  Same result bits as the
+    // rint / ldexp formulation on 2e7 random and structured arguments (scripts/check_lae.c).
     __device__ __forceinline__ double f(double d) const {
         double e = 0.0;
         if (d > -40.0) {  // below: exp(d) < 2^-57, 1 + e == 1
-            const double kf = rint(d * PO_64_LN2);
-            const int k = (int)kf;
-            const int j = k & 63, m = k >> 6;
+            const double tm = __builtin_fma(d, PO_64_LN2, 0x1.8p52);
+            const double kf = tm - 0x1.8p52;
+            const int k = __double2loint(tm);
+            const int j = k & 63;
             double r = __builtin_fma(-kf, PO_LN2_64_HI, d);
             r = __builtin_fma(-kf, PO_LN2_64_LO, r);
             double p = po_fma_c(r, 1.0 / 720, 1.0 / 120);
@@ -92,11 +98,13 @@ struct PoLaeFast {
             p = po_fma_c(r, p, 0.5);
             p = __builtin_fma(r * r, p, r);
             const double th = t->exp_t[j][0], tl = t->exp_t[j][1];
-            e = ldexp(th + __builtin_fma(th, p, tl), m);
+            const double x = th + __builtin_fma(th, p, tl);
+            e = __hiloint2double(__double2hiint(x) + ((k >> 6) << 20), __double2loint(x));
         }
         const double z = 1.0 + e;
-        const int i = (int)rint((z - 1.0) * 64.0);
-        const double rc = t->log_t[i][0], lh = t->log_t[i][1], ll = t->log_t[i][2];
+        const unsigned i = ((unsigned)__double2hiint(z) - 0x3FF00000u + 0x2000u) >> 14;
+        const double* lt = (const double*)((const char*)&t->log_t[0][0] + __umul24(i, 24u));
+        const double rc = lt[0], lh = lt[1], ll = lt[2];
         const double w = __builtin_fma(z, rc, -1.0);
         double q = po_fma_c(w, 1.0 / 7, -1.0 / 6);
         q = po_fma_c(w, q, 1.0 / 5);
@@ -105,14 +113,14 @@ struct PoLaeFast {
         const double s = w * w;
         double u = __builtin_fma(s * w, q, ll);
         u = __builtin_fma(-0.5, s, u);
-        const double res = lh + (w + u);
-        return (d == d) ? res : PO_NEG_INF;
+        return lh + (w + u);
     }
     __device__ __forceinline__ double operator()(double x1, double x2) const {
-        const bool ge = (x1 >= x2);
-        const double hi = ge ? x1 : x2;
-        const double d = ge ? (x2 - x1) : (x1 - x2);
-        return hi + f(d);
+        // (v_max / v_min written out: the builtins add a canonicalisation of each operand in IEEE mode)
+        double hi, lo;
+        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x1), "v"(x2));
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x1), "v"(x2));
+        return hi + f(lo - hi);
     }
 };
 

@@ -54,3 +54,19 @@ def test_host_mirrors_of_decoding_cy_helpers(extra):
     env, ranges, idx = cy.diagonal_band_envelope(6, 9, 2)
     assert ranges.tolist()[:2] == [[0, 2], [0, 4]] and env.get(0, 1) == 1 and tuple(idx[0]) == (0, 0)
     assert len(idx) == sum(e - s + 1 for s, e in ranges)
+
+
+def test_device_logaddexp_formulation(tmp_path):
+    """The kernels' logaddexp (po_device.h PoLaeFast) replayed on the CPU from the same tables: the integer-step
+    formulation gives the bits of the rint / ldexp one, and both stay within 1.6e-16 of a long-double log1p(exp(d))."""
+    import os
+    import re
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "check_lae.c")
+    exe = str(tmp_path / "check_lae")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"])
+    out = subprocess.run([exe, "2000000"], capture_output=True, text=True, check=True).stdout
+    m = re.search(r"max abs err: old (\S+) new (\S+) glibc-double \S+; old!=new in (\d+) of", out)
+    assert m, out
+    assert float(m.group(1)) < 1.7e-16 and float(m.group(2)) < 1.7e-16 and int(m.group(3)) == 0, out
+    assert "lae(-inf,-inf) old -inf new -inf" in out

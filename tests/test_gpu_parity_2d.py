@@ -391,7 +391,9 @@ def test_exact_ties_follow_the_reference(eng, oracle):
     """Beam::prune with exact score ties = libstdc++'s partial_sort on the creation-ordered candidates.  Seed 20127
     (bonito model, row, W = 8) is a pair on which score-then-creation-order gives a different string than the
     reference's own C++ does; plus a sweep of quantised pairs, every one against the oracle (which replays libstdc++
-    and is pinned to the compiled reference on such inputs by tests/test_oracle_vs_ref.py)."""
+    and is pinned to the compiled reference on this input by tests/test_oracle_vs_ref.py — in a fresh process: the
+    reference sorts node POINTERS, which is creation order only while malloc hands out ascending addresses, and in a
+    long-lived test process with a fragmented heap its answer on this very pair flips between runs)."""
     rng = np.random.default_rng(5)
     Ts = [int(rng.integers(40, 200)) for _ in range(128)]      # the draw sequence that found the pair
     y1, y2 = synth_pair(20127, T=Ts[127])
@@ -399,8 +401,6 @@ def test_exact_ties_follow_the_reference(eng, oracle):
     U, V = len(y1), len(y2)
     env = np.array([(max(0, int(u * V / U) - 8), min(V, int(u * V / U) + 9)) for u in range(U)])
     want = oracle.cpp_beam_search_2d(y1, y2, env, 8, model_="ctc_merge_repeats", method_="row")
-    if oracle.have_ref():
-        assert want == oracle.ref_beam_search_2d(y1, y2, env, 8, model_="ctc_merge_repeats", method_="row")
     assert eng.beam_search_2d_batch([y1], [y2], [env], 8, model="ctc_merge_repeats", method="row") == [want]
     for kind, model in (("poreover", "ctc"), ("bonito", "ctc_merge_repeats"), ("flipflop", "ctc_flipflop")):
         a, b, envs = [], [], []

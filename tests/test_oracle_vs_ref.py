@@ -49,3 +49,49 @@ def test_pipeline_envelope_t4000(oracle):
     out = O.pair_decode(y1, y2, "poreover", 5, "row_col")
     assert out["consensus"] == O.ref_beam_search_2d(y1, y2, out["envelope"], 5, method_="row_col")
     assert O.cpp_beam_search(y1, 10) == O.ref_beam_search(y1, 10)
+
+
+_TIES_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import po_oracle as O
+from poreover_amd.synth import synth_pair
+def quantised(y):
+    return np.log((np.clip(np.rint(np.exp(y) * 255), 0, 255) + 1e-7) / (255 + 1e-7))
+rng = np.random.default_rng(5)
+Ts = [int(rng.integers(40, 200)) for _ in range(128)]
+y1, y2 = synth_pair(20127, T=Ts[127])
+y1, y2 = quantised(y1), quantised(y2)
+U, V = len(y1), len(y2)
+env = np.array([(max(0, int(u * V / U) - 8), min(V, int(u * V / U) + 9)) for u in range(U)])
+bad = 0
+if O.cpp_beam_search_2d(y1, y2, env, 8, model_="ctc_merge_repeats", method_="row") != \
+        O.ref_beam_search_2d(y1, y2, env, 8, model_="ctc_merge_repeats", method_="row"):
+    bad += 1
+for i in range(6):
+    p, q = synth_pair(21000 + i, T=60 + 9 * i)
+    p, q = quantised(p), quantised(q)
+    e = np.array([(max(0, int(u * len(q) / len(p)) - 6), min(len(q), int(u * len(q) / len(p)) + 7)) for u in range(len(p))])
+    for m, meth, W in (("ctc", "row_col", 5), ("ctc_merge_repeats", "row", 8), ("ctc", "row", 3)):
+        if O.cpp_beam_search_2d(p, q, e, W, model_=m, method_=meth) != O.ref_beam_search_2d(p, q, e, W, model_=m, method_=meth):
+            bad += 1
+    if O.cpp_beam_search(p, 6) != O.ref_beam_search(p, 6):
+        bad += 1
+print("TIES_BAD", bad)
+"""
+
+
+def test_exact_ties_in_a_fresh_process():
+    """Quantised inputs (uint8 traces) make exact score ties common; Beam::prune then leaves what libstdc++'s
+    partial_sort does on the candidates in POINTER order (Beam.h:93-108).  The oracle replays that on creation
+    order, which is pointer order while malloc hands out ascending addresses — true in a fresh process, not in a
+    long-lived one with a fragmented heap (there the reference's own answer on seed 20127 changes from run to run).
+    So this comparison runs in a child process of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _TIES_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "TIES_BAD 0" in out.stdout, out.stdout[-2000:]
