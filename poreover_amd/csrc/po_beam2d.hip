@@ -2171,6 +2171,7 @@ struct GridSmem {
     int e[G_COUNT][NCM];
     int fc[WMAX], crow[WMAX], isnew[WMAX];
     int dup[NCM];
+    int ord[NCM];           // prune with exact score ties: candidate slots in node-id order (po_stl_prune)
     int sel[WMAX];
     int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
     int sh[8];
@@ -2401,18 +2402,41 @@ __global__ __launch_bounds__(GRID_THREADS(WMAX)) void beam2d_grid_kernel(B2Args 
                 }
                 if (tid == 0) sm.nupd += 2u * (unsigned)ne;
                 __syncthreads();
-                // ---- 5. prune: the W best of the distinct candidates by alpha0[u] + alpha1[v], ties by node id
+                // ---- 5. prune: the W best of the distinct candidates by alpha0[u] + alpha1[v]; an exact tie that reaches
+                // into the beam (narrow bands: candidates that are all -inf) is resolved as libstdc++'s partial_sort / sort
+                // leave the creation-ordered candidates (po_device.h), like every other prune
                 const bool live = (r == 0) && s < ne && !sm.dup[s];
+                bool teq = false;
                 if (live) {
                     const double my = sm.sc[0][s] + sm.sc[1][s];
                     const int myid = sm.e[G_ID][s];
-                    int rank = 0;
-                    for (int o = 0; o < ne; ++o)
-                        if (!sm.dup[o] && po_better(sm.sc[0][o] + sm.sc[1][o], sm.e[G_ID][o], my, myid)) rank++;
+                    int rank = 0, neq = 0;
+                    for (int o = 0; o < ne; ++o) {
+                        const double so = sm.sc[0][o] + sm.sc[1][o];
+                        if (!sm.dup[o] && po_better(so, sm.e[G_ID][o], my, myid)) rank++;
+                        if (!sm.dup[o] && so == my) neq++;
+                    }
                     if (rank < W) sm.sel[rank] = s;
+                    teq = (neq > 1) && (rank < W);
                 }
                 const int ncand = __syncthreads_count(live);
                 const int nn = min(W, ncand);
+                if (__syncthreads_or(teq)) {
+                    if (live) {
+                        const int myid = sm.e[G_ID][s];
+                        int pos = 0;
+                        for (int o = 0; o < ne; ++o) pos += (!sm.dup[o] && sm.e[G_ID][o] < myid) ? 1 : 0;
+                        sm.ord[pos] = s;
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        const double* s0 = sm.sc[0];
+                        const double* s1 = sm.sc[1];
+                        po_stl_prune<WMAX>(sm.ord, ncand, W, [&](int slot) { return s0[slot] + s1[slot]; });
+                        for (int j = 0; j < nn; ++j) sm.sel[j] = sm.ord[j];
+                    }
+                    __syncthreads();
+                }
                 // ---- 6. the cell's beam goes to HBM for cell (u+1, v+1)
                 int* cc = cur + (size_t)v * CI;
                 if (tid < nn * G_COUNT) cc[1 + tid] = sm.e[tid % G_COUNT][sm.sel[tid / G_COUNT]];

@@ -18,6 +18,7 @@ for i in range(nb):
     base.append((y1, y2, O.pair_decode(y1, y2, kind, 5, "row_col")["envelope"]))
 y1s = [base[i % nb][0] for i in range(n)]; y2s = [base[i % nb][1] for i in range(n)]; envs = [base[i % nb][2] for i in range(n)]
 lib = _lib.load()
+if os.environ.get("PO_ROUTE"): _lib.set_pair_route(os.environ["PO_ROUTE"])   # auto | x2 | legacy
 import ctypes as C
 for rep in range(2):
     lib.po_profile_enable(1); lib.po_profile_reset()

@@ -382,6 +382,22 @@ def test_grid_limits(eng, oracle):
         oracle.cpp_beam_search_2d(y1, y2, gap, 5, method_="grid")
 
 
+def test_grid_exact_ties(eng, oracle):
+    """Beams wider than the finite candidates of a narrow band fill up with -inf scores: exact ties, resolved as
+    libstdc++ leaves the creation-ordered candidates (the oracle's rule; two pairs the open-ended fuzz run found, on
+    which score-then-creation-order gives other strings — 'ATTTT' and 'AAACACCATTT...')."""
+    y1, y2 = synth_pair(773929922, T=178)
+    env = np.asarray(oracle.pair_decode(y1, y2, "poreover", 5, "row_col")["envelope"])
+    want = oracle.cpp_beam_search_2d(y1, y2, env, 9, method_="grid")
+    assert want == "AAAAATTTT"
+    assert eng.beam_search_2d_batch([y1], [y2], [env], 9, method="grid") == [want]
+    y1, y2 = synth_pair(962012875, T=254)
+    env = np.asarray(oracle.diagonal_envelope(len(y1), len(y2), 11))
+    want = oracle.cpp_beam_search_2d(y1, y2, env, 13, method_="grid")
+    assert want.startswith("CACATATTTACG")
+    assert eng.beam_search_2d_batch([y1], [y2], [env], 13, method="grid") == [want]
+
+
 def _quantised(y):
     """log-probabilities as a uint8 trace would give them (decode.py:92): exact score ties become common"""
     return np.log((np.clip(np.rint(np.exp(y) * 255), 0, 255) + 1e-7) / (255 + 1e-7))
