@@ -63,6 +63,37 @@ def test_fuzz_pair_beam_kernels(eng, oracle):
     assert pairs > 100 and bad == 0, "%d of %d random pairs differ from the oracle" % (bad, pairs)
 
 
+def test_fuzz_grid_method(eng, oracle):
+    """method grid, every model, beams up to 25 wide in bands a few cells wide — where most candidates are -inf and
+    the beam is decided by the tie rule alone (the oracle's: libstdc++ on creation order)"""
+    from poreover_amd import _lib
+    rng = np.random.default_rng(20260203)
+    pairs = bad = 0
+    for rnd in range(10):
+        kind = ["poreover", "poreover", "bonito", "flipflop"][rng.integers(4)]
+        W = int([3, 5, 7, 9, 10, 12, 13, 16, 25][rng.integers(9)])
+        style = ["diag", "stairs", "bursts"][rng.integers(3)]
+        pad = int(rng.integers(2, 14))
+        y1s, y2s, envs = [], [], []
+        for i in range(int(rng.integers(5, 10))):
+            y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=int(rng.integers(30, 240)), flipflop=(kind == "flipflop"))
+            if rng.random() < 0.15:
+                y2 = y2[: max(2, (2 * len(y2)) // 3)]
+            y1s.append(y1); y2s.append(y2); envs.append(_band_env(rng, len(y1), len(y2), style, pad))
+        got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=MODELS[kind], method="grid", return_status=True)
+        for i in range(len(y1s)):
+            try:
+                want, code = oracle.cpp_beam_search_2d(y1s[i], y2s[i], envs[i], W, model_=MODELS[kind], method_="grid"), 0
+            except oracle.OracleError as e:
+                want, code = "", e.code
+            pairs += 1
+            if st[i] == _lib.E_NOMEM and code == 0:
+                continue          # (capacity refusal of the grid store: reported, not a wrong answer)
+            if st[i] != code or (code == 0 and got[i] != want):
+                bad += 1
+    assert pairs > 50 and bad == 0, "%d of %d random grid pairs differ from the oracle" % (bad, pairs)
+
+
 def test_fuzz_pipeline(eng, oracle):
     """random kinds / methods / widths through the whole stage chain: statuses, basecalls, envelopes, consensus"""
     rng = np.random.default_rng(20260202)
