@@ -134,6 +134,25 @@ __device__ __forceinline__ bool b2_any(bool p) {
     }
 }
 
+// One (uniform) int2 through the SCALAR data cache.  The walk of row_col reads two envelope entries per round; as vector
+// loads they share the wave's vmcnt with its value-store writes, which complete in order — using an entry meant waiting
+// for every store issued before the load was (a drain per round).  Scalar loads count on lgkmcnt.  The scalar cache is
+// not coherent with vector stores: b2_scalar_cache_inv() before the first read of anything the kernel wrote itself.
+__device__ __forceinline__ int2 b2_sload2(const int2* p) {
+#ifdef PO_NO_SLOAD   // A/B switch
+    return *p;
+#else
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
+#endif
+}
+__device__ __forceinline__ void b2_scalar_cache_inv() {
+#ifndef PO_NO_SLOAD
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
 // element-table field indices
 enum { F_ID, F_ROW, F_PSLOT, F_SYM, F_FC, F_CROW, F_PAR, F_GPAR, F_PROW, F_DEPTH, F_COUNT };
 // F_SYM packs: own symbol (bits 0-2) | parent's symbol (bits 4-6) | parent-is-root (bit 9)
@@ -1034,9 +1053,10 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             int u = 0, v = 0;
             const int2* env2 = (const int2*)env;
             const int2* envt2 = (const int2*)envt;
-            int2 er_c = env2[0], ec_c = envt2[0], er_n = er_c, ec_n = ec_c;
+            b2_scalar_cache_inv();   // envt was written by this workgroup (vector stores, complete since the barrier after the pre-pass)
+            int2 er_c = b2_sload2(env2), ec_c = b2_sload2(envt2), er_n = er_c, ec_n = ec_c;
             while (u <= U - 1 && v <= V - 1) {
-                er_n = env2[min(u + 1, U - 1)]; ec_n = envt2[min(v + 1, V - 1)];
+                er_n = b2_sload2(env2 + min(u + 1, U - 1)); ec_n = b2_sload2(envt2 + min(v + 1, V - 1));
                 const int ers = er_c.x, ere = er_c.y;
                 const int ecs = ec_c.x, ece = ec_c.y;
                 const bool row_ok = (v >= ers && v < ere);
