@@ -779,6 +779,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 
         // expansion of the processed elements + children slots.  Regular shape: every beam node is
         // processed, child c of beam node j sits at nb + A*j + c.  lo0/lo1: see alloc_group.
+        bool steady_tbl = false;   // the last build_regular took the steady-table path (nothing allocated: it cannot fail)
         auto build_regular = [&](int lo0, int lo1, int hi0, int hi1) -> int {
             // STEADY TABLE.  After a prune that left the beam exactly as it was (same nodes, same slots: sh[14]), every
             // beam node was expanded in the previous main step and its children's row group was marked with that
@@ -786,7 +787,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             // is created, nothing re-allocated, and the element table of the previous step IS this step's, entry for
             // entry (catch-up scans keep their parent slots elsewhere).  Only the window ends written into the row
             // groups move on.
-            if (sm.sh[14] != 0 && sm.sh[15] != 0) {
+            steady_tbl = (sm.sh[14] != 0 && sm.sh[15] != 0);
+            if (steady_tbl) {
                 if (tid < nb) {
                     const int gc = sm.e[F_CROW][tid], go = sm.e[F_ROW][tid] / PO_A;
                     atomicMax(&sm.g_hi0[gc], hi0); atomicMax(&sm.g_hi1[gc], hi1);
@@ -1055,6 +1057,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             const int2* envt2 = (const int2*)envt;
             b2_scalar_cache_inv();   // envt was written by this workgroup (vector stores, complete since the barrier after the pre-pass)
             int2 er_c = b2_sload2(env2), ec_c = b2_sload2(envt2), er_n = er_c, ec_n = ec_c;
+            int we0 = INT_MIN, we1 = INT_MIN;   // = sh[8], sh[9] (window ends of the last main step), without the LDS round trip
             while (u <= U - 1 && v <= V - 1) {
                 er_n = b2_sload2(env2 + min(u + 1, U - 1)); ec_n = b2_sload2(envt2 + min(v + 1, V - 1));
                 const int ers = er_c.x, ere = er_c.y;
@@ -1067,7 +1070,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     const int nbe = min(W, nb);  // the reference indexes b < beam_width
                     // (node, t) of a beam node is already stored with these very bits when the last main step's
                     // window on this read covered t (see the store-skipping note in scan): nothing to do then
-                    const bool need = cu_v ? (v >= sm.sh[9]) : (u >= sm.sh[8]);
+                    const bool need = cu_v ? (v >= we1) : (u >= we0);
                     if (need) {
                         if (tid < nbe) {
                             sm.cu_ps[tid] = beam_parent(tid, nbe, false);
@@ -1090,11 +1093,12 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 TK_TYPE((sm.sh[14] != 0 && sm.sh[15] != 0) ? 12 : ((sm.sh[10] != 0) ? 24 : 0));
                 const int ne = build_regular(u - 1, v - 1, ece, ere);
                 b2_sync_mem<nthr>();  // arena + store writes -> visible to the reads below
-                if (sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
+                if (!steady_tbl && sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
                 TK(2);
                 scan(true, true, ne, 0, 0, u, ece - u, v, ere - v);
                 po_lds_barrier();
                 if (tid == 0) { sm.sh[8] = ece; sm.sh[9] = ere; }
+                we0 = ece; we1 = ere;
                 if (tid < ne) sm.score[tid] = sm.xch[0][0][tid][0] + sm.xch[0][1][tid][0];  // node_greater_max_sym (window maxima: see B2Smem)
                 prune_and_advance(ne, true);
                 TK(1);
