@@ -796,7 +796,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 }
                 if (tid < nb) sm.cnew[tid] = 0;
                 if (tid == 0) sm.sh[11] = 1;
-                po_lds_barrier();
+                b2_sync_lds<nthr>();
                 return nb * (A + 1);
             }
             // one lane per beam node (nb <= 25: the first wave).  New node ids are handed out in beam order — a prefix
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     atomicMax(&sm.g_hi0[go], hi0); atomicMax(&sm.g_hi1[go], hi1);
                 }
             }
-            po_lds_barrier();
+            b2_sync_lds<nthr>();
             const int ne = nb * (A + 1);
             if (tid == 0) sm.sh[15] = 1;   // a regular table now stands in e[]
             if (tid < ne) {
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 }
                 sm.sh[2] = next_id; sm.sh[6] = ne; sm.sh[7] = np; sm.sh[11] = 0; sm.sh[15] = 0;
             }
-            po_lds_barrier();
+            b2_sync_lds<nthr>();
             *nproc = sm.sh[7];
             return sm.sh[6];
         };
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 sm.dup[tid] = d;
             }
             if (tid == 0) sm.sh[5] = 0;
-            po_lds_barrier();
+            b2_sync_lds<nthr>();
             // Most steps keep the beam as it is: that holds iff the beam nodes are still in order and the last of
             // them still beats every child — two comparisons per thread instead of a ranking against everybody.
             bool same_beam = false;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             if (same_beam) {
                 if (tid < nb) sm.stay[tid] = 1;
                 if (tid == 0) { sm.sh[10] = 1; sm.sh[14] = 1; }
-                po_lds_barrier();
+                b2_sync_lds<nthr>();
                 return;
             }
             if (tid == 0) sm.sh[14] = 0;
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     for (int o = 0; o < ne; ++o) pos += (!sm.dup[o] && sm.e[F_ID][o] < id) ? 1 : 0;
                     ord[pos] = tid;
                 }
-                po_lds_barrier();
+                b2_sync_lds<nthr>();
                 if (tid == 0) {
                     const int m = sm.sh[5];
                     const double* scp = sm.score;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     for (int j = 0; j < min(W, m); ++j) sm.sel[j] = ord[j];
                 }
             }
-            po_lds_barrier();
+            b2_sync_lds<nthr>();
             const int nbn = min(W, sm.sh[5]);
             if (tid < nbn) sm.stay[tid] = (regular && sm.sel[tid] < nb) ? 1 : 0;
             {
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #pragma unroll
                     for (int q = 0; q < K; ++q) { sf0[q] = sm.xch[1][0][src][q]; sf1[q] = sm.xch[1][1][src][q]; }
                 }
-                po_lds_barrier();
+                b2_sync_lds<nthr>();
                 if (perm && tid < ne) {
                     sm.cmx[0][tid] = c0; sm.cmx[1][tid] = c1; sm.cmt[0][tid] = t0_; sm.cmt[1][tid] = t1_;
                     sm.ctd[0][tid] = d0_; sm.ctd[1][tid] = d1_;
@@ -1039,13 +1039,13 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     sm.nx[F_FC][tid] = fc; sm.nx[F_CROW][tid] = cr;
                 }
             }
-            po_lds_barrier();
+            b2_sync_lds<nthr>();
             if (tid < nbn) {
 #pragma unroll
                 for (int f = 0; f < F_COUNT; ++f) sm.e[f][tid] = sm.nx[f][tid];
             }
             nb = nbn;
-            po_lds_barrier();
+            b2_sync_lds<nthr>();
         };
 
         if (!is_row) {
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                         TK(6);
                         if (cu_v) scan(false, false, nbe, 0, 0, 0, 0, v, 1);
                         else scan(false, false, nbe, 0, 0, u, 1, 0, 0);
-                        po_lds_barrier();
+                        b2_sync_lds<nthr>();
                     }
                     TKC(11);
                     if (!need && a.upd_count != nullptr && tid == 0) sm.nupd += (unsigned)nbe;   // (a catch-up the reference computes and this kernel need not)
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 if (!steady_tbl && sm.sh[4] != PO_OK) { st = sm.sh[4]; break; }
                 TK(2);
                 scan(true, true, ne, 0, 0, u, ece - u, v, ere - v);
-                po_lds_barrier();
+                b2_sync_lds<nthr>();
                 if (tid == 0) { sm.sh[8] = ece; sm.sh[9] = ere; }
                 we0 = ece; we1 = ere;
                 if (tid < ne) sm.score[tid] = sm.xch[0][0][tid][0] + sm.xch[0][1][tid][0];  // node_greater_max_sym (window maxima: see B2Smem)
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 // the read-1 band of a row mostly repeats the previous row's: the same redundant-store rule as in
                 // row_col applies (regular shape; in the growing first rows every element stores everything)
                 scan(true, regular, ne, skip_lo, skip_hi, u, 1, rs, wlen);
-                po_lds_barrier();
+                b2_sync_lds<nthr>();
                 if (tid == 0) { sm.sh[8] = u + 1; sm.sh[9] = (wlen > 0) ? re : sm.sh[9]; }
                 if (tid < ne) {  // node_greater_max: last_prob[0] + max_prob[1]
                     const int id = sm.e[F_ID][tid];
