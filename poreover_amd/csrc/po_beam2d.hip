@@ -534,6 +534,12 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             double self[K], mx = PO_NEG_INF;
             int mt = -1;
             int td = t0f;   // the values of this window are non-increasing from time td on (maintained as they are computed)
+            Ent wm_e;                    // a window maximum still on its way from the store (see below)
+            unsigned long long wm_tag = 0;
+            bool wm_pend = false;
+            wm_e.tag = 0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) wm_e.v[q] = PO_NEG_INF;
             if (partf && t0 > t0f) {   // the carried part [t0f, t0) of the window
                 const double pm = sm.cmx[r][s];
                 const int pt = sm.cmt[r][s];
@@ -549,9 +555,11 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     const unsigned long long tg = make_tag(epoch, sm.e[F_ID][s], 0);
                     if (td <= t0f) {
                         // ... whose carried part is non-increasing (a node past its peak decays frame by frame — the usual
-                        // case): its maximum is its first value, one entry of the element's own ring row
-                        const Ent e = rp[t0f & Rm];
-                        mx = (e.tag == tg + (unsigned)t0f) ? e.v[0] : PO_NEG_INF;
+                        // case): its maximum is its first value, one entry of the element's own ring row.  Requested
+                        // here, looked at after the y rows have been waited for (one round trip instead of two).
+                        wm_e = rp[t0f & Rm];
+                        wm_tag = tg + (unsigned)t0f;
+                        wm_pend = true;
                         mt = t0f;
                     } else {
                         // ... otherwise stored values are read back — only those of [t0f, td]: from td on the values fall,
@@ -693,6 +701,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #endif
             }
             b2_sync_lds<nthr>();  // y rows (and, first time, the seeds in xch[1]) -> visible to the iterations
+            if (wm_pend) { mx = (wm_e.tag == wm_tag) ? wm_e.v[0] : PO_NEG_INF; wm_pend = false; }
             TK(is_main ? 3 : 7);  // scan: self read + y rows
             const int kchunk = min(Lmax, k0 + yrows);
             const double* ypa = sm.ybuf[r] + ca;   // this lane's two y entries of the chunk's first row; one row on per iteration
@@ -743,6 +752,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             td = max(td, tr);   // (times may be computed again after a window end moved back: td never decreases)
             TK(is_main ? 5 : 9);  // scan: iterations
             }
+            if (wm_pend) mx = (wm_e.tag == wm_tag) ? wm_e.v[0] : PO_NEG_INF;   // (a scan without new times)
             if (s < nelem) sm.xch[0][r][s][0] = mx;   // "mxs"
             if (is_main && partf) { sm.cmx[r][s] = mx; sm.cmt[r][s] = mt; sm.ctd[r][s] = td; }
             if (is_main && part) {   // the last value of this window: the seed of a window that continues it
@@ -815,7 +825,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 const unsigned long long bn = __ballot(isnew), bg = __ballot(need_group);
                 const int base = sm.sh[2];
                 if (isnew) {
-                    const int fc = base + A * __popcll(bn & ((1ull << tid) - 1ull));
+                    // (lanes below this one that create nodes: mbcnt, not a 64-bit lane mask that lives in two registers)
+                    const int fc = base + A * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bn, 0u));
                     sm.e[F_FC][tid] = fc;
                     afc[id] = fc;
                     for (int c = 0; c < A; ++c) {
