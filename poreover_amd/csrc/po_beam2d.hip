@@ -142,8 +142,12 @@ __device__ __forceinline__ int2 b2_sload2(const int2* p) {
 #ifdef PO_NO_SLOAD   // A/B switch
     return *p;
 #else
+    // (the "s" constraint does not move a pointer the compiler keeps in vector registers: readfirstlane does)
+    const unsigned long long pv = (unsigned long long)p;
+    const unsigned long long ps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pv >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv);
     unsigned long long v;
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ps) : "memory");
     return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
 #endif
 }
