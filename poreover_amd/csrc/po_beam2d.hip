@@ -206,7 +206,9 @@ template <int MODEL, int WMAX>
 // (4 waves per SIMD are what the W <= 6 class lives on — see B2_YD6.  It compiles to 124 / 128 VGPRs (ctc / merge
 // repeats); an edit that costs four more registers costs a quarter of the throughput — check with
 // -Rpass-analysis=kernel-resource-usage.  Forcing the bound here makes the allocator's choices 2 % worse today.)
-__global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <= 12) ? 4 : 1)) void beam2d_kernel(B2Args a) {
+// (The three-value models sit at 163 - 173 VGPRs in the W <= 6 class: 168 is the step between three waves per SIMD and
+// two, so that bound is explicit too.)
+__global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <= 12) ? 4 : (WMAX <= 6 ? 3 : 1))) void beam2d_kernel(B2Args a) {
     using SM = B2Smem<MODEL, WMAX>;
     constexpr int K = SM::K, NCM = SM::NCM, NCP = SM::NCP, nthr = 2 * NCP;
     using Ent = Entry<K>;
@@ -689,19 +691,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #ifdef PO_ABL_NOYLOAD     // timing ablation only (results are wrong)
                 if (nrow * C > 1000000) sm.ybuf[r][s] = src[s];
 #else
-#ifdef PO_YUNROLL
-                {   // every load of the chunk in flight before the first is waited for
-                    constexpr int NQ = (SM::YD + NCP - 1) / NCP;
-                    double yv[NQ];
-                    const int nv = nrow * C;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) { const int i = s + q * NCP; yv[q] = (i < nv) ? src[i] : 0.0; }
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) { const int i = s + q * NCP; if (i < nv) sm.ybuf[r][i] = yv[q]; }
-                }
-#else
                 for (int i = s; i < nrow * C; i += NCP) sm.ybuf[r][i] = src[i];
-#endif
 #endif
             }
             b2_sync_lds<nthr>();  // y rows (and, first time, the seeds in xch[1]) -> visible to the iterations
