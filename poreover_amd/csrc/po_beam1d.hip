@@ -212,7 +212,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             if ((int64_t)base > acap) st = PO_E_NOMEM;
             next_id = base;
         }
-        __syncthreads();
+        po_wave_sync();   // (one wave per read)
         if (st != PO_OK) break;
 
         // ---- phase 2: the A children of every beam node
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             Q.id[s] = x; Q.fc[s] = fcx; Q.depth[s] = Q.depth[j] + 1;
             for (int k = 0; k < K; ++k) Q.val[k * NC + s] = out[k];
         }
-        __syncthreads();
+        po_wave_sync();   // (one wave per read)
 
         // ---- phase 3: prune (Beam.h:93-108).  A child slot whose node is also a beam slot is the
         //      same node pushed twice: std::unique removes it.
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             }
             dup[s] = d;
         }
-        __syncthreads();
+        po_wave_sync();   // (one wave per read)
         int kept = 0;
         bool tie = false;
         for (int s0 = 0; s0 < NCc; s0 += PO_WAVE) {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             tie |= (__ballot(teq) != 0ull);
             kept += __popcll(__ballot(valid));
         }
-        __syncthreads();
+        po_wave_sync();   // (one wave per read)
         if (tie) {
             // exact ties decide by what libstdc++'s partial_sort / sort leave (po_device.h): candidates in node-id
             // order (each live candidate's position = live candidates with a smaller id), then one lane replays it
@@ -283,13 +283,13 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                     ord[pos] = s;
                 }
             }
-            __syncthreads();
+            po_wave_sync();   // (one wave per read)
             if (lane == 0) {
                 const double* val0 = Q.val;
                 po_stl_prune<64>(ord, kept, W, [&](int slot) { return val0[slot]; });
                 for (int j = 0; j < min(W, kept); ++j) nsel[j] = ord[j];
             }
-            __syncthreads();
+            po_wave_sync();   // (one wave per read)
         }
         const int Wn = min(W, kept);
         for (int j = lane; j < Wn; j += PO_WAVE) sel[j] = nsel[j];
@@ -297,9 +297,10 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         cur ^= 1;
         Pnb = Wc;
         Wc = Wn;
-        __syncthreads();
+        po_wave_sync();   // (one wave per read)
     }
 
+    __syncthreads();
     // ---- label of the top node (PrefixTree::get_label, PrefixTree.h:449-457)
     if (lane == 0) {
         int n = 0;

@@ -189,6 +189,15 @@ __device__ __forceinline__ void po_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// LDS hand-over inside a ONE-WAVE workgroup: a wave's LDS (and vector memory) operations are performed in program
+// order, so only the compiler needs a fence — __syncthreads() would also drain every outstanding global store
+// (s_waitcnt vmcnt(0)), a full round trip each time in a loop that writes tree nodes as it goes.
+__device__ __forceinline__ void po_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Candidate ordering used by every prune: higher score first; exact ties by node creation
 // order (ascending id).  The reference's tie order is heap-address order (Beam.h:96-107).
 __device__ __forceinline__ bool po_better(double sa, int ia, double sb, int ib) {
