@@ -258,12 +258,16 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 const double sc = Q.val[s];
                 const int id = Q.id[s];
                 int rank = 0, neq = 0;
+                // (branch-free, every load unconditional: the compiler batches the LDS reads of eight candidates
+                //  instead of two dependent round trips per candidate)
 #pragma unroll 8
                 for (int o = 0; o < NCc; ++o) {
                     const double so = Q.val[o];
-                    const bool live = !dup[o];
-                    if (live && po_better(so, Q.id[o], sc, id)) rank++;
-                    if (live && so == sc) neq++;
+                    const int io = Q.id[o];
+                    const int live = dup[o] ? 0 : 1;
+                    const int better = ((so > sc) | (!(sc > so) & (io < id))) ? 1 : 0;
+                    rank += live & better;
+                    neq += live & ((so == sc) ? 1 : 0);
                 }
                 if (rank < W) nsel[rank] = s;
                 teq = (neq > 1) && (rank < W);   // an exact tie that reaches into the beam
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 if (!dup[s]) {
                     const int id = Q.id[s];
                     int pos = 0;
-                    for (int o = 0; o < NCc; ++o) pos += (!dup[o] && Q.id[o] < id) ? 1 : 0;
+                    for (int o = 0; o < NCc; ++o) pos += ((dup[o] ? 0 : 1) & ((Q.id[o] < id) ? 1 : 0));
                     ord[pos] = s;
                 }
             }

@@ -966,12 +966,15 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 const double sc = sm.score[tid];
                 const int id = sm.e[F_ID][tid];
                 int rank = 0, neq = 0;
+                // (branch-free, every load unconditional: the LDS reads of eight candidates go out together)
 #pragma unroll 8
                 for (int o = 0; o < ne; ++o) {
                     const double so = sm.score[o];
-                    const bool live = !sm.dup[o];
-                    if (live && po_better(so, sm.e[F_ID][o], sc, id)) rank++;
-                    if (live && so == sc) neq++;
+                    const int io = sm.e[F_ID][o];
+                    const int live = sm.dup[o] ? 0 : 1;
+                    const int better = ((so > sc) | (!(sc > so) & (io < id))) ? 1 : 0;
+                    rank += live & better;
+                    neq += live & ((so == sc) ? 1 : 0);
                 }
                 if (rank < W) sm.sel[rank] = tid;
                 teq = (neq > 1) && (rank < W);   // an exact score tie that reaches into the beam
@@ -2061,10 +2064,11 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
                 int rank = 0, neq = 0;
                 const X2Cand me = h.cand[s];
 #pragma unroll 8
-                for (int o = 0; o < SG; ++o) {
+                for (int o = 0; o < SG; ++o) {   // (branch-free: the candidates' LDS reads go out in batches)
                     const X2Cand c = h.cand[o];
-                    if (!c.dup && po_better(c.sc, c.id, me.sc, me.id)) rank++;
-                    if (!c.dup && c.sc == me.sc) neq++;
+                    const int lv = c.dup ? 0 : 1;
+                    rank += lv & (((c.sc > me.sc) | (!(me.sc > c.sc) & (c.id < me.id))) ? 1 : 0);
+                    neq += lv & ((c.sc == me.sc) ? 1 : 0);
                 }
                 if (rank < W) h.sel[rank] = s;
                 teq = (neq > 1) && (rank < W);   // an exact score tie that reaches into the beam
@@ -2440,10 +2444,13 @@ __global__ __launch_bounds__(GRID_THREADS(WMAX)) void beam2d_grid_kernel(B2Args 
                     const double my = sm.sc[0][s] + sm.sc[1][s];
                     const int myid = sm.e[G_ID][s];
                     int rank = 0, neq = 0;
-                    for (int o = 0; o < ne; ++o) {
+#pragma unroll 8
+                    for (int o = 0; o < ne; ++o) {   // (branch-free: the candidates' LDS reads go out in batches)
                         const double so = sm.sc[0][o] + sm.sc[1][o];
-                        if (!sm.dup[o] && po_better(so, sm.e[G_ID][o], my, myid)) rank++;
-                        if (!sm.dup[o] && so == my) neq++;
+                        const int io = sm.e[G_ID][o];
+                        const int lv = sm.dup[o] ? 0 : 1;
+                        rank += lv & (((so > my) | (!(my > so) & (io < myid))) ? 1 : 0);
+                        neq += lv & ((so == my) ? 1 : 0);
                     }
                     if (rank < W) sm.sel[rank] = s;
                     teq = (neq > 1) && (rank < W);
