@@ -535,6 +535,18 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             const bool partf = (s < nelem) && (lenf > 0) && !(r == 0 && s >= skip_lo && s < skip_hi);
             const bool part = partf && (len > 0);
             const int Lmax = max(len0, len1);
+            // Everything this lane's slot holds, read unconditionally in one go (one LDS round trip instead of one per
+            // block below; the slots beyond the table read harmless neighbours).
+            const int sx = (s < SM::NCM) ? s : SM::NCM - 1;
+            const double l_pm = sm.cmx[r][s];
+            const int l_pt = sm.cmt[r][s], l_td = sm.ctd[r][s];
+            const int l_id = sm.e[F_ID][sx], l_sy = sm.e[F_SYM][sx], l_row = sm.e[F_ROW][sx];
+            const int l_ps = is_main ? sm.e[F_PSLOT][sx] : sm.cu_ps[(s < WMAX) ? s : WMAX - 1];
+            const int l_prow = sm.e[F_PROW][sx], l_par = sm.e[F_PAR][sx];
+            const int l_sdt = sm.sh[16 + r];
+            double l_seed[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) l_seed[q] = sm.xch[1][r][s][q];
             int pslot = PS_ROOT, sym = 0;
             bool same = false, rootpar = false;
             double self[K], mx = PO_NEG_INF;
@@ -547,9 +559,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #pragma unroll
             for (int q = 0; q < K; ++q) wm_e.v[q] = PO_NEG_INF;
             if (partf && t0 > t0f) {   // the carried part [t0f, t0) of the window
-                const double pm = sm.cmx[r][s];
-                const int pt = sm.cmt[r][s];
-                td = sm.ctd[r][s];
+                const double pm = l_pm;
+                const int pt = l_pt;
+                td = l_td;
 #ifdef PO_ABL_NOREREAD   // timing ablation only (results are wrong)
                 if (true) { mx = pm; mt = pt; }
 #else
@@ -557,8 +569,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #endif
                 else {
                     // the carried maximum's time has left the window
-                    const Ent* rp = pool + ((size_t)sm.e[F_ROW][s] * 2 + r) * R;
-                    const unsigned long long tg = make_tag(epoch, sm.e[F_ID][s], 0);
+                    const Ent* rp = pool + ((size_t)l_row * 2 + r) * R;
+                    const unsigned long long tg = make_tag(epoch, l_id, 0);
                     if (td <= t0f) {
                         // ... whose carried part is non-increasing (a node past its peak decays frame by frame — the usual
                         // case): its maximum is its first value, one entry of the element's own ring row.  Requested
@@ -605,11 +617,11 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             const Ent* prow = pool;     // a frozen parent's ring row
             unsigned long long tag0 = 0, ptag0 = 0;
             if (part) {
-                const int node = sm.e[F_ID][s];
-                pslot = is_main ? sm.e[F_PSLOT][s] : sm.cu_ps[s];
-                const int sy = sm.e[F_SYM][s];
+                const int node = l_id;
+                pslot = l_ps;
+                const int sy = l_sy;
                 sym = sym_last(sy); same = (sym_plast(sy) == sym); rootpar = (sy >> 9) & 1;
-                myrow = pool + ((size_t)sm.e[F_ROW][s] * 2 + r) * R;
+                myrow = pool + ((size_t)l_row * 2 + r) * R;
                 tag0 = make_tag(epoch, node, 0);
                 // The value at t0 - 1.  A window that continues where this read's elements last computed (same slot
                 // layout; sh[16 + r] = the time after the last value a main scan computed on read r) starts from the
@@ -617,9 +629,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 // store.  (Window ends can move backwards — envelopes with a wide row now and then: the continuation
                 // then starts before the last computed time, and the seed comes from the store.)  Catch-up scans only
                 // touch the slots of the read they advance, and a read they advance restarts its windows from t0f.
-                if (t0 > t0f && t0 == sm.sh[16 + r]) {
+                if (t0 > t0f && t0 == l_sdt) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) self[k] = sm.xch[1][r][s][k];
+                    for (int k = 0; k < K; ++k) self[k] = l_seed[k];
                 } else {
                     bool hit = false;
                     if (t0 >= 1) {
@@ -636,8 +648,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     for (int k = 0; k < K; ++k) sm.xch[1][r][s][k] = self[k];
                 }
                 if (pslot == PS_FROZEN) {
-                    prow = pool + ((size_t)sm.e[F_PROW][s] * 2 + r) * R;
-                    ptag0 = make_tag(epoch, sm.e[F_PAR][s], 0);
+                    prow = pool + ((size_t)l_prow * 2 + r) * R;
+                    ptag0 = make_tag(epoch, l_par, 0);
                 }
             }
             // Redundant stores (row_col main steps, `reuse`).  An element that was an element in the previous
@@ -942,12 +954,15 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             bool same_beam = false;
             if (regular && nb == W) {
                 bool viol = false;
-                if (tid < ne && !sm.dup[tid]) {
-                    const double sc = sm.score[tid];
-                    const int id = sm.e[F_ID][tid];
+                {   // (every operand read unconditionally: one LDS round trip)
+                    const int tx = (tid < SM::NCM - 1) ? tid : SM::NCM - 2;
+                    const int dupf = sm.dup[tx];
+                    const double sc = sm.score[tx], scn = sm.score[tx + 1], scl = sm.score[nb - 1];
                     // (strictly: an exact tie is resolved by the full path below, as the reference's partial_sort does)
-                    if (tid >= nb) viol = !(sm.score[nb - 1] > sc);
-                    else if (tid + 1 < nb) viol = !(sc > sm.score[tid + 1]);
+                    if (tid < ne && !dupf) {
+                        if (tid >= nb) viol = !(scl > sc);
+                        else if (tid + 1 < nb) viol = !(sc > scn);
+                    }
                 }
                 same_beam = !b2_any<nthr>(viol);
 #ifdef PO_ABL_ALWAYSSAME   // timing ablation only (results are wrong): every prune keeps the beam
