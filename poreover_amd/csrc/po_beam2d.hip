@@ -955,9 +955,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             if (regular && nb == W) {
                 bool viol = false;
                 {   // (every operand read unconditionally: one LDS round trip)
-                    const int tx = (tid < SM::NCM - 1) ? tid : SM::NCM - 2;
+                    const int tx = (tid < SM::NCM) ? tid : SM::NCM - 1, tn = (tid + 1 < SM::NCM) ? tid + 1 : SM::NCM - 1;
                     const int dupf = sm.dup[tx];
-                    const double sc = sm.score[tx], scn = sm.score[tx + 1], scl = sm.score[nb - 1];
+                    const double sc = sm.score[tx], scn = sm.score[tn], scl = sm.score[nb - 1];
                     // (strictly: an exact tie is resolved by the full path below, as the reference's partial_sort does)
                     if (tid < ne && !dupf) {
                         if (tid >= nb) viol = !(scl > sc);

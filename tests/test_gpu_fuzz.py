@@ -63,6 +63,30 @@ def test_fuzz_pair_beam_kernels(eng, oracle):
     assert pairs > 100 and bad == 0, "%d of %d random pairs differ from the oracle" % (bad, pairs)
 
 
+def test_full_element_tables(eng, oracle):
+    """W = 6 / 12 / 25 fill their kernel class's element table to the last slot (30 / 60 / 125 elements); the child in
+    that last slot entering the beam is a 1-in-100-pairs event — a clamp that read the slot before it instead went
+    through every other test of this suite (the open-ended fuzz run found it)."""
+    from poreover_amd import _lib
+    rng = np.random.default_rng(20260204)
+    pairs = bad = 0
+    for W, n, tlo, thi in ((6, 150, 500, 1300), (6, 150, 500, 1300), (12, 60, 400, 1000), (25, 24, 300, 700)):
+        for method in ("row_col", "row"):
+            kind = ["poreover", "poreover", "bonito"][rng.integers(3)]
+            y1s, y2s, envs = [], [], []
+            for i in range(n // 2):
+                y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=int(rng.integers(tlo, thi)))
+                style = ["diag", "stairs", "wobble"][rng.integers(3)]
+                y1s.append(y1); y2s.append(y2); envs.append(_band_env(rng, len(y1), len(y2), style, int(rng.integers(5, 14))))
+            got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=MODELS[kind], method=method, return_status=True)
+            for i in range(len(y1s)):
+                want = oracle.cpp_beam_search_2d(y1s[i], y2s[i], envs[i], W, model_=MODELS[kind], method_=method)
+                pairs += 1
+                if st[i] != 0 or got[i] != want:
+                    bad += 1
+    assert bad == 0, "%d of %d pairs differ from the oracle" % (bad, pairs)
+
+
 def test_fuzz_grid_method(eng, oracle):
     """method grid, every model, beams up to 25 wide in bands a few cells wide — where most candidates are -inf and
     the beam is decided by the tie rule alone (the oracle's: libstdc++ on creation order)"""
