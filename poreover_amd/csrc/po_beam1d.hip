@@ -50,6 +50,31 @@ __device__ __forceinline__ char* carve(char*& p, size_t bytes) {
 
 }  // namespace
 
+// One row of y (N doubles at a wave-uniform address) through the SCALAR data cache: y is read-only input, the row
+// of the next frame used to be requested a frame ahead by vector loads — and waiting for those (vmcnt counts in
+// order) also waited for every tree-node store of the frame.  Scalar loads count on lgkmcnt.
+template <int N>
+__device__ __forceinline__ void b1_sload_row(const double* p, double* out) {
+    const unsigned long long pv = (unsigned long long)p;
+    const unsigned long long ps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pv >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv);
+    unsigned long long v0, v1, v2, v3, v4, v5 = 0, v6 = 0, v7 = 0;
+    if constexpr (N == 5) {
+        asm volatile("s_load_dwordx2 %0, %5, 0x0\n\ts_load_dwordx2 %1, %5, 0x8\n\ts_load_dwordx2 %2, %5, 0x10\n\t"
+                     "s_load_dwordx2 %3, %5, 0x18\n\ts_load_dwordx2 %4, %5, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3), "=&s"(v4) : "s"(ps) : "memory");
+    } else {
+        static_assert(N == 8, "row width");
+        asm volatile("s_load_dwordx2 %0, %8, 0x0\n\ts_load_dwordx2 %1, %8, 0x8\n\ts_load_dwordx2 %2, %8, 0x10\n\t"
+                     "s_load_dwordx2 %3, %8, 0x18\n\ts_load_dwordx2 %4, %8, 0x20\n\ts_load_dwordx2 %5, %8, 0x28\n\t"
+                     "s_load_dwordx2 %6, %8, 0x30\n\ts_load_dwordx2 %7, %8, 0x38\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3), "=&s"(v4), "=&s"(v5), "=&s"(v6), "=&s"(v7) : "s"(ps) : "memory");
+    }
+    const unsigned long long v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+    for (int c = 0; c < N; ++c) out[c] = __longlong_as_double((long long)v[c]);
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     const double* __restrict__ y, const int64_t* __restrict__ y_off, int A, uint32_t alphabet, int W,
@@ -139,17 +164,21 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     // (vmcnt counts in order) together with every arena store of the previous step
     double yn[CMAX];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) yn[c] = (c < C && T > 1) ? yr0[(int64_t)C + c] : 0.0;
+    for (int c = 0; c < CMAX; ++c) yn[c] = (c < C && T > 1 && C != CMAX) ? yr0[(int64_t)C + c] : 0.0;
     for (int t = 1; t < T; ++t) {
         const Table P = cur ? T1 : T0;
         const Table Q = cur ? T0 : T1;
         const bool first = (t == 1);
         double yr[CMAX];
+        if (C == CMAX) {   // (the standard alphabets: whole rows of CMAX doubles)
+            b1_sload_row<CMAX>(yr0 + (int64_t)t * C, yr);
+        } else {
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) yr[c] = yn[c];
-        if (t + 1 < T) {
+            for (int c = 0; c < CMAX; ++c) yr[c] = yn[c];
+            if (t + 1 < T) {
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) yn[c] = (c < C) ? yr0[(int64_t)(t + 1) * C + c] : 0.0;
+                for (int c = 0; c < CMAX; ++c) yn[c] = (c < C) ? yr0[(int64_t)(t + 1) * C + c] : 0.0;
+            }
         }
 
         // ---- phase 1: beam slots
