@@ -30,6 +30,9 @@ struct ModelTraits {
     static constexpr int CMAX = (MODEL == PO_MODEL_FLIPFLOP) ? 2 * PO_A : PO_A + 1;
 };
 
+// a candidate as the ranking reads it (score, node id, duplicate flag): one ds_read_b128 instead of three reads
+struct alignas(16) B1Cand { double sc; int id; int dup; };
+
 // one candidate table (struct of arrays carved from dynamic LDS)
 struct Table {
     int* id;      // [NC]  node id
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     int* dup = (int*)carve(p, sizeof(int) * NC);
     int* nsel = (int*)carve(p, sizeof(int) * WM);
     int* ord = (int*)carve(p, sizeof(int) * NC);     // prune with exact score ties: candidate slots in node-id order
+    B1Cand* cand = (B1Cand*)carve(p, sizeof(B1Cand) * NC);   // the candidates packed for the ranking: one 16-byte read each
 
     if (T < 1) {
         if (lane == 0) { seq_len[r] = 0; status[r] = PO_E_ARG; }
@@ -275,6 +279,9 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 for (int j = 0; j < Wc; ++j) d |= (Q.id[j] == x);
             }
             dup[s] = d;
+            B1Cand c;
+            c.sc = Q.val[s]; c.id = Q.id[s]; c.dup = d;
+            cand[s] = c;
         }
         po_wave_sync();   // (one wave per read)
         int kept = 0;
@@ -291,12 +298,11 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 //  instead of two dependent round trips per candidate)
 #pragma unroll 8
                 for (int o = 0; o < NCc; ++o) {
-                    const double so = Q.val[o];
-                    const int io = Q.id[o];
-                    const int live = dup[o] ? 0 : 1;
-                    const int better = ((so > sc) | (!(sc > so) & (io < id))) ? 1 : 0;
+                    const B1Cand c = cand[o];
+                    const int live = c.dup ? 0 : 1;
+                    const int better = ((c.sc > sc) | (!(sc > c.sc) & (c.id < id))) ? 1 : 0;
                     rank += live & better;
-                    neq += live & ((so == sc) ? 1 : 0);
+                    neq += live & ((c.sc == sc) ? 1 : 0);
                 }
                 if (rank < W) nsel[rank] = s;
                 teq = (neq > 1) && (rank < W);   // an exact tie that reaches into the beam
@@ -361,7 +367,7 @@ extern "C" size_t po_beam1d_lds_bytes(int W, int model) {
     const int WM = W > PO_A ? W : PO_A, NC = WM * (PO_A + 1);
     auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
     size_t per = 3 * al(sizeof(int) * NC) + al(sizeof(double) * K * NC) + 4 * al(sizeof(int) * WM);
-    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + 2 * al(sizeof(int) * NC);
+    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + 2 * al(sizeof(int) * NC) + al(16 * (size_t)NC);
 }
 
 // node-arena entries for a batch: per read root + A children + A * max(W, A) new nodes per frame
