@@ -202,7 +202,10 @@ struct B2Smem {
 // threads per workgroup for a beam-width class: 2 reads x (element slots padded to 32 / 64 / 128)
 #define B2_THREADS(WM) ((WM) * (PO_A + 1) <= 32 ? 64 : ((WM) * (PO_A + 1) <= 64 ? 128 : 256))
 
-template <int MODEL, int WMAX>
+// RC_ONLY: an instantiation without the `row` method's paths (is_row folds to false).  Same code, but the register
+// allocator no longer has to cover both walks: 28 instead of 68 bytes of scratch per lane in the W <= 6 ctc kernel and
+// +1.4 % on the headline configuration, so that one instantiation exists twice.
+template <int MODEL, int WMAX, bool RC_ONLY = false>
 // (4 waves per SIMD are what the W <= 6 class lives on — see B2_YD6.  It compiles to 124 / 128 VGPRs (ctc / merge
 // repeats); an edit that costs four more registers costs a quarter of the throughput — check with
 // -Rpass-analysis=kernel-resource-usage.  Forcing the bound here makes the allocator's choices 2 % worse today.)
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
     const int s = tid - r * NCP;       // element slot handled by this thread
     const int A = a.A, W = a.W, C = a.C;
     const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here (x < 1024, A <= 8)
-    const bool is_row = (a.method == PO_METHOD_ROW);
+    const bool is_row = RC_ONLY ? false : (a.method == PO_METHOD_ROW);
 
     // ---- per-workgroup workspace
     Ent* pool = (Ent*)(a.pool + (size_t)blockIdx.x * a.pool_bytes);
@@ -2766,6 +2769,12 @@ void grid_launch_w(const GridGeom& g, const B2Args& a, hipStream_t stream) {
 
 template <int MODEL, int WMAX>
 void b2_launch(const B2Geom& g, const B2Args& a, hipStream_t stream) {
+    if constexpr (MODEL == PO_MODEL_CTC && WMAX == 6) {
+        if (a.method != PO_METHOD_ROW) {
+            hipLaunchKernelGGL((beam2d_kernel<MODEL, WMAX, true>), dim3(g.blocks), dim3(g.threads), 0, stream, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((beam2d_kernel<MODEL, WMAX>), dim3(g.blocks), dim3(g.threads), 0, stream, a);
 }
 template <int MODEL>
