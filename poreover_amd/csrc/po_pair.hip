@@ -77,6 +77,13 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
     char* al1 = a.aln + (size_t)blockIdx.x * 2 * a.aln_cap;
     char* al2 = al1 + a.aln_cap;
 
+    // LDS hand-over in the DP fill.  A one-wave workgroup's LDS and vector-memory operations are performed in order:
+    // only the compiler needs a fence — __syncthreads() would also wait for the row's table stores to be acknowledged
+    // (s_waitcnt vmcnt(0)), four times per row.
+    auto psync = [&]() {
+        if constexpr (NT == PO_WAVE) po_wave_sync();
+        else __syncthreads();
+    };
     // block-wide inclusive prefix max of one int per thread
     auto block_prefix_max = [&](int v) {
 #pragma unroll
@@ -85,10 +92,10 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             if (lane >= o) v = max(v, t);
         }
         if (lane == PO_WAVE - 1) wsum[wave] = v;
-        __syncthreads();
+        psync();
         int carry = INT_MIN;
         for (int w = 0; w < wave; ++w) carry = max(carry, wsum[w]);
-        __syncthreads();
+        psync();
         return max(v, carry);
     };
     // block-wide sum / exclusive prefix sum of one int per thread
@@ -276,14 +283,14 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             // the value left of the first computed cell
             const int incl = block_prefix_max(m);
             pm[tid] = incl;
-            __syncthreads();
+            psync();
             const int excl = max(left0 - a.gap * (jfirst - 1), tid > 0 ? pm[tid - 1] : INT_MIN);
 #pragma unroll
             for (int q = 0; q < PERMAX; ++q) {
                 const int j = j0 + q;
                 if (q < per && j < je) { const int cell = max(loc[q], excl) + a.gap * j; row[j - js] = cell; cur[j - js] = cell; }
             }
-            __syncthreads();
+            psync();
             ps = js; pe = je;
         }
         if (sh[1]) {
