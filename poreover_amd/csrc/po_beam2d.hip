@@ -2769,7 +2769,7 @@ void grid_launch_w(const GridGeom& g, const B2Args& a, hipStream_t stream) {
 
 template <int MODEL, int WMAX>
 void b2_launch(const B2Geom& g, const B2Args& a, hipStream_t stream) {
-    if constexpr (MODEL == PO_MODEL_CTC && WMAX == 6) {
+    if constexpr (WMAX == 6) {
         if (a.method != PO_METHOD_ROW) {
             hipLaunchKernelGGL((beam2d_kernel<MODEL, WMAX, true>), dim3(g.blocks), dim3(g.threads), 0, stream, a);
             return;
