@@ -514,6 +514,14 @@ static int beam2d_row(tree_t* tr, beam_t* beam, const int* env, int U, int V) {
     return 0;
 }
 
+#ifdef PO_ORACLE_STATS
+/* Workload statistics of the row_col walk (scripts/rowcol_stats.py builds a scratch library with this flag; the
+ * shipped oracle does not carry it).  Indices: see scripts/rowcol_stats.py. */
+long long g_rc_stats[64];
+long long* oracle_rowcol_stats(void) { return g_rc_stats; }
+static int rc_in(const int* el, int n, int x) { for (int i = 0; i < n; ++i) if (el[i] == x) return 1; return 0; }
+#endif
+
 /* beam_search_2d_by_row_col, BeamSearch.h:262-397 */
 static int beam2d_row_col(tree_t* tr, beam_t* beam, const int* env, int U, int V) {
     const int A = tr->A, W = beam->width;
@@ -528,6 +536,9 @@ static int beam2d_row_col(tree_t* tr, beam_t* beam, const int* env, int U, int V
             else envt[2 * x + 1]++;
         }
     int u = 0, v = 0;
+#ifdef PO_ORACLE_STATS
+    int we0 = -1, we1 = -1, pmaxw = 0;
+#endif
     while (u <= U - 1 && v <= V - 1) {
         int ers = env[2 * u], ere = env[2 * u + 1];
         int ecs = envt[2 * v], ece = envt[2 * v + 1];
@@ -536,6 +547,9 @@ static int beam2d_row_col(tree_t* tr, beam_t* beam, const int* env, int U, int V
             row_start = v; row_end = ere; row_ok = 1;
         } else if (v < ers) { /* catch-up along read 1, :314-322 */
             int nb = W < beam->n ? W : beam->n; /* reference indexes b < beam_width (UB if larger) */
+#ifdef PO_ORACLE_STATS
+            g_rc_stats[1]++; if (v >= we1) g_rc_stats[2]++;
+#endif
             for (int b = 0; b < nb; ++b) tree_update(tr, beam->el[b], 1, v);
             v++;
             continue;
@@ -544,6 +558,9 @@ static int beam2d_row_col(tree_t* tr, beam_t* beam, const int* env, int U, int V
             col_start = u; col_end = ece; col_ok = 1;
         } else if (u < ecs) { /* catch-up along read 0, :328-336 */
             int nb = W < beam->n ? W : beam->n;
+#ifdef PO_ORACLE_STATS
+            g_rc_stats[1]++; if (u >= we0) g_rc_stats[2]++;
+#endif
             for (int b = 0; b < nb; ++b) tree_update(tr, beam->el[b], 0, u);
             u++;
             continue;
@@ -551,6 +568,22 @@ static int beam2d_row_col(tree_t* tr, beam_t* beam, const int* env, int U, int V
         if (!row_ok || !col_ok) { rc = PO_E_ENVELOPE; goto done; } /* uninitialised bounds, :309 */
 
         int beam_size = beam->n;
+#ifdef PO_ORACLE_STATS
+        int old[64], nold = beam_size < 64 ? beam_size : 64;
+        for (int b = 0; b < nold; ++b) old[b] = beam->el[b];
+        {
+            int l0 = col_end - col_start, l1 = row_end - row_start;
+            g_rc_stats[0]++; g_rc_stats[3] += l0; g_rc_stats[4] += l1;
+            if (l0 > pmaxw) pmaxw = l0;
+            if (l1 > pmaxw) pmaxw = l1;
+            if (col_end < we0) g_rc_stats[5]++;
+            if (row_end < we1) g_rc_stats[5]++;
+            /* new times this step if everything were incremental */
+            g_rc_stats[6] += (col_end > we0 ? col_end - (we0 > col_start ? we0 : col_start) : 0);
+            g_rc_stats[7] += (row_end > we1 ? row_end - (we1 > row_start ? we1 : row_start) : 0);
+            we0 = col_end; we1 = row_end;
+        }
+#endif
         for (int b = 0; b < beam_size; ++b) {
             int node = beam->el[b];
             tree_update(tr, node, 0, col_start);
@@ -570,9 +603,55 @@ static int beam2d_row_col(tree_t* tr, beam_t* beam, const int* env, int U, int V
         for (int v_ = row_start; v_ < row_end; ++v_)
             for (int b = 0; b < beam->n; ++b) tree_update(tr, beam->el[b], 1, v_);
         if (beam_prune(beam, tr, SCORE_ROW_COL) || tr->oom) { rc = PO_E_NOMEM; goto done; }
+#ifdef PO_ORACLE_STATS
+        {
+            int nn = beam->n, same = (nn == nold), sameset = (nn == nold), enter = 0;
+            for (int b = 0; b < nn; ++b) {
+                if (b >= nold || beam->el[b] != old[b]) same = 0;
+                if (!rc_in(old, nold, beam->el[b])) {
+                    sameset = 0; enter++;
+                    const node_t* nd = &tr->nodes[beam->el[b]];
+                    if (nd->first_child >= 0) {
+                        g_rc_stats[12]++;   /* re-entry: node already has children */
+                        const node_t* c = &tr->nodes[nd->first_child];
+                        if (c->last_t[0] >= u || c->last_t[1] >= v) g_rc_stats[13]++;   /* ... whose stale values the next step can read */
+                    }
+                }
+            }
+            if (same) g_rc_stats[8]++; else if (sameset) g_rc_stats[9]++; else g_rc_stats[10]++;
+            g_rc_stats[11] += enter;
+            if (enter > 1) g_rc_stats[20]++;
+            for (int b = 0; b < nn; ++b) {   /* frozen parents */
+                const node_t* nd = &tr->nodes[beam->el[b]];
+                int p = nd->parent;
+                if (p <= 0) continue;
+                int gp = tr->nodes[p].parent;
+                if (rc_in(beam->el, nn, p) || (gp >= 0 && rc_in(beam->el, nn, gp))) continue;
+                g_rc_stats[14]++;
+                const node_t* pn = &tr->nodes[p];
+                if (pn->last_t[0] > nd->last_t[0] || pn->last_t[1] > nd->last_t[1]) g_rc_stats[15]++;  /* claim violated */
+                if (pn->last_t[0] == nd->last_t[0] || pn->last_t[1] == nd->last_t[1]) g_rc_stats[16]++; /* frozen value at done-1 exists */
+            }
+            if (nn == W) {   /* exact tie at the beam boundary or inside it */
+                int tie = 0;
+                for (int b = 0; b + 1 < nn; ++b)
+                    if (node_score(tr, beam->el[b], SCORE_ROW_COL) == node_score(tr, beam->el[b + 1], SCORE_ROW_COL)) tie = 1;
+                if (tie) g_rc_stats[17]++;
+            }
+        }
+#endif
         v++;
         u++;
     }
+#ifdef PO_ORACLE_STATS
+    g_rc_stats[18]++;                       /* pairs */
+    if (pmaxw > g_rc_stats[19]) g_rc_stats[19] = pmaxw;
+    if (pmaxw <= 14) g_rc_stats[21]++;
+    else if (pmaxw <= 30) g_rc_stats[22]++;
+    else if (pmaxw <= 62) g_rc_stats[23]++;
+    else g_rc_stats[24]++;
+    g_rc_stats[25] += tr->n;                /* nodes created */
+#endif
 done:
     free(envt);
     return rc;
