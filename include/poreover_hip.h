@@ -84,6 +84,7 @@ int po_device_info(int device, char* name, int name_cap, int* compute_units, int
 #define PO_ROUTE_AUTO 0
 #define PO_ROUTE_X2 1
 #define PO_ROUTE_LEGACY 2
+#define PO_ROUTE_RING 3
 int po_set_pair_route(int route, int defer_odd);
 
 /* ---- trace ingest ------------------------------------------------------------------------------

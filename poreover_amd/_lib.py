@@ -155,7 +155,7 @@ def load(require_gpu=True):
     return _lib
 
 
-ROUTES = {"auto": 0, "x2": 1, "legacy": 2}
+ROUTES = {"auto": 0, "x2": 1, "legacy": 2, "ring": 3}
 
 
 def set_pair_route(route="auto", defer_odd=False):

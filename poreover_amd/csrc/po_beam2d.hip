@@ -43,11 +43,13 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "po_device.h"
+#include "po_beam2d_common.h"
 
 namespace {
-
 constexpr int B2_YD = 256;   // doubles per read in the y window buffer (51 rows of 5, 32 rows of 8)
 // The W <= 6 class (64 threads per pair) runs at 124 VGPRs, i.e. 4 waves per SIMD — if its LDS lets 16 workgroups
 // share a CU.  The chains of dependent f64 operations in logaddexp leave a wave idle most of the time, so resident
@@ -59,111 +61,6 @@ constexpr int B2_YD = 256;   // doubles per read in the y window buffer (51 rows
 #ifndef B2_NGL6
 #define B2_NGL6 112
 #endif
-
-template <int K>
-struct alignas(K == 1 ? 16 : 32) Entry {
-    unsigned long long tag;
-    double v[K];
-};
-
-__device__ __forceinline__ unsigned long long make_tag(unsigned epoch, int node, int t) {
-    return ((unsigned long long)(epoch & 0xffffu) << 48) | ((unsigned long long)(node & 0xffffff) << 24) |
-           (unsigned long long)(t & 0xffffff);
-}
-
-struct B2Args {
-    const double* y1; const int64_t* y1_off;
-    const double* y2; const int64_t* y2_off;
-    const int32_t* env;       // NULL: no envelope (method row only)
-    int n, A, W, C, method;
-    uint32_t alphabet;
-    char* seq; const int64_t* seq_off; int32_t* seq_len; int32_t* status;
-    int use_pre_status;       // status[] already holds skip / error codes for some pairs: leave those alone
-    // workspace (per persistent workgroup unless noted)
-    int* queue;               // one counter for the launch
-    char* pool; size_t pool_bytes;
-    int* arena; long long arena_cap;   // 3 int arrays (packed(parent,last), first_child, row group) + 1 double array
-    double* cum; long long tcap;       // 2 arrays of tcap doubles: blank prefix sums of each read
-    int* envt; long long vcap;         // 2 * vcap ints: transposed envelope
-    long long* dbg;                    // optional phase cycle counters (PO_B2_TIMING builds)
-    const int2* only_meta;             // non-NULL: decode only the pairs the two-pairs-per-wave path deferred (meta.y == -2)
-    int* cellb;                        // grid method: two rows of per-cell beams per workgroup (2 * vcap * (1 + 6 W) ints)
-    int retry_nomem;                   // second pass with a larger store: decode only the pairs the first one gave PO_E_NOMEM
-    unsigned long long* upd_count;     // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
-    unsigned long long* wgstate;       // per workgroup {magic, epoch counter}: what its slice of the value store was last tagged with
-    unsigned long long magic;          // names this workspace geometry: a slice whose state word differs is cleared before use
-};
-
-// F_PSLOT of an element whose parent does not move in the scan: a frozen parent (its values are read from
-// its ring row in the store), or the root (closed form / blank prefix sums)
-constexpr int PS_FROZEN = -1, PS_ROOT = -2;
-// meta.y of a pair the two-pairs-per-wave kernel hands to beam2d_kernel (window too wide for its store
-// geometry, or its row-group table ran out)
-constexpr int X2_DEFERRED = -2;
-
-// LDS hand-over between iterations.  One wave per workgroup: a wave's LDS operations execute in order,
-// only the compiler needs fencing.  More waves: LDS-only barrier (outstanding stores are not waited for).
-template <int NTHR>
-__device__ __forceinline__ void b2_sync_lds() {
-    if constexpr (NTHR == 64) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-        po_lds_barrier();
-    }
-}
-
-// Workgroup barrier that also makes earlier GLOBAL stores of the workgroup visible to its later loads.  With one
-// wave per workgroup nothing has to be waited for: a wave's vector memory operations are performed in execution
-// order and its CU's L1 is write-through, so a load issued after a store of the same wave sees it — __syncthreads()
-// would drain every outstanding store (s_waitcnt vmcnt(0)) once per step for nothing.
-template <int NTHR>
-__device__ __forceinline__ void b2_sync_mem() {
-    if constexpr (NTHR == 64) b2_sync_lds<64>();
-    else __syncthreads();
-}
-// barrier + "does any thread of the workgroup say yes"
-template <int NTHR>
-__device__ __forceinline__ bool b2_any(bool p) {
-    if constexpr (NTHR == 64) {
-        b2_sync_lds<64>();
-        return __ballot(p) != 0ull;
-    } else {
-        return __syncthreads_or(p) != 0;
-    }
-}
-
-// One (uniform) int2 through the SCALAR data cache.  The walk of row_col reads two envelope entries per round; as vector
-// loads they share the wave's vmcnt with its value-store writes, which complete in order — using an entry meant waiting
-// for every store issued before the load was (a drain per round).  Scalar loads count on lgkmcnt.  The scalar cache is
-// not coherent with vector stores: b2_scalar_cache_inv() before the first read of anything the kernel wrote itself.
-__device__ __forceinline__ int2 b2_sload2(const int2* p) {
-#ifdef PO_NO_SLOAD   // A/B switch
-    return *p;
-#else
-    // (the "s" constraint does not move a pointer the compiler keeps in vector registers: readfirstlane does)
-    const unsigned long long pv = (unsigned long long)p;
-    const unsigned long long ps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pv >> 32)) << 32) |
-                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv);
-    unsigned long long v;
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ps) : "memory");
-    return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
-#endif
-}
-__device__ __forceinline__ void b2_scalar_cache_inv() {
-#ifndef PO_NO_SLOAD
-    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-}
-
-// element-table field indices
-enum { F_ID, F_ROW, F_PSLOT, F_SYM, F_FC, F_CROW, F_PAR, F_GPAR, F_PROW, F_DEPTH, F_COUNT };
-// F_SYM packs: own symbol (bits 0-2) | parent's symbol (bits 4-6) | parent-is-root (bit 9)
-__device__ __forceinline__ int sym_pack(int last, int plast, bool rootpar) { return last | (plast << 4) | (rootpar ? 512 : 0); }
-__device__ __forceinline__ int sym_last(int s) { return s & 7; }
-__device__ __forceinline__ int sym_plast(int s) { return (s >> 4) & 7; }
-
 template <int MODEL, int WMAX>
 struct B2Smem {
     static constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
@@ -1232,29 +1129,6 @@ constexpr int X2_NGL = X2_NGL_;   // row groups tracked per pair
 #endif
 constexpr int X2_YD = X2_YD_;    // doubles in the per-pair y window buffer (256: 51 rows of 5, 32 rows of 8)
 
-struct X2Args {
-    const double* y1; const int64_t* y1_off;
-    const double* y2; const int64_t* y2_off;
-    const int32_t* env;
-    int n, A, W, C;
-    uint32_t alphabet;
-    char* seq; const int64_t* seq_off; int32_t* seq_len; int32_t* status;
-    int use_pre_status;
-    int* queue;
-    int2* meta;                    // per pair: {status, R}; R < 0: skipped upstream, leave status alone
-    int4* sched;                   // the diagonal walk, one record per MAIN step: {u, v, column-window end, row-window
-                                   // end}, at the pair's read-1 row offset (a pair has at most min(U, V) main steps)
-    int* nmain;                    // per pair: number of main steps
-    int* envt;                     // transposed envelope: 2 ints per read-1 row of the batch
-    double* cum1; double* cum2;    // blank prefix sums at the batch row offsets (CTC root)
-    char* pool; size_t pool_bytes; // value store per half-wave
-    int* arena; long long arena_cap;  // per half-wave: 3 int arrays
-    long long* dbg;
-    int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
-    int pre_vcols;                    // pre-pass: columns its LDS table holds
-    int ngl;                          // row groups the main kernel tracks per pair
-    unsigned long long* upd_count;    // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
-};
 
 struct alignas(16) X2Cand { double sc; int id; int dup; };
 // SG = lanes (element slots) per pair: 32 -> two pairs per wave (W <= 6), 64 -> one pair per wave (W <= 12)
@@ -2640,13 +2514,14 @@ constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over 
 // PO_ROUTE_LEGACY (always beam2d_kernel) — the last two exist for the tests, which run the pair path on both kernels,
 // and for A/B timing.  The environment variables PO_X2_FORCE / PO_B2_LEGACY / PO_X2_DEFER_ODD only give the INITIAL
 // value, read once when the library is first used, so that a workspace size and the launch that follows always agree.
-struct B2Route { int route, defer_odd, x2_per_cu, debug_occ; };
+struct B2Route { int route, defer_odd, x2_per_cu, debug_occ, ring_auto; };
 B2Route& b2_route() {
     static B2Route r = [] {
         B2Route x;
-        x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_X2_FORCE") ? PO_ROUTE_X2 : PO_ROUTE_AUTO);
+        x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_X2_FORCE") ? PO_ROUTE_X2 : (getenv("PO_RING_FORCE") ? PO_ROUTE_RING : PO_ROUTE_AUTO));
         x.defer_odd = getenv("PO_X2_DEFER_ODD") ? 1 : 0;
         x.debug_occ = getenv("PO_DEBUG_OCC") ? 1 : 0;
+        x.ring_auto = getenv("PO_RING_AUTO") ? 1 : 0;   // (beam2d_ring_kernel as the engine's own choice: not yet)
         const char* e = getenv("PO_X2_PER_CU");
         x.x2_per_cu = e ? atoi(e) : 0;
         return x;
@@ -2724,6 +2599,55 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     return g;
 }
 
+// ---- LDS-ring path (beam2d_ring_kernel, po_beam2d_ring.hip): row_col with an envelope, one-value model, W * (A + 1)
+// elements within its ring rows.  One wave per pair; pre-pass and walk are the two-pairs-per-wave path's.
+extern "C" int po_ring_blocks_per_cu();
+extern "C" int po_ring_max_elements();
+extern "C" int po_ring_ngl();
+extern "C" void po_ring_launch(const void* x2args, int blocks, hipStream_t stream);
+bool ring_eligible(int W, int A, int model, int method) {
+    const int rt = b2_route().route;
+    if (rt != PO_ROUTE_RING && !(rt == PO_ROUTE_AUTO && b2_route().ring_auto)) return false;
+    return model == PO_MODEL_CTC && method == PO_METHOD_ROW_COL && W <= 6 && A >= 1 && W * (A + 1) <= po_ring_max_elements();
+}
+struct RingGeom {
+    int blocks;
+    size_t pool_bytes, arena_cap;
+    size_t off_queue, off_state, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
+    unsigned long long magic;
+};
+RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model) {
+    RingGeom g;
+    g.blocks = b2_num_cus() * po_ring_blocks_per_cu();
+    if (g.blocks > n) g.blocks = n > 0 ? n : 1;
+    g.pool_bytes = (size_t)4 << 20;   // tier 2: 128 row groups at R = 256 (windows up to 254 frames), 112 tracked
+    const int64_t WM = W > PO_A ? W : PO_A;
+    g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
+    {
+        const size_t per_block = g.pool_bytes + sizeof(int) * 3 * g.arena_cap;
+        const size_t fit = std::max<size_t>(1, b2_mem_budget() / std::max<size_t>(per_block, 1));
+        if ((size_t)g.blocks > fit) g.blocks = (int)fit;
+    }
+    size_t o = 0;
+    g.off_queue = o; o += 256;
+    g.off_state = o; o += al256(sizeof(unsigned long long) * 2 * (size_t)g.blocks);
+    g.off_meta = o; o += al256(sizeof(int2) * (size_t)(n > 0 ? n : 1));
+    g.off_nmain = o; o += al256(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    g.off_sched = o; o += al256(sizeof(int4) * (size_t)(tr2 > 0 ? tr2 : 1));
+    g.off_envt = o; o += al256(sizeof(int) * 2 * (size_t)tr2);
+    g.off_cum1 = o; o += al256(sizeof(double) * (size_t)tr1);
+    g.off_cum2 = o; o += al256(sizeof(double) * (size_t)tr2);
+    g.off_pool = o; o += g.pool_bytes * g.blocks;
+    g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * g.blocks);
+    g.off_fb = o;
+    g.fb_bytes = b2_geometry(n, mr1, mr2, W, model, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
+    o += al256(g.fb_bytes);
+    g.total = o + 256;
+    g.magic = 0xa0761d6478bd642full ^ ((unsigned long long)g.pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)g.blocks << 40) ^
+              ((unsigned long long)g.off_pool * 0x9e3779b97f4a7c15ull);
+    return g;
+}
+
 // ---- grid method: one workgroup per pair in flight; per workgroup a value store, the tree arena, the blank
 // prefix sums and two rows of cell beams
 struct GridGeom {
@@ -2790,17 +2714,42 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
     (void)C;
     if (method == PO_METHOD_GRID) return grid_geometry(n, mr1, mr2, W, model, true).total;
     if (method == PO_METHOD_GRID_NOENV) return grid_geometry(n, mr1, mr2, W, model, false).total;
+    if (ring_eligible(W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return ring_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     if (x2_eligible(n, W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total + b2_geometry(n, mr1, mr2, W, model, method, X2_FB_BLOCKS).total;
 }
 
 namespace {
+// The pair-beam kernels keep {magic, epoch} words per workgroup in the workspace instead of clearing their value
+// store per launch.  That is only sound while the same layout is used on the same memory: a caller that reuses one
+// buffer for waves of different geometry moves the sub-workspace, and state words of one layout can then survive
+// inside the other's store while both keep writing tags into overlapping memory.  The host therefore remembers, per
+// workspace base pointer, the layout of the last pair-beam launch there; a launch with another layout zeroes the
+// (small) state region first, which makes every workgroup clear its slice.
+struct B2Layout { size_t off_state, total; unsigned long long magic; };
+std::mutex g_b2_layout_mu;
+std::unordered_map<const void*, B2Layout> g_b2_layouts;
+bool b2_ws_layout_changed(const void* ws, size_t off_state, size_t total, unsigned long long magic) {
+    std::lock_guard<std::mutex> lk(g_b2_layout_mu);
+    auto it = g_b2_layouts.find(ws);
+    const bool same = it != g_b2_layouts.end() && it->second.off_state == off_state && it->second.total == total && it->second.magic == magic;
+    // any other remembered buffer that overlaps this one is stale too (freed and reallocated memory)
+    if (!same) {
+        for (auto jt = g_b2_layouts.begin(); jt != g_b2_layouts.end();) {
+            const char* b = (const char*)jt->first;
+            if (jt->first != ws && b < (const char*)ws + total && (const char*)ws < b + jt->second.total) jt = g_b2_layouts.erase(jt);
+            else ++jt;
+        }
+        g_b2_layouts[ws] = B2Layout{off_state, total, magic};
+    }
+    return !same;
+}
 unsigned long long* g_b2_upd_counter = nullptr;
 void (*g_b2_mark)(int begin, hipStream_t stream) = nullptr;   // profiling: brackets the main pair beam kernel
 }
 extern "C" void po_b2_set_mark(void (*f)(int, hipStream_t)) { g_b2_mark = f; g_b2_mark_fwd = f; }
 extern "C" int po_set_pair_route(int route, int defer_odd) {
-    if (route != PO_ROUTE_AUTO && route != PO_ROUTE_X2 && route != PO_ROUTE_LEGACY) return PO_E_ARG;
+    if (route != PO_ROUTE_AUTO && route != PO_ROUTE_X2 && route != PO_ROUTE_LEGACY && route != PO_ROUTE_RING) return PO_E_ARG;
     b2_route().route = route;
     b2_route().defer_odd = defer_odd ? 1 : 0;
     return PO_OK;
@@ -2878,8 +2827,12 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     a.dbg = dbg_buf;
 #endif
     // the queue counter starts from zero on every launch; the value store is NOT cleared: its tags are told apart by
-    // the epoch counters the workgroups keep in the workspace (see beam2d_kernel)
+    // the epoch counters the workgroups keep in the workspace (see beam2d_kernel) — unless this memory was last used
+    // with another layout (b2_ws_layout_changed)
     if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    if (b2_ws_layout_changed(ws, g.off_state, g.total, g.magic) &&
+        hipMemsetAsync(w + g.off_state, 0, sizeof(unsigned long long) * 2 * (size_t)g.blocks, stream) != hipSuccess)
+        return PO_E_HIP;
     if (g_b2_mark && !only_meta && !retry) g_b2_mark(1, stream);
     if (model == PO_MODEL_CTC) b2_launch_w<PO_MODEL_CTC>(g, a, stream);
     else if (model == PO_MODEL_MERGE) b2_launch_w<PO_MODEL_MERGE>(g, a, stream);
@@ -2942,6 +2895,44 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         else if (model == PO_MODEL_MERGE) grid_launch_w<PO_MODEL_MERGE>(g, a, stream);
         else grid_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
         return PO_OK;
+    }
+    if (ring_eligible(W, A, model, method)) {
+        const RingGeom g = ring_geometry(n, tr1, tr2, mr1, mr2, W, model);
+        if (ws_bytes < g.total) return PO_E_CAP;
+        char* w = (char*)ws;
+        X2Args a;
+        a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
+        a.n = n; a.A = A; a.W = W; a.C = C; a.alphabet = alphabet;
+        a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status; a.use_pre_status = use_pre_status;
+        a.queue = (int*)(w + g.off_queue);
+        a.meta = (int2*)(w + g.off_meta);
+        a.nmain = (int*)(w + g.off_nmain);
+        a.sched = (int4*)(w + g.off_sched);
+        a.envt = (int*)(w + g.off_envt);
+        a.cum1 = (double*)(w + g.off_cum1); a.cum2 = (double*)(w + g.off_cum2);
+        a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
+        a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
+        a.dbg = nullptr;
+        a.upd_count = g_b2_upd_counter;
+        a.defer_odd = b2_route().defer_odd;
+        a.wgstate = (unsigned long long*)(w + g.off_state);
+        a.magic = g.magic;
+        a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
+        const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
+        a.ngl = po_ring_ngl();
+        if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+        if (b2_ws_layout_changed(ws, g.off_state, g.total, g.magic) &&
+            hipMemsetAsync(w + g.off_state, 0, sizeof(unsigned long long) * 2 * (size_t)g.blocks, stream) != hipSuccess)
+            return PO_E_HIP;
+        hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
+        hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
+        if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
+        po_ring_launch(&a, g.blocks, stream);
+        if (g_b2_mark_fwd) g_b2_mark_fwd(0, stream);
+        // pairs the pre-pass or the kernel deferred (tier-2 row groups exhausted, windows beyond the store's ring):
+        // one small pass of beam2d_kernel, a no-op when there are none
+        return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off,
+                                seq_len, status, use_pre_status, w + g.off_fb, g.fb_bytes, stream, X2_FB_BLOCKS, a.meta);
     }
     if (x2_eligible(n, W, model, method)) {
         const X2Geom g = x2_geometry(n, tr1, tr2, mr1, mr2, W, model);
