@@ -33,11 +33,11 @@
 
 namespace {
 
-constexpr int RG_NRP = 28;    // LDS ring rows = elements that can be live at once
+constexpr int RG_NRP = 26;    // LDS ring rows = elements that can be live at once
 constexpr int RG_RL = 32;     // times per ring row
-constexpr int RG_NY = 16;     // y rows per read resident in LDS
+constexpr int RG_NY = 32;     // y rows per read resident in LDS
 constexpr int RG_YC = 5;      // doubles per y row (A + 1 <= 5)
-constexpr int RG_NGL = 112;   // tier-2 row groups tracked per pair
+constexpr int RG_NGL = 96;   // tier-2 row groups tracked per pair
 constexpr int RG_FRESH = INT_MIN / 2;
 
 struct RingSmem {
@@ -88,6 +88,21 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
     const PoLaeFast lae{&sm.lae};
     if (lane == 0) { sm.nupd = 0; sm.nupd_x = 0; }
     __syncthreads();
+#ifdef PO_RING_TIMING
+    // phase timers of workgroup 0 (wall_clock64: 100 MHz): see po_ring_launch for the names
+    long long tk[32], tlast = wall_clock64();
+    for (int i = 0; i < 32; ++i) tk[i] = 0;
+    int tko = 0;
+#define RT(i) do { const long long n_ = wall_clock64(); tk[tko + (i)] += n_ - tlast; tlast = n_; } while (0)
+#define RTC(i, n) do { tk[(i)] += (n); } while (0)
+#define RTX(i) do { const long long n_ = wall_clock64(); tk[(i)] += n_ - tlast; tlast = n_; } while (0)
+#define RT_SET(o) do { tko = (o); } while (0)
+#else
+#define RT(i) do {} while (0)
+#define RTC(i, n) do {} while (0)
+#define RTX(i) do {} while (0)
+#define RT_SET(o) do {} while (0)
+#endif
 
     for (;;) {
         // ---------------------------------------------------------------- next pair from the queue
@@ -191,8 +206,18 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
         rg_sync();
 
         int mstep = 0, up = -1, vp = -1;
-        int4 rec = sched[0], rec_n = sched[min(1, max(nmain - 1, 0))];
+        // The walk's records, 64 at a time: lane l holds record 64 * batch + l of the current batch and of the next one
+        // (requested a batch ahead: the load's latency never shows), the step's own record comes out with v_readlane.
+        int4 rcur = sched[min(lane, max(nmain - 1, 0))], rnxt = sched[min(64 + lane, max(nmain - 1, 0))];
+        auto rec_at = [&](int i) -> int4 {   // record of main step i (uniform i within the current batch)
+            const int l = i & 63;
+            return make_int4(__builtin_amdgcn_readlane(rcur.x, l), __builtin_amdgcn_readlane(rcur.y, l),
+                             __builtin_amdgcn_readlane(rcur.z, l), __builtin_amdgcn_readlane(rcur.w, l));
+        };
+        int4 rec = rec_at(0);
         bool have_children = false;   // the table has its children slots (false only before the first expansion)
+        bool tbl_fresh = true;        // the table has elements that have not computed yet (set by rebuild)
+        bool tbl_uneven = false;      // a catch-up scan moved the beam nodes beyond their children
         unsigned long long cnt_ref = 0, cnt_x = 0;
 
         // ---------------------------------------------------------------- own ring / tier-2 value at time tq
@@ -216,7 +241,10 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
         // child at t reads its parent's t - 1, computed one iteration earlier or long ago: it is in the ring or in tier 2).
         // MAIN steps (is_main) track the window maximum; catch-up scans (BeamSearch.h:314-336) move the beam nodes only.
         double smx = PO_NEG_INF;   // out: max over this read's window (main steps)
-        auto scan = [&](bool is_main, int ws0, int we0, int ws1, int we1, int nlanes) {
+        int c_plrow = 0;           // ring row of the parent element (e_ps >= 0), refreshed by rebuild
+        // `uni`: the table is the previous main step's and every live lane's values end at the same time (no new
+        // element, no catch-up since): nothing has to be asked of the parent's lane.
+        auto scan = [&](bool is_main, int ws0, int we0, int ws1, int we1, int nlanes, bool uni) {
             const int ws = r ? ws1 : ws0, we = r ? we1 : we0;
             const bool part = live && s < nlanes && we > ws;
             // the window end moved back (an envelope with an occasional wide row): forget what lies beyond it, as the
@@ -228,6 +256,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             }
             int start = max(v_done, ws);
             double self = PO_NEG_INF;
+            bool contin = false;   // continues where its values end (no new incarnation, no gap)
             if (part) {
                 if (v_fresh != 0) {
                     start = ws;
@@ -237,6 +266,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                     v_lo = start; v_done = start; v_hiw = start;
                 } else {
                     self = v_self;
+                    contin = true;
                 }
             }
             const bool part2 = part && start < we;
@@ -261,56 +291,171 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                     }
                 }
             }
-            // ---- the parent's values
-            const int a_lo = (v_fresh != 0 && !part) ? INT_MAX : v_lo;
-            const int a_done0 = (v_fresh != 0 && !part) ? INT_MAX : v_done;
-            const int a_hiw0 = v_hiw;
-            const int a_start = part2 ? start : INT_MAX;
-            const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
-            const int p_lo = __shfl(a_lo, plane), p_done0 = __shfl(a_done0, plane), p_hiw0 = __shfl(a_hiw0, plane);
-            const int p_start = __shfl(a_start, plane), p_lrow = __shfl(e_lrow, plane);
             const int sym = sym_last(e_sym);
-            // ---- lockstep over t, the y rows of both reads through LDS
-            int tmin = part2 ? start : INT_MAX;
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) tmin = min(tmin, __shfl_xor(tmin, off));
-            const int span = (tmin == INT_MAX) ? 0 : we - tmin;   // (half-uniform)
-            const int niter = max(__builtin_amdgcn_readlane(span, 0), __builtin_amdgcn_readlane(span, 32));
-            // The FAST loop: every parent value an iteration needs is in the ring (or is the captured last value of a
-            // frozen parent) and no slot that is overwritten can be read again — true for all but a few percent of
-            // the scans (windows beyond 31 times, the root's children, elements restored from tier 2, catch-ups).
-            bool slowlane = false;
-            if (part2) {
-                const int tm0 = start - 1;
-                if (we - ws > RG_RL - 1) slowlane = true;
-                if (e_ps >= 0) {
-                    const bool plain0 = tm0 >= p_lo && tm0 >= p_hiw0 - RG_RL && (tm0 < p_done0 || tm0 >= p_start);
-                    if (!plain0 || p_start > p_done0) slowlane = true;
-                } else if (e_ps == PS_ROOT) slowlane = true;
-                else if (tm0 < fz_t) slowlane = true;
+            // ---- which loop.  FAST: every parent value an iteration needs is in the ring (or is the captured last value
+            // of a frozen parent) and no slot that is overwritten can be read again — all but a few percent of the scans
+            // (windows beyond 31 times, the root's children, elements restored from tier 2, catch-ups).
+            bool fast = false;
+            int p_lo = 0, p_done0 = 0, p_hiw0 = 0, p_start = 0, p_lrow = c_plrow;
+            int tmin = 0, tph2 = 0;      // (half-uniform) first time computed by any lane / by the lanes that continue
+            bool isP1 = false;           // starts before the continuing lanes do: a new element's full window
+            if (uni) {
+                const bool sl = part2 && (e_ps == PS_ROOT || (e_ps == PS_FROZEN && start - 1 < fz_t) || we - ws > RG_RL - 1);
+                fast = is_main && (__ballot(sl) == 0ull);
+                tmin = __builtin_amdgcn_readlane(start, 0);
+                const int t1 = __builtin_amdgcn_readlane(start, 32);
+                tmin = r ? t1 : tmin;   // (beam slot 0 is always live: every live lane of the half starts there)
+                tph2 = tmin;
             }
-            const bool fast = is_main && (__ballot(slowlane) == 0ull);
-            int k = 0;
-            while (k < niter) {
-                const int tcur = tmin + k;   // (garbage when this half has nothing to do: guarded by span)
-                const bool hw = k < span;    // this half still has times to compute
-                if (hw && !(tcur >= yhi - RG_NY && tcur < yhi)) { y_reload(tcur); yhi = tcur + RG_NY; }
+            if (!fast) {
+                // the parent's lane: what it holds and where it starts
+                const int a_lo = (v_fresh != 0 && !part) ? INT_MAX : v_lo;
+                const int a_done0 = (v_fresh != 0 && !part) ? INT_MAX : v_done;
+                const int a_start = part2 ? start : INT_MAX;
+                const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
+                p_lo = __shfl(a_lo, plane); p_done0 = __shfl(a_done0, plane); p_hiw0 = __shfl(v_hiw, plane);
+                p_start = __shfl(a_start, plane); p_lrow = __shfl(e_lrow, plane);
+                // the lanes that continue all start where the previous window ended
+                const unsigned long long cb = __ballot(part2 && contin);
+                const unsigned ch = r ? (unsigned)(cb >> 32) : (unsigned)cb;
+                const int cl = (ch != 0u) ? (hb | __builtin_ctz(ch)) : lane;
+                tph2 = (ch != 0u) ? __shfl(start, cl) : we;
+                isP1 = part2 && !contin;
+                const unsigned long long pb = __ballot(isP1);
+                const unsigned ph = r ? (unsigned)(pb >> 32) : (unsigned)pb;
+                tmin = (ph != 0u) ? min(ws, tph2) : tph2;
+                bool sl = false;
+                if (part2) {
+                    const int tm0 = start - 1;
+                    if (we - ws > RG_RL - 1) sl = true;
+                    if (contin && start != tph2) sl = true;
+                    if (e_ps >= 0) {
+                        // [tm0, we - 2] must be there: old values (below p_done0) or computed in lockstep (from p_start on)
+                        const bool plain0 = tm0 >= p_lo && tm0 >= p_hiw0 - RG_RL && (tm0 < p_done0 || tm0 >= p_start);
+                        if (!plain0 || (p_start > p_done0 && p_done0 < we - 1)) sl = true;
+                        if (isP1 && p_start < tph2) sl = true;   // (a new element under a parent that moves before the others do)
+                    } else if (e_ps == PS_ROOT || isP1) sl = true;
+                    else if (tm0 < fz_t) sl = true;
+                }
+                fast = is_main && (__ballot(sl) == 0ull);
+#ifdef PO_RING_TIMING
+                if (is_main && !fast) {
+                    if (__ballot(part2 && we - ws > RG_RL - 1) != 0ull) RTC(uni ? 14 : 15, 1);
+                    else if (__ballot(part2 && e_ps == PS_ROOT) != 0ull) RTC(23, 1);
+                    else RTC(11, 1);
+                }
+#endif
+                if (!fast) {   // the general loop walks every lane from the earliest start
+                    int tm_ = part2 ? start : INT_MAX;
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) tm_ = min(tm_, __shfl_xor(tm_, off));
+                    tmin = tm_;
+                }
+            }
+            RT(1);
+            if (fast) {
+                // ---- y rows of [tmin, we) resident (the window has at most 31 times)
+                const bool hwk = (tmin < we) && (__ballot(part2) != 0ull);
+                if (hwk && !(tmin >= yhi - RG_NY && we <= yhi)) { y_reload(tmin); yhi = tmin + RG_NY; RTC(20, 1); }
                 rg_sync();
-                const int cend = hw ? (min(we, yhi) - tmin) : niter;
-                const int kend = min(__builtin_amdgcn_readlane(cend, 0), __builtin_amdgcn_readlane(cend, 32));
-                if (fast) {
-                    const double* ringp = &sm.ring[r][0][p_lrow];
-                    double* ringm = &sm.ring[r][0][e_lrow];
+                const double* const ringp = &sm.ring[r][0][p_lrow];
+                double* const ringm = &sm.ring[r][0][e_lrow];
+                const double* const yb_ = &sm.ybuf[r][0][0];
+                // ---- phase 1: the new elements' windows up to where everybody else starts.  Their parents do not move
+                // there: every operand of an iteration is known before the previous one ends, nothing is handed over.
+                const int n1 = max(min(tph2, we) - tmin, 0);   // (half-uniform)
+                const int n1max = max(__builtin_amdgcn_readlane(n1, 0), __builtin_amdgcn_readlane(n1, 32));
+                RTC(16, 1); RTC(18, n1max);
+                if (n1max > 0) {
+                    int t = tmin;
+                    double nya = 0.0, nyb = 0.0, npp = 0.0;
+                    if (isP1) {
+                        const double* yrow = yb_ + (t & (RG_NY - 1)) * RG_YC;
+                        nya = yrow[sym]; nyb = yrow[A]; npp = ringp[((t - 1) & (RG_RL - 1)) * RG_NRP];
+                    }
+                    for (int k = 0; k < n1max; ++k) {
+                        if (isP1 && k < n1) {
+                            const double ya = nya, yb = nyb, pp = npp;
+                            const int tn = t + 1;
+                            const double* yrow = yb_ + (tn & (RG_NY - 1)) * RG_YC;
+                            nya = yrow[sym]; nyb = yrow[A]; npp = ringp[(t & (RG_RL - 1)) * RG_NRP];   // (one past the end: read, never used)
+                            const double out = lae(pp + ya, self + yb);
+                            ringm[(t & (RG_RL - 1)) * RG_NRP] = out;
+                            if (out > self) tr = t;   // the last time a value rose
+                            self = out;
+                            mt = (out >= mx) ? t : mt;
+                            asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(out));
+                            t = tn;
+                        }
+                    }
+                    rg_sync();
+                }
+                RTX(24);
+                // ---- phase 2: everybody, in lockstep (a child reads what its parent wrote one iteration earlier)
+                const int t2 = min(tph2, we);
+                const int n2 = we - t2;
+                const int n2max = max(__builtin_amdgcn_readlane(n2, 0), __builtin_amdgcn_readlane(n2, 32));
+                RTC(17, 1); RTC(19, n2max);
+                for (int k = 0; k < n2max; ++k) {
+                    const int t = t2 + k;
+                    if (part2 && k < n2) {
+                        const double* yrow = yb_ + (t & (RG_NY - 1)) * RG_YC;
+                        const double ya = yrow[sym], yb = yrow[A];
+                        const int tm = t - 1;
+                        double pp = ringp[(tm & (RG_RL - 1)) * RG_NRP];
+                        if (e_ps < 0) pp = (tm == fz_t) ? fz_val : PO_NEG_INF;
+                        const double out = lae(pp + ya, self + yb);
+                        ringm[(t & (RG_RL - 1)) * RG_NRP] = out;
+                        if (out > self) tr = t;
+                        self = out;
+                        mt = (out >= mx) ? t : mt;
+                        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(out));
+                    }
+                    rg_sync();
+                }
+                if (part2) v_hiw = max(v_hiw, we);
+                RTX(25);
+            } else {
+                const int span = (tmin == INT_MAX) ? 0 : we - tmin;   // (half-uniform)
+                const int niter = max(__builtin_amdgcn_readlane(span, 0), __builtin_amdgcn_readlane(span, 32));
+                RTC(21, 1); RTC(22, niter);
+                int k = 0;
+                while (k < niter) {
+                    const int tcur = tmin + k;   // (garbage when this half has nothing to do: guarded by span)
+                    const bool hw = k < span;    // this half still has times to compute
+                    if (hw && !(tcur >= yhi - RG_NY && tcur < yhi)) { y_reload(tcur); yhi = tcur + RG_NY; RTC(20, 1); }
+                    rg_sync();
+                    const int cend = hw ? (min(we, yhi) - tmin) : niter;
+                    const int kend = min(__builtin_amdgcn_readlane(cend, 0), __builtin_amdgcn_readlane(cend, 32));
                     for (; k < kend; ++k) {
                         const int t = tmin + k;
                         if (part2 && t >= start && t < we) {
-                            const double* yrow = &sm.ybuf[r][t & (RG_NY - 1)][0];
-                            const double ya = yrow[sym], yb = yrow[A];
+                            const double ya = sm.ybuf[r][t & (RG_NY - 1)][sym], yb = sm.ybuf[r][t & (RG_NY - 1)][A];
                             const int tm = t - 1;
-                            double pp = ringp[(tm & (RG_RL - 1)) * RG_NRP];
-                            if (e_ps < 0) pp = (tm == fz_t) ? fz_val : PO_NEG_INF;
+                            double pp;
+                            if (e_ps >= 0) {
+                                if (tm >= p_start || (tm >= p_lo && tm < p_done0 && tm >= p_hiw0 - RG_RL))
+                                    pp = sm.ring[r][tm & (RG_RL - 1)][p_lrow];
+                                else if (tm < p_lo || tm < p_done0) pp = t2_read(e_prow2, e_par, tm);   // an earlier incarnation's, or evicted
+                                else pp = PO_NEG_INF;                                                    // never computed
+                            } else if (e_ps == PS_ROOT) {
+                                pp = (tm < 0) ? 0.0 : cumr[tm];
+                            } else if (tm >= fz_t) {
+                                pp = (tm == fz_t) ? fz_val : PO_NEG_INF;                                 // frozen parent: its last value, then nothing
+                            } else {
+                                pp = t2_read(e_prow2, e_par, tm);
+                            }
                             const double out = lae(pp + ya, self + yb);
-                            ringm[(t & (RG_RL - 1)) * RG_NRP] = out;
+                            double* slot = &sm.ring[r][t & (RG_RL - 1)][e_lrow];
+                            if (t >= v_hiw) {
+                                const int to = t - RG_RL;
+                                if (to >= v_lo && to >= ws - 1) {   // the slot's old value can still be read: tier 2 takes it
+                                    t2_write(e_row2, e_id, to, *slot);
+                                    atomicMax(&g_hi[e_row2 >> 2], to + 1);
+                                }
+                                v_hiw = t + 1;
+                            }
+                            *slot = out;
                             if (out > self) tr = t;   // the last time a value rose
                             self = out;
                             mt = (out >= mx) ? t : mt;
@@ -318,45 +463,10 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                         }
                         rg_sync();
                     }
-                    if (part2) v_hiw = max(v_hiw, min(we, tmin + kend));
-                } else
-                for (; k < kend; ++k) {
-                    const int t = tmin + k;
-                    if (part2 && t >= start && t < we) {
-                        const double ya = sm.ybuf[r][t & (RG_NY - 1)][sym], yb = sm.ybuf[r][t & (RG_NY - 1)][A];
-                        const int tm = t - 1;
-                        double pp;
-                        if (e_ps >= 0) {
-                            if (tm >= p_start || (tm >= p_lo && tm < p_done0 && tm >= p_hiw0 - RG_RL))
-                                pp = sm.ring[r][tm & (RG_RL - 1)][p_lrow];
-                            else if (tm < p_lo || tm < p_done0) pp = t2_read(e_prow2, e_par, tm);   // an earlier incarnation's, or evicted
-                            else pp = PO_NEG_INF;                                                    // never computed
-                        } else if (e_ps == PS_ROOT) {
-                            pp = (tm < 0) ? 0.0 : cumr[tm];
-                        } else if (tm >= fz_t) {
-                            pp = (tm == fz_t) ? fz_val : PO_NEG_INF;                                 // frozen parent: its last value, then nothing
-                        } else {
-                            pp = t2_read(e_prow2, e_par, tm);
-                        }
-                        const double out = lae(pp + ya, self + yb);
-                        double* slot = &sm.ring[r][t & (RG_RL - 1)][e_lrow];
-                        if (t >= v_hiw) {
-                            const int to = t - RG_RL;
-                            if (to >= v_lo && to >= ws - 1) {   // the slot's old value can still be read: tier 2 takes it
-                                t2_write(e_row2, e_id, to, *slot);
-                                atomicMax(&g_hi[e_row2 >> 2], to + 1);
-                            }
-                            v_hiw = t + 1;
-                        }
-                        *slot = out;
-                        if (out > self) tr = t;   // the last time a value rose
-                        self = out;
-                        mt = (out >= mx) ? t : mt;
-                        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(out));
-                    }
-                    rg_sync();
                 }
+                RTX(26);
             }
+            RT(2);
             if (part2) { v_done = we; v_self = self; v_fresh = 0; }
             if (is_main) {
                 if (part) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
@@ -537,6 +647,8 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                     }
             }
             e_ps = n_ps;
+            c_plrow = __shfl(e_lrow, hb | max(e_ps, 0));
+            tbl_fresh = __ballot(live && v_fresh != 0) != 0ull;
             have_children = true;
             if (sm.sh[4] != PO_OK) st = sm.sh[4];
             rg_sync();
@@ -544,6 +656,8 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
 
         // the first table: the root's children are the beam, their children come from the first expansion
         rebuild(A, rec.x, rec.y, rec.z, rec.w, 0, 0);
+        RT_SET(0); RT(0);
+        bool after_event = true;
 
         // ---------------------------------------------------------------- the diagonal walk (BeamSearch.h:300-393)
         while (st == PO_OK && mstep < nmain) {
@@ -554,11 +668,18 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                 const int nbe = min(W, nb);
                 const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
                 if (a.upd_count != nullptr) cnt_ref += (unsigned)((max(u - up - 1, 0) + max(v - vp - 1, 0)) * nbe);
-                if (u - 1 >= max(up + 1, d0)) scan(false, up + 1, u, 0, 0, nbe);
-                if (v - 1 >= max(vp + 1, d1)) scan(false, 0, 0, vp + 1, v, nbe);
+                if (u - 1 >= max(up + 1, d0)) { scan(false, up + 1, u, 0, 0, nbe, false); tbl_uneven = true; }
+                if (v - 1 >= max(vp + 1, d1)) { scan(false, 0, 0, vp + 1, v, nbe, false); tbl_uneven = true; }
             }
             // ---- MAIN step at (u, v): windows [u, ce) x [v, re)  (:342-375)
-            scan(true, u, ce, v, re, 32);
+            RT_SET(after_event ? 4 : 0); RT(3);
+            RTC(after_event ? 13 : 12, 1);
+            {
+                const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
+                const bool uni = !tbl_fresh && !tbl_uneven && u <= d0 && d0 <= ce && v <= d1 && d1 <= re;
+                scan(true, u, ce, v, re, 32, uni);
+                tbl_fresh = false; tbl_uneven = false;
+            }
             if (a.upd_count != nullptr) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
             // node_greater_max_sym: max over read 0's window + max over read 1's
             const double sc = smx + __shfl_xor(smx, 32);
@@ -567,15 +688,26 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             // last of them still beats every child (strictly: exact ties go the full way, as partial_sort decides them)
             bool viol = (nb != W);
             if (!viol && cand) {
-                const double scl = rg_readlane_d(sc, nb - 1), scn = __shfl(sc, lane + 1);
+                // (the next beam slot's score: a lane shift within the row of 16 — the beam slots sit in lanes 0..5 / 32..37)
+                const double scl = rg_readlane_d(sc, nb - 1);
+                const double scn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sc), 0x101, 0xf, 0xf, false),
+                                                    __builtin_amdgcn_update_dpp(0, __double2loint(sc), 0x101, 0xf, 0xf, false));
                 if (s >= nb) viol = !(scl > sc);
                 else if (s + 1 < nb) viol = !(sc > scn);
             }
             up = u; vp = v;
             mstep++;
-            rec = rec_n;
-            rec_n = sched[max(0, min(mstep + 1, nmain - 1))];
+            if ((mstep & 63) == 0) {   // the next batch becomes the current one, the one after it is requested
+                rcur = rnxt;
+                rnxt = sched[min(mstep + 64 + lane, max(nmain - 1, 0))];
+            }
+            rec = rec_at(min(mstep, nmain - 1));
+            RT(3);
+#ifdef PO_RING_TIMING
+            after_event = false;
+#endif
             if (__ballot(viol) == 0ull) continue;
+            RT_SET(8);
             // ---- full ranking among the distinct candidates
             const unsigned cm = (unsigned)__ballot(cand && r == 0);
             const int ncand = __popc(cm);
@@ -608,8 +740,14 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                 for (int jx = 0; jx < 6; ++jx) sel[jx] = (jx < nbn) ? sm.ord[jx] : 0;
                 rg_sync();
             }
+            RT(0);
             rebuild(nbn, rec.x, rec.y, rec.z, rec.w, u, v);
+            RT(1);
+#ifdef PO_RING_TIMING
+            after_event = true;
+#endif
         }
+        RT_SET(8);
 
         // ---------------------------------------------------------------- label of the top node
         if (st == PO_E_NOMEM && lane == 0) {   // out of tier-2 row groups: beam2d_kernel takes the pair
@@ -634,7 +772,12 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
         }
         if (a.upd_count != nullptr && lane == 0) { sm.nupd += cnt_ref; sm.nupd_x += cnt_x; }
         rg_sync();
+        RT(2);
     }
+#ifdef PO_RING_TIMING
+    if (lane == 0 && a.dbg && blockIdx.x == 0)
+        for (int i = 0; i < 32; ++i) a.dbg[i] = tk[i];
+#endif
     if (lane == 0) {   // the next launch on this workspace continues from here
         unsigned long long* stp = a.wgstate + 2 * (size_t)blockIdx.x;
         stp[0] = a.magic ^ (unsigned long long)blockIdx.x;
@@ -658,5 +801,27 @@ extern "C" int po_ring_blocks_per_cu() {
 extern "C" int po_ring_max_elements() { return RG_NRP; }
 extern "C" int po_ring_ngl() { return RG_NGL; }
 extern "C" void po_ring_launch(const void* x2args, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(beam2d_ring_kernel, dim3(blocks), dim3(64), 0, stream, *(const X2Args*)x2args);
+    X2Args a = *(const X2Args*)x2args;
+#ifdef PO_RING_TIMING
+    static long long* dbg = nullptr;
+    if (!dbg) { (void)hipMalloc((void**)&dbg, 32 * sizeof(long long)); }
+    (void)hipMemsetAsync(dbg, 0, 32 * sizeof(long long), stream);
+    a.dbg = dbg;
+#endif
+    hipLaunchKernelGGL(beam2d_ring_kernel, dim3(blocks), dim3(64), 0, stream, a);
+#ifdef PO_RING_TIMING
+    {
+        long long h[32];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[po_ring_timing] workgroup 0, 10 ns ticks.  steps after a steady prune | steps after a rebuild\n");
+        const char* nm[4] = {"(pair setup / -)", "scan prologue", "scan loop", "catch-up test + score + prune test"};
+        for (int i = 0; i < 4; ++i) fprintf(stderr, "   %-36s %12lld %12lld\n", nm[i], h[i], h[4 + i]);
+        fprintf(stderr, "   ranking %lld, rebuild %lld, label walk + queue %lld\n", h[8], h[9], h[10]);
+        fprintf(stderr, "   loops: y + phase 1 %lld, phase 2 %lld, general %lld ticks\n", h[24], h[25], h[26]);
+        fprintf(stderr, "   general main scans because of: a window beyond 31 times %lld (steady table) + %lld (new elements), the root's children %lld, other %lld\n", h[14], h[15], h[23], h[11]);
+        fprintf(stderr, "   main steps: %lld after a steady prune, %lld after a rebuild; fast scans %lld: phase-1 iterations %lld, phase-2 iterations %lld; general scans %lld (iterations %lld); y reloads %lld\n",
+                h[12], h[13], h[17], h[18], h[19], h[21], h[22], h[20]);
+    }
+#endif
 }
