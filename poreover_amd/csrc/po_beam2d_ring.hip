@@ -147,21 +147,6 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             e.v[0] = v;
             pool[((size_t)row2 * 2 + r) * R2 + (tq & Rm2)] = e;
         };
-        auto alloc_group = [&](int owner, int lo0, int lo1) -> int {   // (one lane)
-            int cur = sm.sh[3];
-            int gg = -1;
-            for (int tries = 0; tries < NG; ++tries) {
-                const int c = cur;
-                cur = (cur + 1 == NG) ? 0 : cur + 1;
-                if (sm.g_owner[c] < 0 || (sm.g_hi0[c] <= lo0 && sm.g_hi1[c] <= lo1)) { gg = c; break; }
-            }
-            sm.sh[3] = cur;
-            if (gg < 0) { sm.sh[4] = PO_E_NOMEM; gg = 0; }
-            sm.g_owner[gg] = owner;
-            sm.g_hi0[gg] = 0; sm.g_hi1[gg] = 0;
-            return gg;
-        };
-
         // ---------------------------------------------------------------- per-lane element state (slot s, read r)
         // table fields (the same in both halves of the wave)
         int e_id = 0, e_row2 = -1, e_lrow = 0, e_sym = 0, e_fc = -1, e_crow2 = -1, e_par = 0, e_gpar = -1, e_prow2 = -1,
@@ -179,6 +164,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
         int nb = A, ne = A;
         unsigned lfree = (RG_NRP >= 32) ? 0xffffffffu : ((1u << RG_NRP) - 1u);
         int next_id = 1 + A;
+        int gcur = 1;               // tier-2 group allocation cursor
         int yhi = 0;                // y rows [yhi - RG_NY, yhi) of this lane's read are in sm.ybuf
         int sel[6] = {0, 1, 2, 3, 4, 5};
 
@@ -270,28 +256,57 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                 }
             }
             const bool part2 = part && start < we;
-            // ---- window maximum of the part [ws, start) that is not recomputed
-            double mx = PO_NEG_INF;
-            int mt = -1, td = ws, tr = INT_MIN;
-            if (is_main && part && start > ws) {
-                const double pm = v_mx;
-                const int pt = v_mt;
+            // ---- window maximum of the part [ws, start) that is not recomputed: carried from the previous step, unless its
+            // time has left the window — then the stored values are looked at again (rr_need).  In the FAST loops the
+            // ring reads for that are issued here and looked at after the iterations (the new values' maximum is
+            // combined with the carried part's at the end: the new times are later, so `>=` keeps the latest maximum).
+            double mx = PO_NEG_INF, cmx = PO_NEG_INF;
+            int mt = -1, cmt = -1, td = ws, tr = INT_MIN;
+            bool rr_need = false;
+            const bool has_c = is_main && part && start > ws;
+            if (has_c) {
                 td = v_td;
-                if (pm == PO_NEG_INF || (pt >= ws && pt < start)) { mx = pm; mt = pt; }
-                else if (td <= ws) { mx = read_own(ws); mt = ws; }   // non-increasing since before the window start: its first value
-                else {
-                    double pv = PO_NEG_INF;
-                    const int te = min(td + 1, start);
-                    td = ws;
-                    for (int tq = ws; tq < te; ++tq) {
-                        const double v = read_own(tq);
-                        if (v >= mx) { mx = v; mt = tq; }
-                        if (tq > ws && v > pv) td = tq;
-                        pv = v;
-                    }
-                }
+#ifdef PO_ABL_NOREREAD   // timing ablation only (results are wrong)
+                if (true) { cmx = v_mx; cmt = v_mt; }
+#else
+                if (v_mx == PO_NEG_INF || (v_mt >= ws && v_mt < start)) { cmx = v_mx; cmt = v_mt; }
+#endif
+                else rr_need = true;
             }
+            auto rr_resolve = [&](const double* v4, bool have4) {   // the carried part's maximum from the stored values
+                if (!rr_need) return;
+                const bool inring = (ws >= v_lo && ws >= v_hiw - RG_RL);
+                if (td <= ws) {   // non-increasing since before the window start (a node past its peak): its first value
+                    cmx = (have4 && inring) ? v4[0] : read_own(ws);
+                    cmt = ws;
+                    return;
+                }
+                // otherwise only [ws, td] is looked at: from td on the values fall
+                double pv = PO_NEG_INF;
+                const int te = min(td + 1, start);
+                td = ws;
+                int tq0 = ws;
+                if (have4 && inring) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int tq = ws + q;
+                        if (tq < te) {
+                            if (v4[q] >= cmx) { cmx = v4[q]; cmt = tq; }
+                            if (tq > ws && v4[q] > pv) td = tq;
+                            pv = v4[q];
+                        }
+                    }
+                    tq0 = ws + 4;
+                }
+                for (int tq = tq0; tq < te; ++tq) {
+                    const double v = read_own(tq);
+                    if (v >= cmx) { cmx = v; cmt = tq; }
+                    if (tq > ws && v > pv) td = tq;
+                    pv = v;
+                }
+            };
             const int sym = sym_last(e_sym);
+            if (is_main) RTX(uni ? 27 : 28);
             // ---- which loop.  FAST: every parent value an iteration needs is in the ring (or is the captured last value
             // of a frozen parent) and no slot that is overwritten can be read again — all but a few percent of the scans
             // (windows beyond 31 times, the root's children, elements restored from tier 2, catch-ups).
@@ -351,6 +366,16 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                     for (int off = 16; off >= 1; off >>= 1) tm_ = min(tm_, __shfl_xor(tm_, off));
                     tmin = tm_;
                 }
+            }
+            double rr4[4] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
+            if (fast) {
+                if (rr_need) {   // (window <= 31 times: these slots are not written in this scan)
+                    const double* rp = &sm.ring[r][0][e_lrow];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rr4[q] = rp[((ws + q) & (RG_RL - 1)) * RG_NRP];
+                }
+            } else {
+                rr_resolve(rr4, false);
             }
             RT(1);
             if (fast) {
@@ -467,6 +492,8 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                 RTX(26);
             }
             RT(2);
+            if (fast) rr_resolve(rr4, true);
+            if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
             if (part2) { v_done = we; v_self = self; v_fresh = 0; }
             if (is_main) {
                 if (part) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
@@ -523,17 +550,19 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                 if (rb && !need_group) { atomicMax(&sm.g_hi0[n_crow2], nce); atomicMax(&sm.g_hi1[n_crow2], nre); }
                 rg_sync();
                 unsigned hg = (unsigned)__ballot(need_group && r == 0);
-                while (hg != 0) {   // (uniform)
+                while (hg != 0) {   // (uniform: every lane walks the group table, lane 0 writes)
                     const int jj = __builtin_ctz(hg);
                     hg &= hg - 1;
-                    if (lane == jj) {
-                        const int gg = alloc_group(n_id, nu - 1, nv - 1);
-                        sm.g_hi0[gg] = nce; sm.g_hi1[gg] = nre;
-                        sm.sh[5] = gg;
-                        acrow[n_id] = gg;
+                    const int owner = __builtin_amdgcn_readlane(n_id, jj);
+                    int gg = -1;
+                    for (int tries = 0; tries < NG; ++tries) {
+                        const int c = gcur;
+                        gcur = (gcur + 1 == NG) ? 0 : gcur + 1;
+                        if (sm.g_owner[c] < 0 || (sm.g_hi0[c] <= nu - 1 && sm.g_hi1[c] <= nv - 1)) { gg = c; break; }
                     }
-                    rg_sync();
-                    if (s == jj) n_crow2 = sm.sh[5];
+                    if (gg < 0) { st = PO_E_NOMEM; gg = 0; }
+                    if (lane == 0) { sm.g_owner[gg] = owner; sm.g_hi0[gg] = nce; sm.g_hi1[gg] = nre; acrow[owner] = gg; }
+                    if (s == jj) n_crow2 = gg;
                     rg_sync();
                 }
             }
@@ -582,7 +611,15 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             if (leaving) {
                 if (v_fresh == 0) {
                     const int from = max(max(r ? cv : cu, v_lo), v_hiw - RG_RL);
-                    for (int tq = from; tq < v_done; ++tq) t2_write(e_row2, e_id, tq, sm.ring[r][tq & (RG_RL - 1)][e_lrow]);
+                    const double* rp = &sm.ring[r][0][e_lrow];
+                    for (int bt = from; bt < v_done; bt += 4) {   // (four ring reads in flight, then the stores)
+                        double v4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v4[q] = rp[((bt + q) & (RG_RL - 1)) * RG_NRP];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (bt + q < v_done) t2_write(e_row2, e_id, bt + q, v4[q]);
+                    }
                 }
                 if (r == 0) atomicOr((unsigned*)&sm.sh[6], 1u << e_lrow);
             }
@@ -650,7 +687,6 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             c_plrow = __shfl(e_lrow, hb | max(e_ps, 0));
             tbl_fresh = __ballot(live && v_fresh != 0) != 0ull;
             have_children = true;
-            if (sm.sh[4] != PO_OK) st = sm.sh[4];
             rg_sync();
         };
 
@@ -672,7 +708,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                 if (v - 1 >= max(vp + 1, d1)) { scan(false, 0, 0, vp + 1, v, nbe, false); tbl_uneven = true; }
             }
             // ---- MAIN step at (u, v): windows [u, ce) x [v, re)  (:342-375)
-            RT_SET(after_event ? 4 : 0); RT(3);
+            RT_SET(after_event ? 4 : 0); RTX(29);
             RTC(after_event ? 13 : 12, 1);
             {
                 const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
@@ -711,15 +747,24 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             // ---- full ranking among the distinct candidates
             const unsigned cm = (unsigned)__ballot(cand && r == 0);
             const int ncand = __popc(cm);
-            int rank = 0, neq = 0, pos = 0;
-            for (int o = 0; o < ne; ++o) {
+            // Only the beam nodes and the children that reach the smallest beam score can be among the W best (every
+            // other child has W candidates above it), and nothing outside that set outranks a member of it: the ranks
+            // are taken within it (a handful of candidates instead of W * (A + 1)).
+            unsigned smask = cm;
+            if (nb == W) {
+                double thr = rg_readlane_d(sc, 0);
+                for (int i = 1; i < nb; ++i) thr = fmin(thr, rg_readlane_d(sc, i));
+                smask = (unsigned)__ballot(cand && r == 0 && (s < nb || sc >= thr));
+            }
+            int rank = 0, neq = 0;
+            for (unsigned mm = smask; mm != 0u; mm &= mm - 1u) {
+                const int o = __builtin_ctz(mm);
                 const double so = rg_readlane_d(sc, o);
                 const int io = __builtin_amdgcn_readlane(e_id, o);
-                const int lv = (int)((cm >> o) & 1u);
-                rank += lv & (((so > sc) | (!(sc > so) & (io < e_id))) ? 1 : 0);
-                neq += lv & ((so == sc) ? 1 : 0);
-                pos += lv & ((io < e_id) ? 1 : 0);
+                rank += ((so > sc) | (!(sc > so) & (io < e_id))) ? 1 : 0;
+                neq += (so == sc) ? 1 : 0;
             }
+            if (!((smask >> s) & 1u)) { rank = 64; neq = 0; }
             const int nbn = min(W, ncand);
 #pragma unroll
             for (int jx = 0; jx < 6; ++jx) {
@@ -729,6 +774,11 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             if (__ballot(cand && neq > 1 && rank < W) != 0ull) {
                 // exact ties reaching into the beam: what libstdc++'s partial_sort / sort leave on the candidates in
                 // creation order (po_device.h), replayed by one lane
+                int pos = 0;   // (the replay runs over ALL candidates in creation order)
+                for (int o = 0; o < ne; ++o) {
+                    const int io = __builtin_amdgcn_readlane(e_id, o);
+                    pos += (int)((cm >> o) & 1u) & ((io < e_id) ? 1 : 0);
+                }
                 if (cand && r == 0) { sm.ord[pos] = s; sm.csc[s] = sc; }
                 rg_sync();
                 if (lane == 0) {
@@ -818,6 +868,7 @@ extern "C" void po_ring_launch(const void* x2args, int blocks, hipStream_t strea
         const char* nm[4] = {"(pair setup / -)", "scan prologue", "scan loop", "catch-up test + score + prune test"};
         for (int i = 0; i < 4; ++i) fprintf(stderr, "   %-36s %12lld %12lld\n", nm[i], h[i], h[4 + i]);
         fprintf(stderr, "   ranking %lld, rebuild %lld, label walk + queue %lld\n", h[8], h[9], h[10]);
+        fprintf(stderr, "   step top (record, catch-up tests) %lld; scan prologue up to the carried maximum: %lld (steady table) %lld (other)\n", h[29], h[27], h[28]);
         fprintf(stderr, "   loops: y + phase 1 %lld, phase 2 %lld, general %lld ticks\n", h[24], h[25], h[26]);
         fprintf(stderr, "   general main scans because of: a window beyond 31 times %lld (steady table) + %lld (new elements), the root's children %lld, other %lld\n", h[14], h[15], h[23], h[11]);
         fprintf(stderr, "   main steps: %lld after a steady prune, %lld after a rebuild; fast scans %lld: phase-1 iterations %lld, phase-2 iterations %lld; general scans %lld (iterations %lld); y reloads %lld\n",
