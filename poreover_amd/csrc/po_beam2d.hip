@@ -2921,7 +2921,8 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
         a.ngl = po_ring_ngl();
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-        if (b2_ws_layout_changed(ws, g.off_state, g.total, g.magic) &&
+        // (the range this layout answers for ends where the nested workspace of the deferred-pairs pass begins)
+        if (b2_ws_layout_changed(ws, g.off_state, g.off_fb, g.magic) &&
             hipMemsetAsync(w + g.off_state, 0, sizeof(unsigned long long) * 2 * (size_t)g.blocks, stream) != hipSuccess)
             return PO_E_HIP;
         hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
