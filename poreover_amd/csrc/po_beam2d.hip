@@ -71,6 +71,10 @@ struct B2Smem {
     int sel[WMAX];
     int cu_ps[WMAX];        // parent slots of the beam nodes in catch-up scans (parents among the beam nodes only)
     int stay[WMAX];         // beam slot was a beam slot in the previous main step (its children were elements then)
+    // a beam node whose parent is no element any more: the parent's last value and its time, taken from the parent's
+    // slot when it left (later times are absent, earlier ones are in the store).  fzt = INT_MAX: nothing captured.
+    double fzv[2][WMAX][(MODEL == PO_MODEL_CTC) ? 1 : 3];
+    int fzt[2][WMAX];
     int cnew[WMAX];         // its children got new rows in this step
     int badf[NCM];          // element may not skip redundant stores (see scan)
     int dup[NCM];
@@ -391,8 +395,9 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             sm.sh[8] = INT_MIN; sm.sh[9] = INT_MIN;  // window ends of the previous row_col main step: none yet
             sm.sh[10] = 0; sm.sh[11] = 0; sm.sh[12] = 0; sm.sh[13] = 0; sm.sh[14] = 0; sm.sh[15] = 0;  // incremental steps: nothing to build on yet
             sm.sh[16] = INT_MIN; sm.sh[17] = INT_MIN;
+            sm.sh[18] = INT_MIN; sm.sh[19] = INT_MIN;   // the latest time any main scan computed on read 0 / 1
         }
-        if (tid < WMAX) sm.stay[tid] = 0;
+        if (tid < WMAX) { sm.stay[tid] = 0; sm.fzt[0][tid] = INT_MAX; sm.fzt[1][tid] = INT_MAX; }
         if (tid < A) {
             apl[1 + tid] = po_pack_node(0, tid); afc[1 + tid] = -1; acrow[1 + tid] = -1;
             sm.e[F_ID][tid] = 1 + tid; sm.e[F_ROW][tid] = tid; sm.e[F_PROW][tid] = -1; sm.e[F_PAR][tid] = 0;
@@ -552,6 +557,20 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     ptag0 = make_tag(epoch, l_par, 0);
                 }
             }
+            // A frozen parent's values: nothing after its last one, and that one was captured when the parent left (see
+            // prune_and_advance) — a beam node with a frozen parent (about three of the five, step after step) then never
+            // touches the store in the iterations, and the loop below keeps no vector-memory load to wait for.
+            bool fz_fast = false;
+            int fz_tt = INT_MAX;
+            double fz_v[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) fz_v[q] = PO_NEG_INF;
+            if (is_main && !is_row && part && pslot == PS_FROZEN && s < WMAX) {
+                fz_tt = sm.fzt[r][s];
+#pragma unroll
+                for (int q = 0; q < K; ++q) fz_v[q] = sm.fzv[r][s][q];
+                fz_fast = (t0 - 1 >= fz_tt);
+            }
             // Redundant stores (row_col main steps, `reuse`).  An element that was an element in the previous
             // main step too recomputes, over the part of its window that step already covered, exactly the
             // bits that are stored — if every ancestor of it inside the element set is in the same situation.
@@ -587,10 +606,10 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                 if (pslot == PS_ROOT) root_at(r, tp, pr_n);
                 else if (tp >= 0) pe_n = prow[tp & Rm];
             };
-            if (part && pslot < 0) fetch(0);
+            if (part && pslot < 0 && !fz_fast) fetch(0);
             // (wave-uniform: most scans have no such element, and then the iterations skip its handling with one
             //  scalar branch instead of two masked blocks)
-            const bool any_static = __ballot(part && pslot < 0) != 0ull;
+            const bool any_static = __ballot(part && pslot < 0 && !fz_fast) != 0ull;
             // The y rows of both windows go through LDS, B2_YD doubles per read at a time (buffer row =
             // iteration index).  With no vector-memory LOAD left in the iteration loop the wave never
             // waits there for the acknowledgement of its value-store writes: vmcnt counts loads and stores
@@ -623,13 +642,17 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
                     double pp[K], out[K];
 #pragma unroll
                     for (int q = 0; q < K; ++q) pp[q] = sm.xch[(k + 1) & 1][r][xsl][q];
+                    if (fz_fast) {
+#pragma unroll
+                        for (int q = 0; q < K; ++q) pp[q] = (t - 1 == fz_tt) ? fz_v[q] : PO_NEG_INF;
+                    }
                     if (any_static) {
-                        if (pslot < 0) {  // rare: the parent does not move in this scan
+                        if (pslot < 0 && !fz_fast) {  // rare: the parent does not move in this scan
                             const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
 #pragma unroll
                             for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
                         }
-                        if (pslot < 0 && k + 1 < len) fetch(k + 1);
+                        if (pslot < 0 && !fz_fast && k + 1 < len) fetch(k + 1);
                     }
                     po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
                     // direct 16-byte store per lane.  (Tried: buffering 8 iterations in LDS and flushing
@@ -668,8 +691,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             if (is_main && tid == 0) {
                 if (len0_ > 0) sm.sh[12] = 1;
                 if (len1_ > 0) sm.sh[13] = 1;
-                if (len0 > 0) sm.sh[16] = s0 + len0;   // xch[1] of read 0 / read 1 now holds the values at these times - 1
-                if (len1 > 0) sm.sh[17] = s1 + len1;
+                if (len0 > 0) { sm.sh[16] = s0 + len0; sm.sh[18] = max(sm.sh[18], s0 + len0); }   // xch[1] of read 0 / read 1 now holds the values at these times - 1
+                if (len1 > 0) { sm.sh[17] = s1 + len1; sm.sh[19] = max(sm.sh[19], s1 + len1); }
             }
             if (a.upd_count != nullptr && tid == 0) {   // profiling (skipped slots counted too)
                 sm.nupd += (unsigned)(nelem * (len0_ + len1_));
@@ -917,6 +940,32 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             b2_sync_lds<nthr>();
             const int nbn = min(W, sm.sh[5]);
             if (tid < nbn) sm.stay[tid] = (regular && sm.sel[tid] < nb) ? 1 : 0;
+            // the last value of each new beam node's parent, as this step's table holds it (see B2Smem::fzv): of the
+            // parent's slot if it is an element now, else what was captured earlier
+            double cfv[2][K];
+            int cft[2] = {INT_MAX, INT_MAX};
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int q = 0; q < K; ++q) cfv[rr][q] = PO_NEG_INF;
+            if (regular && tid < nbn) {
+                const int e = sm.sel[tid];
+                const int op = sm.e[F_PSLOT][e];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    if (op >= 0) {
+                        // (after a window end moved back the store holds later values than the last one computed: no capture)
+                        const int te = sm.sh[16 + rr];
+                        cft[rr] = (te == INT_MIN || te != sm.sh[18 + rr]) ? INT_MAX : te - 1;
+#pragma unroll
+                        for (int q = 0; q < K; ++q) cfv[rr][q] = sm.xch[1][rr][op][q];
+                    } else if (op == PS_FROZEN && e < nb) {
+                        cft[rr] = sm.fzt[rr][e];
+#pragma unroll
+                        for (int q = 0; q < K; ++q) cfv[rr][q] = sm.fzv[rr][e][q];
+                    }
+                }
+            }
             {
                 // The same beam nodes in another order: every element of the next step was an element of this one, in
                 // the slot the permutation says (beam slot i <- sel[i]; its children follow it), so the carried maxima
@@ -966,6 +1015,12 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             if (tid < nbn) {
 #pragma unroll
                 for (int f = 0; f < F_COUNT; ++f) sm.e[f][tid] = sm.nx[f][tid];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    sm.fzt[rr][tid] = cft[rr];
+#pragma unroll
+                    for (int q = 0; q < K; ++q) sm.fzv[rr][tid][q] = cfv[rr][q];
+                }
             }
             nb = nbn;
             b2_sync_lds<nthr>();

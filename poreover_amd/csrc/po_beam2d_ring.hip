@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
 
         // ---------------------------------------------------------------- own ring / tier-2 value at time tq
         auto read_own = [&](int tq) -> double {
-            if (tq < v_lo || tq >= v_done) return t2_read(e_row2, e_id, tq);    // an earlier incarnation's, or absent
+            if (tq < v_lo || tq >= v_hiw) return t2_read(e_row2, e_id, tq);     // an earlier incarnation's, or absent
             if (tq >= v_hiw - RG_RL) return sm.ring[r][tq & (RG_RL - 1)][e_lrow];
             return t2_read(e_row2, e_id, tq);                                   // evicted
         };
@@ -324,11 +324,14 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             }
             if (!fast) {
                 // the parent's lane: what it holds and where it starts
+                // (the values of [lo, hiw) exist: a window end that moved back lowers `done`, where the element resumes, not
+                //  what the reference's maps hold)
                 const int a_lo = (v_fresh != 0 && !part) ? INT_MAX : v_lo;
                 const int a_done0 = (v_fresh != 0 && !part) ? INT_MAX : v_done;
+                const int a_hiw = (v_fresh != 0 && !part) ? INT_MAX : v_hiw;
                 const int a_start = part2 ? start : INT_MAX;
                 const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
-                p_lo = __shfl(a_lo, plane); p_done0 = __shfl(a_done0, plane); p_hiw0 = __shfl(v_hiw, plane);
+                p_lo = __shfl(a_lo, plane); p_done0 = __shfl(a_done0, plane); p_hiw0 = __shfl(a_hiw, plane);
                 p_start = __shfl(a_start, plane); p_lrow = __shfl(e_lrow, plane);
                 // the lanes that continue all start where the previous window ended
                 const unsigned long long cb = __ballot(part2 && contin);
@@ -346,8 +349,8 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                     if (contin && start != tph2) sl = true;
                     if (e_ps >= 0) {
                         // [tm0, we - 2] must be there: old values (below p_done0) or computed in lockstep (from p_start on)
-                        const bool plain0 = tm0 >= p_lo && tm0 >= p_hiw0 - RG_RL && (tm0 < p_done0 || tm0 >= p_start);
-                        if (!plain0 || (p_start > p_done0 && p_done0 < we - 1)) sl = true;
+                        const bool plain0 = tm0 >= p_lo && tm0 >= p_hiw0 - RG_RL && (tm0 < p_hiw0 || tm0 >= p_start);
+                        if (!plain0 || (p_start > p_hiw0 && p_hiw0 < we - 1)) sl = true;
                         if (isP1 && p_start < tph2) sl = true;   // (a new element under a parent that moves before the others do)
                     } else if (e_ps == PS_ROOT || isP1) sl = true;
                     else if (tm0 < fz_t) sl = true;
@@ -459,9 +462,9 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                             const int tm = t - 1;
                             double pp;
                             if (e_ps >= 0) {
-                                if (tm >= p_start || (tm >= p_lo && tm < p_done0 && tm >= p_hiw0 - RG_RL))
+                                if (tm >= p_start || (tm >= p_lo && tm < p_hiw0 && tm >= p_hiw0 - RG_RL))
                                     pp = sm.ring[r][tm & (RG_RL - 1)][p_lrow];
-                                else if (tm < p_lo || tm < p_done0) pp = t2_read(e_prow2, e_par, tm);   // an earlier incarnation's, or evicted
+                                else if (tm < p_lo || tm < p_hiw0) pp = t2_read(e_prow2, e_par, tm);    // an earlier incarnation's, or evicted
                                 else pp = PO_NEG_INF;                                                    // never computed
                             } else if (e_ps == PS_ROOT) {
                                 pp = (tm < 0) ? 0.0 : cumr[tm];
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             int n_fc = __shfl(e_fc, hb | srcb), n_crow2 = __shfl(e_crow2, hb | srcb), n_par = __shfl(e_par, hb | srcb);
             int n_gpar = __shfl(e_gpar, hb | srcb), n_prow2 = __shfl(e_prow2, hb | srcb), n_depth = __shfl(e_depth, hb | srcb);
             // ---- every old element marks its tier-2 group with what it may still write there
-            if (live && v_fresh == 0) atomicMax(&g_hi[e_row2 >> 2], v_done);
+            if (live && v_fresh == 0) atomicMax(&g_hi[e_row2 >> 2], v_hiw);
             // ---- B. expansion of the new beam nodes
             if (rb && n_fc == -2) { n_fc = afc[n_id]; n_crow2 = acrow[n_id]; }   // a node whose parent re-entered: the arena knows
             rg_sync();
@@ -612,13 +615,13 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                 if (v_fresh == 0) {
                     const int from = max(max(r ? cv : cu, v_lo), v_hiw - RG_RL);
                     const double* rp = &sm.ring[r][0][e_lrow];
-                    for (int bt = from; bt < v_done; bt += 4) {   // (four ring reads in flight, then the stores)
+                    for (int bt = from; bt < v_hiw; bt += 4) {   // (four ring reads in flight, then the stores)
                         double v4[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v4[q] = rp[((bt + q) & (RG_RL - 1)) * RG_NRP];
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (bt + q < v_done) t2_write(e_row2, e_id, bt + q, v4[q]);
+                            if (bt + q < v_hiw) t2_write(e_row2, e_id, bt + q, v4[q]);
                     }
                 }
                 if (r == 0) atomicOr((unsigned*)&sm.sh[6], 1u << e_lrow);
@@ -638,11 +641,12 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             {
                 const int op = __shfl(e_ps, gsrc);                 // the parent's slot in the old table (or ROOT / FROZEN)
                 const int opl = hb | max(op, 0);
-                const int o_done = __shfl(v_done, opl), o_fresh = __shfl(v_fresh, opl);
-                const double o_self = __shfl(v_self, opl), q_val = __shfl(fz_val, gsrc);
+                const int o_hiw = __shfl(v_hiw, opl), o_fresh = __shfl(v_fresh, opl), o_lrow = __shfl(e_lrow, opl);
+                const double q_val = __shfl(fz_val, gsrc);
                 const int q_t = __shfl(fz_t, gsrc);
-                c_val = (op >= 0) ? o_self : q_val;
-                c_t = (op >= 0) ? ((o_fresh == 0) ? o_done - 1 : INT_MAX) : q_t;
+                const double o_last = sm.ring[r][(o_hiw - 1) & (RG_RL - 1)][o_lrow];   // (the ring rows still hold the old table's values)
+                c_val = (op >= 0) ? o_last : q_val;
+                c_t = (op >= 0) ? ((o_fresh == 0) ? o_hiw - 1 : INT_MAX) : q_t;
             }
             const bool fresh = nlive && src < 0;
             e_id = n_id; e_row2 = n_row2; e_sym = n_sym; e_par = n_par; e_gpar = n_gpar; e_prow2 = n_prow2; e_depth = n_depth;

@@ -9,12 +9,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "x2"])
+@pytest.fixture(autouse=True, params=["default", "x2", "ring"])
 def kernel_route(request, monkeypatch):
-    """every test runs twice: with the engine's own choice between beam2d_kernel and beam2d_x2_kernel (small batches
-    of W <= 6 go to the former) and with the two-pairs-per-wave kernel forced wherever it can run (_lib.set_pair_route)"""
+    """every test runs three times: with the engine's own choice of pair beam kernel, with the two-pairs-per-wave kernel
+    forced wherever it can run, and with the LDS-ring kernel wherever it can run (_lib.set_pair_route)"""
     from poreover_amd import _lib
-    _lib.set_pair_route("x2" if request.param == "x2" else "auto")
+    _lib.set_pair_route({"x2": "x2", "ring": "ring"}.get(request.param, "auto"))
     yield request.param
     _lib.set_pair_route("auto")
 

@@ -49,17 +49,26 @@ def test_fuzz_pair_beam_kernels(eng, oracle):
         for i in range(int(rng.integers(6, 14))):
             y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=int(rng.integers(30, 900)), flipflop=(kind == "flipflop"))
             y1s.append(y1); y2s.append(y2); envs.append(_band_env(rng, len(y1), len(y2), style, pad))
-        got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=MODELS[kind], method=method, return_status=True)
+        wants = []
         for i in range(len(y1s)):
             try:
-                want, code = oracle.cpp_beam_search_2d(y1s[i], y2s[i], envs[i], W, model_=MODELS[kind], method_=method), 0
+                wants.append((oracle.cpp_beam_search_2d(y1s[i], y2s[i], envs[i], W, model_=MODELS[kind], method_=method), 0))
             except oracle.OracleError as e:
-                want, code = "", e.code
-            pairs += 1
-            if st[i] == _lib.E_NOMEM and code == 0:      # a capacity refusal is not a wrong answer (none expected at these sizes)
-                bad += 1
-            elif st[i] != code or (code == 0 and got[i] != want):
-                bad += 1
+                wants.append(("", e.code))
+        # the engine's choice, and the LDS-ring kernel where it can run (the one-value model, row_col, W * (A + 1) <= 26)
+        for route in (("auto", "ring") if (kind == "poreover" and method == "row_col" and W <= 5) else ("auto",)):
+            _lib.set_pair_route(route)
+            try:
+                got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=MODELS[kind], method=method, return_status=True)
+            finally:
+                _lib.set_pair_route("auto")
+            for i in range(len(y1s)):
+                want, code = wants[i]
+                pairs += 1
+                if st[i] == _lib.E_NOMEM and code == 0:      # a capacity refusal is not a wrong answer (none expected at these sizes)
+                    bad += 1
+                elif st[i] != code or (code == 0 and got[i] != want):
+                    bad += 1
     assert pairs > 100 and bad == 0, "%d of %d random pairs differ from the oracle" % (bad, pairs)
 
 
