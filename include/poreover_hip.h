@@ -341,6 +341,28 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
 /* host milliseconds of the last call: packing, waiting for the device, whole call; number of waves */
 int po_pipeline_stats(po_pipeline* p, double* pack_ms, double* wait_ms, double* total_ms, int* waves);
 
+/* ---- several devices, one process ------------------------------------------------------------
+ * Replaces the reference's fan-out over worker processes on a multi-GPU node (pair_decode.py:292-297: a
+ * multiprocessing.Pool over pair_decode_helper): one pipeline per entry of `devices` (an index may repeat), each driven
+ * by its own host thread inside the call, all taking waves of the batch from one planner — uneven pairs balance
+ * themselves — and writing their results straight into the caller's arrays at the pairs' own indices (input order; no
+ * gather, no copy between processes, no collective).  Arguments and results as po_pipeline_pair_decode; synchronous.
+ * po_multi_stats: pairs decoded and pack / wait / total milliseconds of pipeline i in the last call. */
+typedef struct po_multi po_multi;
+po_multi* po_multi_create(const int* devices, int ndev, int wave_pairs, int64_t wave_rows, int host_threads);
+void po_multi_destroy(po_multi* m);
+int po_multi_devices(po_multi* m);
+int po_multi_pair_decode(po_multi* m, const void* const* y1_h, const int64_t* rows1, const void* const* y2_h,
+                         const int64_t* rows2, int n, int C, int in_mode, const int* perm1, const int* perm2,
+                         int reverse2, const po_pair_options* opt, char* seq1d_h, const int64_t* seq1d_off_h,
+                         int32_t* len1_h, int32_t* len2_h, double* identity_h, int32_t* env_out_h, char* seq_h,
+                         const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h);
+int po_multi_stats(po_multi* m, int i, int* pairs, double* pack_ms, double* wait_ms, double* total_ms, int* waves);
+/* the waves such a call is cut into, in the order they are handed out (touches no device): first[k], count[k] for
+ * k < returned number of waves (at most cap are written); wave_pairs / wave_rows 0 = the pipeline's defaults */
+int po_wave_plan(const int64_t* rows1, const int64_t* rows2, int n, int wave_pairs, int64_t wave_rows, int ndev, int* first,
+                 int* count, int cap);
+
 /* ---- timing aid for bench.py: HIP events on the stream the kernels run on ----------------- */
 void* po_event_create(void);
 int po_event_record(void* ev, void* stream);

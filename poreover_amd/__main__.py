@@ -21,7 +21,7 @@ def build_parser():
     p.add_argument('--algorithm', default='viterbi', choices=['viterbi', 'beam', 'prefix'], help='')
     p.add_argument('--window', type=int, default=400, help='Use chunks of this size for prefix search')
     p.add_argument('--beam_width', type=int, default=25, help='Width for beam search')
-    p.add_argument('--threads', type=int, default=1, help='Accepted for compatibility; batching replaces processes')
+    p.add_argument('--threads', type=int, default=1, help='Upper bound on the GPUs one call is spread over when > 1 (the reference: worker processes); batching replaces processes on each device')
     p.add_argument('-v', '--version', action='version', version=__version__)
     p.set_defaults(func="decode")
 
@@ -33,7 +33,7 @@ def build_parser():
     p.add_argument('--basecaller', choices=['poreover', 'flappie', 'guppy', 'bonito'], help='Basecaller used to generate probabilities')
     p.add_argument('--reverse_complement', default=False, action='store_true', help='Whether to reverse complement the second sequence')
     p.add_argument('--out', default='out', help='Prefix for FASTA sequence output')
-    p.add_argument('--threads', type=int, default=1, help='Accepted for compatibility; batching replaces processes')
+    p.add_argument('--threads', type=int, default=1, help='Upper bound on the GPUs one call is spread over when > 1 (the reference: worker processes); batching replaces processes on each device')
     p.add_argument('--method', choices=['align', 'split', 'envelope'], default='envelope', help=argparse.SUPPRESS)
     p.add_argument('--single', choices=['beam', 'viterbi'], default='viterbi', help='Algorithm for 1D basecalling (used to build alignment envelope)')
     p.add_argument('--logging', default="info", choices=['info', 'debug'], help='Level for logging')

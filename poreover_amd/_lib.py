@@ -121,6 +121,15 @@ PROTOTYPES = {
     "po_pipeline_pair_decode": (C.c_int, [C.c_void_p, _vp, _i64p, _vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                           C.POINTER(C.c_int), C.c_int, C.POINTER(PairOptions), _cp, _i64p, _i32p, _i32p, _dp,
                                           _i32p, _cp, _i64p, _i32p, _i32p]),
+    "po_multi_create": (C.c_void_p, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int64, C.c_int]),
+    "po_multi_destroy": (None, [C.c_void_p]),
+    "po_multi_devices": (C.c_int, [C.c_void_p]),
+    "po_multi_pair_decode": (C.c_int, [C.c_void_p, _vp, _i64p, _vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int), C.c_int, C.POINTER(PairOptions), _cp, _i64p, _i32p, _i32p, _dp,
+                                       _i32p, _cp, _i64p, _i32p, _i32p]),
+    "po_wave_plan": (C.c_int, [_i64p, _i64p, C.c_int, C.c_int, C.c_int64, C.c_int, _i32p, _i32p, C.c_int]),
+    "po_multi_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "po_pipeline_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int)]),
     "po_event_create": (C.c_void_p, []),
@@ -153,6 +162,23 @@ def load(require_gpu=True):
         raise EngineUnavailable("no HIP device visible: the decoding engine needs an MI355X (gfx950) GPU; "
                                 "there is no CPU fallback")
     return _lib
+
+
+_CURRENT_DEVICE = [None]
+
+
+def set_device(device):
+    """Bind this process (its calling thread, as HIP does) to `device` for every later engine call, and remember it:
+    the cached pipelines of batch.pair_decode_stream are per device and ask current_device()."""
+    check(load().po_set_device(int(device)), "po_set_device(%d)" % int(device))
+    _CURRENT_DEVICE[0] = int(device)
+
+
+def current_device():
+    """The device set_device() chose, else POREOVER_DEVICE (what dist.run_sharded gives its workers), else 0."""
+    if _CURRENT_DEVICE[0] is not None:
+        return _CURRENT_DEVICE[0]
+    return int(os.environ.get("POREOVER_DEVICE", "0") or 0)
 
 
 ROUTES = {"auto": 0, "x2": 1, "legacy": 2, "ring": 3}

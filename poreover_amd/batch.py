@@ -218,10 +218,11 @@ _PIPELINES = {}
 INGEST_MODES = {np.dtype(np.float32): 0, np.dtype(np.uint8): 1, np.dtype(np.float64): 2}
 
 
-def _pipeline(wave_pairs=0, wave_rows=0, threads=0):
+def _pipeline(wave_pairs=0, wave_rows=0, threads=0, device=None):
     """One po_pipeline per (process, device, geometry): its pinned staging buffers, device buffers and workspace
-    are allocated once and reused by every call."""
-    dev = int(os.environ.get("POREOVER_DEVICE", "0") or 0)
+    are allocated once and reused by every call.  The device is the caller's (`device`), else the one the process was
+    bound to (_lib.set_device — the torchrun branches of the drivers, dist.run_sharded's workers), else 0."""
+    dev = int(device) if device is not None else L.current_device()
     key = (os.getpid(), dev, int(wave_pairs), int(wave_rows), int(threads))
     pl = _PIPELINES.get(key)
     if pl is None:
@@ -233,16 +234,37 @@ def _pipeline(wave_pairs=0, wave_rows=0, threads=0):
     return pl
 
 
+_MULTIS = {}
+
+
+def _multi(devices, wave_pairs=0, wave_rows=0, threads=0):
+    """One po_multi (a pipeline and a host thread per device, one wave planner) per (process, device list, geometry)."""
+    devs = tuple(int(d) for d in devices)
+    key = (os.getpid(), devs, int(wave_pairs), int(wave_rows), int(threads))
+    m = _MULTIS.get(key)
+    if m is None:
+        lib = L.load()
+        m = lib.po_multi_create((C.c_int * len(devs))(*devs), len(devs), int(wave_pairs), int(wave_rows), int(threads))
+        if not m:
+            raise L.EngineError(L.E_HIP, "po_multi_create", (lib.po_last_error() or b"").decode())
+        _MULTIS[key] = m
+    return m
+
+
 def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="row_col", padding=5, alignment="banded",
                        diagonal_envelope=False, diagonal_width=50, perm1=None, perm2=None, reverse2=False,
-                       return_envelope=False, wave_pairs=0, wave_rows=0, threads=0, strict=True, stats=None):
+                       return_envelope=False, wave_pairs=0, wave_rows=0, threads=0, strict=True, stats=None,
+                       devices=None):
     """The pair-decode stage chain for a list of pairs, HOST ARRAYS IN -> STRINGS OUT, through the engine's
     pipelined host layer (po_pipeline_pair_decode): the arrays are uploaded as they are — float32 logits, uint8
     flip-flop traces or float64 log-probabilities, all of one dtype — in waves, log-softmax / trace scaling /
     column order (perm1, perm2: out[:, c] = in[:, perm[c]]) / time reversal of read 2 (reverse2; reverse_complement =
     reverse2 + perm2 [3,2,1,0,4]) run on the device, and wave k + 1 uploads while wave k decodes.
     Returns the same records as pair_decode_batch (envelope only with return_envelope).  strict=False: a per-pair
-    engine error is left in the record's status instead of raising for the whole batch."""
+    engine error is left in the record's status instead of raising for the whole batch.
+    devices: a list of device indices (an index may repeat) -> ONE process drives them all (po_multi_pair_decode: a
+    pipeline and a host thread per device, waves dealt as devices become free, results written in input order);
+    None -> the process's own device."""
     import time as _time
     _t0 = _time.perf_counter()
     lib = L.load()
@@ -290,15 +312,27 @@ def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="
     env = np.zeros((max(int(r1.sum()), 1), 2), dtype=np.int32) if return_envelope else None
     pm1 = (C.c_int * Cc)(*perm1) if perm1 is not None else None
     pm2 = (C.c_int * Cc)(*perm2) if perm2 is not None else None
-    pl = _pipeline(wave_pairs, wave_rows, threads)
+    multi = devices is not None and len(devices) > 1
+    pl = _multi(devices, wave_pairs, wave_rows, threads) if multi else _pipeline(
+        wave_pairs, wave_rows, threads, device=(devices[0] if devices else None))
     _t1 = _time.perf_counter()
-    L.check(lib.po_pipeline_pair_decode(pl, _ptr(p1), _ptr(r1), _ptr(p2), _ptr(r2), n, Cc, mode, pm1, pm2, 1 if reverse2 else 0,
-                                        C.byref(opt), _ptr(seq1d), _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(ident), _ptr(env),
-                                        _ptr(seq), _ptr(so), _ptr(lens), _ptr(st)), "po_pipeline_pair_decode")
+    fn = lib.po_multi_pair_decode if multi else lib.po_pipeline_pair_decode
+    L.check(fn(pl, _ptr(p1), _ptr(r1), _ptr(p2), _ptr(r2), n, Cc, mode, pm1, pm2, 1 if reverse2 else 0,
+               C.byref(opt), _ptr(seq1d), _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(ident), _ptr(env),
+               _ptr(seq), _ptr(so), _ptr(lens), _ptr(st)), "po_multi_pair_decode" if multi else "po_pipeline_pair_decode")
     if stats is not None:
-        pk, wt, tot, wv = C.c_double(), C.c_double(), C.c_double(), C.c_int()
-        lib.po_pipeline_stats(pl, C.byref(pk), C.byref(wt), C.byref(tot), C.byref(wv))
-        stats.update(pack_ms=pk.value, wait_ms=wt.value, total_ms=tot.value, waves=wv.value)
+        pk, wt, tot, wv, np_ = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        if multi:
+            per = []
+            for i in range(len(devices)):
+                lib.po_multi_stats(pl, i, C.byref(np_), C.byref(pk), C.byref(wt), C.byref(tot), C.byref(wv))
+                per.append({"device": int(devices[i]), "pairs": np_.value, "pack_ms": pk.value, "wait_ms": wt.value,
+                            "total_ms": tot.value, "waves": wv.value})
+            stats.update(per_device=per, waves=sum(d["waves"] for d in per), pack_ms=max(d["pack_ms"] for d in per),
+                         wait_ms=max(d["wait_ms"] for d in per), total_ms=max(d["total_ms"] for d in per))
+        else:
+            lib.po_pipeline_stats(pl, C.byref(pk), C.byref(wt), C.byref(tot), C.byref(wv))
+            stats.update(pack_ms=pk.value, wait_ms=wt.value, total_ms=tot.value, waves=wv.value)
     _t2 = _time.perf_counter()
     raw1, raw = memoryview(seq1d), memoryview(seq)     # (the buffers are capacity-sized, ~18 x the text: no bulk copy)
     eo = np.zeros(n + 1, dtype=np.int64)
@@ -323,51 +357,23 @@ def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="
     return out
 
 
-def _sharded_pair_worker(items, extra):
-    """One worker of pair_decode_batch_sharded (a spawned process bound to its device by dist.run_sharded): maps the
-    packed inputs the parent left in shared memory and decodes the pairs whose indices it was given."""
-    y1 = np.load(extra["y1"], mmap_mode="r")
-    y2 = np.load(extra["y2"], mmap_mode="r")
-    o1, o2 = extra["o1"], extra["o2"]
-    a = [y1[o1[i]:o1[i + 1]] for i in items]
-    b = [y2[o2[i]:o2[i + 1]] for i in items]
-    res = pair_decode_batch(a, b, **extra["kw"])
-    if not extra["keep_envelope"]:
-        for r in res:
-            r["envelope"] = None
-    return res
-
-
-def pair_decode_batch_sharded(arrays1, arrays2, devices=None, keep_envelope=True, **kw):
+def pair_decode_batch_sharded(arrays1, arrays2, devices=None, keep_envelope=True, single="viterbi", **kw):
     """pair_decode_batch over several GPUs of one node (BASELINE config 4; the reference's Pool fan-out,
-    pair_decode.py:292-297): pairs are split by cost U + V (greedy longest-first, dist.shard_by_cost), each device
-    gets one spawned worker process that decodes its share through the C-ABI, and the results come back in input
-    order.  Inputs travel through shared memory (one packed copy, mapped by every worker), outputs are small.
-    devices: list of device indices (default: every visible device; an index may repeat); with one device — or one
-    pair — this is pair_decode_batch.  The CALLING process must not have initialised the GPU when more than one
-    worker is spawned (see dist.py)."""
+    pair_decode.py:292-297), IN THIS PROCESS: one pipeline and one host thread per device inside
+    po_multi_pair_decode, waves of pairs dealt to whichever device is free, inputs uploaded as they are (float32
+    logits / uint8 traces / float64 log-probabilities: no packed copy, no shared memory, no worker processes),
+    results written in input order.  devices: list of device indices (default: every visible device; an index may
+    repeat); with one device this is the single-device pipeline.  single="beam" (1-D beam search basecalls first) is
+    not a pipeline stage: it runs pair_decode_batch on the first device."""
     from . import dist as podist
     n = len(arrays1)
     devs = podist.plan_devices(n, devices)
-    if len(devs) <= 1:
+    if single != "viterbi":
         if devs and devs[0] != 0:
-            L.check(L.load().po_set_device(devs[0]), "po_set_device")
-        return pair_decode_batch(arrays1, arrays2, **kw)
-    import shutil
-    import tempfile
-    y1, o1, Cc = pack_rows(arrays1)
-    y2, o2, _ = pack_rows(arrays2, Cc)
-    tmp = tempfile.mkdtemp(prefix="poreover_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    try:
-        f1, f2 = os.path.join(tmp, "y1.npy"), os.path.join(tmp, "y2.npy")
-        np.save(f1, y1)
-        np.save(f2, y2)
-        del y1, y2
-        extra = {"y1": f1, "y2": f2, "o1": o1, "o2": o2, "kw": kw, "keep_envelope": keep_envelope}
-        costs = [int(o1[i + 1] - o1[i] + o2[i + 1] - o2[i]) for i in range(n)]
-        return podist.run_sharded(list(range(n)), costs, _sharded_pair_worker, devs, extra)
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+            L.set_device(devs[0])
+        return pair_decode_batch(arrays1, arrays2, single=single, **kw)
+    return pair_decode_stream(arrays1, arrays2, return_envelope=keep_envelope, devices=(devs if len(devs) > 1 else None) or
+                              (devs[:1] if devs else None), **kw)
 
 
 def _pack_labels(labels):

@@ -18,8 +18,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -79,12 +81,40 @@ struct Slot {
 };
 }  // namespace
 
+// Hands out the waves of one call, in input order: pairs [first, first + wn) with their row totals and maxima.  One
+// pipeline walks it alone; the pipelines of several devices share it (each takes the next wave when it has a free slot),
+// which balances pairs of uneven length across the devices without a plan made in advance.
+struct WavePlanner {
+    const int64_t *rows1, *rows2;
+    int n, wave_pairs;
+    int64_t wave_rows;
+    int next = 0;
+    bool bad = false;
+    std::mutex mu;
+    bool take(int* first, int* wn, int64_t* r1, int64_t* r2, int64_t* m1, int64_t* m2) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (bad || next >= n) return false;
+        int k = 0;
+        int64_t a1 = 0, a2 = 0, x1 = 0, x2 = 0;
+        while (next + k < n && k < wave_pairs) {
+            const int64_t a = rows1[next + k], b = rows2[next + k];
+            if (a < 0 || b < 0) { bad = true; return false; }
+            if (k > 0 && a1 + a2 + a + b > wave_rows) break;
+            a1 += a; a2 += b; x1 = std::max(x1, a); x2 = std::max(x2, b);
+            ++k;
+        }
+        *first = next; *wn = k; *r1 = a1; *r2 = a2; *m1 = x1; *m2 = x2;
+        next += k;
+        return true;
+    }
+};
+
 struct po_pipeline {
     int device = 0, wave_pairs = 4096, threads = 8;
     int64_t wave_rows = (int64_t)64 << 20;
     Slot slot[2];
     double pack_ms = 0, wait_ms = 0, total_ms = 0;
-    int waves = 0;
+    int waves = 0, pairs = 0;
     std::string err;
 };
 
@@ -167,27 +197,38 @@ int po_pipeline_stats(po_pipeline* p, double* pack_ms, double* wait_ms, double* 
     return PO_OK;
 }
 
-int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64_t* rows1, const void* const* y2_h,
-                            const int64_t* rows2, int n, int C, int in_mode, const int* perm1, const int* perm2,
-                            int reverse2, const po_pair_options* opt, char* seq1d_h, const int64_t* seq1d_off_h,
-                            int32_t* len1_h, int32_t* len2_h, double* identity_h, int32_t* env_out_h, char* seq_h,
-                            const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
-    if (!p) return PO_E_ARG;
-    if (n < 0 || !y1_h || !rows1 || !y2_h || !rows2 || !opt || !seq1d_h || !seq1d_off_h || !len1_h || !len2_h ||
-        !identity_h || !seq_h || !seq_off_h || !seq_len_h || !status_h)
-        return fail(p, PO_E_ARG, "po_pipeline_pair_decode: null argument");
-    if (C < 1 || C > 8 || in_mode < 0 || in_mode > 2) return fail(p, PO_E_ARG, "po_pipeline_pair_decode: bad C / input mode");
-    PCHK(hipSetDevice(p->device));
+}  // extern "C"
+
+// the arguments of one call, as po_pipeline_pair_decode receives them
+struct PairCall {
+    const void* const* y1_h; const int64_t* rows1; const void* const* y2_h; const int64_t* rows2;
+    int n, C, in_mode; const int* perm1; const int* perm2; int reverse2; const po_pair_options* opt;
+    char* seq1d_h; const int64_t* seq1d_off_h; int32_t* len1_h; int32_t* len2_h; double* identity_h; int32_t* env_out_h;
+    char* seq_h; const int64_t* seq_off_h; int32_t* seq_len_h; int32_t* status_h;
+    const int64_t* env_row0;   // global row offset of every pair's envelope in env_out_h (NULL without env_out_h)
+};
+
+// One pipeline (one device, the calling thread) decodes the waves the planner hands it, two in flight.  Whatever way the
+// call ends, no slot is left marked busy: a failed call's results are discarded, never drained into a later call's arrays.
+static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
+    struct Quiesce {   // entry and every exit: both streams drained, both slots free
+        po_pipeline* p;
+        void run() {
+            for (auto& s : p->slot) {
+                if (s.busy) (void)hipStreamSynchronize(s.st);
+                s.busy = false;
+            }
+        }
+        explicit Quiesce(po_pipeline* p_) : p(p_) { run(); }
+        ~Quiesce() { run(); }
+    } quiesce(p);
+    const int C = c.C, in_mode = c.in_mode;
     const size_t esz = in_mode == PO_INGEST_LOGITS_F32 ? 4 : (in_mode == PO_INGEST_TRACE_U8 ? 1 : 8);
     const size_t row_in = esz * (size_t)C, row_y = sizeof(double) * (size_t)C;
     const double t_begin = now_ms();
     p->pack_ms = p->wait_ms = 0;
     p->waves = 0;
-    std::vector<int64_t> env_row0;   // global row offset of every pair's envelope in env_out_h
-    if (env_out_h) {
-        env_row0.resize((size_t)n + 1, 0);
-        for (int i = 0; i < n; ++i) env_row0[i + 1] = env_row0[i] + rows1[i];
-    }
+    p->pairs = 0;
 
     // results of the wave a slot holds -> the caller's arrays (after the slot's stream has drained)
     auto drain = [&](Slot& s) -> int {
@@ -204,36 +245,29 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
         const int64_t* o1 = (const int64_t*)s.h_off.p;
         for (int i = 0; i < s.n; ++i) {
             const int g = s.first + i;
-            len1_h[g] = l1[i]; len2_h[g] = l2[i]; seq_len_h[g] = ln[i]; status_h[g] = st[i]; identity_h[g] = idn[i];
-            const int64_t c1 = seq1d_off_h[2 * g + 1] - seq1d_off_h[2 * g], c2 = seq1d_off_h[2 * g + 2] - seq1d_off_h[2 * g + 1];
-            const int64_t cc = seq_off_h[g + 1] - seq_off_h[g];
-            if (l1[i] > c1 || l2[i] > c2 || ln[i] > cc) { status_h[g] = PO_E_CAP; seq_len_h[g] = 0; continue; }
-            std::memcpy(seq1d_h + seq1d_off_h[2 * g], ho + s.o_seq1d + s.s1o[2 * i], (size_t)std::max(0, l1[i]));
-            std::memcpy(seq1d_h + seq1d_off_h[2 * g + 1], ho + s.o_seq1d + s.s1o[2 * i + 1], (size_t)std::max(0, l2[i]));
-            std::memcpy(seq_h + seq_off_h[g], ho + s.o_seq + s.so[i], (size_t)std::max(0, ln[i]));
-            if (env_out_h)
-                std::memcpy(env_out_h + 2 * env_row0[g], ho + s.o_env + sizeof(int32_t) * 2 * (size_t)o1[i],
-                            sizeof(int32_t) * 2 * (size_t)rows1[g]);
+            c.len1_h[g] = l1[i]; c.len2_h[g] = l2[i]; c.seq_len_h[g] = ln[i]; c.status_h[g] = st[i]; c.identity_h[g] = idn[i];
+            const int64_t c1 = c.seq1d_off_h[2 * g + 1] - c.seq1d_off_h[2 * g], c2 = c.seq1d_off_h[2 * g + 2] - c.seq1d_off_h[2 * g + 1];
+            const int64_t cc = c.seq_off_h[g + 1] - c.seq_off_h[g];
+            if (l1[i] > c1 || l2[i] > c2 || ln[i] > cc) { c.status_h[g] = PO_E_CAP; c.seq_len_h[g] = 0; continue; }
+            std::memcpy(c.seq1d_h + c.seq1d_off_h[2 * g], ho + s.o_seq1d + s.s1o[2 * i], (size_t)std::max(0, l1[i]));
+            std::memcpy(c.seq1d_h + c.seq1d_off_h[2 * g + 1], ho + s.o_seq1d + s.s1o[2 * i + 1], (size_t)std::max(0, l2[i]));
+            std::memcpy(c.seq_h + c.seq_off_h[g], ho + s.o_seq + s.so[i], (size_t)std::max(0, ln[i]));
+            if (c.env_out_h)
+                std::memcpy(c.env_out_h + 2 * c.env_row0[g], ho + s.o_env + sizeof(int32_t) * 2 * (size_t)o1[i],
+                            sizeof(int32_t) * 2 * (size_t)c.rows1[g]);
         }
         s.busy = false;
         return PO_OK;
     };
 
-    int first = 0, wave = 0;
-    while (first < n) {
-        // ---- plan the wave: pairs [first, first + wn)
-        int wn = 0;
-        int64_t r1 = 0, r2 = 0, m1 = 0, m2 = 0;
-        while (first + wn < n && wn < p->wave_pairs) {
-            const int64_t a = rows1[first + wn], b = rows2[first + wn];
-            if (a < 0 || b < 0) return fail(p, PO_E_ARG, "po_pipeline_pair_decode: negative row count");
-            if (wn > 0 && r1 + r2 + a + b > p->wave_rows) break;
-            r1 += a; r2 += b; m1 = std::max(m1, a); m2 = std::max(m2, b);
-            ++wn;
-        }
+    int wave = 0;
+    int first = 0, wn = 0;
+    int64_t r1 = 0, r2 = 0, m1 = 0, m2 = 0;
+    for (;;) {
         Slot& s = p->slot[wave & 1];
-        int rc = drain(s);   // the wave this slot ran two waves ago
+        int rc = drain(s);   // the wave this slot ran two waves ago (before asking for another: a device takes work when it can start it)
         if (rc != PO_OK) return rc;
+        if (!plan.take(&first, &wn, &r1, &r2, &m1, &m2)) break;
         s.first = first; s.n = wn; s.tr1 = r1; s.tr2 = r2;
 
         // ---- offsets: [o1 (wn+1) | o2 (wn+1) | s1o (2wn+1) | so (wn+1)], pinned, uploaded as one block
@@ -246,7 +280,7 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
         int64_t* so = s1o + (2 * wn + 1);
         o1[0] = o2[0] = s1o[0] = so[0] = 0;
         for (int i = 0; i < wn; ++i) {
-            const int64_t a = rows1[first + i], b = rows2[first + i];
+            const int64_t a = c.rows1[first + i], b = c.rows2[first + i];
             o1[i + 1] = o1[i] + a; o2[i + 1] = o2[i] + b;
             s1o[2 * i + 1] = s1o[2 * i] + a; s1o[2 * i + 2] = s1o[2 * i + 1] + b;   // a basecall has at most one base per frame
             so[i + 1] = so[i] + a + b;
@@ -268,8 +302,8 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
         s.o_id = o; o += al256(sizeof(double) * wn);
         s.o_env = o; o += al256(sizeof(int32_t) * 2 * (size_t)r1);
         s.out_bytes = o;
-        const size_t wsb = po_pair_ws_bytes_impl(wn, r1, r2, m1, m2, C, opt);
-        const bool direct = (in_mode == PO_INGEST_F64 && !perm1 && !perm2 && !reverse2);   // log-probabilities as they are
+        const size_t wsb = po_pair_ws_bytes_impl(wn, r1, r2, m1, m2, C, c.opt);
+        const bool direct = (in_mode == PO_INGEST_F64 && !c.perm1 && !c.perm2 && !c.reverse2);   // log-probabilities as they are
         if (!s.h_in.ensure(in1 + in2) || !s.d_y.ensure(yb1 + yb2) || (!direct && !s.d_in.ensure(in1 + in2)) ||
             !s.d_out.ensure(s.out_bytes) || !s.h_out.ensure(s.out_bytes) || !s.d_ws.ensure(wsb))
             return fail(p, PO_E_HIP, "po_pipeline_pair_decode: out of memory (wave buffers; lower wave_pairs / wave_rows)");
@@ -277,8 +311,8 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
         // ---- pack: item arrays -> pinned staging (the GPU is busy with the previous wave meanwhile)
         const double tp = now_ms();
         char* hin = (char*)s.h_in.p;
-        pack_items(y1_h, rows1, first, wn, row_in, hin, off1, p->threads);
-        pack_items(y2_h, rows2, first, wn, row_in, hin + in1, off2, p->threads);
+        pack_items(c.y1_h, c.rows1, first, wn, row_in, hin, off1, p->threads);
+        pack_items(c.y2_h, c.rows2, first, wn, row_in, hin + in1, off2, p->threads);
         p->pack_ms += now_ms() - tp;
 
         // ---- upload + ingest + decode + download, all on the slot's stream
@@ -296,12 +330,12 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
             char* din = (char*)s.d_in.p;
             PCHK(hipMemcpyAsync(din, hin, row_in * (size_t)r1, hipMemcpyHostToDevice, s.st));
             PCHK(hipMemcpyAsync(din + in1, hin + in1, row_in * (size_t)r2, hipMemcpyHostToDevice, s.st));
-            rc = po_launch_ingest(din, d_o1, wn, C, in_mode, perm1, 0, r1, dy1, s.st);
-            if (rc == PO_OK) rc = po_launch_ingest(din + in1, d_o2, wn, C, in_mode, perm2, reverse2, r2, dy2, s.st);
+            rc = po_launch_ingest(din, d_o1, wn, C, in_mode, c.perm1, 0, r1, dy1, s.st);
+            if (rc == PO_OK) rc = po_launch_ingest(din + in1, d_o2, wn, C, in_mode, c.perm2, c.reverse2, r2, dy2, s.st);
             if (rc != PO_OK) return fail(p, rc, "po_pipeline_pair_decode: bad permutation / input mode");
         }
         char* dout = (char*)s.d_out.p;
-        rc = po_launch_pair_decode_geom(dy1, d_o1, dy2, d_o2, wn, C, opt, r1, r2, m1, m2, nullptr, nullptr, dout + s.o_seq1d, d_s1o,
+        rc = po_launch_pair_decode_geom(dy1, d_o1, dy2, d_o2, wn, C, c.opt, r1, r2, m1, m2, nullptr, nullptr, dout + s.o_seq1d, d_s1o,
                                         (int32_t*)(dout + s.o_l1), (int32_t*)(dout + s.o_l2), (double*)(dout + s.o_id),
                                         (int32_t*)(dout + s.o_env), dout + s.o_seq, d_so, (int32_t*)(dout + s.o_len),
                                         (int32_t*)(dout + s.o_st), s.d_ws.p, s.d_ws.cap, s.st);
@@ -309,17 +343,154 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
         PCHK(hipGetLastError());
         // results: everything but the envelope in one copy; the envelope only when asked for
         PCHK(hipMemcpyAsync(s.h_out.p, s.d_out.p, s.o_env, hipMemcpyDeviceToHost, s.st));
-        if (env_out_h)
+        if (c.env_out_h)
             PCHK(hipMemcpyAsync((char*)s.h_out.p + s.o_env, dout + s.o_env, sizeof(int32_t) * 2 * (size_t)r1, hipMemcpyDeviceToHost, s.st));
         s.busy = true;
-        first += wn;
+        p->pairs += wn;
         ++wave;
     }
+    if (plan.bad) return fail(p, PO_E_ARG, "po_pipeline_pair_decode: negative row count");
     p->waves = wave;
     int rc = drain(p->slot[wave & 1]);          // the older wave first, then the last one
     if (rc == PO_OK) rc = drain(p->slot[(wave + 1) & 1]);
     p->total_ms = now_ms() - t_begin;
     return rc;
+}
+
+static int check_call(const PairCall& c, std::string* why) {
+    if (c.n < 0 || !c.y1_h || !c.rows1 || !c.y2_h || !c.rows2 || !c.opt || !c.seq1d_h || !c.seq1d_off_h || !c.len1_h || !c.len2_h ||
+        !c.identity_h || !c.seq_h || !c.seq_off_h || !c.seq_len_h || !c.status_h) { *why = "null argument"; return PO_E_ARG; }
+    if (c.C < 1 || c.C > 8 || c.in_mode < 0 || c.in_mode > 2) { *why = "bad C / input mode"; return PO_E_ARG; }
+    return PO_OK;
+}
+
+extern "C" {
+
+int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64_t* rows1, const void* const* y2_h,
+                            const int64_t* rows2, int n, int C, int in_mode, const int* perm1, const int* perm2,
+                            int reverse2, const po_pair_options* opt, char* seq1d_h, const int64_t* seq1d_off_h,
+                            int32_t* len1_h, int32_t* len2_h, double* identity_h, int32_t* env_out_h, char* seq_h,
+                            const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
+    if (!p) return PO_E_ARG;
+    PairCall c{y1_h, rows1, y2_h, rows2, n, C, in_mode, perm1, perm2, reverse2, opt, seq1d_h, seq1d_off_h, len1_h, len2_h,
+               identity_h, env_out_h, seq_h, seq_off_h, seq_len_h, status_h, nullptr};
+    std::string why;
+    if (check_call(c, &why) != PO_OK) return fail(p, PO_E_ARG, "po_pipeline_pair_decode: " + why);
+    PCHK(hipSetDevice(p->device));
+    std::vector<int64_t> env_row0;
+    if (env_out_h) {
+        env_row0.resize((size_t)n + 1, 0);
+        for (int i = 0; i < n; ++i) env_row0[i + 1] = env_row0[i] + rows1[i];
+        c.env_row0 = env_row0.data();
+    }
+    WavePlanner plan;
+    plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n; plan.wave_pairs = p->wave_pairs; plan.wave_rows = p->wave_rows;
+    return pipeline_run(p, plan, c);
+}
+
+// ---- several devices, one process -------------------------------------------------------------------------------
+// The native replacement of the reference's fan-out over worker processes (pair_decode.py:292-297) on a multi-GPU node:
+// one po_pipeline per device, each driven by its own host thread, all taking waves from one planner and writing their
+// results straight into the caller's arrays at the pairs' own indices — input order, no gather, no inter-process copy.
+struct po_multi {
+    std::vector<po_pipeline*> pipes;
+    std::vector<int> pairs_done;
+    std::string err;
+    int wave_pairs = 4096;
+};
+
+// The waves a call over `ndev` devices is cut into (no device is touched: what po_multi_pair_decode's planner hands out,
+// in order): first[k], count[k] for k < returned number of waves (at most cap are written).
+int po_wave_plan(const int64_t* rows1, const int64_t* rows2, int n, int wave_pairs, int64_t wave_rows, int ndev, int* first,
+                 int* count, int cap) {
+    if (!rows1 || !rows2 || n < 0 || ndev < 1) return PO_E_ARG;
+    WavePlanner plan;
+    plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n;
+    const int wp = wave_pairs > 0 ? wave_pairs : 4096;
+    plan.wave_pairs = (ndev > 1) ? std::max(1, std::min(wp, (n + 2 * ndev - 1) / (2 * ndev))) : wp;
+    plan.wave_rows = wave_rows > 0 ? wave_rows : ((int64_t)64 << 20);
+    int k = 0, f = 0, c = 0;
+    int64_t r1, r2, m1, m2;
+    while (plan.take(&f, &c, &r1, &r2, &m1, &m2)) {
+        if (k < cap) { if (first) first[k] = f; if (count) count[k] = c; }
+        ++k;
+    }
+    return plan.bad ? PO_E_ARG : k;
+}
+
+po_multi* po_multi_create(const int* devices, int ndev, int wave_pairs, int64_t wave_rows, int threads) {
+    if (!devices || ndev < 1) { po_set_error("po_multi_create: no devices"); return nullptr; }
+    po_multi* m = new po_multi();
+    if (wave_pairs > 0) m->wave_pairs = wave_pairs;
+    for (int i = 0; i < ndev; ++i) {
+        po_pipeline* p = po_pipeline_create(devices[i], wave_pairs, wave_rows, threads);
+        if (!p) { for (auto* q : m->pipes) po_pipeline_destroy(q); delete m; return nullptr; }
+        m->pipes.push_back(p);
+    }
+    m->pairs_done.assign((size_t)ndev, 0);
+    return m;
+}
+
+void po_multi_destroy(po_multi* m) {
+    if (!m) return;
+    for (auto* p : m->pipes) po_pipeline_destroy(p);
+    delete m;
+}
+
+int po_multi_devices(po_multi* m) { return m ? (int)m->pipes.size() : 0; }
+
+// pairs decoded by pipeline i in the last call, and its pack / wait / total milliseconds
+int po_multi_stats(po_multi* m, int i, int* pairs, double* pack_ms, double* wait_ms, double* total_ms, int* waves) {
+    if (!m || i < 0 || i >= (int)m->pipes.size()) return PO_E_ARG;
+    if (pairs) *pairs = m->pipes[(size_t)i]->pairs;
+    return po_pipeline_stats(m->pipes[(size_t)i], pack_ms, wait_ms, total_ms, waves);
+}
+
+int po_multi_pair_decode(po_multi* m, const void* const* y1_h, const int64_t* rows1, const void* const* y2_h,
+                         const int64_t* rows2, int n, int C, int in_mode, const int* perm1, const int* perm2,
+                         int reverse2, const po_pair_options* opt, char* seq1d_h, const int64_t* seq1d_off_h,
+                         int32_t* len1_h, int32_t* len2_h, double* identity_h, int32_t* env_out_h, char* seq_h,
+                         const int64_t* seq_off_h, int32_t* seq_len_h, int32_t* status_h) {
+    if (!m || m->pipes.empty()) return PO_E_ARG;
+    PairCall c{y1_h, rows1, y2_h, rows2, n, C, in_mode, perm1, perm2, reverse2, opt, seq1d_h, seq1d_off_h, len1_h, len2_h,
+               identity_h, env_out_h, seq_h, seq_off_h, seq_len_h, status_h, nullptr};
+    std::string why;
+    if (check_call(c, &why) != PO_OK) { po_set_error(("po_multi_pair_decode: " + why).c_str()); return PO_E_ARG; }
+    std::vector<int64_t> env_row0;
+    if (env_out_h) {
+        env_row0.resize((size_t)n + 1, 0);
+        for (int i = 0; i < n; ++i) env_row0[i + 1] = env_row0[i] + rows1[i];
+        c.env_row0 = env_row0.data();
+    }
+    const int nd = (int)m->pipes.size();
+    // waves small enough that every device gets at least two (one decoding while the next uploads), never larger than
+    // one pipeline's own wave size
+    WavePlanner plan;
+    plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n;
+    plan.wave_pairs = std::max(1, std::min(m->wave_pairs, (n + 2 * nd - 1) / (2 * nd)));
+    plan.wave_rows = m->pipes[0]->wave_rows;
+    std::vector<int> rcs((size_t)nd, PO_OK);
+    std::vector<std::string> errs((size_t)nd);
+    std::vector<std::thread> th;
+    for (int i = 0; i < nd; ++i)
+        th.emplace_back([&, i]() {
+            po_pipeline* p = m->pipes[(size_t)i];
+            if (hipSetDevice(p->device) != hipSuccess) { rcs[(size_t)i] = PO_E_HIP; errs[(size_t)i] = "hipSetDevice failed"; return; }
+            rcs[(size_t)i] = pipeline_run(p, plan, c);
+            if (rcs[(size_t)i] != PO_OK) {
+                errs[(size_t)i] = p->err;
+                std::lock_guard<std::mutex> lk(plan.mu);   // the other devices finish what they hold and stop taking waves
+                plan.next = plan.n;
+            }
+        });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < nd; ++i)
+        if (rcs[(size_t)i] != PO_OK) {
+            m->err = "device " + std::to_string(m->pipes[(size_t)i]->device) + ": " + errs[(size_t)i];
+            po_set_error(m->err.c_str());
+            return rcs[(size_t)i];
+        }
+    return PO_OK;
 }
 
 }  // extern "C"

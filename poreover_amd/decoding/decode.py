@@ -191,13 +191,13 @@ def decode_files(in_files, args, devices=None, decode_fn=None):
             costs.append(1)
     if world > 1:
         if decode_fn is None:
-            _lib.check(_lib.load().po_set_device(local_rank), "po_set_device")
+            _lib.set_device(local_rank)
         return podist.decode_distributed(in_files, costs, fn, args)
     threads = getattr(args, 'threads', 1)
     devs = podist.plan_devices(len(in_files), devices, threads if threads and threads > 1 else None)
     if len(devs) <= 1:
         if devs and devs[0] != 0 and decode_fn is None:
-            _lib.check(_lib.load().po_set_device(devs[0]), "po_set_device")
+            _lib.set_device(devs[0])
         return fn(in_files, args)
     return podist.run_sharded(in_files, costs, fn, devs, args, bind_device=decode_fn is None)
 

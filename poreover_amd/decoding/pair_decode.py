@@ -213,8 +213,10 @@ def decode_pairs(in_paths, args, devices=None, decode_fn=None):
     over processes (pair_decode.py:292-297): returns the reference's return tuples in input order.
       * under torchrun (WORLD_SIZE > 1): this rank decodes its shard on device LOCAL_RANK, rank 0 gets every record,
         the other ranks None;
-      * otherwise one spawned worker process per visible device (devices=[...] names them; an index may repeat),
-        or this process alone when there is one device or one pair.
+      * otherwise THIS process drives every visible device (devices=[...] names them; an index may repeat): the
+        pipelined engine call takes the device list (po_multi_pair_decode: a pipeline and a host thread per device, waves
+        dealt as devices become free).  The `split` / `--skip_matches` routes, which make several engine calls per
+        pair, and an injected decode_fn still go through one spawned worker process per device (dist.run_sharded).
     decode_fn(list_of_pairs, args) -> records replaces the engine call (tests inject a CPU function)."""
     from .. import dist as podist
     fn = decode_fn or decode_pairs_local
@@ -222,14 +224,17 @@ def decode_pairs(in_paths, args, devices=None, decode_fn=None):
     costs = [_pair_cost(p, args) for p in in_paths]
     if world > 1:
         if decode_fn is None:
-            _lib.check(_lib.load().po_set_device(local_rank), "po_set_device")
+            _lib.set_device(local_rank)
         return podist.decode_distributed(in_paths, costs, fn, args)
     threads = getattr(args, 'threads', 1)
     devs = podist.plan_devices(len(in_paths), devices, threads if threads and threads > 1 else None)
     if len(devs) <= 1:
         if devs and devs[0] != 0 and decode_fn is None:
-            _lib.check(_lib.load().po_set_device(devs[0]), "po_set_device")
+            _lib.set_device(devs[0])
         return fn(in_paths, args)
+    if decode_fn is None and getattr(args, 'method', 'envelope') != 'split' and not getattr(args, 'skip_matches', False) \
+            and getattr(args, 'single', 'viterbi') == 'viterbi':
+        return decode_pairs_local(in_paths, args, devices=devs)
     return podist.run_sharded(in_paths, costs, fn, devs, args, bind_device=decode_fn is None)
 
 
@@ -251,9 +256,10 @@ def _write_debug_pickle(pair, rec, args):
                      'sequence_to_signal2': [int(x) for x in maps[1]], 'alignment': alignment}, pfile)
 
 
-def decode_pairs_local(in_paths, args):
-    """pair_decode_helper for a list of pairs on THIS process's device: returns a list of the reference's return
-    tuples (1-, 2- or 3-tuples, pair_decode.py:375,398,526-529)."""
+def decode_pairs_local(in_paths, args, devices=None):
+    """pair_decode_helper for a list of pairs in THIS process — on its device, or on every device of `devices` through
+    the multi-device pipeline: returns a list of the reference's return tuples (1-, 2- or 3-tuples,
+    pair_decode.py:375,398,526-529)."""
     _check_supported(args)
     loaded = [_load_pair(p, args) for p in in_paths]
     out = [None] * len(loaded)
@@ -283,19 +289,27 @@ def decode_pairs_local(in_paths, args):
                                            single=args.single, **common)
         elif key[1] == 'host':
             res = _batch.pair_decode_stream([loaded[i][2].log_prob for i in idx], [loaded[i][3].log_prob for i in idx],
-                                            strict=False, return_envelope=want_env, **common)
+                                            strict=False, return_envelope=want_env, devices=devices, **common)
         else:
             ident = list(range(len(key[2])))
             res = _batch.pair_decode_stream([loaded[i][2].engine_input()[0] for i in idx],
                                             [loaded[i][3].engine_input()[0] for i in idx],
                                             perm1=None if list(key[2]) == ident else list(key[2]),
                                             perm2=None if list(key[4]) == ident else list(key[4]), reverse2=key[5],
-                                            strict=False, return_envelope=want_env, **common)
+                                            strict=False, return_envelope=want_env, devices=devices, **common)
         if getattr(args, 'debug', False) and not args.diagonal_envelope:
             _write_debug_pickle(loaded[idx[-1]], res[-1], args)
         for i, r in zip(idx, res):
             in_path = in_paths[i]
             path1, path2 = loaded[i][0], loaded[i][1]
+            if r["status"] not in (0, _lib.SKIP_LENGTH, _lib.SKIP_IDENTITY):
+                # a per-pair engine refusal (capacity, an envelope the reference itself is undefined on): the pair is
+                # reported and skipped, the other pairs of the batch are unaffected — whatever the output route
+                logging.getLogger("poreover_amd").warning("pair %s %s not decoded: %s", in_path[0], in_path[1],
+                                                          _lib._CODE_NAMES.get(r["status"], r["status"]))
+                out[i] = [{'read1': in_path[0], 'read2': in_path[1], 'length1': r["length1"], 'length2': r["length2"],
+                           'skipped': 1, 'error': _lib._CODE_NAMES.get(r["status"], str(r["status"]))}]
+                continue
             if getattr(args, 'debug_envelope', False) and r["status"] == 0:
                 # pair_decode.py:503-507: band statistics of the envelope instead of a consensus
                 import numpy as np
@@ -312,15 +326,6 @@ def decode_pairs_local(in_paths, args):
                           {'read1': in_path[0], 'read2': in_path[1]})
                 continue
             summary = {'read1': in_path[0], 'read2': in_path[1], 'length1': r["length1"], 'length2': r["length2"]}
-            if r["status"] not in (0, _lib.SKIP_LENGTH, _lib.SKIP_IDENTITY):
-                # a per-pair engine refusal (capacity, an envelope the reference itself is undefined on): the pair is
-                # reported and skipped, the other pairs of the batch are unaffected
-                logging.getLogger("poreover_amd").warning("pair %s %s not decoded: %s", in_path[0], in_path[1],
-                                                          _lib._CODE_NAMES.get(r["status"], r["status"]))
-                summary['skipped'] = 1
-                summary['error'] = _lib._CODE_NAMES.get(r["status"], str(r["status"]))
-                out[i] = [summary]
-                continue
             if r["status"] == _lib.SKIP_LENGTH:
                 summary['skipped'] = 1
                 out[i] = [summary]

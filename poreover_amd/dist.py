@@ -126,7 +126,7 @@ def _shard_worker(rank, device, fn, items, extra):
     os.environ["POREOVER_DEVICE"] = str(device)
     if device is not None and device >= 0:
         from . import _lib
-        _lib.check(_lib.load().po_set_device(int(device)), "po_set_device(%d)" % device)
+        _lib.set_device(int(device))
     return fn(items, extra)
 
 

@@ -1,6 +1,7 @@
-"""GPU: the multi-GPU decode path (BASELINE config 4: pairs sharded across the GPUs of a node, host gather).
-One spawned worker process per device (dist.run_sharded), results in input order.  With one GPU in the box both
-workers share device 0 — same code path, same processes, same gather."""
+"""GPU: the multi-GPU decode path (BASELINE config 4: pairs sharded across the GPUs of a node).  ONE process drives
+every device (po_multi_pair_decode: a pipeline and a host thread per device, waves dealt as devices become free,
+results written in input order); the file drivers' `split` / `--skip_matches` routes keep one spawned worker per
+device (dist.run_sharded).  With one GPU in the box both pipelines share device 0 — same code path, same threads."""
 import argparse
 import os
 
@@ -58,3 +59,66 @@ def test_driver_sharded_files(tmp_path, golden, golden_inputs):
         if len(x) == 3:
             assert "".join(x[1].split("\n")[1:]) == "".join(run["fasta_2d"].split("\n")[1:])
             assert x[2]["length1"] == run["summary"]["length1"]
+
+
+def test_multi_device_stream_256_pairs_vs_oracle(oracle):
+    """the in-process multi-device pipeline on devices [0, 0] (or [0, 1]): 256 pairs of uneven length, every consensus
+    equal to the oracle's and to the single-device pipeline's, input order kept, every pair decoded exactly once, both
+    pipelines used"""
+    from poreover_amd import batch
+    from poreover_amd.synth import synth_pair
+    rng = np.random.default_rng(77)
+    y1s, y2s = [], []
+    for i in range(256):
+        a, b = synth_pair(20000 + i, T=int(rng.integers(150, 700)))
+        y1s.append(a); y2s.append(b)
+    st = {}
+    got = batch.pair_decode_stream(y1s, y2s, "poreover", 5, "row_col", devices=_devices(), wave_pairs=40, stats=st)
+    one = batch.pair_decode_stream(y1s, y2s, "poreover", 5, "row_col")
+    assert len(got) == 256 and sum(d["pairs"] for d in st["per_device"]) == 256
+    assert all(d["pairs"] > 0 for d in st["per_device"]), st
+    bad = 0
+    for i in range(256):
+        want = oracle.pair_decode(y1s[i], y2s[i], "poreover", 5, "row_col")
+        assert got[i]["status"] == one[i]["status"] == want["status"], i
+        assert (got[i]["seq1"], got[i]["seq2"]) == (one[i]["seq1"], one[i]["seq2"]), i
+        assert got[i]["consensus"] == one[i]["consensus"], i
+        bad += got[i]["consensus"] != want["consensus"]
+    assert bad == 0, "%d of 256 pairs differ from the oracle" % bad
+
+
+def test_shard_of_the_strong_scaling_job(oracle):
+    """1250 pairs — one GPU's share of the 10 000-pair job on eight — through the pipeline on both pair-beam routes:
+    digests of the consensus strings equal the single-call batch's"""
+    import hashlib
+    from poreover_amd import batch, _lib
+    from poreover_amd.synth import synth_pair
+    base = [synth_pair(30000 + i, T=900) for i in range(50)]
+    y1s = [base[i % 50][0] for i in range(1250)]
+    y2s = [base[i % 50][1] for i in range(1250)]
+    want = [oracle.pair_decode(a, b, "poreover", 5, "row_col")["consensus"] for a, b in base]
+    for route in ("auto", "ring"):
+        _lib.set_pair_route(route)
+        try:
+            got = batch.pair_decode_stream(y1s, y2s, "poreover", 5, "row_col", devices=_devices())
+        finally:
+            _lib.set_pair_route("auto")
+        d = hashlib.sha256("".join(r["consensus"] or "-" for r in got).encode()).hexdigest()
+        w = hashlib.sha256("".join(want[i % 50] or "-" for i in range(1250)).encode()).hexdigest()
+        assert d == w, route
+
+
+def test_failed_call_leaves_the_pipeline_usable():
+    """a call that fails inside the wave loop (here: a column permutation the ingest kernel refuses) must not leave a
+    slot marked busy: the next call on the same cached pipeline decodes correctly"""
+    from poreover_amd import batch, _lib
+    from poreover_amd.synth import synth_pair
+    y1s, y2s = [], []
+    for i in range(9):
+        a, b = synth_pair(40000 + i, T=260)
+        y1s.append(a.astype(np.float32)); y2s.append(b.astype(np.float32))
+    good = batch.pair_decode_stream(y1s, y2s, "poreover", 5, "row_col", wave_pairs=3)
+    with pytest.raises(_lib.EngineError):
+        batch.pair_decode_stream(y1s, y2s, "poreover", 5, "row_col", wave_pairs=3, perm1=[0, 1, 2, 3, 9])
+    again = batch.pair_decode_stream(y1s[:4], y2s[:4], "poreover", 5, "row_col", wave_pairs=3)
+    assert [r["consensus"] for r in again] == [r["consensus"] for r in good[:4]]

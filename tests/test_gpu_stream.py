@@ -136,3 +136,33 @@ def test_driver_logits_files_revcomp(eng, tmp_path, oracle):
         edits += levenshtein(_cons(">" + rec), w["consensus"])
         total += len(w["consensus"])
     assert edits <= 0.001 * total
+
+
+@pytest.mark.parametrize("kind", ["bonito", "poreover"])
+def test_alternating_wave_geometries_on_one_pipeline(eng, kind):
+    """the pair beam kernels keep {magic, epoch} words in the workspace instead of clearing their value
+    store per launch; a pipeline reuses ONE workspace buffer for waves of different geometry, which moves the
+    sub-workspace.  Alternating two geometries for many calls (the steady state a single pass never reaches) must
+    give, call after call, the results of the first call (the host now tracks the layout last used on a buffer)."""
+    from poreover_amd import _lib
+    batches = []
+    for base, n, T in ((9300, 41, 330), (9400, 17, 520)):
+        y1s, y2s = [], []
+        for i in range(n):
+            a, b = synth_pair(base + i, T=T + 29 * (i % 7))
+            y1s.append(a); y2s.append(b)
+        batches.append((y1s, y2s))
+    for route in ("auto", "ring"):
+        _lib.set_pair_route(route)
+        try:
+            first = [None, None]
+            for rep in range(8):
+                j = rep & 1
+                got = [r["consensus"] for r in eng.pair_decode_stream(batches[j][0], batches[j][1], kind, 5, "row_col", wave_pairs=16)]
+                if first[j] is None:
+                    first[j] = got
+                assert got == first[j], (route, rep)
+        finally:
+            _lib.set_pair_route("auto")
+    want = [r["consensus"] for r in eng.pair_decode_batch(batches[0][0], batches[0][1], kind, 5, "row_col")]
+    assert first[0] == want

@@ -81,3 +81,49 @@ def test_workspace_bounded_for_long_reads():
     opt = _lib.PairOptions(5, _lib.MODELS["ctc"], _lib.METHODS["row_col"], 5, 0, 0, 50)
     small = lib.po_pair_decode_workspace_bytes(10000, 40000000, 40000000, 4000, 4400, 5, C.byref(opt))
     assert small < 48 * 2**30      # (the bench configuration keeps its full occupancy: ~16 GB of DP slices + ~15 GB for the pair beam)
+
+
+def test_wave_plan_covers_every_pair_in_order():
+    """the planner of the multi-device pipeline (po_wave_plan: what po_multi_pair_decode hands out): every pair in
+    exactly one wave, waves in input order, no wave beyond the pair / frame limits, and with several devices at
+    least two waves per device so that each has one decoding while the next uploads"""
+    from poreover_amd import _lib
+    lib = _lib.load(require_gpu=False)
+    rng = np.random.default_rng(5)
+    for n, ndev, wp, wr in ((10000, 8, 4096, 0), (10000, 1, 4096, 0), (37, 2, 7, 0), (5, 8, 4096, 0), (1000, 4, 100, 50000), (0, 2, 0, 0)):
+        r1 = rng.integers(50, 4500, size=max(n, 1)).astype(np.int64)
+        r2 = rng.integers(50, 4500, size=max(n, 1)).astype(np.int64)
+        cap = n + 8
+        first = np.zeros(cap, dtype=np.int32)
+        count = np.zeros(cap, dtype=np.int32)
+        k = lib.po_wave_plan(r1.ctypes.data_as(_lib._i64p), r2.ctypes.data_as(_lib._i64p), n, wp, wr, ndev,
+                             first.ctypes.data_as(_lib._i32p), count.ctypes.data_as(_lib._i32p), cap)
+        assert k >= 0
+        assert int(count[:k].sum()) == n
+        pos = 0
+        for j in range(k):
+            assert first[j] == pos and count[j] >= 1
+            limit = wp or 4096
+            assert count[j] <= limit
+            if wr:
+                tot = int(r1[pos:pos + count[j]].sum() + r2[pos:pos + count[j]].sum())
+                assert count[j] == 1 or tot <= wr
+            pos += count[j]
+        if ndev > 1 and n >= 2 * ndev:
+            assert k >= 2 * ndev, (n, ndev, k)
+            # near-equal waves: no device is handed a wave more than one pair larger than another's (frame limit aside)
+            if not wr:
+                assert count[:k].max() - count[:k - 1].min() <= 1
+
+
+def test_pipeline_device_follows_set_device(monkeypatch):
+    """batch._pipeline() asks the library layer for the process's device (under torchrun every rank's
+    pipeline sat on GPU 0 because only POREOVER_DEVICE was looked at)"""
+    from poreover_amd import _lib
+    monkeypatch.delenv("POREOVER_DEVICE", raising=False)
+    monkeypatch.setattr(_lib, "_CURRENT_DEVICE", [None])
+    assert _lib.current_device() == 0
+    monkeypatch.setenv("POREOVER_DEVICE", "3")
+    assert _lib.current_device() == 3
+    monkeypatch.setattr(_lib, "_CURRENT_DEVICE", [5])      # what set_device(5) records
+    assert _lib.current_device() == 5
