@@ -329,8 +329,18 @@ def main():
                                                               d_w.data_ptr(), wsz, stream), "po_beam1d_batch"))
             assert int((d_stt != 0).sum().item()) == 0
             nb = int(d_ln.sum().item())
+            # what bounds it: T serial steps per read, one wave per read (latency), not HBM and not the VALU — both
+            # fractions are reported so that nobody has to take that on trust.  Algorithmic bytes 8*T*C + L per read;
+            # update_prob evaluations: every beam node and every child once per frame (W * (A + 1) * logaddexp-per-update).
+            lae_per_update = 1 if model == "ctc" else 3
+            evals = float(rows) * W * 5 * lae_per_update
             return {"reads": n, "beam_width": W, "kernel_ms": round(ms, 3), "reads_per_s": round(n / ms * 1e3, 1),
-                    "mbases_per_s": round(nb / ms / 1e3, 3)}
+                    "mbases_per_s": round(nb / ms / 1e3, 3),
+                    "us_per_frame": round(ms * 1e3 / max(maxrows, 1), 3),
+                    "roofline": {"bound": "hbm", "achieved": round((8.0 * Cn * rows + nb) / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                                 "unit": "GB/s", "frac": round((8.0 * Cn * rows + nb) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)},
+                    "logaddexp_per_s": round(evals / (ms * 1e-3), 1),
+                    "logaddexp_frac_of_peak": round(evals / (ms * 1e-3) / lae_peak.value, 5) if lae_peak.value > 0 else None}
 
         n2 = min(1000, P)
         sec["config2_beam1d_1k_reads_W10"] = beam1d_config(d_y1, d_o1, n2, Cc, int(o1[n2]), mr1, "ctc", 10)

@@ -78,6 +78,16 @@ __device__ __forceinline__ void b1_sload_row(const double* p, double* out) {
     for (int c = 0; c < N; ++c) out[c] = __longlong_as_double((long long)v[c]);
 }
 
+// yr[i] for a per-lane index without a runtime-indexed private array (which would live in scratch memory): the row
+// sits in scalar registers, the lane picks its entry with a compare-select chain
+template <int N>
+__device__ __forceinline__ double b1_pick(const double* yr, int i) {
+    double r = yr[0];
+#pragma unroll
+    for (int c = 1; c < N; ++c) r = (i == c) ? yr[c] : r;
+    return r;
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     const double* __restrict__ y, const int64_t* __restrict__ y_off, int A, uint32_t alphabet, int W,
@@ -124,6 +134,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     int* nsel = (int*)carve(p, sizeof(int) * WM);
     int* ord = (int*)carve(p, sizeof(int) * NC);     // prune with exact score ties: candidate slots in node-id order
     B1Cand* cand = (B1Cand*)carve(p, sizeof(B1Cand) * NC);   // the candidates packed for the ranking: one 16-byte read each
+    int* stl_stk = (int*)carve(p, sizeof(int) * 48);         // the explicit stack of the exact-tie replay (po_stl_sort)
 
     if (T < 1) {
         if (lane == 0) { seq_len[r] = 0; status[r] = PO_E_ARG; }
@@ -150,16 +161,17 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         if (lane < A) {
             double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, pp[3], out[3];
             root_values<MODEL>(-1, 0.0, pp);
-            po_update<MODEL>(sp, pp, yr[lane], (MODEL == PO_MODEL_FLIPFLOP) ? yr[lane + A] : yr[A], false, true, out, lae);
+            po_update<MODEL>(sp, pp, b1_pick<CMAX>(yr, lane), (MODEL == PO_MODEL_FLIPFLOP) ? b1_pick<CMAX>(yr, lane + A) : b1_pick<CMAX>(yr, A), false, true, out, lae);
             P.id[lane] = 1 + lane;
             P.fc[lane] = -1;
             P.depth[lane] = 1;
+#pragma unroll
             for (int k = 0; k < K; ++k) P.val[k * NC + lane] = out[k];
             apl[1 + lane] = po_pack_node(0, lane);
             afc[1 + lane] = -1;
             sel[lane] = lane;
         }
-        if (MODEL == PO_MODEL_CTC) blank_cum = yr[A];
+        if (MODEL == PO_MODEL_CTC) blank_cum = b1_pick<CMAX>(yr, A);
     }
     int Wc = A;  // beam size entering step 1 (all root children; the first prune is at t = 1)
     __syncthreads();
@@ -208,15 +220,17 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 }
             }
             double sp[3], pp[3], out[3];
+#pragma unroll
             for (int k = 0; k < K; ++k) sp[k] = P.val[k * NC + s];
             if (pslot >= 0) { for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + pslot]; }
             else if (pslot == -1) root_values<MODEL>(t - 1, blank_cum, pp);
             else { for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF; }
-            po_update<MODEL>(sp, pp, yr[last], (MODEL == PO_MODEL_FLIPFLOP) ? yr[last + A] : yr[A], plast == last, false, out, lae);
+            po_update<MODEL>(sp, pp, b1_pick<CMAX>(yr, last), (MODEL == PO_MODEL_FLIPFLOP) ? b1_pick<CMAX>(yr, last + A) : b1_pick<CMAX>(yr, A), plast == last, false, out, lae);
             int fc = P.fc[s];
             if (fc == -2) fc = afc[P.id[s]];  // re-entered the beam: the arena remembers
             Q.id[j] = P.id[s]; Q.depth[j] = P.depth[s];
             Q.par[j] = par; Q.gpar[j] = gpar; Q.plast[j] = plast; Q.last[j] = last;
+#pragma unroll
             for (int k = 0; k < K; ++k) Q.val[k * NC + j] = out[k];
             Q.fc[j] = fc;
             need = (fc == -1);
@@ -262,9 +276,11 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             double sp[3], pp[3], out[3];
             if (slot >= 0) { fcx = P.fc[slot]; for (int k = 0; k < K; ++k) sp[k] = P.val[k * NC + slot]; }
             else { for (int k = 0; k < K; ++k) sp[k] = PO_NEG_INF; }
+#pragma unroll
             for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + sj];
-            po_update<MODEL>(sp, pp, yr[c], (MODEL == PO_MODEL_FLIPFLOP) ? yr[c + A] : yr[A], Q.last[j] == c, false, out, lae);
+            po_update<MODEL>(sp, pp, b1_pick<CMAX>(yr, c), (MODEL == PO_MODEL_FLIPFLOP) ? b1_pick<CMAX>(yr, c + A) : b1_pick<CMAX>(yr, A), Q.last[j] == c, false, out, lae);
             Q.id[s] = x; Q.fc[s] = fcx; Q.depth[s] = Q.depth[j] + 1;
+#pragma unroll
             for (int k = 0; k < K; ++k) Q.val[k * NC + s] = out[k];
         }
         po_wave_sync();   // (one wave per read)
@@ -286,6 +302,32 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         po_wave_sync();   // (one wave per read)
         int kept = 0;
         bool tie = false;
+        // Two-stage select (tables of at most 64 candidates: W <= 12).  When the beam is full, its W own continuations
+        // are W candidates at or above the smallest of their scores (thr): a child below thr cannot be among the W best,
+        // and nothing below thr outranks anything at or above it — so the ranks are taken within {beam slots} +
+        // {children >= thr}: about W + a few candidates instead of W * (A + 1), each one broadcast LDS read.  (Exact
+        // ties reaching into the beam go the full way below.)
+        if (NCc <= PO_WAVE) {
+            const int s = lane;
+            const bool valid = (s < NCc) && !dup[s];
+            const B1Cand me = cand[min(s, NCc - 1)];
+            double thr = PO_NEG_INF;
+            if (Wc == W) {
+                thr = cand[0].sc;
+                for (int j = 1; j < Wc; ++j) thr = fmin(thr, cand[j].sc);
+            }
+            const bool inS = valid && (s < Wc || me.sc >= thr);
+            const unsigned long long sm_ = __ballot(inS);
+            kept = __popcll(__ballot(valid));
+            int rank = 0, neq = 0;
+            for (unsigned long long mm = sm_; mm != 0ull; mm &= mm - 1ull) {   // (uniform)
+                const B1Cand c = cand[__builtin_ctzll(mm)];
+                rank += ((c.sc > me.sc) | (!(me.sc > c.sc) & (c.id < me.id))) ? 1 : 0;
+                neq += (c.sc == me.sc) ? 1 : 0;
+            }
+            if (inS && rank < W) nsel[rank] = s;
+            tie = __ballot(inS && (neq > 1) && (rank < W)) != 0ull;   // an exact tie that reaches into the beam
+        } else
         for (int s0 = 0; s0 < NCc; s0 += PO_WAVE) {
             const int s = s0 + lane;
             const bool valid = (s < NCc) && !dup[s];
@@ -325,14 +367,14 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             po_wave_sync();   // (one wave per read)
             if (lane == 0) {
                 const double* val0 = Q.val;
-                po_stl_prune<64>(ord, kept, W, [&](int slot) { return val0[slot]; });
+                po_stl_prune<64>(ord, kept, W, [&](int slot) { return val0[slot]; }, stl_stk);
                 for (int j = 0; j < min(W, kept); ++j) nsel[j] = ord[j];
             }
             po_wave_sync();   // (one wave per read)
         }
         const int Wn = min(W, kept);
         for (int j = lane; j < Wn; j += PO_WAVE) sel[j] = nsel[j];
-        if (MODEL == PO_MODEL_CTC) blank_cum += yr[A];
+        if (MODEL == PO_MODEL_CTC) blank_cum += b1_pick<CMAX>(yr, A);
         cur ^= 1;
         Pnb = Wc;
         Wc = Wn;
@@ -367,7 +409,7 @@ extern "C" size_t po_beam1d_lds_bytes(int W, int model) {
     const int WM = W > PO_A ? W : PO_A, NC = WM * (PO_A + 1);
     auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
     size_t per = 3 * al(sizeof(int) * NC) + al(sizeof(double) * K * NC) + 4 * al(sizeof(int) * WM);
-    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + 2 * al(sizeof(int) * NC) + al(16 * (size_t)NC);
+    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + 2 * al(sizeof(int) * NC) + al(16 * (size_t)NC) + al(sizeof(int) * 48);
 }
 
 // node-arena entries for a batch: per read root + A children + A * max(W, A) new nodes per frame

@@ -257,8 +257,9 @@ __device__ inline void po_stl_insertion_sort(int* o, int first, int last, const 
         else po_stl_unguarded_linear_insert(o, i, sc);
     }
 }
+// (stk: 48 ints for the explicit stack when MAXN > 16 — callers hand LDS, a private array would live in scratch memory)
 template <int MAXN, class S>
-__device__ inline void po_stl_sort(int* o, int n, const S& sc) {   // std::sort of n <= MAXN <= 64 elements
+__device__ inline void po_stl_sort(int* o, int n, const S& sc, int* stk = nullptr) {   // std::sort of n <= MAXN <= 64 elements
     if (n == 0) return;
     if (MAXN <= 16) {   // (introsort leaves ranges of <= 16 elements to the final insertion sort)
         po_stl_insertion_sort(o, 0, n, sc);
@@ -267,7 +268,7 @@ __device__ inline void po_stl_sort(int* o, int n, const S& sc) {   // std::sort 
     int lg = 0;
     for (int k = n; k > 1; k >>= 1) ++lg;
     // __introsort_loop without recursion: an explicit stack of (first, last, depth)
-    int stk[3 * 16], sp = 0;
+    int sp = 0;
     stk[0] = 0; stk[1] = n; stk[2] = 2 * lg; sp = 1;
     while (sp > 0) {
         --sp;
@@ -301,9 +302,9 @@ __device__ inline void po_stl_sort(int* o, int n, const S& sc) {   // std::sort 
 }
 // the W best of the n candidates o[0..n) (slots in node-id order) exactly as Beam::prune orders them, in o[0..min(W, n))
 template <int WMAX, class S>
-__device__ inline void po_stl_prune(int* o, int n, int W, const S& sc) {   // W <= WMAX
+__device__ inline void po_stl_prune(int* o, int n, int W, const S& sc, int* stk = nullptr) {   // W <= WMAX
     if (n > W) po_stl_partial_sort(o, W, n, sc);
-    else po_stl_sort<WMAX>(o, n, sc);
+    else po_stl_sort<WMAX>(o, n, sc, stk);
 }
 
 // node arena entry: parent id and last symbol packed as (parent << 3) | last  (last <= 4)
