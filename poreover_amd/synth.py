@@ -6,7 +6,7 @@ float64 — the form the reference's decoders receive (decode.py:34-51).
 """
 import numpy as np
 
-__all__ = ["synth_pair", "synth_read", "synth_truth", "log_softmax"]
+__all__ = ["synth_pair", "synth_read", "synth_truth", "synth_pair_noise", "log_softmax"]
 
 
 def log_softmax(logits):
@@ -28,7 +28,7 @@ def _mutate(rng, ref):
     return np.asarray(out, dtype=np.int64)
 
 
-def _render(rng, seq, T, flipflop):
+def _render(rng, seq, T, flipflop, peak=6.0, sigma=1.0):
     C = 8 if flipflop else 5
     L = len(seq)
     if L > T:
@@ -49,8 +49,8 @@ def _render(rng, seq, T, flipflop):
     else:
         lab = np.full(T, 4, dtype=np.int64)
         lab[pos] = seq
-    logits = rng.normal(0, 1, (T, C)).astype(np.float32)
-    logits[np.arange(T), lab] += 6.0
+    logits = rng.normal(0, sigma, (T, C)).astype(np.float32)
+    logits[np.arange(T), lab] += peak
     return log_softmax(logits)
 
 
@@ -73,3 +73,17 @@ def synth_truth(index, T=4000, base_seed=0):
     rng = np.random.default_rng(base_seed + index)
     ref = rng.integers(4, size=max(1, int(T / 9.4)))
     return "".join("ACGT"[b] for b in ref)
+
+
+def synth_pair_noise(index, T=4000, base_seed=0, peak=5.0, sigma=1.6):
+    """(y1, y2, truth): the SAME sequence rendered twice with independent basecaller noise and no mutations — the
+    setting the reference's pair decoding is for (README.md:5,12: two reads of one molecule).  The labelled column
+    stands only `peak` above noise of width `sigma`, so a single read's Viterbi basecall has errors that the other
+    read's evidence can correct; synth_pair's reads differ from their truth by real mutations, which no consensus
+    of two can tell from signal."""
+    rng = np.random.default_rng(base_seed + 7919 * 1000003 + index)
+    ref = rng.integers(4, size=max(1, int(T / 9.4)))
+    T2 = int(T * rng.uniform(0.9, 1.1))
+    y1 = _render(rng, ref, T, False, peak, sigma)
+    y2 = _render(rng, ref, T2, False, peak, sigma)
+    return y1, y2, "".join("ACGT"[b] for b in ref)

@@ -48,6 +48,24 @@ def main():
     G["pair_prefix_prob"] = {"alpha1": [MG.jf(x) for x in a1], "alpha2": [MG.jf(x) for x in a2],
                              "from_vec": MG.jf(decoding.decoding_cy.pair_prefix_prob_log_from_vec(a1, a2, g)),
                              "outer": MG.jf(decoding.decoding_cy.pair_prefix_prob_log(np.add.outer(a1, a2), g))}
+    # decoding_cy.pair_gamma_log_envelope (decoding_cy.pyx:224-271) on small banded pairs: the reference's own Cython,
+    # its PySparseMatrix rows pushed as the tests of this repo push them, the cells in row-major order
+    cyg = []
+    for seed, U_, V_, half in ((7300, 14, 11, 3), (7301, 20, 23, 4), (7302, 9, 9, 2)):
+        ya, yb = synth_pair(seed, T=40)
+        ya, yb = np.ascontiguousarray(ya[:U_]), np.ascontiguousarray(yb[:V_])
+        rows = [(max(0, int(u * V_ / U_) - half), min(V_, int(u * V_ / U_) + half)) for u in range(U_ + 1)]
+
+        def fresh():
+            m = decoding.decoding_cy.PySparseMatrix()
+            for s_, e_ in rows:
+                m.push_row(s_, e_)
+            return m
+        cells = np.array([(u, v) for u in range(U_ + 1) for v in range(rows[u][0], rows[u][1] + 1)], dtype=np.intp)
+        gm = decoding.decoding_cy.pair_gamma_log_envelope(ya, yb, fresh(), cells, fresh(), fresh())
+        cyg.append({"seed": seed, "U": U_, "V": V_, "half": half, "rows": [list(r) for r in rows],
+                    "cells": cells.tolist(), "gamma": [MG.jf(gm.get(int(u), int(v))) for u, v in cells]})
+    G["pair_gamma_cy_envelope"] = cyg
     with open(os.path.join(HERE, "extra_golden.json"), "w") as f:
         json.dump(G, f, indent=0, sort_keys=True)
     print("wrote extra_golden.json", os.path.getsize(os.path.join(HERE, "extra_golden.json")))

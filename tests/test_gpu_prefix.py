@@ -1,11 +1,13 @@
 """GPU parity of the 1-D prefix search (prefix_search_log_cy) and of `decode --algorithm prefix`
 vs the reference's golden values and the oracle."""
 import argparse
+import json
+import os
 
 import numpy as np
 import pytest
 
-from conftest import hexf
+from conftest import GOLDEN_DIR, hexf
 from poreover_amd.synth import synth_pair
 
 pytestmark = pytest.mark.gpu
@@ -204,35 +206,26 @@ def test_alignment_with_score_arguments(eng):
 
 
 def test_decoding_cy_pair_gamma_log_envelope(eng):
-    """decoding_cy.pyx:224-271 on a small banded pair vs the function as written (python loops, in this test)"""
+    """decoding_cy.pyx:224-271 on small banded pairs vs the values the reference's own Cython build returned for the
+    same inputs (tests/golden/make_golden_extra.py runs it; round 2 compared with a restatement written in this test)"""
     from poreover_amd.decoding import decoding_cy as cy
-    y1, y2 = synth_pair(7300, T=40)
-    y1, y2 = y1[:14], y2[:11]
-    U, V = len(y1), len(y2)
-    rows = [(max(0, int(u * V / U) - 3), min(V, int(u * V / U) + 3)) for u in range(U + 1)]
+    with open(os.path.join(GOLDEN_DIR, "extra_golden.json")) as f:
+        cases = json.load(f)["pair_gamma_cy_envelope"]
+    assert len(cases) >= 3
+    for c in cases:
+        y1, y2 = synth_pair(c["seed"], T=40)
+        y1, y2 = y1[:c["U"]], y2[:c["V"]]
 
-    def fresh():
-        m = cy.PySparseMatrix()
-        for s, e in rows:
-            m.push_row(s, e)
-        return m
-    got = cy.pair_gamma_log_envelope(y1, y2, fresh(), None, fresh(), fresh())
-    g, ga = fresh(), fresh()
-    g.set(U, V, 0.0); ga.set(U, V, 0.0)
-    for v in range(V):
-        g.set(U, v, float(sum(y2[v:, 4])))
-    for u in range(U):
-        g.set(u, V, float(sum(y1[u:, 4])))
-    cells = [(u, v) for u in range(U + 1) for v in range(rows[u][0], rows[u][1] + 1)]
-    with np.errstate(divide="ignore"):
-        for u, v in reversed(cells):
-            if u < U and v < V:
-                ge = g.get(u + 1, v) + y1[u, 4]
-                gae = ga.get(u, v + 1) + y2[v, 4]
-                tot = sum(np.exp(y1[u, t] + y2[v, t]) for t in range(4))
-                gaa = g.get(u + 1, v + 1) + np.log(tot)
-                ga.set(u, v, np.log(np.exp(gae) + np.exp(gaa)))
-                g.set(u, v, np.log(np.exp(ge) + np.exp(ga.get(u, v))))
-    for u, v in cells:
-        a, b = got.get(u, v), g.get(u, v)
-        assert (np.isneginf(a) and np.isneginf(b)) or np.isclose(a, b, rtol=1e-12), (u, v, a, b)
+        def fresh():
+            m = cy.PySparseMatrix()
+            for s, e in c["rows"]:
+                m.push_row(s, e)
+            return m
+        got = cy.pair_gamma_log_envelope(y1, y2, fresh(), np.array(c["cells"], dtype=np.intp), fresh(), fresh())
+        none = cy.pair_gamma_log_envelope(y1, y2, fresh(), None, fresh(), fresh())
+        for (u, v), w in zip(c["cells"], c["gamma"]):
+            a = got.get(u, v)
+            w = hexf(w)
+            assert (np.isneginf(a) and np.isneginf(w)) or np.isclose(a, w, rtol=1e-12), (c["seed"], u, v, a, w)
+            b = none.get(u, v)
+            assert (np.isneginf(a) and np.isneginf(b)) or a == b, (c["seed"], u, v)
