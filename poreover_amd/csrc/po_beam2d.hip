@@ -900,6 +900,35 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             }
             if (tid == 0) sm.sh[14] = 0;
             bool teq = false;
+            if constexpr (nthr == 64) {
+                // One wave per pair (the W <= 6 class).  Only the beam nodes and the children that reach the smallest
+                // beam score can be among the W best (every other child has W candidates above it), and nothing outside
+                // that set outranks a member of it: the ranks are taken within it — a handful of broadcast LDS reads
+                // instead of W * (A + 1) candidates.  (Regular table with a full beam; otherwise everybody is in.)
+                const bool cnd = tid < ne && !sm.dup[min(tid, SM::NCM - 1)];
+                const int tx = min(tid, SM::NCM - 1);
+                const double sc = sm.score[tx];
+                const int id = sm.e[F_ID][tx];
+                bool inS = cnd;
+                if (regular && nb == W) {
+                    double thr = sm.score[0];
+                    for (int i = 1; i < nb; ++i) thr = fmin(thr, sm.score[i]);
+                    inS = cnd && (tid < nb || sc >= thr);
+                }
+                const unsigned long long smk = __ballot(inS);
+                int rank = 0, neq = 0;
+                for (unsigned long long mm = smk; mm != 0ull; mm &= mm - 1ull) {   // (uniform)
+                    const int o = __builtin_ctzll(mm);
+                    const double so = sm.score[o];
+                    const int io = sm.e[F_ID][o];
+                    rank += ((so > sc) | (!(sc > so) & (io < id))) ? 1 : 0;
+                    neq += (so == sc) ? 1 : 0;
+                }
+                if (inS && rank < W) sm.sel[rank] = tid;
+                teq = inS && (neq > 1) && (rank < W);   // an exact score tie that reaches into the beam
+                const int ncnd = __popcll(__ballot(cnd));
+                if (tid == 0) sm.sh[5] = ncnd;
+            } else
             if (tid < ne && !sm.dup[tid]) {
                 const double sc = sm.score[tid];
                 const int id = sm.e[F_ID][tid];
