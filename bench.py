@@ -38,8 +38,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-MAIN_KERNEL = "beam2d_kernel<0, 6"  # the pair beam search kernel this workload runs on (row_col, ctc, W = 5): name prefix
-# (profiles before the row_col-only instantiation existed call it beam2d_kernel<0, 6>, later ones beam2d_kernel<0, 6, true>)
+# the pair beam search kernel this workload runs on (row_col, ctc, W = 5): name prefix in the profiles
+# (profiles before the row_col-only instantiation existed call it beam2d_kernel<0, 6>, later ones beam2d_kernel<0, 6, true>;
+#  PO_RING_AUTO=1 makes the LDS-ring kernel the engine's choice: an A/B switch)
+RING = bool(os.environ.get("PO_RING_AUTO"))
+MAIN_KERNEL = "beam2d_ring_kernel" if RING else "beam2d_kernel<0, 6"
 
 
 def _cpu_pair_worker(args):
@@ -514,7 +517,7 @@ def main():
                                    "HBM" % (P, T, args.beam_width),
                        "pairs_per_gpu": P, "T": T, "beam_width": args.beam_width, "method": "row_col",
                        "decoded_pairs_rank0": decoded, "parallelism": "shard%d (no collective)" % args.gpus},
-            "roofline": {"bound": "hbm", "kernel": MAIN_KERNEL + ", true>", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": MAIN_KERNEL + ("" if RING else ", true>"), "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bk_avg, 3),
                          "launches": bk_n, "stage_ms": round(b2_avg, 3),

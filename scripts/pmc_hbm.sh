@@ -5,7 +5,7 @@ tag=${1:-rXX}; pairs=${2:-1250}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $root/gpurun_out/hbm_${tag}_$c -- python3 $root/bench.py --pairs $pairs --gen_procs 1 --steps 1 --warmup 1 --cpu_sample 0 --no_secondary > $root/gpurun_out/hbm_${tag}_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $root/gpurun_out/hbm_${tag}_$c -- python3 $root/bench.py --pairs $pairs --gen_procs 1 --steps 1 --warmup 1 --cpu_sample 0 --no_secondary --no_strong > $root/gpurun_out/hbm_${tag}_$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
@@ -28,7 +28,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k in last:
         if any(x in k for x in ("beam2d", "viterbi", "pair_prep")):
             out[k][c + "_KB_per_launch"] = round(last[k][1], 1); out[k]["launches_seen"] = n[k]
-res = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python3 bench.py --pairs $pairs --gen_procs 1 --steps 1 --warmup 0 --cpu_sample 0",
+res = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python3 bench.py --pairs $pairs --gen_procs 1 --steps 1 --warmup 1 --cpu_sample 0 --no_secondary --no_strong",
        "note": "one pass per counter; values of the LAST launch of each kernel (steady state: workspace already tagged); KB as rocprofv3 reports; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X guide), WRITE_SIZE uncalibrated",
        "workload": "$pairs synthetic pairs, T~4000, W=5", "pairs_per_launch": $pairs, "kernels": out}
 json.dump(res, open("$root/gpurun_out/pmc_hbm_$tag.json", "w"), indent=1)
