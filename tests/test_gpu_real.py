@@ -88,13 +88,19 @@ def test_beam1d_real(eng, real):
         assert eng.beam_search_batch([y1], W)[0] == g["beam1d_read1"][str(W)], W
 
 
-@pytest.mark.parametrize("method", ["row_col", "row"])
-def test_pair_decode_real_revcomp(eng, real, method):
-    """the reference's float64 log-probabilities in, every stage output compared"""
+@pytest.mark.parametrize("method,route", [("row_col", "auto"), ("row_col", "ring"), ("row", "auto")])
+def test_pair_decode_real_revcomp(eng, real, method, route):
+    """the reference's float64 log-probabilities in, every stage output compared (row_col on both one-pair-per-wave
+    kernels: 62 000 x 75 600 frames, windows up to 257 wide — far beyond the LDS ring of the `ring` route)"""
+    from poreover_amd import _lib
     g, inp, y1, y2 = real
     y2rc = np.ascontiguousarray(y2[::-1][:, [3, 2, 1, 0, 4]])           # transducer.py:68-70
     want = g["pair_revcomp"][method + "_w5"]
-    res = eng.pair_decode_batch([y1], [y2rc], "poreover", 5, method)[0]
+    _lib.set_pair_route(route)
+    try:
+        res = eng.pair_decode_batch([y1], [y2rc], "poreover", 5, method)[0]
+    finally:
+        _lib.set_pair_route("auto")
     assert res["status"] == 0
     assert res["seq1"] == g["viterbi1"] and res["seq2"] == g["viterbi2_revcomp"]
     assert res["sequence_identity"] == hexf(want["summary"]["sequence_identity"])
