@@ -2598,14 +2598,15 @@ constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over 
 // PO_ROUTE_LEGACY (always beam2d_kernel) — the last two exist for the tests, which run the pair path on both kernels,
 // and for A/B timing.  The environment variables PO_X2_FORCE / PO_B2_LEGACY / PO_X2_DEFER_ODD only give the INITIAL
 // value, read once when the library is first used, so that a workspace size and the launch that follows always agree.
-struct B2Route { int route, defer_odd, x2_per_cu, debug_occ, ring_auto; };
+struct B2Route { int route, defer_odd, x2_per_cu, debug_occ, ring_auto, ring_small; };
 B2Route& b2_route() {
     static B2Route r = [] {
         B2Route x;
         x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_X2_FORCE") ? PO_ROUTE_X2 : (getenv("PO_RING_FORCE") ? PO_ROUTE_RING : PO_ROUTE_AUTO));
         x.defer_odd = getenv("PO_X2_DEFER_ODD") ? 1 : 0;
         x.debug_occ = getenv("PO_DEBUG_OCC") ? 1 : 0;
-        x.ring_auto = getenv("PO_RING_AUTO") ? 1 : 0;   // (beam2d_ring_kernel as the engine's own choice: not yet)
+        x.ring_auto = getenv("PO_RING_AUTO") ? 1 : 0;     // beam2d_ring_kernel at every batch size (A/B)
+        x.ring_small = getenv("PO_RING_NEVER") ? 0 : 1;   // ... for launches within its resident workgroups (the default)
         const char* e = getenv("PO_X2_PER_CU");
         x.x2_per_cu = e ? atoi(e) : 0;
         return x;
@@ -2689,10 +2690,16 @@ extern "C" int po_ring_blocks_per_cu();
 extern "C" int po_ring_max_elements();
 extern "C" int po_ring_ngl();
 extern "C" void po_ring_launch(const void* x2args, int blocks, hipStream_t stream);
-bool ring_eligible(int W, int A, int model, int method) {
+// The engine's own choice (PO_ROUTE_AUTO): the LDS-ring kernel for launches that fit its resident workgroups (8 per
+// CU: 2 048 pairs) — there a pair's latency is what counts and it is 5 - 8 % faster (single pair 19.4 vs 20.7 ms, 1 250
+// pairs 45.3k vs 43.2k pairs/s) — and beam2d_kernel beyond, where throughput counts (104k vs 82k pairs/s at 10 000).
+bool ring_eligible(int n, int W, int A, int model, int method) {
     const int rt = b2_route().route;
-    if (rt != PO_ROUTE_RING && !(rt == PO_ROUTE_AUTO && b2_route().ring_auto)) return false;
-    return model == PO_MODEL_CTC && method == PO_METHOD_ROW_COL && W <= 6 && A >= 1 && W * (A + 1) <= po_ring_max_elements();
+    if (!(model == PO_MODEL_CTC && method == PO_METHOD_ROW_COL && W <= 6 && A >= 1 && W * (A + 1) <= po_ring_max_elements())) return false;
+    if (rt == PO_ROUTE_RING) return true;
+    if (rt != PO_ROUTE_AUTO) return false;
+    if (b2_route().ring_auto) return true;
+    return b2_route().ring_small && n <= b2_num_cus() * po_ring_blocks_per_cu();
 }
 struct RingGeom {
     int blocks;
@@ -2798,7 +2805,7 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
     (void)C;
     if (method == PO_METHOD_GRID) return grid_geometry(n, mr1, mr2, W, model, true).total;
     if (method == PO_METHOD_GRID_NOENV) return grid_geometry(n, mr1, mr2, W, model, false).total;
-    if (ring_eligible(W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return ring_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
+    if (ring_eligible(n, W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return ring_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     if (x2_eligible(n, W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total + b2_geometry(n, mr1, mr2, W, model, method, X2_FB_BLOCKS).total;
 }
@@ -2980,7 +2987,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         else grid_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
         return PO_OK;
     }
-    if (ring_eligible(W, A, model, method)) {
+    if (ring_eligible(n, W, A, model, method)) {
         const RingGeom g = ring_geometry(n, tr1, tr2, mr1, mr2, W, model);
         if (ws_bytes < g.total) return PO_E_CAP;
         char* w = (char*)ws;

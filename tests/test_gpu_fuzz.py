@@ -55,8 +55,8 @@ def test_fuzz_pair_beam_kernels(eng, oracle):
                 wants.append((oracle.cpp_beam_search_2d(y1s[i], y2s[i], envs[i], W, model_=MODELS[kind], method_=method), 0))
             except oracle.OracleError as e:
                 wants.append(("", e.code))
-        # the engine's choice, and the LDS-ring kernel where it can run (the one-value model, row_col, W * (A + 1) <= 26)
-        for route in (("auto", "ring") if (kind == "poreover" and method == "row_col" and W <= 5) else ("auto",)):
+        # the engine's choice, beam2d_kernel always, and the LDS-ring kernel where it can run (one-value model, row_col, W * (A + 1) <= 26)
+        for route in (("auto", "ring", "legacy") if (kind == "poreover" and method == "row_col" and W <= 5) else ("auto", "legacy")):
             _lib.set_pair_route(route)
             try:
                 got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=MODELS[kind], method=method, return_status=True)
