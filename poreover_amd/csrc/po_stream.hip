@@ -89,14 +89,20 @@ struct WavePlanner {
     int n, wave_pairs;
     int64_t wave_rows;
     int next = 0;
+    int handed = 0;      // waves handed out so far
+    int ramp = 0;        // > 0: the first waves are short (ramp, 2 * ramp, ... up to wave_pairs).  Measured on the 10 000-pair job
+                         // (1024, 2048, 4096, ...): no gain — the short waves decode at small-batch rates — so nobody sets it
     bool bad = false;
     std::mutex mu;
     bool take(int* first, int* wn, int64_t* r1, int64_t* r2, int64_t* m1, int64_t* m2) {
         std::lock_guard<std::mutex> lk(mu);
         if (bad || next >= n) return false;
+        int limit = wave_pairs;
+        if (ramp > 0 && handed < 8) limit = std::min<long long>(wave_pairs, (long long)ramp << handed);
+        ++handed;
         int k = 0;
         int64_t a1 = 0, a2 = 0, x1 = 0, x2 = 0;
-        while (next + k < n && k < wave_pairs) {
+        while (next + k < n && k < limit) {
             const int64_t a = rows1[next + k], b = rows2[next + k];
             if (a < 0 || b < 0) { bad = true; return false; }
             if (k > 0 && a1 + a2 + a + b > wave_rows) break;
@@ -245,16 +251,23 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
         const int64_t* o1 = (const int64_t*)s.h_off.p;
         for (int i = 0; i < s.n; ++i) {
             const int g = s.first + i;
-            c.len1_h[g] = l1[i]; c.len2_h[g] = l2[i]; c.seq_len_h[g] = ln[i]; c.status_h[g] = st[i]; c.identity_h[g] = idn[i];
+            c.len1_h[g] = l1[i]; c.len2_h[g] = l2[i]; c.seq_len_h[g] = ln[i]; c.identity_h[g] = idn[i];
             const int64_t c1 = c.seq1d_off_h[2 * g + 1] - c.seq1d_off_h[2 * g], c2 = c.seq1d_off_h[2 * g + 2] - c.seq1d_off_h[2 * g + 1];
             const int64_t cc = c.seq_off_h[g + 1] - c.seq_off_h[g];
-            if (l1[i] > c1 || l2[i] > c2 || ln[i] > cc) { c.status_h[g] = PO_E_CAP; c.seq_len_h[g] = 0; continue; }
-            std::memcpy(c.seq1d_h + c.seq1d_off_h[2 * g], ho + s.o_seq1d + s.s1o[2 * i], (size_t)std::max(0, l1[i]));
-            std::memcpy(c.seq1d_h + c.seq1d_off_h[2 * g + 1], ho + s.o_seq1d + s.s1o[2 * i + 1], (size_t)std::max(0, l2[i]));
-            std::memcpy(c.seq_h + c.seq_off_h[g], ho + s.o_seq + s.so[i], (size_t)std::max(0, ln[i]));
-            if (c.env_out_h)
-                std::memcpy(c.env_out_h + 2 * c.env_row0[g], ho + s.o_env + sizeof(int32_t) * 2 * (size_t)o1[i],
-                            sizeof(int32_t) * 2 * (size_t)c.rows1[g]);
+            int code = st[i];
+            if (l1[i] > c1 || l2[i] > c2 || ln[i] > cc) { code = PO_E_CAP; c.seq_len_h[g] = 0; }
+            else {
+                std::memcpy(c.seq1d_h + c.seq1d_off_h[2 * g], ho + s.o_seq1d + s.s1o[2 * i], (size_t)std::max(0, l1[i]));
+                std::memcpy(c.seq1d_h + c.seq1d_off_h[2 * g + 1], ho + s.o_seq1d + s.s1o[2 * i + 1], (size_t)std::max(0, l2[i]));
+                std::memcpy(c.seq_h + c.seq_off_h[g], ho + s.o_seq + s.so[i], (size_t)std::max(0, ln[i]));
+                if (c.env_out_h)
+                    std::memcpy(c.env_out_h + 2 * c.env_row0[g], ho + s.o_env + sizeof(int32_t) * 2 * (size_t)o1[i],
+                                sizeof(int32_t) * 2 * (size_t)c.rows1[g]);
+            }
+            // the status is written LAST: a caller that watches status_h from another thread (it filled it with a value no
+            // decode returns) may read a pair's outputs as soon as its status has changed
+            std::atomic_thread_fence(std::memory_order_release);
+            ((volatile int32_t*)c.status_h)[g] = code;
         }
         s.busy = false;
         return PO_OK;
