@@ -2555,6 +2555,8 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
     g.blocks = b2_num_cus() * per_cu;
     if (max_blocks > 0 && g.blocks > max_blocks) g.blocks = max_blocks;
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
+    // (tried: as many workgroups as make the rounds even — 3 334 for 10 000 pairs instead of 4 096 + a 44 % third round:
+    //  95.5k vs 108k pairs/s kernel-only; resident waves are worth more than an even tail)
     // value store per workgroup: 4 / 8 MB (one / three values per entry); four times that for the widest beam class
     // and for the pass over the pairs the two-pairs-per-wave path handed back (max_blocks > 0: few workgroups, and
     // those pairs are the ones with windows hundreds of frames wide, whose live rows grow with the window squared)

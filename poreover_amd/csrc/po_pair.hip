@@ -403,16 +403,31 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
                 lo_s[tid] = lo; hi_s[tid] = hi;
             }
             __syncthreads();
-            if (tid == 0) {
+            // The fix-up is a state machine over the rows — prev_end moves only where a row starts beyond it — so the
+            // first wave walks it from trigger to trigger: all 64 rows of a sub-chunk test `lo > prev_end` at once
+            // (ballot), the first one that does takes prev_end as its start and hands its end on (readlane); a chunk
+            // without triggers (the usual case) costs one ballot instead of 64 serial LDS round trips.
+            if (tid < PO_WAVE) {
                 const int cnt = min(NT, U - u0);
-                for (int q = 0; q < cnt; ++q) {
-                    int lo = lo_s[q];
-                    const int hi = hi_s[q];
+                int pe_ = prev_end;
+                for (int b0 = 0; b0 < cnt; b0 += PO_WAVE) {
+                    const int q = b0 + lane;
+                    const bool in = q < cnt;
+                    int lo = in ? lo_s[q] : 0;
+                    const int hi = in ? hi_s[q] : 0;
                     if (lo > hi) lo = 0;
-                    if (lo > prev_end) { lo = prev_end; prev_end = hi; }
-                    lo_s[q] = lo;
+                    int pos = 0;   // rows below `pos` of this sub-chunk are settled
+                    for (;;) {
+                        const unsigned long long mk = __ballot(in && lane >= pos && lo > pe_);
+                        if (mk == 0ull) break;
+                        const int qs = __builtin_ctzll(mk);
+                        if (lane == qs) lo = pe_;
+                        pe_ = __builtin_amdgcn_readlane(hi, qs);
+                        pos = qs + 1;
+                    }
+                    if (in) lo_s[q] = lo;
                 }
-                sh[4] = prev_end;
+                if (lane == 0) sh[4] = pe_;
             }
             __syncthreads();
             prev_end = sh[4];
