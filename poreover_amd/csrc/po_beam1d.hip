@@ -80,6 +80,9 @@ __device__ __forceinline__ void b1_sload_row(const double* p, double* out) {
 
 // yr[i] for a per-lane index without a runtime-indexed private array (which would live in scratch memory): the row
 // sits in scalar registers, the lane picks its entry with a compare-select chain
+__device__ __forceinline__ double rg1_readlane_d(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
 template <int N>
 __device__ __forceinline__ double b1_pick(const double* yr, int i) {
     double r = yr[0];
@@ -404,6 +407,272 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same search with the candidate table in REGISTERS: W * (PO_A + 1) <= 64, i.e. W <= 12 (BASELINE configs 2 and 5:
+// W = 10).  One wave per read, lane s = candidate slot s of the table; what a lane needs from another slot — the source
+// slot of a beam node, its parent's and its own previous values, the beam's node ids — comes by v_readlane / ds_bpermute
+// instead of LDS arrays and their search loops, and the two update passes of a frame (beam slots, then children: both
+// read the PREVIOUS table only) are one pass with one logaddexp latency.  Semantics, arena layout and tie handling are
+// beam1d_kernel's, statement for statement; only the exact-tie replay still goes through LDS.
+template <int MODEL>
+__global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
+    const double* __restrict__ y, const int64_t* __restrict__ y_off, int A, uint32_t alphabet, int W,
+    int* __restrict__ arena_pl, int* __restrict__ arena_fc, char* __restrict__ seq,
+    const int64_t* __restrict__ seq_off, int32_t* __restrict__ seq_len, int32_t* __restrict__ status) {
+    constexpr int K = ModelTraits<MODEL>::K, CMAX = ModelTraits<MODEL>::CMAX;
+    const int C = (MODEL == PO_MODEL_FLIPFLOP) ? 2 * A : A + 1;
+    __shared__ PoLaeTables lae_tab;
+    __shared__ int ord[64];
+    __shared__ double tsc[64];
+    __shared__ int stl_stk[48];
+    // y rows, 32 frames at a time, double-buffered: the next block is requested a block ahead (four doubles per lane
+    // held in registers for 32 frames) and written when the walk enters it, so no frame waits for memory — the row of a
+    // frame is two broadcast-free LDS reads per lane, issued together with the table permutes
+    __shared__ double yblk[2][32][CMAX];
+    const int lane = po_lane();
+    po_lae_tables_load(&lae_tab, lane, PO_WAVE);
+    __syncthreads();
+    const PoLaeFast lae{&lae_tab};
+    const int r = blockIdx.x;
+    const int64_t r0 = y_off[r];
+    const int T = (int)(y_off[r + 1] - r0);
+    const double* yr0 = y + r0 * C;
+    const int WM = max(W, PO_A);
+    const int64_t aoff = (int64_t)r * (1 + PO_A) + (int64_t)PO_A * WM * (r0 - y_off[0]);
+    const int64_t acap = (1 + PO_A) + (int64_t)PO_A * WM * T;
+    int* apl = arena_pl + aoff;
+    int* afc = arena_fc + aoff;
+    if (T < 1) { if (lane == 0) { seq_len[r] = 0; status[r] = PO_E_ARG; } return; }
+    if (acap < 1 + A) { if (lane == 0) { seq_len[r] = 0; status[r] = PO_E_NOMEM; } return; }
+
+    // ---- the previous step's table, one slot per lane
+    int p_id = 0, p_fc = -1, p_depth = 0, p_par = 0, p_gpar = -1, p_plast = A, p_last = 0;
+    double p_val[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) p_val[k] = PO_NEG_INF;
+    int selv = lane;      // lane j < Wc: the previous table's slot of beam node j
+    int Pnb = 0, Wc = A, next_id = 1 + A, st = PO_OK;
+    double blank_cum = 0.0;
+    {   // t = 0: the A children of the root (BeamSearch.h:25-30), no prune
+        double yr[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) yr[c] = (c < C) ? yr0[c] : 0.0;
+        if (lane == 0) { apl[0] = po_pack_node(-1, A); afc[0] = 1; }
+        if (lane < A) {
+            double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, pp[3], out[3];
+            root_values<MODEL>(-1, 0.0, pp);
+            po_update<MODEL>(sp, pp, b1_pick<CMAX>(yr, lane), (MODEL == PO_MODEL_FLIPFLOP) ? b1_pick<CMAX>(yr, lane + A) : b1_pick<CMAX>(yr, A), false, true, out, lae);
+            p_id = 1 + lane; p_fc = -1; p_depth = 1;
+#pragma unroll
+            for (int k = 0; k < K; ++k) p_val[k] = out[k];
+            apl[1 + lane] = po_pack_node(0, lane);
+            afc[1 + lane] = -1;
+        }
+        if (MODEL == PO_MODEL_CTC) blank_cum = b1_pick<CMAX>(yr, A);
+    }
+    auto shf = [&](int v, int src) { return __shfl(v, src); };
+    const int divA = (65536 + A - 1) / A;
+    constexpr int YPL = (32 * CMAX + PO_WAVE - 1) / PO_WAVE;   // doubles of a block per lane
+    const int divC = (65536 + C - 1) / C;
+    double ynx[YPL];
+    auto y_request = [&](int blk) {   // rows [32 blk, 32 blk + 32) -> registers
+#pragma unroll
+        for (int q = 0; q < YPL; ++q) {
+            const int i = lane + q * PO_WAVE;
+            const int64_t row = (int64_t)blk * 32 + ((i * divC) >> 16);
+            ynx[q] = (i < 32 * C && row < T) ? yr0[(int64_t)blk * 32 * C + i] : 0.0;
+        }
+    };
+    auto y_commit = [&](int blk) {    // registers -> LDS buffer of block blk
+#pragma unroll
+        for (int q = 0; q < YPL; ++q) {
+            const int i = lane + q * PO_WAVE;
+            if (i < 32 * C) { const int rw = (i * divC) >> 16; yblk[blk & 1][rw][i - rw * C] = ynx[q]; }
+        }
+    };
+    y_request(0); y_commit(0);
+    y_request(1);
+    po_wave_sync();
+
+    for (int t = 1; t < T; ++t) {
+        const bool first = (t == 1);
+        if ((t & 31) == 0) { y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync(); }
+        const double* yrow = &yblk[(t >> 5) & 1][t & 31][0];
+        const int NCc = Wc * (A + 1);
+        const bool rb = lane < Wc, rc = !rb && lane < NCc;
+        const int j = rc ? (((lane - Wc) * divA) >> 16) : 0, c = rc ? (lane - Wc) - j * A : 0;   // (x / A for x < 64)
+        // ---- beam slots: fields from the previous table's slot selv
+        const int src = rb ? selv : 0;
+        int q_id = shf(p_id, src), q_depth = shf(p_depth, src), q_fc = shf(p_fc, src);
+        int par = 0, gpar = -1, plast = A, last = 0, pslot = -2, sl0 = -2;
+        const int q_fc_pre = q_fc;
+        const int xpre = shf(q_fc_pre, j) + c;   // a child's node id if its parent has children already
+        {
+            const int s_par = shf(p_par, src), s_gpar = shf(p_gpar, src), s_plast = shf(p_plast, src), s_last = shf(p_last, src);
+            const int b = (src >= Pnb) ? (((src - Pnb) * divA) >> 16) : 0;
+            const int b_id = shf(p_id, b), b_par = shf(p_par, b), b_last = shf(p_last, b);
+            if (first) { par = 0; gpar = -1; plast = A; last = src; pslot = -1; }
+            else if (src >= Pnb) { par = b_id; gpar = b_par; plast = b_last; last = (src - Pnb) - b * A; pslot = b; }
+            else {
+                par = s_par; gpar = s_gpar; plast = s_plast; last = s_last;
+                if (par == 0) pslot = -1;
+            }
+            if (!first) {   // the parent's slot in the previous table: a beam slot, or a child of its grand-parent's
+                // (the same pass over the previous beam's ids finds, for a child lane, its node's previous beam slot: its
+                //  id is known before the expansion whenever its parent is not new)
+                int ps1 = -2, ps2 = -2;
+                for (int i = 0; i < Pnb; ++i) {
+                    const int bid = __builtin_amdgcn_readlane(p_id, i);
+                    if (bid == par) ps1 = i;
+                    if (bid == gpar) ps2 = Pnb + A * i + plast;
+                    if (bid == xpre) sl0 = i;
+                }
+                if (src < Pnb && par != 0) pslot = (ps1 >= 0) ? ps1 : ps2;
+            }
+        }
+        if (rb && q_fc == -2) q_fc = afc[q_id];   // re-entered the beam: the arena remembers
+        // ---- expansion: A fresh ids per beam node that has never had children, in beam order
+        const bool need = rb && (q_fc == -1);
+        {
+            const unsigned long long m = __ballot(need);
+            if (need) {
+                const int fc = next_id + A * __popcll(m & ((1ull << lane) - 1ull));
+                if ((int64_t)fc + A <= acap) {
+                    q_fc = fc;
+                    afc[q_id] = fc;
+                    for (int cc = 0; cc < A; ++cc) { apl[fc + cc] = po_pack_node(q_id, cc); afc[fc + cc] = -1; }
+                } else q_fc = 0;
+            }
+            next_id += A * __popcll(m);
+            if ((int64_t)next_id > acap) st = PO_E_NOMEM;
+        }
+        if (st != PO_OK) break;
+        // ---- children: id, previous slot, fields of the parent beam node j
+        const int pj_fc = shf(q_fc, j), pj_new = shf((int)need, j), pj_sel = shf(selv, j), pj_depth = shf(q_depth, j), pj_last = shf(last, j);
+        int slot = -2, fcx = -2;
+        if (rc) {
+            q_id = pj_fc + c; q_depth = pj_depth + 1; fcx = pj_new ? -1 : -2;
+        }
+        if (!first) {
+            int sl = sl0;
+            if (__ballot(rb && q_fc_pre == -2) != 0ull) {   // (a parent's first child came from the arena: look again)
+                sl = -2;
+                for (int i = 0; i < Pnb; ++i) {
+                    const int bid = __builtin_amdgcn_readlane(p_id, i);
+                    if (bid == q_id) sl = i;
+                }
+            }
+            if (rc && !pj_new) {
+                slot = sl;
+                if (slot < 0 && pj_sel < Pnb) slot = Pnb + A * pj_sel + c;
+            }
+        }
+        {   // (every lane takes part in the permute: a lane that sits out cannot be read from)
+            const int sfc = shf(p_fc, max(slot, 0));
+            if (rc) { if (slot >= 0) fcx = sfc; q_fc = fcx; }
+        }
+        // ---- one update for every slot of the new table
+        const int s_self = rb ? src : max(slot, 0), s_parent = rb ? max(pslot, 0) : pj_sel;
+        double sp[3], pp[3], out[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
+#pragma unroll
+        for (int k = 0; k < K; ++k) { sp[k] = __shfl(p_val[k], s_self); pp[k] = __shfl(p_val[k], s_parent); }
+        if (rb) {
+            if (pslot == -1) root_values<MODEL>(t - 1, blank_cum, pp);
+            else if (pslot < 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF;
+            }
+        } else if (slot < 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) sp[k] = PO_NEG_INF;
+        }
+        const int sym = rb ? last : c;
+        const bool samef = rb ? (plast == last) : (pj_last == c);
+        const double ya = yrow[(rb || rc) ? sym : 0], yb = yrow[(MODEL == PO_MODEL_FLIPFLOP) ? ((rb || rc) ? sym + A : 0) : A];
+        if (rb || rc)
+            po_update<MODEL>(sp, pp, ya, yb, samef, false, out, lae);
+        // ---- prune (Beam.h:93-108): a child slot whose node is also a beam slot is the same node pushed twice
+        bool dupf = false;
+        const double sc = out[0];
+        double thr = rg1_readlane_d(sc, 0);
+        for (int i = 0; i < Wc; ++i) {   // (one pass over the beam lanes: duplicate test and the smallest beam score)
+            const int bid = __builtin_amdgcn_readlane(q_id, i);
+            if (rc && bid == q_id) dupf = true;
+            thr = fmin(thr, rg1_readlane_d(sc, i));
+        }
+        if (Wc != W) thr = PO_NEG_INF;
+        const bool valid = (rb || rc) && !dupf;
+        const bool inS = valid && (rb || sc >= thr);
+        const unsigned long long smk = __ballot(inS);
+        const int kept = __popcll(__ballot(valid));
+        int rank = 0, neq = 0;
+        for (unsigned long long mm = smk; mm != 0ull; mm &= mm - 1ull) {
+            const int o = __builtin_ctzll(mm);
+            const double so = rg1_readlane_d(sc, o);
+            const int io = __builtin_amdgcn_readlane(q_id, o);
+            rank += ((so > sc) | (!(sc > so) & (io < q_id))) ? 1 : 0;
+            neq += (so == sc) ? 1 : 0;
+        }
+        const int Wn = min(W, kept);
+        int nsel = 0;   // lane jx < Wn: the slot of the candidate of rank jx
+        if (__ballot(inS && neq > 1 && rank < W) != 0ull) {
+            // exact ties reaching into the beam: libstdc++'s partial_sort / sort on the candidates in node-id order
+            int pos = 0;
+            for (int o = 0; o < NCc; ++o) {
+                const int io = __builtin_amdgcn_readlane(q_id, o);
+                const int vo = (int)((__ballot(valid) >> o) & 1ull);
+                pos += vo & ((io < q_id) ? 1 : 0);
+            }
+            if (valid) ord[pos] = lane;
+            tsc[lane] = sc;
+            po_wave_sync();
+            if (lane == 0) {
+                const double* tp = tsc;
+                po_stl_prune<64>(ord, kept, W, [&](int slot_) { return tp[slot_]; }, stl_stk);
+            }
+            po_wave_sync();
+            nsel = ord[min(lane, 63)];
+            po_wave_sync();
+        } else {
+            for (int jx = 0; jx < Wn; ++jx) {
+                const unsigned long long bj = __ballot(inS && rank == jx);
+                const int sj = (bj != 0ull) ? (int)__builtin_ctzll(bj) : 0;
+                if (lane == jx) nsel = sj;
+            }
+        }
+        // ---- the new table becomes the previous one
+        p_id = q_id; p_fc = q_fc; p_depth = q_depth;
+#pragma unroll
+        for (int k = 0; k < K; ++k) p_val[k] = out[k];
+        p_par = par; p_gpar = gpar; p_plast = plast; p_last = last;
+        selv = nsel;
+        if (MODEL == PO_MODEL_CTC) blank_cum += yrow[A];
+        Pnb = Wc;
+        Wc = Wn;
+    }
+    // ---- label of the top node (PrefixTree::get_label, PrefixTree.h:449-457)
+    const int top = __builtin_amdgcn_readlane(selv, 0);
+    const int node0 = __shfl(p_id, top), depth0 = __shfl(p_depth, top);
+    if (lane == 0) {
+        int n = 0;
+        if (st == PO_OK) {
+            int node = node0;
+            n = depth0;
+            char* out = seq + seq_off[r];
+            const int cap = (int)(seq_off[r + 1] - seq_off[r]);
+            if (n > cap) { st = PO_E_CAP; n = 0; }
+            else
+                for (int i = n - 1; i >= 0; --i) {
+                    const int pk = apl[node];
+                    out[i] = (char)((alphabet >> (8 * (po_node_last(pk) & 3))) & 0xffu);
+                    node = po_node_parent(pk);
+                }
+        }
+        seq_len[r] = n;
+        status[r] = st;
+    }
+}
+
 extern "C" size_t po_beam1d_lds_bytes(int W, int model) {
     const int K = (model == PO_MODEL_CTC) ? 1 : 3;
     const int WM = W > PO_A ? W : PO_A, NC = WM * (PO_A + 1);
@@ -427,8 +696,14 @@ extern "C" int po_launch_beam1d(const double* y, const int64_t* y_off, int n, in
     if (W < 1 || W > 64 || A < 1 || A > PO_A) return PO_E_ARG;
     const size_t lds = po_beam1d_lds_bytes(W, model);
     if (lds > 160 * 1024) return PO_E_ARG;
+    const bool small = (W > PO_A ? W : PO_A) * (PO_A + 1) <= PO_WAVE && !getenv("PO_B1_TABLES");   // the table fits one wave's lanes
 #define PO_LAUNCH_B1(M)                                                                                   \
     do {                                                                                                  \
+        if (small) {                                                                                      \
+            hipLaunchKernelGGL(beam1d_wave_kernel<M>, dim3(n), dim3(PO_WAVE), 0, stream, y, y_off, A, alphabet, W, arena_pl, \
+                               arena_fc, seq, seq_off, seq_len, status);                                  \
+            break;                                                                                        \
+        }                                                                                                 \
         if (lds > 64 * 1024)                                                                              \
             (void)hipFuncSetAttribute((const void*)beam1d_kernel<M>,                                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
