@@ -257,9 +257,10 @@ __device__ inline void po_stl_insertion_sort(int* o, int first, int last, const 
         else po_stl_unguarded_linear_insert(o, i, sc);
     }
 }
-// (stk: 48 ints for the explicit stack when MAXN > 16 — callers hand LDS, a private array would live in scratch memory)
+// (stk: 48 ints for the explicit stack when MAXN > 16 — a caller in a hot kernel hands LDS: a private array lives in
+//  scratch memory; the overload without it keeps its own)
 template <int MAXN, class S>
-__device__ inline void po_stl_sort(int* o, int n, const S& sc, int* stk = nullptr) {   // std::sort of n <= MAXN <= 64 elements
+__device__ inline void po_stl_sort(int* o, int n, const S& sc, int* stk) {   // std::sort of n <= MAXN <= 64 elements
     if (n == 0) return;
     if (MAXN <= 16) {   // (introsort leaves ranges of <= 16 elements to the final insertion sort)
         po_stl_insertion_sort(o, 0, n, sc);
@@ -301,10 +302,20 @@ __device__ inline void po_stl_sort(int* o, int n, const S& sc, int* stk = nullpt
     else po_stl_insertion_sort(o, 0, n, sc);
 }
 // the W best of the n candidates o[0..n) (slots in node-id order) exactly as Beam::prune orders them, in o[0..min(W, n))
+template <int MAXN, class S>
+__device__ inline void po_stl_sort(int* o, int n, const S& sc) {
+    int stk[(MAXN > 16) ? 48 : 1];
+    po_stl_sort<MAXN>(o, n, sc, stk);
+}
 template <int WMAX, class S>
-__device__ inline void po_stl_prune(int* o, int n, int W, const S& sc, int* stk = nullptr) {   // W <= WMAX
+__device__ inline void po_stl_prune(int* o, int n, int W, const S& sc, int* stk) {   // W <= WMAX; stk: 48 ints (see po_stl_sort)
     if (n > W) po_stl_partial_sort(o, W, n, sc);
     else po_stl_sort<WMAX>(o, n, sc, stk);
+}
+template <int WMAX, class S>
+__device__ inline void po_stl_prune(int* o, int n, int W, const S& sc) {
+    if (n > W) po_stl_partial_sort(o, W, n, sc);
+    else po_stl_sort<WMAX>(o, n, sc);
 }
 
 // node arena entry: parent id and last symbol packed as (parent << 3) | last  (last <= 4)
