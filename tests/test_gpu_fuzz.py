@@ -127,6 +127,32 @@ def test_fuzz_grid_method(eng, oracle):
     assert pairs > 50 and bad == 0, "%d of %d random grid pairs differ from the oracle" % (bad, pairs)
 
 
+def test_wide_beams_sort_more_than_sixteen_tied_candidates(eng, oracle):
+    """W = 25 in bands a few cells wide: between 17 and 25 candidates, most of them -inf — Beam::prune takes its std::sort
+    branch (at most W candidates) beyond the 16 elements libstdc++ leaves to insertion sort, i.e. the introsort loop with
+    its explicit stack on the device.  (Round 3: a defaulted null stack pointer went through every seeded test; the
+    open-ended fuzz run found it.)"""
+    from poreover_amd import _lib
+    rng = np.random.default_rng(20260301)
+    pairs = bad = 0
+    for kind, method in (("poreover", "grid"), ("flipflop", "grid"), ("poreover", "row_col"), ("bonito", "row")):
+        y1s, y2s, envs = [], [], []
+        for i in range(12):
+            y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=int(rng.integers(60, 260)), flipflop=(kind == "flipflop"))
+            y1s.append(y1); y2s.append(y2); envs.append(_band_env(rng, len(y1), len(y2), "stairs", int(rng.integers(2, 6))))
+        got, st = eng.beam_search_2d_batch(y1s, y2s, envs, 25, model=MODELS[kind], method=method, return_status=True)
+        for i in range(len(y1s)):
+            try:
+                want, code = oracle.cpp_beam_search_2d(y1s[i], y2s[i], envs[i], 25, model_=MODELS[kind], method_=method), 0
+            except oracle.OracleError as e:
+                want, code = "", e.code
+            pairs += 1
+            if st[i] == _lib.E_NOMEM and code == 0:
+                continue
+            bad += int(st[i] != code or (code == 0 and got[i] != want))
+    assert pairs >= 40 and bad == 0, "%d of %d pairs differ from the oracle" % (bad, pairs)
+
+
 def test_fuzz_pipeline(eng, oracle):
     """random kinds / methods / widths through the whole stage chain: statuses, basecalls, envelopes, consensus"""
     rng = np.random.default_rng(20260202)
