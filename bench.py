@@ -206,7 +206,7 @@ def main():
 
     from poreover_amd import _lib
     lib = _lib.load()
-    _lib.check(lib.po_set_device(local_rank), "po_set_device")
+    _lib.set_device(local_rank)   # (binds the library AND tells the cached pipelines of the strong-scaling leg which device they are on)
 
     tr1, tr2 = int(o1[-1]), int(o2[-1])
     mr1, mr2 = int(np.diff(o1).max()), int(np.diff(o2).max())

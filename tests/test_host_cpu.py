@@ -127,3 +127,21 @@ def test_pipeline_device_follows_set_device(monkeypatch):
     assert _lib.current_device() == 3
     monkeypatch.setattr(_lib, "_CURRENT_DEVICE", [5])      # what set_device(5) records
     assert _lib.current_device() == 5
+
+
+def test_devices_are_bound_through_set_device_only():
+    """po_set_device must be reached through _lib.set_device, which also records the device for the cached pipelines
+    (batch._pipeline): a direct call leaves every rank's pipeline on GPU 0 (bench.py's strong-scaling leg
+    repeated it in round 3)"""
+    offenders = []
+    for root in ("poreover_amd", "."):
+        base = os.path.join(REPO, root)
+        for dirpath, _dirs, files in os.walk(base):
+            if root == "." and dirpath != base:
+                continue
+            for f in files:
+                if f.endswith(".py") and f != "_lib.py":
+                    with open(os.path.join(dirpath, f)) as fh:
+                        if "po_set_device(" in fh.read():
+                            offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
