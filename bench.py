@@ -489,18 +489,24 @@ def main():
         try:
             import glob
             pdir = os.path.join(REPO, "profiles")
-            for pj in sorted(glob.glob(os.path.join(pdir, "r*_pmc_hbm*.json")), key=os.path.basename, reverse=True):   # newest round first
+            cands = []
+            for pj in glob.glob(os.path.join(pdir, "r*_pmc_hbm*.json")):
                 with open(pj) as f:
                     pm = json.load(f)
                 kks = [v for k, v in pm.get("kernels", {}).items() if k.startswith(MAIN_KERNEL)]
                 if not kks or not (T == 4000 and args.beam_width == 5):
                     continue
                 per_launch = float(pm.get("pairs_per_launch", 1250))
-                per_pair = (2.0 * kks[0]["FETCH_SIZE_KB_per_launch"] + kks[0]["WRITE_SIZE_KB_per_launch"]) * 1024.0 / per_launch
+                rnd = os.path.basename(pj).split("_")[0]
+                # newest round first, then the pass whose pairs per launch is closest to this run's (traffic per pair
+                # grows with the launch size: 34 x the algorithmic bytes at 1 250 pairs per launch, 43 x at 10 000)
+                cands.append((rnd, -abs(per_launch - P), pj, kks[0], per_launch))
+            if cands:
+                rnd, _, pj, kk, per_launch = sorted(cands, key=lambda c: (c[0], c[1]), reverse=True)[0]
+                per_pair = (2.0 * kk["FETCH_SIZE_KB_per_launch"] + kk["WRITE_SIZE_KB_per_launch"]) * 1024.0 / per_launch
                 traffic = per_pair * P
                 traffic_src = ("NOT measured in this run: %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at %d "
-                               "pairs per launch), scaled by pairs" % (os.path.relpath(pj, REPO), int(per_launch)))
-                break
+                               "pairs per launch; FETCH_SIZE x 2 on gfx950), scaled by pairs" % (os.path.relpath(pj, REPO), int(per_launch)))
         except Exception:
             pass
         out = {
