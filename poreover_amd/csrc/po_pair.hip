@@ -84,13 +84,25 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         if constexpr (NT == PO_WAVE) po_wave_sync();
         else __syncthreads();
     };
-    // block-wide inclusive prefix max of one int per thread
+    // block-wide inclusive prefix max of one int per thread.  Within the wave: data-parallel-primitive moves instead of
+    // six ds_bpermute round trips (this scan sits on the per-row dependency chain of the DP fill) — Hillis-Steele inside
+    // each row of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31
+    // into rows 2 and 3 (row_bcast:31); a lane without a source keeps the identity.
     auto block_prefix_max = [&](int v) {
+#ifdef PO_PP_SHFL_SCAN   // A/B switch: the permute form
 #pragma unroll
         for (int o = 1; o < PO_WAVE; o <<= 1) {
             const int t = __shfl_up(v, o);
             if (lane >= o) v = max(v, t);
         }
+#else
+        v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+        v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+        v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+        v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+        v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+        v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+#endif
         if (lane == PO_WAVE - 1) wsum[wave] = v;
         psync();
         int carry = INT_MIN;
