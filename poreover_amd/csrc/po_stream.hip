@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -398,6 +399,13 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
     }
     WavePlanner plan;
     plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n; plan.wave_pairs = p->wave_pairs; plan.wave_rows = p->wave_rows;
+    // (Tried: a job within the latency-bound regime of the pair beam kernel — <= 2 048 pairs, one GPU's share of a multi-GPU
+    //  job — cut into two waves whose kernels run side by side while the second uploads: 36.8 vs 36.9 ms for 1 250 pairs,
+    //  three waves on the two slots 60 ms.  The upload is not what such a job waits for.  PO_PIPELINE_SPLIT=1 still does it.)
+    {
+        static const int split_env = [] { const char* e = getenv("PO_PIPELINE_SPLIT"); return e ? atoi(e) : 0; }();
+        if (split_env > 0 && n >= 4) plan.wave_pairs = std::max(1, std::min(plan.wave_pairs, (n + 1) / 2));
+    }
     return pipeline_run(p, plan, c);
 }
 
