@@ -22,12 +22,15 @@
 // output rows; its final fix-up pass carries one scalar (prev_end) and runs from LDS.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "po_device.h"
 
 namespace {
 
 constexpr int NW_MATCH = 2, NW_MISMATCH = -1, NW_GAP = -1, NW_BAND = 500;
+// skewed-wavefront DP: cells per lane, columns per block (one wave), column blocks a basecall may span
+constexpr int SK_PER = 8, SK_BW = SK_PER * 64, SK_MAXB = 256, SK_SEG = 1024;
 
 struct PPArgs {
     const int64_t* y1_off; const int64_t* y2_off;  // U_i, V_i
@@ -42,6 +45,7 @@ struct PPArgs {
     long long seq_lds_cap;                          // bytes of dynamic LDS per basecall (0: read them from global memory)
     int mode;                                       // 0: align + skips + envelope; 1: align only; 2: envelope from a given alignment
     int retry_cap;                                  // second pass with the big DP slices: only the pairs the first one gave PO_E_CAP
+    int maps_increasing;                            // map1 / map2 come from the engine's own Viterbi basecalls: strictly increasing frames
     const int32_t* lenU; const int32_t* lenV;       // mode 2: U_i, V_i given explicitly (y*_off unused)
     const int64_t* map1_off; const int64_t* map2_off;  // mode 2: offsets of the frame maps
     char* aln_out1; char* aln_out2; const int64_t* aln_off; int32_t* ncol_out;  // mode 1 out / mode 2 in (forward order)
@@ -58,8 +62,10 @@ __device__ __forceinline__ int py_idx(int i, int len) { return i < 0 ? i + len :
 
 }  // namespace
 
-template <int NT>
+// SKEW (one-wave workgroups, banded alignment): the DP as a skewed wavefront — see the block comment at its code.
+template <int NT, bool SKEW>
 __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
+    static_assert(!SKEW || NT == PO_WAVE, "the skewed wavefront is a one-wave schedule");
     constexpr int PERMAX = (NT == 64) ? 16 : 8;  // consecutive DP cells per thread: a banded row (<= 1001 cells) fits one wave
     constexpr int NWAVES = NT / PO_WAVE;
     __shared__ int wsum[NWAVES];
@@ -67,7 +73,10 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
     __shared__ int lo_s[NT], hi_s[NT], pm[NT];
     // the DP row just filled, for the next row's reads: the fill never reads the table back from HBM (a
     // store -> barrier -> load round trip per row); the table is only written, for the trace-back
-    __shared__ int rowbuf[2][PERMAX * NT + 4];
+    __shared__ int rowbuf[2][SKEW ? 1 : PERMAX * NT + 4];
+    // SKEW: per column block of SK_BW columns, the rows it is walked over and where its flag rows start
+    __shared__ int blk_lo[SKEW ? SK_MAXB : 1], blk_hi[SKEW ? SK_MAXB : 1], blk_base[SKEW ? SK_MAXB : 1];
+    __shared__ unsigned char stepbuf[SKEW ? SK_SEG : 4];   // SKEW: the trace-back's steps (three bits each) before they become columns
     extern __shared__ __attribute__((aligned(16))) char seq_lds[];  // 2 x a.seq_lds_cap bytes: the two basecalls
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* dp = a.dp + (size_t)blockIdx.x * a.dp_cap;
@@ -206,6 +215,224 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             __syncthreads();
         } else {
 
+        if constexpr (SKEW) {
+        // ------------------------------------------------------------------ banded DP as a skewed wavefront
+        // Lane L owns the SK_PER columns [cb + 8 L, cb + 8 L + 8) of a block of SK_BW = 512 columns and, at step tau,
+        // fills row ilo + tau - L of them: the cell left of its strip was produced by lane L - 1 one step earlier (one
+        // wave_shr:1 move), the diagonal one two steps earlier (the value it fetched in the previous step), the row
+        // above is its own registers.  No scan, no LDS hand-over, no barrier: a row costs its 8 cells.  Cells outside
+        // a row's [start, end) hold 0, which is what SparseMatrix::get answers for them.  A basecall wider than one
+        // block is walked block by block (the rows whose band touches the block), the last column of a block handed
+        // to the next one through a small array.
+        //   The score table itself is never stored.  The trace-back (align.pyx:137-174) only asks, at a position
+        // (i, j), which of  cell(i-1,j-1) + score,  cell(i-1,j) + gap,  cell(i,j-1) + gap  equal their maximum — the
+        // operands of the fill at that position — so the fill stores those three bits per position (scored with the
+        // DEFAULT match / mismatch as the reference's trace-back does), for every position of every (row, block) it
+        // visits: one dword per lane and step, written coalesced in step order (slot = row - ilo + lane).  Visited are,
+        // per block, the rows i with end(i) >= cb and start(i-1) <= cb + 511, plus the row below the last one: every
+        // position with a computed neighbour.  Anywhere else the three neighbours read 0 and the walk decides from the
+        // two characters alone.
+        int nblocks = 0;
+        int* const flags = dp;
+        if (l1 >= 1 && l2 >= 1) {
+            const double ratio = (double)l2 / (double)l1;
+            auto row_s = [&](int i) -> int { const int c = (int)rint(ratio * (double)i); return max(c - a.band, 0); };
+            auto row_e = [&](int i) -> int {
+                const int c = (int)rint(ratio * (double)i);
+                const int s_ = max(c - a.band, 0), e_ = min(c + a.band, l2 - 1);
+                return e_ < s_ ? s_ : e_;
+            };
+            nblocks = row_e(l1 - 1) / SK_BW + 1;
+            if (nblocks > SK_MAXB) {
+                if (tid == 0) { a.status[pi] = PO_E_UNSUPPORTED; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
+                continue;
+            }
+            psync();
+            for (int b0 = 0; b0 < nblocks; b0 += PO_WAVE) {
+                const int b = b0 + lane;
+                if (b < nblocks) {
+                    const int cb = b * SK_BW;
+                    int lo = 0, hi = l1;        // first row in [0, l1] whose end reaches the block (row l1 counts as row l1 - 1)
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (row_e(min(mid, l1 - 1)) >= cb) hi = mid; else lo = mid + 1; }
+                    int lo2 = 0, hi2 = l1 + 1;  // first row in [0, l1 + 1) whose predecessor starts beyond the block
+                    while (lo2 < hi2) {
+                        const int mid = (lo2 + hi2) >> 1;
+                        if ((mid == 0 ? 0 : row_s(mid - 1)) > cb + SK_BW - 1) hi2 = mid; else lo2 = mid + 1;
+                    }
+                    blk_lo[b] = lo; blk_hi[b] = lo2 - 1;
+                }
+            }
+            psync();
+            if (lane == 0) {
+                long long acc = 0;
+                for (int b = 0; b < nblocks; ++b) { blk_base[b] = (int)acc; acc += blk_hi[b] - blk_lo[b] + 1 + (PO_WAVE - 1); }
+                sh[1] = (acc * PO_WAVE > a.dp_cap) ? 1 : 0;
+            }
+            psync();
+            if (sh[1]) {
+                if (tid == 0) { a.status[pi] = PO_E_CAP; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
+                continue;
+            }
+            PPTK(0);  // setup + block geometry
+            const bool dflt = (a.match == NW_MATCH && a.mismatch == NW_MISMATCH);
+            for (int b = 0; b < nblocks; ++b) {
+                const int cb = b * SK_BW, ilo = blk_lo[b], ihi = blk_hi[b], nr = ihi - ilo + 1;
+                int* const frow = flags + (size_t)blk_base[b] * PO_WAVE + lane;
+                int* const bout = r_start + (size_t)(b & 1) * 2 * a.row_cap;          // last column of this block, by row
+                const int* const bin = r_start + (size_t)((b & 1) ^ 1) * 2 * a.row_cap;  // ... of the previous block
+                const int plo = b > 0 ? blk_lo[b - 1] : 0, phi = b > 0 ? blk_hi[b - 1] : -1;
+                auto bin_val = [&](int i) -> int { return (i >= plo && i <= phi) ? bin[i] : 0; };
+                const int j0 = cb + lane * SK_PER;
+                int c2[SK_PER];
+#pragma unroll
+                for (int q = 0; q < SK_PER; ++q) c2[q] = s2[py_idx(min(j0 + q, l2) - 1, l2)];
+                int prev[SK_PER];
+#pragma unroll
+                for (int q = 0; q < SK_PER; ++q) prev[q] = 0;
+                int last = 0;                                        // this lane's newest right-most cell
+                int lfp = (lane == 0 && b > 0) ? bin_val(ilo - 1) : 0;  // what it fetched from its left in the previous step
+                int bch = 0, bnx = (b > 0) ? bin_val(ilo + lane) : 0;   // lane 0's left column, 64 rows per register
+                const bool wr_b = (b + 1 < nblocks) && lane == PO_WAVE - 1;
+                auto step = [&](auto DF, int tau, int i, int dg0, int lf) {
+                    constexpr bool DFLT = decltype(DF)::value;
+                    const bool real = i < l1;
+                    const int c = (int)rint(ratio * (double)min(i, l1 - 1));
+                    const int s_ = max(c - a.band, 0);
+                    int e_ = min(c + a.band, l2 - 1);
+                    if (e_ < s_) e_ = s_;
+                    const unsigned w_ = real ? (unsigned)(e_ - s_) : 0u;
+                    const int t0 = j0 - s_;
+                    const int c1 = s1[py_idx(i - 1, l1)];
+                    int diag = dg0, left = lf;
+                    unsigned acc = 0;
+#pragma unroll
+                    for (int q = 0; q < SK_PER; ++q) {
+                        const int up = prev[q];
+                        const bool eq = (c1 == c2[q]);
+                        const int d0 = diag + (eq ? a.match : a.mismatch);
+                        const int d1 = up + a.gap, d2 = left + a.gap;
+                        const int cm = max(d0, max(d1, d2));
+                        int e0 = d0, mx = cm;
+                        if constexpr (!DFLT) { e0 = diag + (eq ? NW_MATCH : NW_MISMATCH); mx = max(e0, max(d1, d2)); }
+                        // three "is not the maximum" bits per position, first pushed = highest
+                        acc = __builtin_amdgcn_alignbit(acc, (unsigned)(e0 - mx), 31);
+                        acc = __builtin_amdgcn_alignbit(acc, (unsigned)(d1 - mx), 31);
+                        acc = __builtin_amdgcn_alignbit(acc, (unsigned)(d2 - mx), 31);
+                        const int cell = ((unsigned)(t0 + q) < w_) ? cm : 0;
+                        diag = up; left = cell; prev[q] = cell;
+                    }
+                    last = left;
+                    frow[(size_t)tau * PO_WAVE] = (int)acc;
+                    if (wr_b) bout[i] = left;
+                };
+                for (int tau = 0; tau < nr + PO_WAVE - 1; ++tau) {
+                    int bval = 0;
+                    if (b > 0) {
+                        if ((tau & (PO_WAVE - 1)) == 0) { bch = bnx; bnx = bin_val(ilo + tau + PO_WAVE + lane); }
+                        bval = __builtin_amdgcn_readlane(bch, tau & (PO_WAVE - 1));
+                    }
+                    const int lf = __builtin_amdgcn_update_dpp(bval, last, 0x138, 0xf, 0xf, false);   // wave_shr:1; lane 0 keeps bval
+                    const int dg0 = lfp;
+                    lfp = lf;
+                    const int i = ilo + tau - lane;
+                    if (i >= ilo && i <= ihi) {
+                        if (dflt) step(std::true_type{}, tau, i, dg0, lf);
+                        else step(std::false_type{}, tau, i, dg0, lf);
+                    }
+                }
+            }
+        }
+        PPTK(1);  // fill
+        // ------------------------------------------------------------------ trace-back over the stored bits
+        // The walk only follows the bits: a batch is 84 rows x 3 flag words around the diagonal through the current
+        // position (four loads in flight, lane 3 k + p + 1 of load m holds row i - 21 m - k, words p = -1..1 around
+        // column j - 21 m - k), read back with v_readlane on scalar indices; every step appends its three bits to an
+        // LDS buffer and moves (i, j).  The alignment columns are written afterwards by all lanes at once: a step's
+        // position and first column are prefix sums over the steps before it.
+        {
+            int i = __builtin_amdgcn_readfirstlane(l1), j = __builtin_amdgcn_readfirstlane(l2);
+            const int cap = (int)a.aln_cap;
+            int ci = i, cj = j, cn = 0;     // position / column count at the start of the buffered steps
+            int nst = 0;
+            auto put = [&](int nn, char x, char y) { if (nn < cap) { al1[nn] = x; al2[nn] = y; } };
+            auto flush = [&]() {
+                psync();
+                for (int c0 = 0; c0 < nst; c0 += PO_WAVE) {
+                    const int f = (c0 + lane < nst) ? (int)stepbuf[c0 + lane] : 0;
+                    const int f0 = (f >> 2) & 1, f1 = (f >> 1) & 1, f2 = f & 1;
+                    const int mine = (f0 + f1) | ((f0 + f2) << 10) | ((f0 + f1 + f2) << 20);
+                    int v = mine;   // inclusive wave sum of the packed (rows, columns, alignment columns) moved
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+                    const int ex = v - mine;
+                    int ii = ci - (ex & 1023), jj = cj - ((ex >> 10) & 1023), nn = cn + (ex >> 20);
+                    if (f0) { ii--; jj--; put(nn++, s1[py_idx(ii, l1)], s2[py_idx(jj, l2)]); }
+                    if (f1) { ii--; put(nn++, s1[py_idx(ii, l1)], '-'); }
+                    if (f2) { jj--; put(nn++, '-', s2[py_idx(jj, l2)]); }
+                    const int tot = __builtin_amdgcn_readlane(v, PO_WAVE - 1);
+                    ci -= tot & 1023; cj -= (tot >> 10) & 1023; cn += tot >> 20;
+                }
+                nst = 0;
+                psync();
+            };
+            while (i > 0 && j > 0) {
+                const int I0 = i, J0 = j;
+                int fw[4];
+                unsigned long long vm[4];
+                {
+                    const int k = lane / 3, p = lane - 3 * k - 1;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int kk = 21 * m + k;
+                        const int Ik = I0 - kk, G = (max(J0 - kk, 0) >> 3) + p;
+                        bool valid = lane < 63 && Ik >= 0 && G >= 0 && (G >> 6) < nblocks;
+                        fw[m] = 0;
+                        if (valid) {
+                            const int b = G >> 6, lo = blk_lo[b];
+                            valid = Ik >= lo && Ik <= blk_hi[b];
+                            if (valid) { const int L = G & 63; fw[m] = flags[((size_t)blk_base[b] + (size_t)(Ik - lo + L)) * PO_WAVE + L]; }
+                        }
+                        vm[m] = __ballot(valid);
+                    }
+                }
+                for (;;) {
+                    const int k2 = I0 - i;
+                    if (k2 >= 84) break;
+                    const int pp = (j >> 3) - (max(J0 - k2, 0) >> 3);
+                    if (pp < -1 || pp > 1) break;
+                    const int m = k2 / 21, r = 3 * (k2 - 21 * m) + pp + 1;
+                    const unsigned long long vmm = m == 0 ? vm[0] : (m == 1 ? vm[1] : (m == 2 ? vm[2] : vm[3]));
+                    int t;   // f0 << 2 | f1 << 1 | f2
+                    if ((vmm >> r) & 1ull) {
+                        const int w = m == 0 ? __builtin_amdgcn_readlane(fw[0], r)
+                                             : (m == 1 ? __builtin_amdgcn_readlane(fw[1], r)
+                                                       : (m == 2 ? __builtin_amdgcn_readlane(fw[2], r) : __builtin_amdgcn_readlane(fw[3], r)));
+                        t = ~((unsigned)w >> (21 - 3 * (j & 7))) & 7;
+                    } else {   // no computed neighbour: 0 + score, 0 + gap, 0 + gap
+                        const int sc = (s1[py_idx(i - 1, l1)] == s2[py_idx(j - 1, l2)]) ? NW_MATCH : NW_MISMATCH;
+                        const int mx = max(sc, a.gap);
+                        t = __builtin_amdgcn_readfirstlane((sc == mx ? 4 : 0) | (a.gap == mx ? 3 : 0));
+                    }
+                    if (lane == 0) stepbuf[nst] = (unsigned char)t;
+                    nst++;
+                    i -= ((t >> 2) & 1) + ((t >> 1) & 1);
+                    j -= ((t >> 2) & 1) + (t & 1);
+                    if (nst == SK_SEG) flush();
+                    if (!(i > 0 && j > 0)) break;
+                }
+            }
+            flush();
+            // what is left of one sequence against gaps (align.pyx:168-174)
+            int n = cn;
+            if (i > 0) { for (int c = lane; c < i; c += PO_WAVE) put(n + c, s1[i - 1 - c], '-'); n += i; }
+            else if (j > 0) { for (int c = lane; c < j; c += PO_WAVE) put(n + c, '-', s2[j - 1 - c]); n += j; }
+            if (lane == 0) { sh[2] = n; sh[3] = (n > cap) ? 1 : 0; }
+        }
+        } else {
         // ------------------------------------------------------------------ DP row geometry
         // banded (align.pyx:119-125): center = int(np.round(l2 / l1 * i)); computed cells [start, end)
         // with end = min(center + band, l2 - 1); full: columns [0, l2] all computed
@@ -349,6 +576,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
 #undef PP_EMIT
             if (lane == 0) { sh[2] = n; sh[3] = ovf ? 1 : 0; }
         }
+        }  // !SKEW
         __syncthreads();
         ncol = sh[2];
         if (sh[3]) {
@@ -377,6 +605,75 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         }
 
         PPTK(2);  // trace-back + identity
+        if constexpr (SKEW) if (a.maps_increasing) {
+            // ------------------------------------------------------------------ envelope by base (envelope.py:46-87)
+            // add_block paints the frames of ONE base of read 1 — [map1[b], map1[b+1]) — per alignment column, with the
+            // frames of the column's base of read 2.  Along the alignment both base indices only grow and the frame maps
+            // of the Viterbi basecalls grow strictly, so the minimum start over a base's columns is its FIRST column's
+            // and the maximum end its LAST column's, and every frame of a base ends up with the same pair: two stores per
+            // base instead of two atomics per (column, frame).  The fix-up's state machine (prev_end moves only where a
+            // row starts beyond it) then needs one test per base — only a base's first frame can start beyond prev_end,
+            // the others start at or before its own end — and the rows are written once, final.
+            int* const blo = r_start;
+            int* const bhi = r_start + a.row_cap + 8;
+            int xbase = -1, ybase = -1;
+            for (int k0 = 0; k0 < ncol; k0 += PO_WAVE) {
+                const int k = k0 + lane;  // forward column index
+                const bool in = k < ncol;
+                const char ca = in ? al1[ncol - 1 - k] : '-', cb = in ? al2[ncol - 1 - k] : '-';
+                const char cn = (k + 1 < ncol) ? al1[ncol - 2 - k] : '-';
+                int tx, ty;
+                const int ex = block_excl_sum(ca != '-' ? 1 : 0, &tx);
+                const int ey = block_excl_sum(cb != '-' ? 1 : 0, &ty);
+                if (in) {
+                    const int xi = xbase + ex + (ca != '-' ? 1 : 0);
+                    const int yi = ybase + ey + (cb != '-' ? 1 : 0);
+                    const int i1 = min(max(xi, 0), l1 - 1), i2 = min(max(yi, 0), l2 - 1);
+                    const int i1p = min(max(xi - (ca != '-' ? 1 : 0), 0), l1 - 1);
+                    const int i1n = min(max(xi + (cn != '-' ? 1 : 0), 0), l1 - 1);
+                    if (k == 0 || i1p != i1) blo[i1] = m2[i2];
+                    if (k == ncol - 1 || i1n != i1) bhi[i1] = (i2 + 1 < l2) ? m2[i2 + 1] : V;
+                }
+                xbase += tx;
+                ybase += ty;
+            }
+            psync();
+            {   // frames before the first base: untouched rows (envelope.py:73-75 on the initial -1 / -1)
+                const int f0 = min(m1[0], U);
+                int lo = 0, hi = min(V, -1 + a.padding);
+                if (lo > hi) lo = 0;
+                for (int u = lane; u < f0; u += PO_WAVE) { env[2 * u] = lo; env[2 * u + 1] = hi; }
+            }
+            int pe_ = 0;
+            for (int b0 = 0; b0 < l1; b0 += PO_WAVE) {
+                const int b = b0 + lane;
+                const bool in = b < l1;
+                int lo = 0, hi = 0, r0 = 0, r1 = 0;
+                if (in) {
+                    lo = max(0, blo[b] - a.padding);
+                    hi = min(V, bhi[b] + a.padding);
+                    if (lo > hi) lo = 0;
+                    r0 = m1[b];
+                    r1 = min((b + 1 < l1) ? m1[b + 1] : U, U);
+                }
+                int lo_first = lo, pos = 0;
+                for (;;) {
+                    const unsigned long long mk = __ballot(in && r0 < r1 && lane >= pos && lo_first > pe_);
+                    if (mk == 0ull) break;
+                    const int qs = __builtin_ctzll(mk);
+                    if (lane == qs) lo_first = pe_;
+                    pe_ = __builtin_amdgcn_readlane(hi, qs);
+                    pos = qs + 1;
+                }
+                for (int u = r0; u < r1; ++u) { env[2 * u] = (u == r0) ? lo_first : lo; env[2 * u + 1] = hi; }
+            }
+            if (tid == 0) { a.status[pi] = PO_OK; if (a.identity) a.identity[pi] = identity; }
+            PPTK(3);  // envelope
+#ifdef PO_PP_TIMING
+            if (tid == 0 && pi == 0) printf("[pp timing] pair 0: setup %lld fill %lld traceback %lld envelope %lld ticks (10 ns)\n", tk_[0], tk_[1], tk_[2], tk_[3]);
+#endif
+            continue;
+        }
         // ------------------------------------------------------------------ envelope (envelope.py:46-87)
         for (int u = tid; u < U; u += NT) { env[2 * u] = INT_MAX; env[2 * u + 1] = -1; }
         __syncthreads();
@@ -472,13 +769,28 @@ void pp_launch(PPArgs a, int blocks, int one_wave, hipStream_t stream) {
     if (cap > 24 * 1024) cap = 0;
     a.seq_lds_cap = cap;
     const size_t lds = (size_t)(2 * cap);
-    if (one_wave) hipLaunchKernelGGL(pair_prep_kernel<64>, dim3(blocks), dim3(64), lds, stream, a);
-    else hipLaunchKernelGGL(pair_prep_kernel<256>, dim3(blocks), dim3(256), lds, stream, a);
+    // banded alignment on one-wave workgroups: the skewed wavefront (PO_PP_LEGACY=1: the row-at-a-time fill with
+    // the stored score table, kept for A/B runs and for basecalls beyond SK_MAXB column blocks)
+    const char* lg = getenv("PO_PP_LEGACY");
+    const bool legacy = lg != nullptr && atoi(lg) != 0;
+    const bool skew = one_wave && !a.full_alignment && a.mode != 2 && !legacy && a.row_cap <= (long long)SK_MAXB * SK_BW;
+    if (skew) hipLaunchKernelGGL((pair_prep_kernel<64, true>), dim3(blocks), dim3(64), lds, stream, a);
+    else if (one_wave) hipLaunchKernelGGL((pair_prep_kernel<64, false>), dim3(blocks), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((pair_prep_kernel<256, false>), dim3(blocks), dim3(256), lds, stream, a);
 }
 }  // namespace
 
 namespace {
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+
+// ints of DP slice the skewed-wavefront kernel needs for basecalls of at most l1 x l2 bases: one flag row of 64 dwords
+// per (row, column block) pair it visits plus the 63 drain steps of every block.  A row's visited columns
+// [start(i-1), end(i)] span at most 2 band + 1 cells plus the band's move from one row to the next (l2 in all).
+inline size_t pp_skew_cells(int64_t l1, int64_t l2, int64_t band) {
+    const int64_t nb = l2 / SK_BW + 1;
+    const int64_t rows = 2 * (l1 + 1) + ((l1 + 1) * (2 * band + 1) + l2) / SK_BW + 1 + nb;
+    return (size_t)(64 * (rows + 63 * nb));
+}
 
 struct PPGeom {
     int blocks, one_wave;
@@ -529,6 +841,7 @@ PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.row_cap = (size_t)(lmax1 + 1);
     const int64_t width = opt->full_alignment ? (lmax2 + 1) : std::min<int64_t>(lmax2 + 1, 2 * NW_BAND + 1);
     g.dp_cap = (size_t)((lmax1 + 1) * width);
+    if (g.one_wave) g.dp_cap = std::max(g.dp_cap, pp_skew_cells(lmax1, lmax2, NW_BAND));
     g.aln_cap = (size_t)(lmax1 + lmax2 + 16);
     {   // the first pass's slices within 1/16 of the board's memory (very long reads: fewer workgroups)
         const size_t per_block = sizeof(int) * g.dp_cap + sizeof(int) * 4 * g.row_cap + 2 * g.aln_cap;
@@ -540,6 +853,7 @@ PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
         g.big_row_cap = (size_t)(b1 + 1);
         const int64_t bw = opt->full_alignment ? (b2 + 1) : std::min<int64_t>(b2 + 1, 2 * NW_BAND + 1);
         g.big_dp_cap = (size_t)((b1 + 1) * bw);
+        if (g.one_wave) g.big_dp_cap = std::max(g.big_dp_cap, pp_skew_cells(b1, b2, NW_BAND));
         g.big_aln_cap = (size_t)(b1 + b2 + 16);
         const size_t per_block = sizeof(int) * g.big_dp_cap + sizeof(int) * 4 * g.big_row_cap + 2 * g.big_aln_cap;
         const size_t fit = ((size_t)2 << 30) / std::max<size_t>(per_block, 1);     // 2 GB for the pass; at least one slice
@@ -628,6 +942,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     a.padding = opt->padding; a.full_alignment = opt->full_alignment;
     a.diagonal_envelope = opt->diagonal_envelope; a.diagonal_width = opt->diagonal_width;
     a.band = NW_BAND; a.mode = 0; a.retry_cap = 0;
+    a.maps_increasing = (ext_map1 && ext_map2) ? 0 : 1;
     a.match = NW_MATCH; a.mismatch = NW_MISMATCH; a.gap = NW_GAP;
     a.lenU = a.lenV = nullptr; a.map1_off = a.map2_off = nullptr; a.aln_out1 = a.aln_out2 = nullptr;
     a.aln_off = nullptr; a.ncol_out = nullptr; a.env_off = nullptr;
@@ -690,7 +1005,9 @@ extern "C" int po_launch_pair_decode(const double* y1, const int64_t* y1_off, co
 extern "C" size_t po_align_ws_bytes(int n, int64_t max_len1, int64_t max_len2, int band) {
     const int blocks = std::min(n > 0 ? n : 1, pp_num_cus() * 4);
     const int64_t width = band > 0 ? std::min<int64_t>(max_len2 + 1, 2 * (int64_t)band + 1) : max_len2 + 1;
-    return 256 + al256(sizeof(int) * (size_t)((max_len1 + 1) * width) * blocks) + al256(sizeof(int) * 4 * (size_t)(max_len1 + 2) * blocks) +
+    size_t cells = (size_t)((max_len1 + 1) * width);
+    if (band > 0) cells = std::max(cells, pp_skew_cells(max_len1, max_len2, band));
+    return 256 + al256(sizeof(int) * cells * blocks) + al256(sizeof(int) * 4 * (size_t)(max_len1 + 2) * blocks) +
            al256(2 * (size_t)(max_len1 + max_len2 + 16) * blocks) + 256;
 }
 
@@ -721,7 +1038,9 @@ extern "C" int po_launch_align_scores(const char* seqs, const int64_t* seq_off, 
     a.aln_out1 = aln1; a.aln_out2 = aln2; a.aln_off = aln_off; a.ncol_out = ncol; a.status = status;
     size_t o = 0;
     a.queue = (int*)(w + o); o += 256;
-    a.dp_cap = (long long)((max_len1 + 1) * width); a.dp = (int*)(w + o); o += al256(sizeof(int) * (size_t)a.dp_cap * blocks);
+    a.dp_cap = (long long)((max_len1 + 1) * width);
+    if (band > 0) a.dp_cap = std::max<long long>(a.dp_cap, (long long)pp_skew_cells(max_len1, max_len2, band));
+    a.dp = (int*)(w + o); o += al256(sizeof(int) * (size_t)a.dp_cap * blocks);
     a.row_cap = (long long)(max_len1 + 2); a.rowinfo = (int*)(w + o); o += al256(sizeof(int) * 4 * (size_t)a.row_cap * blocks);
     a.aln_cap = (long long)(max_len1 + max_len2 + 16); a.aln = w + o;
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
