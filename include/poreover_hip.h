@@ -86,6 +86,9 @@ int po_device_info(int device, char* name, int name_cap, int* compute_units, int
 #define PO_ROUTE_LEGACY 2
 #define PO_ROUTE_RING 3
 int po_set_pair_route(int route, int defer_odd);
+/* test / tuning hook: legacy != 0 -> the banded aligner (align.pyx:100-178) runs the row-at-a-time kernel that stores the
+ * score table instead of the skewed-wavefront kernel.  Process-wide; results are identical. */
+int po_set_align_route(int legacy);
 
 /* ---- trace ingest ------------------------------------------------------------------------------
  * replaces decode.logit_to_log_likelihood (decode.py:34-39), the uint8 trace scaling of

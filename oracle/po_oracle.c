@@ -205,6 +205,9 @@ static void tree_update(tree_t* tr, int n, int d, int t) {
         double emit_state = P(par, d, 0, t - 1) + yt[last];
         double stay_state = P(n, d, 0, t - 1) + yt[A];
         double v = LAE(emit_state, stay_state);
+#ifdef PO_ORACLE_TRACE_NODE
+        if (n == PO_ORACLE_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g\n", n, d, t, v, P(par, d, 0, t - 1), P(n, d, 0, t - 1));
+#endif
         node_set(tr, n, d, t, &v);
     } else if (tr->model == PO_MODEL_MERGE) {
         double gap_prob = P(n, d, 0, t - 1) + yt[A];
@@ -602,6 +605,10 @@ static int beam2d_row_col(tree_t* tr, beam_t* beam, const int* env, int U, int V
             for (int b = 0; b < beam->n; ++b) tree_update(tr, beam->el[b], 0, u_);
         for (int v_ = row_start; v_ < row_end; ++v_)
             for (int b = 0; b < beam->n; ++b) tree_update(tr, beam->el[b], 1, v_);
+#ifdef PO_ORACLE_TRACE   /* scratch builds only (scripts/trace_rowcol.py): every candidate's score before the prune */
+        for (int b = 0; b < beam->n; ++b)
+            printf("T %d %d %d %.17g\n", u, v, beam->el[b], node_score(tr, beam->el[b], SCORE_ROW_COL));
+#endif
         if (beam_prune(beam, tr, SCORE_ROW_COL) || tr->oom) { rc = PO_E_NOMEM; goto done; }
 #ifdef PO_ORACLE_STATS
         {

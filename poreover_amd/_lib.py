@@ -51,6 +51,7 @@ PROTOTYPES = {
     "po_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_size_t)]),
     "po_set_pair_route": (C.c_int, [C.c_int, C.c_int]),
+    "po_set_align_route": (C.c_int, [C.c_int]),
     "po_ingest_batch": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _dp, _vp]),
     "po_ingest_batch_h": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _dp]),
     "po_viterbi_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int]),
@@ -187,6 +188,11 @@ ROUTES = {"auto": 0, "x2": 1, "legacy": 2, "ring": 3}
 def set_pair_route(route="auto", defer_odd=False):
     """test / tuning hook (po_set_pair_route): which kernel serves the pair beam search"""
     check(load(False).po_set_pair_route(ROUTES[route], 1 if defer_odd else 0), "po_set_pair_route")
+
+
+def set_align_route(legacy=False):
+    """test / tuning hook (po_set_align_route): the banded aligner on its row-at-a-time kernel (True) or the skewed wavefront"""
+    check(load(False).po_set_align_route(1 if legacy else 0), "po_set_align_route")
 
 
 def check(rc, what):

@@ -1342,7 +1342,9 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             const long long need = 1 + A + (long long)A * max(W, A) * ((long long)min(U, V) + 1);
             if (need > a.arena_cap || need >= (1 << 24)) st = PO_E_NOMEM;
             // too few row groups for this window width here, or (test hook) odd pairs: beam2d_kernel takes it
-            else if (min((long long)a.ngl, ng) < 8 * max(W, PO_A) || (a.defer_odd && (pi & 1))) R = X2_DEFERRED;
+            // ... or an envelope whose row starts / ends move backwards, for a kernel that builds on windows that only
+            // move forward (what build_envelope makes; anything else is a caller's own array)
+            else if (min((long long)a.ngl, ng) < 8 * max(W, PO_A) || (a.defer_odd && (pi & 1)) || (a.need_mono && !mono)) R = X2_DEFERRED;
         }
     }
     // blank prefix sums = the CTC root's alpha (PrefixTree.h:509-515): serial in t so the rounding is the
@@ -3008,6 +3010,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.dbg = nullptr;
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
+        a.need_mono = 1;
         a.wgstate = (unsigned long long*)(w + g.off_state);
         a.magic = g.magic;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
@@ -3047,6 +3050,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.dbg = nullptr;
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
+        a.need_mono = 0;
 #ifdef PO_B2_TIMING
         static long long* dbg_x2 = nullptr;
         if (!dbg_x2) (void)hipMalloc((void**)&dbg_x2, 12 * sizeof(long long));

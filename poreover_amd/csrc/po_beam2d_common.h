@@ -132,6 +132,7 @@ struct X2Args {
     int* arena; long long arena_cap;  // per half-wave: 3 int arrays
     long long* dbg;
     int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
+    int need_mono;                    // the main kernel takes monotone envelopes only (beam2d_ring_kernel): others are deferred
     int pre_vcols;                    // pre-pass: columns its LDS table holds
     int ngl;                          // row groups the main kernel tracks per pair
     unsigned long long* upd_count;    // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}

@@ -408,6 +408,9 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                             const double* yrow = yb_ + (tn & (RG_NY - 1)) * RG_YC;
                             nya = yrow[sym]; nyb = yrow[A]; npp = ringp[(t & (RG_RL - 1)) * RG_NRP];   // (one past the end: read, never used)
                             const double out = lae(pp + ya, self + yb);
+#ifdef PO_RING_TRACE_NODE
+                            if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P1\n", e_id, r, t, out, pp, self);
+#endif
                             ringm[(t & (RG_RL - 1)) * RG_NRP] = out;
                             if (out > self) tr = t;   // the last time a value rose
                             self = out;
@@ -433,6 +436,9 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                         double pp = ringp[(tm & (RG_RL - 1)) * RG_NRP];
                         if (e_ps < 0) pp = (tm == fz_t) ? fz_val : PO_NEG_INF;
                         const double out = lae(pp + ya, self + yb);
+#ifdef PO_RING_TRACE_NODE
+                        if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P2 ps %d fzt %d\n", e_id, r, t, out, pp, self, e_ps, fz_t);
+#endif
                         ringm[(t & (RG_RL - 1)) * RG_NRP] = out;
                         if (out > self) tr = t;
                         self = out;
@@ -474,6 +480,9 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                                 pp = t2_read(e_prow2, e_par, tm);
                             }
                             const double out = lae(pp + ya, self + yb);
+#ifdef PO_RING_TRACE_NODE
+                            if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g G ps %d fzt %d main %d\n", e_id, r, t, out, pp, self, e_ps, fz_t, (int)is_main);
+#endif
                             double* slot = &sm.ring[r][t & (RG_RL - 1)][e_lrow];
                             if (t >= v_hiw) {
                                 const int to = t - RG_RL;
@@ -638,8 +647,8 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             // else what was captured when it stopped being one
             double c_val;
             int c_t;
+            const int op = __shfl(e_ps, gsrc);                     // the parent's slot in the old table (or ROOT / FROZEN)
             {
-                const int op = __shfl(e_ps, gsrc);                 // the parent's slot in the old table (or ROOT / FROZEN)
                 const int opl = hb | max(op, 0);
                 const int o_hiw = __shfl(v_hiw, opl), o_fresh = __shfl(v_fresh, opl), o_lrow = __shfl(e_lrow, opl);
                 const double q_val = __shfl(fz_val, gsrc);
@@ -688,6 +697,28 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                     }
             }
             e_ps = n_ps;
+            // ---- G. a frozen parent that is an element again.  A beam node whose parent had left the table computed its
+            // newest values against "absent" (-inf beyond the parent's last time).  When the grandparent enters the beam the
+            // parent comes back as one of its children, computes its whole window — times it never had — and the
+            // reference's step, which recomputes every window in full, then gives the node (and everything below it)
+            // different values over the part of the window it already had.  Those elements go back to the window start;
+            // the part before it is what both sides keep.  (Everybody else's inputs are unchanged: skipping their old
+            // times rewrites nothing.)
+            {
+                bool rew = rb && nlive && src >= 0 && op == PS_FROZEN && n_ps >= 0;
+                if (__ballot(rew) != 0ull) {
+                    for (int it = 0; it < W; ++it) {   // ... and their descendants in the table, generation by generation
+                        const bool prew = __shfl((int)rew, hb | max(e_ps, 0)) != 0;
+                        if (live && e_ps >= 0 && prew) rew = true;
+                    }
+                    const int wsn = r ? nv : nu;
+                    if (rew && live && v_fresh == 0 && v_done > wsn) {
+                        v_self = read_own(wsn - 1);
+                        v_done = wsn;
+                        v_lo = min(v_lo, wsn);   // (a window start that moved back: the times from it on are this incarnation's again)
+                    }
+                }
+            }
             c_plrow = __shfl(e_lrow, hb | max(e_ps, 0));
             tbl_fresh = __ballot(live && v_fresh != 0) != 0ull;
             have_children = true;
@@ -724,6 +755,9 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             // node_greater_max_sym: max over read 0's window + max over read 1's
             const double sc = smx + __shfl_xor(smx, 32);
             const bool cand = live;
+#ifdef PO_RING_TRACE   // debugging builds only (scripts/trace_rowcol.py): every candidate's score before the prune
+            if (pi == 0 && cand && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
+#endif
             // ---- prune (Beam.h:93-108).  Most steps keep the beam as it is: iff the beam nodes are still in order and the
             // last of them still beats every child (strictly: exact ties go the full way, as partial_sort decides them)
             bool viol = (nb != W);

@@ -21,6 +21,7 @@
 // three independent L2 loads per step).  The envelope is built with integer atomics on the
 // output rows; its final fix-up pass carries one scalar (prev_end) and runs from LDS.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -762,6 +763,22 @@ int po_launch_beam2d_geom(const double*, const int64_t*, const double*, const in
 void po_prof_stage(int kernel, hipStream_t s, int begin, void** tok);
 }
 
+// which kernel aligns with a band: process-wide like po_set_pair_route, initial value from PO_PP_LEGACY (read once)
+static std::atomic<int> g_pp_legacy{-1};
+extern "C" int po_set_align_route(int legacy) {
+    g_pp_legacy.store(legacy ? 1 : 0);
+    return PO_OK;
+}
+static bool pp_legacy() {
+    int v = g_pp_legacy.load();
+    if (v < 0) {
+        const char* e = getenv("PO_PP_LEGACY");
+        v = (e != nullptr && atoi(e) != 0) ? 1 : 0;
+        g_pp_legacy.store(v);
+    }
+    return v != 0;
+}
+
 namespace {
 void pp_launch(PPArgs a, int blocks, int one_wave, hipStream_t stream) {
     // dynamic LDS for the two basecalls, when they fit (row_cap bounds their length)
@@ -769,10 +786,9 @@ void pp_launch(PPArgs a, int blocks, int one_wave, hipStream_t stream) {
     if (cap > 24 * 1024) cap = 0;
     a.seq_lds_cap = cap;
     const size_t lds = (size_t)(2 * cap);
-    // banded alignment on one-wave workgroups: the skewed wavefront (PO_PP_LEGACY=1: the row-at-a-time fill with
-    // the stored score table, kept for A/B runs and for basecalls beyond SK_MAXB column blocks)
-    const char* lg = getenv("PO_PP_LEGACY");
-    const bool legacy = lg != nullptr && atoi(lg) != 0;
+    // banded alignment on one-wave workgroups: the skewed wavefront (po_set_align_route(1) / PO_PP_LEGACY=1: the
+    // row-at-a-time fill with the stored score table, kept for A/B runs and for basecalls beyond SK_MAXB column blocks)
+    const bool legacy = pp_legacy();
     const bool skew = one_wave && !a.full_alignment && a.mode != 2 && !legacy && a.row_cap <= (long long)SK_MAXB * SK_BW;
     if (skew) hipLaunchKernelGGL((pair_prep_kernel<64, true>), dim3(blocks), dim3(64), lds, stream, a);
     else if (one_wave) hipLaunchKernelGGL((pair_prep_kernel<64, false>), dim3(blocks), dim3(64), lds, stream, a);

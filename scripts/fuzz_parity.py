@@ -208,7 +208,11 @@ def main():
             if not ok:
                 bad += 1
                 print("MISMATCH", dict(model=model, method=method, W=W, style=style, U=len(y1s[i]), V=len(y2s[i]),
-                                        status=(c, wc), got=g[:40], want=ws[:40]), flush=True)
+                                        status=(c, wc), got=g[:40], want=ws[:40], round=rounds, index=i, n=n), flush=True)
+                if bad <= 8:   # the case itself, for a replay (scripts/fuzz_replay.py)
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.savez_compressed("gpurun_out/fuzz_fail_%d_%d.npz" % (args.seed, bad), y1=y1s[i], y2=y2s[i], env=envs[i], W=W,
+                                        model=model, method=method, got=g, want=ws, status=np.array([c, wc]), index=i, n=n)
         rounds += 1; pairs += n
     pool.terminate()
     print("fuzz: %d rounds, %d pairs, %d mismatches, %d refused by the engine (PO_E_NOMEM / PO_E_UNSUPPORTED) where the "

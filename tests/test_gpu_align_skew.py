@@ -1,10 +1,8 @@
 """The banded aligner's skewed-wavefront kernel (pair_prep_kernel<64, true>: no score table, three trace-back bits per
 position) against the oracle's restatement of align.global_pair_banded (align/align.pyx:100-178) and against the
-row-at-a-time kernel it replaces (PO_PP_LEGACY=1), over the geometries that exercise its parts: one and several
+row-at-a-time kernel it replaces (po_set_align_route(1)), over the geometries that exercise its parts: one and several
 512-column blocks, bands narrower than the sequences (positions left of / right of / below the computed cells),
 unequal lengths, non-default scores (the trace-back keeps the defaults), degenerate sequences."""
-import os
-
 import numpy as np
 import pytest
 
@@ -48,15 +46,12 @@ def _cases(seed):
 
 
 def _run(pairs, band, scores, legacy):
-    from poreover_amd import batch
-    if legacy:
-        os.environ["PO_PP_LEGACY"] = "1"
-    else:
-        os.environ.pop("PO_PP_LEGACY", None)
+    from poreover_amd import batch, _lib
+    _lib.set_align_route(legacy)
     try:
         return batch.align_batch(pairs, band_width=band, match=scores[0], mismatch=scores[1], gap_cost=scores[2])
     finally:
-        os.environ.pop("PO_PP_LEGACY", None)
+        _lib.set_align_route(False)
 
 
 @pytest.mark.parametrize("band", [500, 64, 17, 3, 1])

@@ -281,3 +281,28 @@ def test_noise_only_pairs_consensus_beats_single_reads(eng, oracle):
         json.dump({"pairs": len(seeds), "T": 1500, "beam_width": 5, "method": "row_col", "workload": "synth_pair_noise: one "
                    "sequence, two renderings with independent noise (peak 5.0 over sigma 1.6), no mutations",
                    "engine_vs_oracle_edits": edits, "oracle_consensus_bases": bases, "identity_vs_truth": summary}, f, indent=1)
+
+
+def test_saved_fuzz_cases_on_every_route(eng, oracle):
+    """Cases the open-ended fuzz runs found (tests/golden/fuzz_cases/*.npz: inputs + the oracle's answer, checked against the
+    compiled reference when they were saved).  seed21_stairs_W5: a beam node whose frozen parent becomes an element again —
+    everything below it recomputes its window; seed21_bursts_W4: an envelope whose row ends move backwards (values of an
+    earlier incarnation beyond a node's last time) — the ring kernel hands such envelopes to beam2d_kernel."""
+    import glob
+    import os
+    from poreover_amd import _lib, batch
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fuzz_cases", "*.npz")))
+    assert files
+    try:
+        for f in files:
+            d = np.load(f, allow_pickle=True)
+            y1, y2, env = d["y1"], d["y2"], d["env"]
+            W, model, method = int(d["W"]), str(d["model"]), str(d["method"])
+            want = oracle.cpp_beam_search_2d(y1, y2, env, W, model_=model, method_=method)
+            assert want == str(d["want"])
+            for route in ("auto", "legacy", "x2", "ring"):
+                _lib.set_pair_route(route)
+                got = batch.beam_search_2d_batch([y1], [y2], [env], W, model=model, method=method)
+                assert got[0] == want, (os.path.basename(f), route)
+    finally:
+        _lib.set_pair_route("auto")
