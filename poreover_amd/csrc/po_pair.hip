@@ -47,6 +47,7 @@ struct PPArgs {
     int mode;                                       // 0: align + skips + envelope; 1: align only; 2: envelope from a given alignment
     int retry_cap;                                  // second pass with the big DP slices: only the pairs the first one gave PO_E_CAP
     int maps_increasing;                            // map1 / map2 come from the engine's own Viterbi basecalls: strictly increasing frames
+    int* cap_flag;                                  // set by the first pass when a pair gets PO_E_CAP: the second pass returns at once otherwise
     const int32_t* lenU; const int32_t* lenV;       // mode 2: U_i, V_i given explicitly (y*_off unused)
     const int64_t* map1_off; const int64_t* map2_off;  // mode 2: offsets of the frame maps
     char* aln_out1; char* aln_out2; const int64_t* aln_off; int32_t* ncol_out;  // mode 1 out / mode 2 in (forward order)
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         return base + inc - v;
     };
 
+    if (a.retry_cap && *a.cap_flag == 0) return;   // nothing was left over (the usual case): not one queue round trip
     for (;;) {
         __syncthreads();
         if (tid == 0) sh[0] = atomicAdd(a.queue, 1);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         const int nrows = full ? l1 + 1 : l1;
         if (st == PO_OK && a.mode != 2 && (nrows > a.row_cap || (long long)l1 + l2 + 8 > a.aln_cap)) st = PO_E_CAP;
         if (st != PO_OK) {
-            if (tid == 0) { a.status[pi] = st; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
+            if (tid == 0) { a.status[pi] = st; if (st == PO_E_CAP) *a.cap_flag = 1; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
             continue;
         }
         int ncol = 0;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
             }
             psync();
             if (sh[1]) {
-                if (tid == 0) { a.status[pi] = PO_E_CAP; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
+                if (tid == 0) { a.status[pi] = PO_E_CAP; *a.cap_flag = 1; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
                 continue;
             }
             PPTK(0);  // setup + block geometry
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         }
         __syncthreads();
         if (sh[1]) {
-            if (tid == 0) { a.status[pi] = PO_E_CAP; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
+            if (tid == 0) { a.status[pi] = PO_E_CAP; *a.cap_flag = 1; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
             continue;
         }
         // SparseMatrix<int>::get (SparseMatrix.h:51-57,108-115): default 0 outside the computed cells
@@ -581,14 +583,14 @@ __global__ __launch_bounds__(NT) void pair_prep_kernel(PPArgs a) {
         __syncthreads();
         ncol = sh[2];
         if (sh[3]) {
-            if (tid == 0) { a.status[pi] = PO_E_CAP; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
+            if (tid == 0) { a.status[pi] = PO_E_CAP; *a.cap_flag = 1; if (a.identity) a.identity[pi] = 0.0; if (a.mode == 1) a.ncol_out[pi] = 0; }
             continue;
         }
         }  // mode != 2
         if (a.mode == 1) {  // alignment only: forward order out
             const int64_t ao = a.aln_off[pi];
             const int capo = (int)(a.aln_off[pi + 1] - ao);
-            if (ncol > capo) { if (tid == 0) { a.status[pi] = PO_E_CAP; a.ncol_out[pi] = 0; } continue; }
+            if (ncol > capo) { if (tid == 0) { a.status[pi] = PO_E_CAP; *a.cap_flag = 1; a.ncol_out[pi] = 0; } continue; }
             for (int k = tid; k < ncol; k += NT) { a.aln_out1[ao + k] = al1[ncol - 1 - k]; a.aln_out2[ao + k] = al2[ncol - 1 - k]; }
             if (tid == 0) { a.ncol_out[pi] = ncol; a.status[pi] = PO_OK; }
             continue;
@@ -964,6 +966,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     a.aln_off = nullptr; a.ncol_out = nullptr; a.env_off = nullptr;
     a.env = env; a.identity = identity; a.status = status;
     a.queue = (int*)(w + g.off_queue);
+    a.cap_flag = a.queue + 32;   // (inside the 256 bytes cleared below)
     a.dp = (int*)(w + g.off_dp); a.dp_cap = (long long)g.dp_cap;
     a.rowinfo = (int*)(w + g.off_rows); a.row_cap = (long long)g.row_cap;
     a.aln = w + g.off_aln; a.aln_cap = (long long)g.aln_cap;
@@ -1054,6 +1057,7 @@ extern "C" int po_launch_align_scores(const char* seqs, const int64_t* seq_off, 
     a.aln_out1 = aln1; a.aln_out2 = aln2; a.aln_off = aln_off; a.ncol_out = ncol; a.status = status;
     size_t o = 0;
     a.queue = (int*)(w + o); o += 256;
+    a.cap_flag = a.queue + 32;
     a.dp_cap = (long long)((max_len1 + 1) * width);
     if (band > 0) a.dp_cap = std::max<long long>(a.dp_cap, (long long)pp_skew_cells(max_len1, max_len2, band));
     a.dp = (int*)(w + o); o += al256(sizeof(int) * (size_t)a.dp_cap * blocks);
@@ -1087,6 +1091,7 @@ extern "C" int po_launch_envelope(const char* aln1, const char* aln2, const int6
     a.map1 = map1; a.map1_off = map1_off; a.map2 = map2; a.map2_off = map2_off; a.lenU = U; a.lenV = V;
     a.env = env; a.env_off = env_off; a.status = status;
     a.queue = (int*)w;
+    a.cap_flag = a.queue + 32;
     a.aln_cap = (long long)(max_ncol + 16); a.aln = w + 256;
     a.dp = nullptr; a.dp_cap = 0; a.rowinfo = (int*)w; a.row_cap = 0;
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
