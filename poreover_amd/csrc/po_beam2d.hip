@@ -187,7 +187,10 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
     for (;;) {
         // ---------------------------------------------------------------- next pair from the queue
         __syncthreads();
-        if (tid == 0) sm.sh[0] = atomicAdd(a.queue, 1);
+        if (tid == 0) {
+            const int q = atomicAdd(a.queue, 1);
+            sm.sh[0] = (a.order != nullptr && q < a.n) ? a.order[q] : q;   // longest pairs first (pair_order_kernel)
+        }
         __syncthreads();
         const int pi = sm.sh[0];
         if (pi >= a.n) break;
@@ -2494,7 +2497,7 @@ namespace {
 struct B2Geom {
     int threads, blocks, wclass;
     size_t pool_bytes, arena_cap, tcap, vcap;
-    size_t off_queue, off_state, off_pool, off_arena, off_cum, off_envt, total;
+    size_t off_queue, off_state, off_pool, off_arena, off_cum, off_envt, off_order, total;
     unsigned long long magic;
 };
 inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
@@ -2586,8 +2589,53 @@ B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method
               ((unsigned long long)g.wclass << 32) ^ ((unsigned long long)K << 36);
     g.off_cum = o; o += al256(sizeof(double) * 2 * g.tcap * g.blocks);
     g.off_envt = o; o += al256(sizeof(int) * 2 * g.vcap * g.blocks);
+    g.off_order = o; o += al256(sizeof(int) * (size_t)std::max(n, 1));   // the queue's order (pair_order_kernel)
     g.total = o + 256;
     return g;
+}
+
+// The order in which a launch's persistent workgroups take their pairs: longest first (frames of both reads, 2048
+// classes, descending; within a class as the atomics fall).  The tail of a launch — the last pair of every workgroup,
+// running on a half-empty device — is then made of the SHORTEST pairs instead of whatever came last in the input:
+// worth a few percent on the bench's pairs (lengths within 10 %), most of the tail on real reads, whose lengths differ
+// tenfold.  Results do not depend on it (every pair is decoded by one workgroup, alone).  One workgroup: a histogram,
+// its prefix sums and a scatter, all in LDS.
+constexpr int ORD_BINS = 2048;
+__global__ __launch_bounds__(1024) void pair_order_kernel(const int64_t* y1_off, const int64_t* y2_off, int n, int* order) {
+    __shared__ int hist[ORD_BINS];
+    __shared__ int part[1024 / 64];
+    __shared__ long long cmax_s;
+    const int tid = threadIdx.x;
+    for (int b = tid; b < ORD_BINS; b += 1024) hist[b] = 0;
+    if (tid == 0) cmax_s = 1;
+    __syncthreads();
+    long long cm = 1;
+    for (int i = tid; i < n; i += 1024) cm = max(cm, (long long)((y1_off[i + 1] - y1_off[i]) + (y2_off[i + 1] - y2_off[i])));
+    atomicMax((unsigned long long*)&cmax_s, (unsigned long long)cm);
+    __syncthreads();
+    const long long cmax = cmax_s;
+    auto bin_of = [&](int i) -> int {
+        const long long c = (y1_off[i + 1] - y1_off[i]) + (y2_off[i + 1] - y2_off[i]);
+        const long long b = (max(c, 0ll) * (ORD_BINS - 1)) / cmax;
+        return ORD_BINS - 1 - (int)min(b, (long long)(ORD_BINS - 1));   // longest -> bin 0
+    };
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[bin_of(i)], 1);
+    __syncthreads();
+    // exclusive prefix sums of the 2048 counts: two per thread, wave scan, wave totals through LDS
+    const int c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+    int v = c0 + c1;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    if (lane == 63) part[wave] = v;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += part[w];
+    __syncthreads();
+    const int ex = base + v - (c0 + c1);
+    hist[2 * tid] = ex; hist[2 * tid + 1] = ex + c0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&hist[bin_of(i)], 1)] = i;
 }
 
 // ---- two-pairs-per-wave path (row_col, envelope, W <= 6, one-value model)
@@ -2602,12 +2650,13 @@ constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over 
 // PO_ROUTE_LEGACY (always beam2d_kernel) — the last two exist for the tests, which run the pair path on both kernels,
 // and for A/B timing.  The environment variables PO_X2_FORCE / PO_B2_LEGACY / PO_X2_DEFER_ODD only give the INITIAL
 // value, read once when the library is first used, so that a workspace size and the launch that follows always agree.
-struct B2Route { int route, defer_odd, x2_per_cu, debug_occ, ring_auto, ring_small; };
+struct B2Route { int route, defer_odd, x2_per_cu, debug_occ, ring_auto, ring_small, no_order; };
 B2Route& b2_route() {
     static B2Route r = [] {
         B2Route x;
         x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_X2_FORCE") ? PO_ROUTE_X2 : (getenv("PO_RING_FORCE") ? PO_ROUTE_RING : PO_ROUTE_AUTO));
         x.defer_odd = getenv("PO_X2_DEFER_ODD") ? 1 : 0;
+        x.no_order = getenv("PO_B2_NO_ORDER") ? 1 : 0;   // A/B: pairs taken in input order
         x.debug_occ = getenv("PO_DEBUG_OCC") ? 1 : 0;
         x.ring_auto = getenv("PO_RING_AUTO") ? 1 : 0;     // beam2d_ring_kernel at every batch size (A/B)
         x.ring_small = getenv("PO_RING_NEVER") ? 0 : 1;   // ... for launches within its resident workgroups (the default)
@@ -2928,6 +2977,11 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     if (b2_ws_layout_changed(ws, g.off_state, g.total, g.magic) &&
         hipMemsetAsync(w + g.off_state, 0, sizeof(unsigned long long) * 2 * (size_t)g.blocks, stream) != hipSuccess)
         return PO_E_HIP;
+    a.order = nullptr;
+    if (n > g.blocks && !only_meta && !retry && !b2_route().no_order) {   // more pairs than resident workgroups: the order of the queue matters
+        a.order = (int*)(w + g.off_order);
+        hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
+    }
     if (g_b2_mark && !only_meta && !retry) g_b2_mark(1, stream);
     if (model == PO_MODEL_CTC) b2_launch_w<PO_MODEL_CTC>(g, a, stream);
     else if (model == PO_MODEL_MERGE) b2_launch_w<PO_MODEL_MERGE>(g, a, stream);
@@ -2981,6 +3035,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.envt = nullptr; a.vcap = (long long)g.vcap;
         a.cellb = (int*)(w + g.off_cell);
         a.retry_nomem = 0;
+        a.order = nullptr;
         a.dbg = nullptr; a.only_meta = nullptr;
         a.upd_count = g_b2_upd_counter;
         a.wgstate = nullptr; a.magic = 0;   // (the grid kernel clears its store per launch)

@@ -76,3 +76,23 @@ def test_batch_1024_pairs_vs_oracle_digest(workload, oracle, route, monkeypatch)
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "batch_scale_%s.json" % route), "w") as f:
         json.dump({"pairs": NPAIRS, "route": route, "digest_mismatches": len(bad), "edits": edits, "consensus_bases": total}, f)
+
+
+def test_more_pairs_than_workgroups_mixed_lengths(oracle):
+    """6 000 pairs of very different lengths (T 200 - 3 000) in one pair_decode_batch call: more than the 4 096 resident
+    workgroups of beam2d_kernel, so the launch takes its pairs longest first (pair_order_kernel).  Every pair must come
+    back in its own place with its own result: 24 distinct pairs, replicated in random order, against the oracle."""
+    from poreover_amd import batch
+    from poreover_amd.synth import synth_pair
+    rng = np.random.default_rng(17)
+    base = []
+    for i in range(24):
+        y1, y2 = synth_pair(1000 + i, T=int(np.exp(rng.uniform(np.log(200), np.log(3000)))))
+        w = oracle.pair_decode(y1, y2, "poreover", 5, "row_col")
+        base.append((y1, y2, w))
+    idx = rng.integers(len(base), size=6000)
+    got = batch.pair_decode_batch([base[i][0] for i in idx], [base[i][1] for i in idx], "poreover", 5, "row_col")
+    assert len(got) == len(idx)
+    for k, i in enumerate(idx):
+        w = base[i][2]
+        assert got[k]["status"] == w["status"] and (got[k]["consensus"] or "") == (w["consensus"] or "") and got[k]["seq1"] == w["seq1"], (k, int(i))
