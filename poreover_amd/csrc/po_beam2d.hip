@@ -1509,7 +1509,10 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         // ------------------------------------------------------------ a half without a pair pulls one
         if (!have && !done) {
             int p = 0;
-            if (s == 0) p = atomicAdd(a.queue, 1);
+            if (s == 0) {
+                p = atomicAdd(a.queue, 1);
+                if (a.order != nullptr && p < a.n) p = a.order[p];   // longest pairs first (pair_order_kernel)
+            }
             p = __shfl(p, lane & ~(SG - 1));
             if (p >= a.n) {
                 done = true;
@@ -2642,7 +2645,7 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(const int64_t* y1_off,
 struct X2Geom {
     int blocks, npw;
     size_t pool_bytes, arena_cap;
-    size_t off_queue, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
+    size_t off_queue, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, off_order, total;
 };
 constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over deferred pairs (16 / 32 MB of store each)
 // Kernel routing is a process-wide setting of the library (po_set_pair_route), not something a launch looks up in the
@@ -2733,6 +2736,7 @@ X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.off_fb = o;
     g.fb_bytes = b2_geometry(n, mr1, mr2, W, model, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
     o += al256(g.fb_bytes);
+    g.off_order = o; o += al256(sizeof(int) * (size_t)std::max(n, 1));   // the queue's order (pair_order_kernel)
     g.total = o + 256;
     return g;
 }
@@ -3066,6 +3070,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
         a.need_mono = 1;
+        a.order = nullptr;   // (at most as many pairs as resident workgroups by default: all start at once)
         a.wgstate = (unsigned long long*)(w + g.off_state);
         a.magic = g.magic;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
@@ -3106,6 +3111,11 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
         a.need_mono = 0;
+        a.order = nullptr;
+        if (n > g.blocks * g.npw && !b2_route().no_order) {   // more pairs than resident half-waves: longest first
+            a.order = (int*)(w + g.off_order);
+            hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
+        }
 #ifdef PO_B2_TIMING
         static long long* dbg_x2 = nullptr;
         if (!dbg_x2) (void)hipMalloc((void**)&dbg_x2, 12 * sizeof(long long));

@@ -134,6 +134,7 @@ struct X2Args {
     long long* dbg;
     int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
     int need_mono;                    // the main kernel takes monotone envelopes only (beam2d_ring_kernel): others are deferred
+    const int* order;                 // optional: the pair the q-th queue ticket stands for (longest first, pair_order_kernel)
     int pre_vcols;                    // pre-pass: columns its LDS table holds
     int ngl;                          // row groups the main kernel tracks per pair
     unsigned long long* upd_count;    // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
