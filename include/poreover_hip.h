@@ -328,9 +328,10 @@ int po_pair_decode_batch_h(const double* y1_h, const int64_t* y1_off_h, const do
  * (rows2[i], C) matrices of float32 logits (in_mode PO_INGEST_LOGITS_F32), uint8 traces (PO_INGEST_TRACE_U8) or
  * float64 log-probabilities (PO_INGEST_F64); perm1 / perm2 (C ints or NULL): column order of read 1 / read 2
  * (out[:, c] = in[:, perm[c]]), reverse2: read 2 is time-reversed.  The pairs are decoded in waves of at most
- * wave_pairs pairs / wave_rows frames through two slots {stream, pinned staging, device buffers, workspace}:
- * wave k + 1 is packed and uploaded while wave k decodes, device memory is bounded by two waves whatever n is,
- * and nothing is allocated per call once the buffers have grown to the wave size.
+ * wave_pairs pairs / wave_rows frames through three slots {stream, pinned staging, device buffers, workspace}:
+ * waves k + 1 and k + 2 are packed and uploaded while wave k decodes, device memory is bounded by three waves whatever
+ * n is, and nothing is allocated per call once the buffers have grown to the wave size.  wave_pairs 0: a job of at
+ * most 4 096 pairs is one wave, a larger one is cut into even waves of about 2 500 pairs.
  * Outputs as po_pair_decode_batch_h (all host); env_out_h may be NULL (rows of pair i at 2 * sum(rows1[:i])).
  * A pipeline belongs to one host thread and one device.  */
 typedef struct po_pipeline po_pipeline;

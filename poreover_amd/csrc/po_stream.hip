@@ -116,10 +116,23 @@ struct WavePlanner {
     }
 };
 
+constexpr int PO_MAX_SLOTS = 4;
+// Wave size when the caller names none.  Measured on the 10 000-pair job (scripts/e2e_ab.sh, one MI355X, host float32 in ->
+// strings out): three waves in flight and four even waves of 2 500 pairs 66.5k pairs/s; 2 x 4 096 + 1 808 on two slots 58.4k;
+// 3 x 3 334 63.4k; 5 x 2 048 (the LDS-ring kernel's range) 50.8k; a short first wave (ramp) 54 - 59k.  The first wave is what
+// the device waits for (pack + upload: 22 ms at 2 500 pairs, 35 ms at 4 096), even waves keep the last one from being a
+// tail, and a third slot lets wave k + 2 upload while k decodes and k + 1 waits.  A job of at most 4 096 pairs stays one wave.
+constexpr int PO_WAVE_TARGET = 2500, PO_WAVE_MAX = 4096;
+static int auto_wave_pairs(int n) {
+    if (n <= PO_WAVE_MAX) return PO_WAVE_MAX;
+    const int waves = (n + PO_WAVE_TARGET - 1) / PO_WAVE_TARGET;
+    return (n + waves - 1) / waves;
+}
 struct po_pipeline {
-    int device = 0, wave_pairs = 4096, threads = 8;
+    int device = 0, wave_pairs = 0 /* 0: auto_wave_pairs(n) */, threads = 8;
     int64_t wave_rows = (int64_t)64 << 20;
-    Slot slot[2];
+    Slot slot[PO_MAX_SLOTS];
+    int nslots = 3;   // waves in flight: one decoding, the next ones packed / uploading behind it (PO_PIPELINE_SLOTS)
     double pack_ms = 0, wait_ms = 0, total_ms = 0;
     int waves = 0, pairs = 0;
     std::string err;
@@ -174,7 +187,9 @@ po_pipeline* po_pipeline_create(int device, int wave_pairs, int64_t wave_rows, i
     po_pipeline* p = new po_pipeline();
     p->device = device;
     if (wave_pairs > 0) p->wave_pairs = wave_pairs;
+    else if (const char* e = getenv("PO_WAVE_PAIRS")) { const int v = atoi(e); if (v > 0) p->wave_pairs = v; }
     if (wave_rows > 0) p->wave_rows = wave_rows;
+    if (const char* e = getenv("PO_PIPELINE_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= PO_MAX_SLOTS) p->nslots = v; }
     const unsigned hc = std::thread::hardware_concurrency();
     p->threads = threads > 0 ? threads : (int)std::max(1u, std::min(16u, hc ? hc / 2 : 4u));
     for (auto& s : p->slot)
@@ -278,7 +293,7 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
     int first = 0, wn = 0;
     int64_t r1 = 0, r2 = 0, m1 = 0, m2 = 0;
     for (;;) {
-        Slot& s = p->slot[wave & 1];
+        Slot& s = p->slot[wave % p->nslots];
         int rc = drain(s);   // the wave this slot ran two waves ago (before asking for another: a device takes work when it can start it)
         if (rc != PO_OK) return rc;
         if (!plan.take(&first, &wn, &r1, &r2, &m1, &m2)) break;
@@ -365,8 +380,8 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
     }
     if (plan.bad) return fail(p, PO_E_ARG, "po_pipeline_pair_decode: negative row count");
     p->waves = wave;
-    int rc = drain(p->slot[wave & 1]);          // the older wave first, then the last one
-    if (rc == PO_OK) rc = drain(p->slot[(wave + 1) & 1]);
+    int rc = PO_OK;
+    for (int k = 0; k < p->nslots && rc == PO_OK; ++k) rc = drain(p->slot[(wave + k) % p->nslots]);   // oldest wave first
     p->total_ms = now_ms() - t_begin;
     return rc;
 }
@@ -398,7 +413,9 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
         c.env_row0 = env_row0.data();
     }
     WavePlanner plan;
-    plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n; plan.wave_pairs = p->wave_pairs; plan.wave_rows = p->wave_rows;
+    plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n; plan.wave_rows = p->wave_rows;
+    plan.wave_pairs = p->wave_pairs > 0 ? p->wave_pairs : auto_wave_pairs(n);
+    if (const char* e = getenv("PO_WAVE_RAMP")) plan.ramp = std::max(0, atoi(e));   // experiment: first wave of this many pairs, doubling
     // (Tried: a job within the latency-bound regime of the pair beam kernel — <= 2 048 pairs, one GPU's share of a multi-GPU
     //  job — cut into two waves whose kernels run side by side while the second uploads: 36.8 vs 36.9 ms for 1 250 pairs,
     //  three waves on the two slots 60 ms.  The upload is not what such a job waits for.  PO_PIPELINE_SPLIT=1 still does it.)
@@ -417,7 +434,7 @@ struct po_multi {
     std::vector<po_pipeline*> pipes;
     std::vector<int> pairs_done;
     std::string err;
-    int wave_pairs = 4096;
+    int wave_pairs = 0;   // 0: auto_wave_pairs(n)
 };
 
 // The waves a call over `ndev` devices is cut into (no device is touched: what po_multi_pair_decode's planner hands out,
@@ -427,7 +444,7 @@ int po_wave_plan(const int64_t* rows1, const int64_t* rows2, int n, int wave_pai
     if (!rows1 || !rows2 || n < 0 || ndev < 1) return PO_E_ARG;
     WavePlanner plan;
     plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n;
-    const int wp = wave_pairs > 0 ? wave_pairs : 4096;
+    const int wp = wave_pairs > 0 ? wave_pairs : auto_wave_pairs(n);
     plan.wave_pairs = (ndev > 1) ? std::max(1, std::min(wp, (n + 2 * ndev - 1) / (2 * ndev))) : wp;
     plan.wave_rows = wave_rows > 0 ? wave_rows : ((int64_t)64 << 20);
     int k = 0, f = 0, c = 0;
@@ -449,6 +466,7 @@ po_multi* po_multi_create(const int* devices, int ndev, int wave_pairs, int64_t 
         m->pipes.push_back(p);
     }
     m->pairs_done.assign((size_t)ndev, 0);
+    if (wave_pairs <= 0) m->wave_pairs = m->pipes[0]->wave_pairs;   // (PO_WAVE_PAIRS, or 0 = auto)
     return m;
 }
 
@@ -488,7 +506,7 @@ int po_multi_pair_decode(po_multi* m, const void* const* y1_h, const int64_t* ro
     // one pipeline's own wave size
     WavePlanner plan;
     plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n;
-    plan.wave_pairs = std::max(1, std::min(m->wave_pairs, (n + 2 * nd - 1) / (2 * nd)));
+    plan.wave_pairs = std::max(1, std::min(m->wave_pairs > 0 ? m->wave_pairs : auto_wave_pairs(n), (n + 2 * nd - 1) / (2 * nd)));
     plan.wave_rows = m->pipes[0]->wave_rows;
     std::vector<int> rcs((size_t)nd, PO_OK);
     std::vector<std::string> errs((size_t)nd);
