@@ -35,6 +35,17 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def _addresses(arrays):
+    """Data pointers of a list of C-contiguous arrays as uint64.  ctypes' from_buffer + addressof is three times faster
+    than __array_interface__ (no dict per array) — 20 000 arrays per call sit on the end-to-end clock — but wants a
+    writable buffer; read-only arrays (memory maps) take the slow way."""
+    fb, ao = C.c_char.from_buffer, C.addressof
+    try:
+        return np.fromiter((ao(fb(a)) for a in arrays), dtype=np.uint64, count=len(arrays))
+    except (TypeError, ValueError, BufferError):
+        return np.fromiter((a.__array_interface__["data"][0] for a in arrays), dtype=np.uint64, count=len(arrays))
+
+
 def _strings(buf, off, lens):
     raw = buf.tobytes()
     return [raw[off[i]:off[i] + lens[i]].decode("ascii") for i in range(len(lens))]
@@ -297,8 +308,8 @@ def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="
                         1 if alignment == "full" else 0, 1 if diagonal_envelope else 0, int(diagonal_width))
     r1 = np.fromiter((a.shape[0] for a in a1), dtype=np.int64, count=n)
     r2 = np.fromiter((a.shape[0] for a in a2), dtype=np.int64, count=n)
-    p1 = np.fromiter((a.__array_interface__["data"][0] for a in a1), dtype=np.uint64, count=n)
-    p2 = np.fromiter((a.__array_interface__["data"][0] for a in a2), dtype=np.uint64, count=n)
+    p1 = _addresses(a1)
+    p2 = _addresses(a2)
     s1o = np.zeros(2 * n + 1, dtype=np.int64)
     caps = np.empty(2 * n, dtype=np.int64)
     caps[0::2], caps[1::2] = r1, r2
