@@ -35,6 +35,9 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+_PENDING = -(2 ** 31)   # a status no decode returns: "not written yet" (pair_decode_stream)
+
+
 def _addresses(arrays):
     """Data pointers of a list of C-contiguous arrays as uint64.  ctypes' from_buffer + addressof is three times faster
     than __array_interface__ (no dict per array) — 20 000 arrays per call sit on the end-to-end clock — but wants a
@@ -328,9 +331,65 @@ def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="
         wave_pairs, wave_rows, threads, device=(devices[0] if devices else None))
     _t1 = _time.perf_counter()
     fn = lib.po_multi_pair_decode if multi else lib.po_pipeline_pair_decode
-    L.check(fn(pl, _ptr(p1), _ptr(r1), _ptr(p2), _ptr(r2), n, Cc, mode, pm1, pm2, 1 if reverse2 else 0,
-               C.byref(opt), _ptr(seq1d), _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(ident), _ptr(env),
-               _ptr(seq), _ptr(so), _ptr(lens), _ptr(st)), "po_multi_pair_decode" if multi else "po_pipeline_pair_decode")
+    what = "po_multi_pair_decode" if multi else "po_pipeline_pair_decode"
+
+    def call():
+        return fn(pl, _ptr(p1), _ptr(r1), _ptr(p2), _ptr(r2), n, Cc, mode, pm1, pm2, 1 if reverse2 else 0,
+                  C.byref(opt), _ptr(seq1d), _ptr(s1o), _ptr(l1), _ptr(l2), _ptr(ident), _ptr(env),
+                  _ptr(seq), _ptr(so), _ptr(lens), _ptr(st))
+    # A job of several waves: the records of a finished wave are built while the later ones decode.  The engine writes a
+    # pair's status LAST (after its strings, behind a release fence) and never writes _PENDING, so a status that has
+    # changed means the pair's outputs are there.  The engine call runs on a helper thread (ctypes drops the GIL).
+    overlap = n > 4096 and not multi and os.environ.get("PO_NO_OVERLAP_RECORDS") is None
+    out = []
+    raw1, raw = memoryview(seq1d), memoryview(seq)     # (the buffers are capacity-sized, ~18 x the text: no bulk copy)
+    eo = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(r1, out=eo[1:])
+    s1l, sol = s1o.tolist(), so.tolist()
+    skip_len, ok_codes = L.SKIP_LENGTH, (0, L.SKIP_LENGTH, L.SKIP_IDENTITY)
+
+    def records(lo, hi):
+        l1l, l2l, lnl, stl, idl = l1[lo:hi].tolist(), l2[lo:hi].tolist(), lens[lo:hi].tolist(), st[lo:hi].tolist(), ident[lo:hi].tolist()
+        for k in range(hi - lo):
+            i = lo + k
+            code = stl[k]
+            if strict and code not in ok_codes:
+                raise L.EngineError(code, "pair decode of pair %d" % i)
+            b1, b2, b = s1l[2 * i], s1l[2 * i + 1], sol[i]
+            out.append({
+                "seq1": str(raw1[b1:b1 + l1l[k]], "ascii"), "seq2": str(raw1[b2:b2 + l2l[k]], "ascii"),
+                "consensus": str(raw[b:b + lnl[k]], "ascii") if code == 0 else None,
+                "length1": l1l[k], "length2": l2l[k],
+                "sequence_identity": idl[k] if code != skip_len else None,
+                "skipped": 0 if code == 0 else 1, "status": code,
+                "envelope": env[eo[i]:eo[i + 1]].astype(np.int64) if (code == 0 and return_envelope) else None})
+
+    done = 0
+    if overlap:
+        import threading
+        st.fill(_PENDING)
+        box = []
+        th = threading.Thread(target=lambda: box.append(call()))
+        th.start()
+        err = None
+        while th.is_alive():
+            seg = st[done:]
+            pend = np.flatnonzero(seg == _PENDING)
+            k = int(pend[0]) if len(pend) else len(seg)
+            if k == 0 or err is not None:
+                _time.sleep(0.001)
+                continue
+            try:
+                records(done, done + k)
+            except L.EngineError as e:      # (strict: raised once the engine call has returned)
+                err = e
+            done += k
+        th.join()
+        L.check(box[0] if box else L.E_HIP, what)
+        if err is not None:
+            raise err
+    else:
+        L.check(call(), what)
     if stats is not None:
         pk, wt, tot, wv, np_ = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_int()
         if multi:
@@ -345,24 +404,7 @@ def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="
             lib.po_pipeline_stats(pl, C.byref(pk), C.byref(wt), C.byref(tot), C.byref(wv))
             stats.update(pack_ms=pk.value, wait_ms=wt.value, total_ms=tot.value, waves=wv.value)
     _t2 = _time.perf_counter()
-    raw1, raw = memoryview(seq1d), memoryview(seq)     # (the buffers are capacity-sized, ~18 x the text: no bulk copy)
-    eo = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(r1, out=eo[1:])
-    s1l, sol, l1l, l2l, lnl, stl, idl = s1o.tolist(), so.tolist(), l1.tolist(), l2.tolist(), lens.tolist(), st.tolist(), ident.tolist()
-    skip_len, ok_codes = L.SKIP_LENGTH, (0, L.SKIP_LENGTH, L.SKIP_IDENTITY)
-    out = []
-    for i in range(n):
-        code = stl[i]
-        if strict and code not in ok_codes:
-            raise L.EngineError(code, "pair decode of pair %d" % i)
-        b1, b2, b = s1l[2 * i], s1l[2 * i + 1], sol[i]
-        out.append({
-            "seq1": str(raw1[b1:b1 + l1l[i]], "ascii"), "seq2": str(raw1[b2:b2 + l2l[i]], "ascii"),
-            "consensus": str(raw[b:b + lnl[i]], "ascii") if code == 0 else None,
-            "length1": l1l[i], "length2": l2l[i],
-            "sequence_identity": idl[i] if code != skip_len else None,
-            "skipped": 0 if code == 0 else 1, "status": code,
-            "envelope": env[eo[i]:eo[i + 1]].astype(np.int64) if (code == 0 and return_envelope) else None})
+    records(done, n)
     if stats is not None:
         stats.update(py_in_ms=(_t1 - _t0) * 1e3, call_ms=(_t2 - _t1) * 1e3, py_out_ms=(_time.perf_counter() - _t2) * 1e3)
     return out
