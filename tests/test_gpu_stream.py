@@ -166,3 +166,26 @@ def test_alternating_wave_geometries_on_one_pipeline(eng, kind):
             _lib.set_pair_route("auto")
     want = [r["consensus"] for r in eng.pair_decode_batch(batches[0][0], batches[0][1], kind, 5, "row_col")]
     assert first[0] == want
+
+
+def test_stream_large_job_records_built_while_decoding(eng, oracle):
+    """More than 4 096 pairs: even waves on three slots, and the Python records of finished waves are built while the later
+    waves decode (the engine writes a pair's status last; batch._PENDING marks "not yet").  4 700 pairs — 14 distinct ones,
+    one of them with a read too short to align (skipped, consensus None) — every record in its place, against the oracle;
+    strict=True raises for an engine error only after the call has come back."""
+    rng = np.random.default_rng(23)
+    base = []
+    for i in range(14):
+        a, b = synth_pair(7300 + i, T=120 + 40 * (i % 5))
+        if i == 5:
+            b = b[:3]                      # length skip / identity skip upstream: no consensus
+        base.append((a, b, oracle.pair_decode(a, b, "poreover", 5, "row_col")))
+    idx = rng.integers(len(base), size=4700)
+    st = {}
+    got = eng.pair_decode_stream([base[i][0] for i in idx], [base[i][1] for i in idx], "poreover", 5, "row_col", strict=False, stats=st)
+    assert st["waves"] == 2 and len(got) == len(idx)
+    for k, i in enumerate(idx):
+        w = base[i][2]
+        assert got[k]["seq1"] == w["seq1"] and got[k]["seq2"] == w["seq2"], k
+        assert (got[k]["consensus"] or None) == (w["consensus"] or None), k
+        assert (got[k]["status"] == 0) == (w["status"] == 0), k
