@@ -114,6 +114,7 @@ template <int MODEL, int WMAX, bool RC_ONLY = false>
 // two, so that bound is explicit too.)
 __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <= 12) ? 4 : (WMAX <= 6 ? 3 : 1))) void beam2d_kernel(B2Args a) {
     using SM = B2Smem<MODEL, WMAX>;
+    if (a.retry_flag != nullptr && *a.retry_flag == 0) return;   // retry pass and the first pass left nothing over: not one queue round trip
     constexpr int K = SM::K, NCM = SM::NCM, NCP = SM::NCP, nthr = 2 * NCP;
     using Ent = Entry<K>;
     __shared__ SM sm;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             if (st == PO_OK && (need > a.arena_cap || need >= (1 << 24))) st = PO_E_NOMEM;
         }
         if (st != PO_OK) {
-            if (tid == 0) { a.status[pi] = st; a.seq_len[pi] = 0; }
+            if (tid == 0) { a.status[pi] = st; a.seq_len[pi] = 0; if (st == PO_E_NOMEM) a.queue[8] = 1; }
             continue;
         }
         const int Rm = R - 1;
@@ -1178,6 +1179,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
             }
             a.seq_len[pi] = nout;
             a.status[pi] = st;
+            if (st == PO_E_NOMEM) a.queue[8] = 1;   // (the retry pass looks at this word first)
         }
         if (a.upd_count && tid == 0) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
         TK(10);  // label walk
@@ -2942,7 +2944,8 @@ namespace {
 int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off, const int32_t* env,
                      int n, int C, int A, uint32_t alphabet, int W, int model, int method, int64_t mr1, int64_t mr2,
                      char* seq, const int64_t* seq_off, int32_t* seq_len, int32_t* status, int use_pre_status, void* ws,
-                     size_t ws_bytes, hipStream_t stream, int max_blocks, const int2* only_meta, int retry = 0) {
+                     size_t ws_bytes, hipStream_t stream, int max_blocks, const int2* only_meta, int retry = 0,
+                     const int* retry_flag = nullptr) {
     const B2Geom g = b2_geometry(n, mr1, mr2, W, model, method, max_blocks);
     if (ws_bytes < g.total) return PO_E_CAP;
     // direct path: a second, small pass (64 workgroups, four times the store) decodes the pairs whose live rows did
@@ -2966,6 +2969,7 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     a.only_meta = only_meta;
     a.cellb = nullptr;
     a.retry_nomem = retry;
+    a.retry_flag = retry_flag;
     a.upd_count = g_b2_upd_counter;
     a.wgstate = (unsigned long long*)(w + g.off_state);
     a.magic = g.magic;
@@ -3007,7 +3011,8 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
 #endif
     if (max_blocks == 0 && !retry)
         return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off, seq_len,
-                                status, use_pre_status, (char*)ws + g.total, ws_bytes - g.total, stream, X2_FB_BLOCKS, nullptr, 1);
+                                status, use_pre_status, (char*)ws + g.total, ws_bytes - g.total, stream, X2_FB_BLOCKS, nullptr, 1,
+                                a.queue + 8);
     return PO_OK;
 }
 }  // namespace
@@ -3039,6 +3044,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.envt = nullptr; a.vcap = (long long)g.vcap;
         a.cellb = (int*)(w + g.off_cell);
         a.retry_nomem = 0;
+        a.retry_flag = nullptr;
         a.order = nullptr;
         a.dbg = nullptr; a.only_meta = nullptr;
         a.upd_count = g_b2_upd_counter;

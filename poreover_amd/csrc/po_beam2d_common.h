@@ -38,6 +38,7 @@ struct B2Args {
     int* cellb;                        // grid method: two rows of per-cell beams per workgroup (2 * vcap * (1 + 6 W) ints)
     int retry_nomem;                   // second pass with a larger store: decode only the pairs the first one gave PO_E_NOMEM
     const int* order;                  // optional: the pair the q-th queue ticket stands for (longest first)
+    const int* retry_flag;             // retry pass: the word the first pass sets when it hands a pair on (queue[8]); 0 -> return at once
     unsigned long long* upd_count;     // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
     unsigned long long* wgstate;       // per workgroup {magic, epoch counter}: what its slice of the value store was last tagged with
     unsigned long long magic;          // names this workspace geometry: a slice whose state word differs is cleared before use
