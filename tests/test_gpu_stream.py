@@ -1,5 +1,5 @@
 """GPU: the pipelined host layer (po_pipeline_pair_decode, batch.pair_decode_stream) — host arrays in the
-basecaller's own form (float32 logits / uint8 traces / float64 log-probabilities) in, strings out, in waves over two
+basecaller's own form (float32 logits / uint8 traces / float64 log-probabilities) in, strings out, in waves over three
 slots — against the one-shot batched call, the oracle and the reference's outputs on its real sample reads."""
 import argparse
 import json
