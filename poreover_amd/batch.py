@@ -35,6 +35,20 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+_SCRATCH = {}
+
+
+def _scratch(name, nbytes):
+    """A uint8 buffer of at least nbytes that survives the call (grow-only, one per thread and name)."""
+    import threading
+    key = (threading.get_ident(), name)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.size < nbytes:
+        buf = np.empty(int(nbytes * 1.25) + 4096, dtype=np.uint8)
+        _SCRATCH[key] = buf
+    return buf[:nbytes]
+
+
 _PENDING = -(2 ** 31)   # a status no decode returns: "not written yet" (pair_decode_stream)
 
 
@@ -319,8 +333,10 @@ def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="
     np.cumsum(caps, out=s1o[1:])
     so = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(r1 + r2, out=so[1:])
-    seq1d = np.empty(max(int(s1o[-1]), 1), dtype=np.uint8)
-    seq = np.empty(max(int(so[-1]), 1), dtype=np.uint8)
+    # (capacity-sized text buffers — a base per frame, ~18 x the text: 160 MB for the 10 000-pair job.  Fresh arrays would be
+    #  page-faulted in while the engine copies results out and unmapped on return, ~10 ms each way; they are kept per thread)
+    seq1d = _scratch("seq1d", max(int(s1o[-1]), 1))
+    seq = _scratch("seq", max(int(so[-1]), 1))
     l1, l2, lens, st = (np.zeros(n, dtype=np.int32) for _ in range(4))
     ident = np.zeros(n, dtype=np.float64)
     env = np.zeros((max(int(r1.sum()), 1), 2), dtype=np.int32) if return_envelope else None
