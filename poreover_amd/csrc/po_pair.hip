@@ -782,7 +782,7 @@ static bool pp_legacy() {
 }
 
 namespace {
-void pp_launch(PPArgs a, int blocks, int one_wave, hipStream_t stream) {
+void pp_launch(PPArgs a, int blocks, int one_wave, hipStream_t stream, long long max_len2 = 0) {
     // dynamic LDS for the two basecalls, when they fit (row_cap bounds their length)
     long long cap = (a.mode == 2) ? 0 : ((a.row_cap + 15) & ~15LL);
     if (cap > 24 * 1024) cap = 0;
@@ -791,7 +791,8 @@ void pp_launch(PPArgs a, int blocks, int one_wave, hipStream_t stream) {
     // banded alignment on one-wave workgroups: the skewed wavefront (po_set_align_route(1) / PO_PP_LEGACY=1: the
     // row-at-a-time fill with the stored score table, kept for A/B runs and for basecalls beyond SK_MAXB column blocks)
     const bool legacy = pp_legacy();
-    const bool skew = one_wave && !a.full_alignment && a.mode != 2 && !legacy && a.row_cap <= (long long)SK_MAXB * SK_BW;
+    // (a basecall of read 2 beyond SK_MAXB column blocks — 131 072 bases — keeps the row-at-a-time kernel)
+    const bool skew = one_wave && !a.full_alignment && a.mode != 2 && !legacy && max_len2 <= (long long)SK_MAXB * SK_BW;
     if (skew) hipLaunchKernelGGL((pair_prep_kernel<64, true>), dim3(blocks), dim3(64), lds, stream, a);
     else if (one_wave) hipLaunchKernelGGL((pair_prep_kernel<64, false>), dim3(blocks), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL((pair_prep_kernel<256, false>), dim3(blocks), dim3(256), lds, stream, a);
@@ -972,7 +973,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     a.aln = w + g.off_aln; a.aln_cap = (long long)g.aln_cap;
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
     po_prof_stage(PO_K_ALIGN, stream, 1, &tok);
-    pp_launch(a, g.blocks, g.one_wave, stream);
+    pp_launch(a, g.blocks, g.one_wave, stream, mr2 + 8);
     if (g.big_blocks > 0 && !opt->diagonal_envelope) {   // pairs whose basecalls did not fit the first pass's slices (none, usually)
         PPArgs b = a;
         b.retry_cap = 1;
@@ -980,7 +981,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
         b.dp = (int*)(w + g.off_big_dp); b.dp_cap = (long long)g.big_dp_cap;
         b.rowinfo = (int*)(w + g.off_big_rows); b.row_cap = (long long)g.big_row_cap;
         b.aln = w + g.off_big_aln; b.aln_cap = (long long)g.big_aln_cap;
-        pp_launch(b, g.big_blocks, g.one_wave, stream);
+        pp_launch(b, g.big_blocks, g.one_wave, stream, mr2 + 8);
     }
     po_prof_stage(PO_K_ALIGN, stream, 0, &tok);
     // (3) the pair beam search inside the envelope (pair_decode.py:166-173,511)
@@ -1064,7 +1065,7 @@ extern "C" int po_launch_align_scores(const char* seqs, const int64_t* seq_off, 
     a.row_cap = (long long)(max_len1 + 2); a.rowinfo = (int*)(w + o); o += al256(sizeof(int) * 4 * (size_t)a.row_cap * blocks);
     a.aln_cap = (long long)(max_len1 + max_len2 + 16); a.aln = w + o;
     if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-    pp_launch(a, blocks, one_wave, stream);
+    pp_launch(a, blocks, one_wave, stream, max_len2);
     return PO_OK;
 }
 
