@@ -377,6 +377,9 @@ def main():
 
         n2 = min(1000, P)
         sec["config2_beam1d_1k_reads_W10"] = beam1d_config(d_y1, d_o1, n2, Cc, int(o1[n2]), mr1, "ctc", 10)
+        # the same search with the device full (every read 1 of the workload): config 2's 1 000 reads are one wave per SIMD,
+        # latency-bound by construction; this is the throughput figure
+        sec["beam1d_%dk_reads_W10" % (P // 1000)] = beam1d_config(d_y1, d_o1, P, Cc, tr1, mr1, "ctc", 10)
         yff, off_ff, Cff = pack_rows(ff_reads)
         d_yff, d_off_ff = torch.from_numpy(yff).to(dev), torch.from_numpy(off_ff).to(dev)
         sec["config5_flipflop_1k_reads_W10"] = beam1d_config(d_yff, d_off_ff, len(ff_reads), Cff, int(off_ff[-1]),
