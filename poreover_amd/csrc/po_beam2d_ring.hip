@@ -214,12 +214,26 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
         };
 
         // ---------------------------------------------------------------- y rows [t0, t0 + RG_NY) of this read -> LDS
+        // (all of a lane's loads go out together — one memory round trip per reload, not one per element: a lone wave
+        //  waits for every one of them, and a pair reloads ~470 times)
         auto y_reload = [&](int t0) {
-            for (int i = s; i < RG_NY * C; i += 32) {
-                const int q = (i * ((65536 + C - 1) / C)) >> 16, c = i - q * C;
+            constexpr int PER = (RG_NY * RG_YC + 31) / 32;   // elements per lane (C <= RG_YC)
+            double v[PER];
+            int slot[PER];
+            const int divC = (65536 + C - 1) / C;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int i = s + 32 * j;
+                const int q = (i * divC) >> 16, c = i - q * C;
                 const int t = t0 + q;
-                if (t < Tr) sm.ybuf[r][t & (RG_NY - 1)][c] = yr[(int64_t)t * C + c];
+                const bool ok = i < RG_NY * C && t < Tr;
+                slot[j] = ok ? (t & (RG_NY - 1)) * RG_YC + c : -1;
+                v[j] = ok ? yr[(int64_t)t * C + c] : 0.0;
             }
+            double* const yb = &sm.ybuf[r][0][0];
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (slot[j] >= 0) yb[slot[j]] = v[j];
         };
 
         // ---------------------------------------------------------------- one scan
