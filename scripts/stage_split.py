@@ -1,6 +1,7 @@
-"""Pair beam stage of n pairs split into its main kernel and everything around it (pre-pass, walk, fallback pass, launch gaps):\n   python scripts/stage_split.py 1250   (ad-hoc; the oracle only builds the envelopes)"""
+"""Pair beam stage of n pairs split into its main kernel and everything around it (pre-pass, walk, fallback pass, launch
+gaps):  python scripts/stage_split.py 1250   (ad-hoc; the oracle only builds the envelopes)"""
 import sys, os, ctypes as C
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from poreover_amd import batch, _lib
 from poreover_amd.synth import synth_pair
