@@ -494,6 +494,16 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
     y_request(1);
     po_wave_sync();
 
+    // STEADY TABLE.  Most frames keep the beam exactly as it was (the same nodes in the same order: nine frames in ten are
+    // blank).  The table of such a frame is the previous one, slot for slot — every lane's node, parent slot, symbol and
+    // duplicate flag are what they were — so nothing of it is rebuilt: a lane reads its own previous value and its
+    // parent's, updates, and the prune is two comparisons per lane (beam scores still strictly in order, the last of them
+    // strictly above every child: anything else, ties included, takes the full ranking below).  `stable`: the previous
+    // frame was itself built that way (identity selection, nothing expanded), so the constants it left (k_*) describe
+    // slots of the table this frame reads.
+    bool stable = false;
+    int k_pslot = -2, k_sym = 0;
+    bool k_samef = false, k_dup = false;
     for (int t = 1; t < T; ++t) {
         const bool first = (t == 1);
         if ((t & 31) == 0) { y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync(); }
@@ -501,10 +511,22 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         const int NCc = Wc * (A + 1);
         const bool rb = lane < Wc, rc = !rb && lane < NCc;
         const int j = rc ? (((lane - Wc) * divA) >> 16) : 0, c = rc ? (lane - Wc) - j * A : 0;   // (x / A for x < 64)
+        const bool ident_in = !first && Wc == Pnb && (__ballot(rb && selv != lane) == 0ull);
+        const bool fastf = stable && ident_in;
+        int q_id, q_depth, q_fc, par, gpar, plast, last, pslot, slot = -2, s_self, s_parent, sym;
+        bool samef, expanded = false;
+        if (fastf) {
+            q_id = p_id; q_depth = p_depth; q_fc = p_fc;
+            par = p_par; gpar = p_gpar; plast = p_plast; last = p_last;
+            pslot = k_pslot; slot = lane;
+            s_self = lane; s_parent = rb ? max(k_pslot, 0) : j;
+            sym = k_sym; samef = k_samef;
+        } else {
         // ---- beam slots: fields from the previous table's slot selv
         const int src = rb ? selv : 0;
-        int q_id = shf(p_id, src), q_depth = shf(p_depth, src), q_fc = shf(p_fc, src);
-        int par = 0, gpar = -1, plast = A, last = 0, pslot = -2, sl0 = -2;
+        q_id = shf(p_id, src); q_depth = shf(p_depth, src); q_fc = shf(p_fc, src);
+        par = 0; gpar = -1; plast = A; last = 0; pslot = -2;
+        int sl0 = -2;
         const int q_fc_pre = q_fc;
         const int xpre = shf(q_fc_pre, j) + c;   // a child's node id if its parent has children already
         {
@@ -530,7 +552,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
                 if (src < Pnb && par != 0) pslot = (ps1 >= 0) ? ps1 : ps2;
             }
         }
-        if (rb && q_fc == -2) q_fc = afc[q_id];   // re-entered the beam: the arena remembers
+        const bool refetch = rb && q_fc == -2;
+        if (refetch) q_fc = afc[q_id];   // re-entered the beam: the arena remembers
         // ---- expansion: A fresh ids per beam node that has never had children, in beam order
         const bool need = rb && (q_fc == -1);
         {
@@ -545,11 +568,12 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             }
             next_id += A * __popcll(m);
             if ((int64_t)next_id > acap) st = PO_E_NOMEM;
+            expanded = (m != 0ull) || (__ballot(refetch) != 0ull);
         }
         if (st != PO_OK) break;
         // ---- children: id, previous slot, fields of the parent beam node j
         const int pj_fc = shf(q_fc, j), pj_new = shf((int)need, j), pj_sel = shf(selv, j), pj_depth = shf(q_depth, j), pj_last = shf(last, j);
-        int slot = -2, fcx = -2;
+        int fcx = -2;
         if (rc) {
             q_id = pj_fc + c; q_depth = pj_depth + 1; fcx = pj_new ? -1 : -2;
         }
@@ -571,11 +595,14 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             const int sfc = shf(p_fc, max(slot, 0));
             if (rc) { if (slot >= 0) fcx = sfc; q_fc = fcx; }
         }
+        s_self = rb ? src : max(slot, 0); s_parent = rb ? max(pslot, 0) : pj_sel;
+        sym = rb ? last : c;
+        samef = rb ? (plast == last) : (pj_last == c);
+        }
         // ---- one update for every slot of the new table
-        const int s_self = rb ? src : max(slot, 0), s_parent = rb ? max(pslot, 0) : pj_sel;
         double sp[3], pp[3], out[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
 #pragma unroll
-        for (int k = 0; k < K; ++k) { sp[k] = __shfl(p_val[k], s_self); pp[k] = __shfl(p_val[k], s_parent); }
+        for (int k = 0; k < K; ++k) { sp[k] = fastf ? p_val[k] : __shfl(p_val[k], s_self); pp[k] = __shfl(p_val[k], s_parent); }
         if (rb) {
             if (pslot == -1) root_values<MODEL>(t - 1, blank_cum, pp);
             else if (pslot < 0) {
@@ -586,22 +613,40 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
 #pragma unroll
             for (int k = 0; k < K; ++k) sp[k] = PO_NEG_INF;
         }
-        const int sym = rb ? last : c;
-        const bool samef = rb ? (plast == last) : (pj_last == c);
         const double ya = yrow[(rb || rc) ? sym : 0], yb = yrow[(MODEL == PO_MODEL_FLIPFLOP) ? ((rb || rc) ? sym + A : 0) : A];
         if (rb || rc)
             po_update<MODEL>(sp, pp, ya, yb, samef, false, out, lae);
         // ---- prune (Beam.h:93-108): a child slot whose node is also a beam slot is the same node pushed twice
-        bool dupf = false;
+        bool dupf = fastf ? k_dup : false;
         const double sc = out[0];
-        double thr = rg1_readlane_d(sc, 0);
-        for (int i = 0; i < Wc; ++i) {   // (one pass over the beam lanes: duplicate test and the smallest beam score)
-            const int bid = __builtin_amdgcn_readlane(q_id, i);
-            if (rc && bid == q_id) dupf = true;
-            thr = fmin(thr, rg1_readlane_d(sc, i));
+        double thr = PO_NEG_INF;
+        if (!fastf) {
+            thr = rg1_readlane_d(sc, 0);
+            for (int i = 0; i < Wc; ++i) {   // (one pass over the beam lanes: duplicate test and the smallest beam score)
+                const int bid = __builtin_amdgcn_readlane(q_id, i);
+                if (rc && bid == q_id) dupf = true;
+                thr = fmin(thr, rg1_readlane_d(sc, i));
+            }
+        }
+        const bool valid = (rb || rc) && !dupf;
+        // the beam as it was?  (strictly: exact ties go through the ranking, as partial_sort decides them)
+        bool same_beam = false;
+        if (Wc == W) {
+            const double scl = rg1_readlane_d(sc, Wc - 1);
+            const double scn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sc), 0x101, 0xf, 0xf, false),
+                                                __builtin_amdgcn_update_dpp(0, __double2loint(sc), 0x101, 0xf, 0xf, false));   // row_shl:1 (W <= 12: one row)
+            bool viol = false;
+            if (rb) { if (lane + 1 < Wc) viol = !(sc > scn); }
+            else if (valid) viol = !(scl > sc);
+            same_beam = (__ballot(viol) == 0ull);
+        }
+        int Wn = Wc, nsel = lane;   // lane jx < Wn: the slot of the candidate of rank jx
+        if (!same_beam) {
+        if (fastf) {   // (the smallest beam score was not needed for the test above)
+            thr = rg1_readlane_d(sc, 0);
+            for (int i = 1; i < Wc; ++i) thr = fmin(thr, rg1_readlane_d(sc, i));
         }
         if (Wc != W) thr = PO_NEG_INF;
-        const bool valid = (rb || rc) && !dupf;
         const bool inS = valid && (rb || sc >= thr);
         const unsigned long long smk = __ballot(inS);
         const int kept = __popcll(__ballot(valid));
@@ -613,8 +658,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             rank += ((so > sc) | (!(sc > so) & (io < q_id))) ? 1 : 0;
             neq += (so == sc) ? 1 : 0;
         }
-        const int Wn = min(W, kept);
-        int nsel = 0;   // lane jx < Wn: the slot of the candidate of rank jx
+        Wn = min(W, kept);
+        nsel = 0;
         if (__ballot(inS && neq > 1 && rank < W) != 0ull) {
             // exact ties reaching into the beam: libstdc++'s partial_sort / sort on the candidates in node-id order
             int pos = 0;
@@ -640,12 +685,15 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
                 if (lane == jx) nsel = sj;
             }
         }
+        }
         // ---- the new table becomes the previous one
         p_id = q_id; p_fc = q_fc; p_depth = q_depth;
 #pragma unroll
         for (int k = 0; k < K; ++k) p_val[k] = out[k];
         p_par = par; p_gpar = gpar; p_plast = plast; p_last = last;
         selv = nsel;
+        k_pslot = pslot; k_sym = sym; k_samef = samef; k_dup = dupf;
+        stable = ident_in && !expanded;   // (this frame's table has the layout of the one before it)
         if (MODEL == PO_MODEL_CTC) blank_cum += yrow[A];
         Pnb = Wc;
         Wc = Wn;
