@@ -138,6 +138,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     int* ord = (int*)carve(p, sizeof(int) * NC);     // prune with exact score ties: candidate slots in node-id order
     B1Cand* cand = (B1Cand*)carve(p, sizeof(B1Cand) * NC);   // the candidates packed for the ranking: one 16-byte read each
     int* stl_stk = (int*)carve(p, sizeof(int) * 48);         // the explicit stack of the exact-tie replay (po_stl_sort)
+    int* kps = (int*)carve(p, sizeof(int) * NC);             // steady table: a slot's parent slot (-1 root, -2 none) ...
+    int* kss = (int*)carve(p, sizeof(int) * NC);             // ... and its symbol | (same symbol as the parent) << 8
 
     if (T < 1) {
         if (lane == 0) { seq_len[r] = 0; status[r] = PO_E_ARG; }
@@ -184,9 +186,13 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     double yn[CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) yn[c] = (c < C && T > 1 && C != CMAX) ? yr0[(int64_t)C + c] : 0.0;
+    // STEADY TABLE (as in beam1d_wave_kernel): a frame that finds the beam exactly as the previous frame left it, in a table
+    // that was itself built that way, rebuilds nothing — every slot updates its value in place (all reads, a fence, all
+    // writes) from its own previous value and its parent's (kps / kss: left by the last frame that built a table), and the
+    // prune is two comparisons per slot; anything but "strictly the same beam" runs the ranking on the table as it stands.
+    bool stable = false;
     for (int t = 1; t < T; ++t) {
         const Table P = cur ? T1 : T0;
-        const Table Q = cur ? T0 : T1;
         const bool first = (t == 1);
         double yr[CMAX];
         if (C == CMAX) {   // (the standard alphabets: whole rows of CMAX doubles)
@@ -199,7 +205,57 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 for (int c = 0; c < CMAX; ++c) yn[c] = (c < C) ? yr0[(int64_t)(t + 1) * C + c] : 0.0;
             }
         }
-
+        const int NCc0 = Wc * (A + 1);
+        const bool ident_in = !first && Wc == Pnb && Wc <= PO_WAVE && (__ballot(lane < Wc && sel[min(lane, WM - 1)] != lane) == 0ull);
+        const bool inplace = stable && ident_in && Wc == W && NCc0 <= 2 * PO_WAVE;
+        bool expanded = false;
+        if (inplace) {
+            double o2[2][3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sl = lane + h * PO_WAVE;
+                if (sl < NCc0) {
+                    const int ps = kps[sl], ks = kss[sl];
+                    const int sym = ks & 0xff;
+                    double sp[3], pp[3];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) sp[k] = P.val[k * NC + sl];
+                    if (ps >= 0) { for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + ps]; }
+                    else if (ps == -1) root_values<MODEL>(t - 1, blank_cum, pp);
+                    else { for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF; }
+                    po_update<MODEL>(sp, pp, b1_pick<CMAX>(yr, sym), (MODEL == PO_MODEL_FLIPFLOP) ? b1_pick<CMAX>(yr, sym + A) : b1_pick<CMAX>(yr, A),
+                                     (ks >> 8) != 0, false, o2[h], lae);
+                }
+            }
+            po_wave_sync();   // every read of the old values before the first write
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sl = lane + h * PO_WAVE;
+                if (sl < NCc0) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) P.val[k * NC + sl] = o2[h][k];
+                }
+            }
+            po_wave_sync();
+            bool viol = false;
+            const double scl = P.val[Wc - 1];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sl = lane + h * PO_WAVE;
+                if (sl < NCc0) {
+                    const double sc = o2[h][0];
+                    if (sl < Wc) { if (sl + 1 < Wc) viol |= !(sc > P.val[sl + 1]); }
+                    else if (!dup[sl]) viol |= !(scl > sc);
+                }
+            }
+            if (__ballot(viol) == 0ull) {   // the same beam, strictly: nothing else moves
+                if (MODEL == PO_MODEL_CTC) blank_cum += b1_pick<CMAX>(yr, A);
+                continue;
+            }
+        }
+        const Table Q = inplace ? P : (cur ? T0 : T1);
+        const int NCc = NCc0;
+        if (!inplace) {
         // ---- phase 1: beam slots
         bool need = false;
         for (int j = lane; j < Wc; j += PO_WAVE) {
@@ -237,7 +293,10 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             for (int k = 0; k < K; ++k) Q.val[k * NC + j] = out[k];
             Q.fc[j] = fc;
             need = (fc == -1);
+            kps[j] = pslot; kss[j] = last | ((plast == last) ? 0x100 : 0);
+            if (P.fc[s] == -2) expanded = true;
         }
+        expanded = (__ballot(expanded || need) != 0ull);
         // ---- expansion: A fresh ids per beam node that has never had children
         //      (PrefixTree::expand, PrefixTree.h:439-446), in beam order
         {
@@ -266,7 +325,6 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         if (st != PO_OK) break;
 
         // ---- phase 2: the A children of every beam node
-        const int NCc = Wc * (A + 1);
         for (int s = Wc + lane; s < NCc; s += PO_WAVE) {
             const int j = (s - Wc) / A, c = (s - Wc) % A;
             const int x = Q.fc[j] + c, sj = sel[j];
@@ -285,8 +343,10 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             Q.id[s] = x; Q.fc[s] = fcx; Q.depth[s] = Q.depth[j] + 1;
 #pragma unroll
             for (int k = 0; k < K; ++k) Q.val[k * NC + s] = out[k];
+            kps[s] = sj; kss[s] = c | ((Q.last[j] == c) ? 0x100 : 0);
         }
         po_wave_sync();   // (one wave per read)
+        }   // !inplace
 
         // ---- phase 3: prune (Beam.h:93-108).  A child slot whose node is also a beam slot is the
         //      same node pushed twice: std::unique removes it.
@@ -378,7 +438,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         const int Wn = min(W, kept);
         for (int j = lane; j < Wn; j += PO_WAVE) sel[j] = nsel[j];
         if (MODEL == PO_MODEL_CTC) blank_cum += b1_pick<CMAX>(yr, A);
-        cur ^= 1;
+        if (!inplace) { cur ^= 1; stable = ident_in && !expanded; }   // (an in-place frame leaves the table, and `stable`, as they are)
         Pnb = Wc;
         Wc = Wn;
         po_wave_sync();   // (one wave per read)
@@ -726,7 +786,8 @@ extern "C" size_t po_beam1d_lds_bytes(int W, int model) {
     const int WM = W > PO_A ? W : PO_A, NC = WM * (PO_A + 1);
     auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
     size_t per = 3 * al(sizeof(int) * NC) + al(sizeof(double) * K * NC) + 4 * al(sizeof(int) * WM);
-    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + 2 * al(sizeof(int) * NC) + al(16 * (size_t)NC) + al(sizeof(int) * 48);
+    return al(sizeof(PoLaeTables)) + 2 * per + 3 * al(sizeof(int) * WM) + 2 * al(sizeof(int) * NC) + al(16 * (size_t)NC) + al(sizeof(int) * 48) +
+           2 * al(sizeof(int) * NC);
 }
 
 // node-arena entries for a batch: per read root + A children + A * max(W, A) new nodes per frame
