@@ -186,8 +186,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     double yn[CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) yn[c] = (c < C && T > 1 && C != CMAX) ? yr0[(int64_t)C + c] : 0.0;
-    // STEADY TABLE (as in beam1d_wave_kernel): a frame that finds the beam exactly as the previous frame left it, in a table
-    // that was itself built that way, rebuilds nothing — every slot updates its value in place (all reads, a fence, all
+    // STEADY TABLE (as in beam1d_wave_kernel): a frame that finds the beam exactly as the previous frame left it
+    // rebuilds nothing — every slot updates its value in place (all reads, a fence, all
     // writes) from its own previous value and its parent's (kps / kss: left by the last frame that built a table), and the
     // prune is two comparisons per slot; anything but "strictly the same beam" runs the ranking on the table as it stands.
     bool stable = false;
@@ -208,7 +208,6 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         const int NCc0 = Wc * (A + 1);
         const bool ident_in = !first && Wc == Pnb && Wc <= PO_WAVE && (__ballot(lane < Wc && sel[min(lane, WM - 1)] != lane) == 0ull);
         const bool inplace = stable && ident_in && Wc == W && NCc0 <= 2 * PO_WAVE;
-        bool expanded = false;
         if (inplace) {
             double o2[2][3];
 #pragma unroll
@@ -293,10 +292,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             for (int k = 0; k < K; ++k) Q.val[k * NC + j] = out[k];
             Q.fc[j] = fc;
             need = (fc == -1);
-            kps[j] = pslot; kss[j] = last | ((plast == last) ? 0x100 : 0);
-            if (P.fc[s] == -2) expanded = true;
+            kss[j] = last | ((plast == last) ? 0x100 : 0);
         }
-        expanded = (__ballot(expanded || need) != 0ull);
         // ---- expansion: A fresh ids per beam node that has never had children
         //      (PrefixTree::expand, PrefixTree.h:439-446), in beam order
         {
@@ -343,9 +340,22 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             Q.id[s] = x; Q.fc[s] = fcx; Q.depth[s] = Q.depth[j] + 1;
 #pragma unroll
             for (int k = 0; k < K; ++k) Q.val[k * NC + s] = out[k];
-            kps[s] = sj; kss[s] = c | ((Q.last[j] == c) ? 0x100 : 0);
-        }
+            kps[s] = j; kss[s] = c | ((Q.last[j] == c) ? 0x100 : 0);   // (what the next frame needs if it finds this beam unchanged:
+        }                                                              //  the parent's slot in THIS table)
         po_wave_sync();   // (one wave per read)
+        for (int j = lane; j < Wc; j += PO_WAVE) {   // ... for a beam node: its parent among this table's beam slots, or a child of its grand-parent's
+            const int par = Q.par[j], gpar = Q.gpar[j], plast = Q.plast[j];
+            int ps = (par == 0) ? -1 : -2;
+            if (par != 0) {
+#pragma unroll 4
+                for (int i = 0; i < Wc; ++i) if (Q.id[i] == par) ps = i;
+                if (ps < 0) {
+#pragma unroll 4
+                    for (int i = 0; i < Wc; ++i) if (Q.id[i] == gpar) ps = Wc + A * i + plast;
+                }
+            }
+            kps[j] = ps;
+        }
         }   // !inplace
 
         // ---- phase 3: prune (Beam.h:93-108).  A child slot whose node is also a beam slot is the
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         const int Wn = min(W, kept);
         for (int j = lane; j < Wn; j += PO_WAVE) sel[j] = nsel[j];
         if (MODEL == PO_MODEL_CTC) blank_cum += b1_pick<CMAX>(yr, A);
-        if (!inplace) { cur ^= 1; stable = ident_in && !expanded; }   // (an in-place frame leaves the table, and `stable`, as they are)
+        if (!inplace) { cur ^= 1; stable = true; }   // (kps / kss describe the table just built; an in-place frame leaves everything as it is)
         Pnb = Wc;
         Wc = Wn;
         po_wave_sync();   // (one wave per read)
@@ -558,9 +568,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
     // blank).  The table of such a frame is the previous one, slot for slot — every lane's node, parent slot, symbol and
     // duplicate flag are what they were — so nothing of it is rebuilt: a lane reads its own previous value and its
     // parent's, updates, and the prune is two comparisons per lane (beam scores still strictly in order, the last of them
-    // strictly above every child: anything else, ties included, takes the full ranking below).  `stable`: the previous
-    // frame was itself built that way (identity selection, nothing expanded), so the constants it left (k_*) describe
-    // slots of the table this frame reads.
+    // strictly above every child: anything else, ties included, takes the full ranking below).  `stable`: a table has been
+    // built and the constants it left (k_*) describe its own slots.
     bool stable = false;
     int k_pslot = -2, k_sym = 0;
     bool k_samef = false, k_dup = false;
@@ -752,8 +761,20 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         for (int k = 0; k < K; ++k) p_val[k] = out[k];
         p_par = par; p_gpar = gpar; p_plast = plast; p_last = last;
         selv = nsel;
-        k_pslot = pslot; k_sym = sym; k_samef = samef; k_dup = dupf;
-        stable = ident_in && !expanded;   // (this frame's table has the layout of the one before it)
+        if (!fastf) {
+            // what the NEXT frame needs if it finds this frame's beam unchanged: every slot's parent slot in THIS table (the
+            // path above knows it in the previous one) — the beam nodes' by one more pass over the beam's ids, a child's is
+            // its beam node's lane.  Nothing will be expanded then: every beam node of this table has its children now.
+            int ps1 = -2, ps2 = -2;
+            for (int i = 0; i < Wc; ++i) {
+                const int bid = __builtin_amdgcn_readlane(q_id, i);
+                if (bid == par) ps1 = i;
+                if (bid == gpar) ps2 = Wc + A * i + plast;
+            }
+            k_pslot = (par == 0) ? -1 : ((ps1 >= 0) ? ps1 : ps2);
+            k_sym = sym; k_samef = samef; k_dup = dupf;
+            stable = true;
+        }
         if (MODEL == PO_MODEL_CTC) blank_cum += yrow[A];
         Pnb = Wc;
         Wc = Wn;
