@@ -195,20 +195,83 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         const Table P = cur ? T1 : T0;
         const bool first = (t == 1);
         double yr[CMAX];
-        if (C == CMAX) {   // (the standard alphabets: whole rows of CMAX doubles)
-            b1_sload_row<CMAX>(yr0 + (int64_t)t * C, yr);
-        } else {
+        auto load_y = [&](int tt) {
+            if (C == CMAX) {   // (the standard alphabets: whole rows of CMAX doubles)
+                b1_sload_row<CMAX>(yr0 + (int64_t)tt * C, yr);
+            } else {
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) yr[c] = yn[c];
-            if (t + 1 < T) {
+                for (int c = 0; c < CMAX; ++c) yr[c] = yn[c];
+                if (tt + 1 < T) {
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) yn[c] = (c < C) ? yr0[(int64_t)(t + 1) * C + c] : 0.0;
+                    for (int c = 0; c < CMAX; ++c) yn[c] = (c < C) ? yr0[(int64_t)(tt + 1) * C + c] : 0.0;
+                }
             }
-        }
+        };
+        load_y(t);
         const int NCc0 = Wc * (A + 1);
         const bool ident_in = !first && Wc == Pnb && Wc <= PO_WAVE && (__ballot(lane < Wc && sel[min(lane, WM - 1)] != lane) == 0ull);
         const bool inplace = stable && ident_in && Wc == W && NCc0 <= 2 * PO_WAVE;
         if (inplace) {
+            // A RUN of such frames (as in beam1d_wave_kernel): a lane's two slots keep their constants and their own values in
+            // registers; a frame reads the parents' values from the table, updates, tests the beam on registers (the beam
+            // slots are lanes 0 .. W-1 of the first half: next slot by wave_shl:1, last one by v_readlane) and only then
+            // writes.  The first frame that does not keep the beam leaves the run with the table untouched and is redone by
+            // the in-place frame below.
+            int ps_[2], ks_[2];
+            bool in_[2], dp_[2];
+            double v_[2][3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sl = lane + h * PO_WAVE;
+                in_[h] = sl < NCc0;
+                const int sx = in_[h] ? sl : 0;
+                ps_[h] = kps[sx]; ks_[h] = kss[sx]; dp_[h] = dup[sx] != 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) v_[h][k] = P.val[k * NC + sx];
+            }
+            for (;;) {
+                double o2[2][3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double pp[3];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) pp[k] = P.val[k * NC + max(ps_[h], 0)];
+                    if (ps_[h] == -1) root_values<MODEL>(t - 1, blank_cum, pp);
+                    else if (ps_[h] < 0) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF;
+                    }
+                    const int sym = ks_[h] & 0xff;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) o2[h][k] = PO_NEG_INF;
+                    if (in_[h])
+                        po_update<MODEL>(v_[h], pp, b1_pick<CMAX>(yr, sym), (MODEL == PO_MODEL_FLIPFLOP) ? b1_pick<CMAX>(yr, sym + A) : b1_pick<CMAX>(yr, A),
+                                         (ks_[h] >> 8) != 0, false, o2[h], lae);
+                }
+                const double sc0 = o2[0][0], sc1 = o2[1][0];
+                const double scl = rg1_readlane_d(sc0, Wc - 1);
+                const double scn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sc0), 0x130, 0xf, 0xf, false),
+                                                    __builtin_amdgcn_update_dpp(0, __double2loint(sc0), 0x130, 0xf, 0xf, false));   // wave_shl:1
+                bool viol = false;
+                if (lane < Wc) { if (lane + 1 < Wc) viol = !(sc0 > scn); }
+                else if (in_[0] && !dp_[0]) viol = !(scl > sc0);
+                if (in_[1] && !dp_[1]) viol |= !(scl > sc1);
+                if (__ballot(viol) != 0ull) break;
+                po_wave_sync();   // every read of the old values before the first write
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (in_[h]) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { P.val[k * NC + lane + h * PO_WAVE] = o2[h][k]; v_[h][k] = o2[h][k]; }
+                    }
+                }
+                po_wave_sync();
+                if (MODEL == PO_MODEL_CTC) blank_cum += b1_pick<CMAX>(yr, A);
+                ++t;
+                if (t >= T) break;
+                load_y(t);
+            }
+            if (t >= T) break;
             double o2[2][3];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -573,6 +636,9 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
     bool stable = false;
     int k_pslot = -2, k_sym = 0;
     bool k_samef = false, k_dup = false;
+#ifdef PO_B1_COUNT
+    int cnt_fast = 0, cnt_same = 0;
+#endif
     for (int t = 1; t < T; ++t) {
         const bool first = (t == 1);
         if ((t & 31) == 0) { y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync(); }
@@ -582,6 +648,50 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         const int j = rc ? (((lane - Wc) * divA) >> 16) : 0, c = rc ? (lane - Wc) - j * A : 0;   // (x / A for x < 64)
         const bool ident_in = !first && Wc == Pnb && (__ballot(rb && selv != lane) == 0ull);
         const bool fastf = stable && ident_in;
+        if (fastf && Wc == W) {
+            // A RUN of frames on the steady table.  A lone wave pays for every instruction of a frame, and the general frame
+            // below spends ~300 on a steady one; here everything a lane needs is hoisted out of the run — a frame is the
+            // parent's value (one permute), the update and two comparisons.  The first frame that does not keep the beam
+            // strictly as it is leaves the run and goes through the regular path below (which computes it again).
+            const bool act = rb || rc;
+            const int par_lane = rb ? max(k_pslot, 0) : j;
+            const bool rootp = rb && k_pslot == -1, nop = rb && k_pslot < -1;
+            const int iya = act ? k_sym : 0, iyb = (MODEL == PO_MODEL_FLIPFLOP) ? (act ? k_sym + A : 0) : A;
+            const bool validc = rc && !k_dup, hasn = rb && lane + 1 < Wc;
+            for (;;) {
+                const double* yq = &yblk[(t >> 5) & 1][t & 31][0];
+                const double ya = yq[iya], yb = yq[iyb];   // (requested before the permute: one LDS round trip for both)
+                double pp[3], o[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
+#pragma unroll
+                for (int k = 0; k < K; ++k) pp[k] = __shfl(p_val[k], par_lane);
+                if (rootp) root_values<MODEL>(t - 1, blank_cum, pp);
+                else if (nop) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF;
+                }
+                if (act) po_update<MODEL>(p_val, pp, ya, yb, k_samef, false, o, lae);
+                const double sc = o[0];
+                const double scl = rg1_readlane_d(sc, Wc - 1);
+                const double scn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sc), 0x101, 0xf, 0xf, false),
+                                                    __builtin_amdgcn_update_dpp(0, __double2loint(sc), 0x101, 0xf, 0xf, false));
+                const bool viol = hasn ? !(sc > scn) : (validc && !(scl > sc));
+                if (__ballot(viol) != 0ull) break;
+#pragma unroll
+                for (int k = 0; k < K; ++k) p_val[k] = o[k];
+                if (MODEL == PO_MODEL_CTC) blank_cum += yb;   // (iyb == A for this model: the blank column)
+#ifdef PO_B1_COUNT
+                ++cnt_fast; ++cnt_same;
+#endif
+                ++t;
+                if (t >= T) break;
+                if ((t & 31) == 0) { y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync(); }
+            }
+            if (t >= T) break;
+            yrow = &yblk[(t >> 5) & 1][t & 31][0];
+        }
+#ifdef PO_B1_COUNT   // debugging builds: how many frames of read 0 take which path
+        if (fastf) ++cnt_fast;
+#endif
         int q_id, q_depth, q_fc, par, gpar, plast, last, pslot, slot = -2, s_self, s_parent, sym;
         bool samef, expanded = false;
         if (fastf) {
@@ -710,6 +820,9 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             same_beam = (__ballot(viol) == 0ull);
         }
         int Wn = Wc, nsel = lane;   // lane jx < Wn: the slot of the candidate of rank jx
+#ifdef PO_B1_COUNT
+        if (same_beam) ++cnt_same;
+#endif
         if (!same_beam) {
         if (fastf) {   // (the smallest beam score was not needed for the test above)
             thr = rg1_readlane_d(sc, 0);
@@ -779,6 +892,9 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         Pnb = Wc;
         Wc = Wn;
     }
+#ifdef PO_B1_COUNT
+    if (r == 0 && lane == 0) printf("[b1 count] read 0: %d frames, %d on the steady table, %d kept the beam\n", T, cnt_fast, cnt_same);
+#endif
     // ---- label of the top node (PrefixTree::get_label, PrefixTree.h:449-457)
     const int top = __builtin_amdgcn_readlane(selv, 0);
     const int node0 = __shfl(p_id, top), depth0 = __shfl(p_depth, top);
