@@ -547,6 +547,16 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
 // instead of LDS arrays and their search loops, and the two update passes of a frame (beam slots, then children: both
 // read the PREVIOUS table only) are one pass with one logaddexp latency.  Semantics, arena layout and tie handling are
 // beam1d_kernel's, statement for statement; only the exact-tie replay still goes through LDS.
+// minimum of x over lanes 0 .. 15 (row 0 of the wave), as a wave-uniform value: four row_shr steps, lane 15 holds it
+__device__ __forceinline__ double b1_row0_min(double x) {
+#define B1_STEP(ctrl)                                                                                                     \
+    x = fmin(x, __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), ctrl, 0xf, 0xf, false), \
+                                 __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), ctrl, 0xf, 0xf, false)))
+    B1_STEP(0x111); B1_STEP(0x112); B1_STEP(0x114); B1_STEP(0x118);
+#undef B1_STEP
+    return rg1_readlane_d(x, 15);
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
     const double* __restrict__ y, const int64_t* __restrict__ y_off, int A, uint32_t alphabet, int W,
@@ -630,8 +640,11 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
     // STEADY TABLE.  Most frames keep the beam exactly as it was (the same nodes in the same order: nine frames in ten are
     // blank).  The table of such a frame is the previous one, slot for slot — every lane's node, parent slot, symbol and
     // duplicate flag are what they were — so nothing of it is rebuilt: a lane reads its own previous value and its
-    // parent's, updates, and the prune is two comparisons per lane (beam scores still strictly in order, the last of them
-    // strictly above every child: anything else, ties included, takes the full ranking below).  `stable`: a table has been
+    // parent's, updates, and the prune is one comparison per child: strictly below the smallest beam score.  The ORDER of
+    // the beam nodes among themselves is not looked at: nothing is created while the set stays (every beam node has its
+    // children), ties are decided on node ids, so the order only matters when the set changes — and that frame ranks
+    // everybody — and for the label, which is why the last frame is always ranked.  (A child AT the smallest beam score,
+    // ties included, takes the full ranking below.)  `stable`: a table has been
     // built and the constants it left (k_*) describe its own slots.
     bool stable = false;
     int k_pslot = -2, k_sym = 0;
@@ -657,8 +670,9 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             const int par_lane = rb ? max(k_pslot, 0) : j;
             const bool rootp = rb && k_pslot == -1, nop = rb && k_pslot < -1;
             const int iya = act ? k_sym : 0, iyb = (MODEL == PO_MODEL_FLIPFLOP) ? (act ? k_sym + A : 0) : A;
-            const bool validc = rc && !k_dup, hasn = rb && lane + 1 < Wc;
+            const bool validc = rc && !k_dup;
             for (;;) {
+                if (t == T - 1) break;   // (the last frame is ranked: the label is the best node's)
                 const double* yq = &yblk[(t >> 5) & 1][t & 31][0];
                 const double ya = yq[iya], yb = yq[iyb];   // (requested before the permute: one LDS round trip for both)
                 double pp[3], o[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
@@ -671,11 +685,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
                 }
                 if (act) po_update<MODEL>(p_val, pp, ya, yb, k_samef, false, o, lae);
                 const double sc = o[0];
-                const double scl = rg1_readlane_d(sc, Wc - 1);
-                const double scn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sc), 0x101, 0xf, 0xf, false),
-                                                    __builtin_amdgcn_update_dpp(0, __double2loint(sc), 0x101, 0xf, 0xf, false));
-                const bool viol = hasn ? !(sc > scn) : (validc && !(scl > sc));
-                if (__ballot(viol) != 0ull) break;
+                const double scmin = b1_row0_min(rb ? sc : HUGE_VAL);   // (W <= 12: the beam lanes sit in row 0)
+                if (__ballot(validc && !(scmin > sc)) != 0ull) break;
 #pragma unroll
                 for (int k = 0; k < K; ++k) p_val[k] = o[k];
                 if (MODEL == PO_MODEL_CTC) blank_cum += yb;   // (iyb == A for this model: the blank column)
@@ -810,14 +821,9 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         const bool valid = (rb || rc) && !dupf;
         // the beam as it was?  (strictly: exact ties go through the ranking, as partial_sort decides them)
         bool same_beam = false;
-        if (Wc == W) {
-            const double scl = rg1_readlane_d(sc, Wc - 1);
-            const double scn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sc), 0x101, 0xf, 0xf, false),
-                                                __builtin_amdgcn_update_dpp(0, __double2loint(sc), 0x101, 0xf, 0xf, false));   // row_shl:1 (W <= 12: one row)
-            bool viol = false;
-            if (rb) { if (lane + 1 < Wc) viol = !(sc > scn); }
-            else if (valid) viol = !(scl > sc);
-            same_beam = (__ballot(viol) == 0ull);
+        if (Wc == W && t != T - 1) {
+            const double scmin = b1_row0_min(rb ? sc : HUGE_VAL);
+            same_beam = (__ballot(rc && valid && !(scmin > sc)) == 0ull);
         }
         int Wn = Wc, nsel = lane;   // lane jx < Wn: the slot of the candidate of rank jx
 #ifdef PO_B1_COUNT
