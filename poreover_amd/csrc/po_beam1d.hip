@@ -91,6 +91,18 @@ __device__ __forceinline__ double b1_pick(const double* yr, int i) {
     return r;
 }
 
+// minimum of x over the wave, as a wave-uniform value (row_shr steps, then the rows' results into lane 63)
+__device__ __forceinline__ double b1_wave_min(double x) {
+#define B1_STEPW(ctrl, rmask)                                                                                                  \
+    x = fmin(x, __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), ctrl, rmask, 0xf, false),   \
+                                 __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), ctrl, rmask, 0xf, false)))
+    B1_STEPW(0x111, 0xf); B1_STEPW(0x112, 0xf); B1_STEPW(0x114, 0xf); B1_STEPW(0x118, 0xf);
+    B1_STEPW(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+    B1_STEPW(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef B1_STEPW
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     const double* __restrict__ y, const int64_t* __restrict__ y_off, int A, uint32_t alphabet, int W,
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 for (int k = 0; k < K; ++k) v_[h][k] = P.val[k * NC + sx];
             }
             for (;;) {
+                if (t == T - 1) break;   // (the last frame is ranked: the label is the best node's)
                 double o2[2][3];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -249,13 +262,11 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                                          (ks_[h] >> 8) != 0, false, o2[h], lae);
                 }
                 const double sc0 = o2[0][0], sc1 = o2[1][0];
-                const double scl = rg1_readlane_d(sc0, Wc - 1);
-                const double scn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sc0), 0x130, 0xf, 0xf, false),
-                                                    __builtin_amdgcn_update_dpp(0, __double2loint(sc0), 0x130, 0xf, 0xf, false));   // wave_shl:1
+                // the same SET (see beam1d_wave_kernel): every child strictly below the smallest beam score
+                const double scmin = b1_wave_min((lane < Wc) ? sc0 : HUGE_VAL);
                 bool viol = false;
-                if (lane < Wc) { if (lane + 1 < Wc) viol = !(sc0 > scn); }
-                else if (in_[0] && !dp_[0]) viol = !(scl > sc0);
-                if (in_[1] && !dp_[1]) viol |= !(scl > sc1);
+                if (lane >= Wc && in_[0] && !dp_[0]) viol = !(scmin > sc0);
+                if (in_[1] && !dp_[1]) viol |= !(scmin > sc1);
                 if (__ballot(viol) != 0ull) break;
                 po_wave_sync();   // every read of the old values before the first write
 #pragma unroll
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                     else if (!dup[sl]) viol |= !(scl > sc);
                 }
             }
-            if (__ballot(viol) == 0ull) {   // the same beam, strictly: nothing else moves
+            if (t != T - 1 && __ballot(viol) == 0ull) {   // the same beam, strictly: nothing else moves
                 if (MODEL == PO_MODEL_CTC) blank_cum += b1_pick<CMAX>(yr, A);
                 continue;
             }
