@@ -474,6 +474,41 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             }
             if (inS && rank < W) nsel[rank] = s;
             tie = __ballot(inS && (neq > 1) && (rank < W)) != 0ull;   // an exact tie that reaches into the beam
+        } else if (NCc <= 2 * PO_WAVE && Wc == W && Wc <= PO_WAVE) {
+            // the same two-stage select for tables of up to 128 candidates (W <= 25): a lane holds two slots, the set
+            // {beam slots} + {children >= the smallest beam score} is two ballot masks, the ranks are taken within it
+            double thr = cand[0].sc;
+            for (int j = 1; j < Wc; ++j) thr = fmin(thr, cand[j].sc);
+            B1Cand me[2];
+            bool val2[2], in2[2];
+            unsigned long long smk[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = lane + h * PO_WAVE;
+                val2[h] = (s < NCc) && !dup[min(s, NCc - 1)];
+                me[h] = cand[min(s, NCc - 1)];
+                in2[h] = val2[h] && (s < Wc || me[h].sc >= thr);
+                smk[h] = __ballot(in2[h]);
+                kept += __popcll(__ballot(val2[h]));
+            }
+            int rank[2] = {0, 0}, neq[2] = {0, 0};
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                for (unsigned long long mm = smk[g]; mm != 0ull; mm &= mm - 1ull) {   // (uniform)
+                    const B1Cand c = cand[g * PO_WAVE + __builtin_ctzll(mm)];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        rank[h] += ((c.sc > me[h].sc) | (!(me[h].sc > c.sc) & (c.id < me[h].id))) ? 1 : 0;
+                        neq[h] += (c.sc == me[h].sc) ? 1 : 0;
+                    }
+                }
+            bool teq = false;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (in2[h] && rank[h] < W) nsel[rank[h]] = lane + h * PO_WAVE;
+                teq |= in2[h] && (neq[h] > 1) && (rank[h] < W);
+            }
+            tie = __ballot(teq) != 0ull;
         } else
         for (int s0 = 0; s0 < NCc; s0 += PO_WAVE) {
             const int s = s0 + lane;
