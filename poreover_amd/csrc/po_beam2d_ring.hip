@@ -772,16 +772,18 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
 #ifdef PO_RING_TRACE   // debugging builds only (scripts/trace_rowcol.py): every candidate's score before the prune
             if (pi == 0 && cand && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
 #endif
-            // ---- prune (Beam.h:93-108).  Most steps keep the beam as it is: iff the beam nodes are still in order and the
-            // last of them still beats every child (strictly: exact ties go the full way, as partial_sort decides them)
-            bool viol = (nb != W);
-            if (!viol && cand) {
-                // (the next beam slot's score: a lane shift within the row of 16 — the beam slots sit in lanes 0..5 / 32..37)
-                const double scl = rg_readlane_d(sc, nb - 1);
-                const double scn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sc), 0x101, 0xf, 0xf, false),
-                                                    __builtin_amdgcn_update_dpp(0, __double2loint(sc), 0x101, 0xf, 0xf, false));
-                if (s >= nb) viol = !(scl > sc);
-                else if (s + 1 < nb) viol = !(sc > scn);
+            // ---- prune (Beam.h:93-108).  Most steps keep the SET of beam nodes: iff every child is strictly below the smallest
+            // beam score (a child AT it, ties included, goes the full way, as partial_sort decides them).  The order of the
+            // beam nodes among themselves is not looked at: nothing is created while the set stays (every beam node has its
+            // children), ties are decided on node ids, and the order matters only where nodes are created — the step in which
+            // the set changes ranks everybody — and for the label: the last main step is always ranked.  (Round 3, late: the
+            // first form also wanted the beam scores still in order, and rebuilt the table for every permutation of the same
+            // five nodes.)
+            bool viol = (nb != W) || (mstep + 1 == nmain);
+            if (!viol && cand && s >= nb) {
+                double scmin = rg_readlane_d(sc, 0);
+                for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rg_readlane_d(sc, i));
+                viol = !(scmin > sc);
             }
             up = u; vp = v;
             mstep++;
