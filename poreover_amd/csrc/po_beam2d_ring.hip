@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                             if (out > self) tr = t;   // the last time a value rose
                             self = out;
                             mt = (out >= mx) ? t : mt;
-                            asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(out));
+                            mx = po_vmax(mx, out);
                             t = tn;
                         }
                     }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                         if (out > self) tr = t;
                         self = out;
                         mt = (out >= mx) ? t : mt;
-                        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(out));
+                        mx = po_vmax(mx, out);
                     }
                     rg_sync();
                 }
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                             if (out > self) tr = t;   // the last time a value rose
                             self = out;
                             mt = (out >= mx) ? t : mt;
-                            asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(out));
+                            mx = po_vmax(mx, out);
                         }
                         rg_sync();
                     }
@@ -565,6 +565,9 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             if (rb) {
                 isnew = n_fc < 0;
                 need_group = isnew || n_crow2 < 0 || n_crow2 >= NG || sm.g_owner[n_crow2] != n_id;   // (old rows recycled: all dead)
+#ifdef PO_EMU_DEBUG
+                if (r == 0) printf("NG nu %d slot %d id %d fc %d crow2 %d NG %d owner %d hi %d %d\n", nu, s, n_id, n_fc, n_crow2, NG, (n_crow2 >= 0 && n_crow2 < NG) ? sm.g_owner[n_crow2] : -9, (n_crow2 >= 0 && n_crow2 < NG) ? sm.g_hi0[n_crow2] : -9, (n_crow2 >= 0 && n_crow2 < NG) ? sm.g_hi1[n_crow2] : -9);
+#endif
             }
             {
                 const unsigned bn = (unsigned)__ballot(isnew && r == 0);
@@ -587,6 +590,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
                         if (sm.g_owner[c] < 0 || (sm.g_hi0[c] <= nu - 1 && sm.g_hi1[c] <= nv - 1)) { gg = c; break; }
                     }
                     if (gg < 0) { st = PO_E_NOMEM; gg = 0; }
+                    rg_sync();   // (every lane has walked the table before lane 0 changes it)
                     if (lane == 0) { sm.g_owner[gg] = owner; sm.g_hi0[gg] = nce; sm.g_hi1[gg] = nre; acrow[owner] = gg; }
                     if (s == jj) n_crow2 = gg;
                     rg_sync();
@@ -597,6 +601,9 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             const int p_sym = __shfl(n_sym, hb | j), p_par = __shfl(n_par, hb | j), p_row2 = __shfl(n_row2, hb | j);
             const int p_depth = __shfl(n_depth, hb | j);
             const bool p_isnew = __shfl((int)isnew, hb | j) != 0;
+#ifdef PO_EMU_DEBUG
+            if (r == 0 && rb) printf("RB nu %d slot %d from %d id %d fc %d crow2 %d isnew %d needg %d\n", nu, s, srcb, n_id, n_fc, n_crow2, (int)isnew, (int)need_group);
+#endif
             int n_alias = -1, n_ps = PS_FROZEN;
             if (rc) {
                 n_id = p_fc + c; n_row2 = p_crow2 * PO_A + c; n_sym = sym_pack(c, sym_last(p_sym), false);
@@ -612,14 +619,14 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             // ---- D. which old slot continues here
             int src = -1;
             if (rb) src = mysel;
-            else if (rc && n_alias < 0) {
-                if (pj < nbo) {   // the parent was a beam node: its children were elements (or aliases of beam slots)
-                    if (have_children) src = nbo + A * pj + c;
-                } else {          // the parent enters the beam: a child of it was an element only as a beam node
-                    for (int i = 0; i < nbo; ++i) {
-                        const int oid = __builtin_amdgcn_readlane(e_id, i);
-                        if (oid == n_id) src = i;
-                    }
+            else if (rc && n_alias < 0 && pj < nbo) {   // the parent was a beam node: its children were elements (or aliases of beam slots)
+                if (have_children) src = nbo + A * pj + c;
+            }
+            {   // the parent enters the beam: a child of it was an element only as a beam node
+                const bool look = !rb && rc && n_alias < 0 && pj >= nbo;
+                for (int i = 0; i < nbo; ++i) {   // (wave-uniform loop: v_readlane)
+                    const int oid = __builtin_amdgcn_readlane(e_id, i);
+                    if (look && oid == n_id) src = i;
                 }
             }
             {   // (an old child slot that was an alias hands over to the beam slot that held the node)
@@ -698,17 +705,17 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             }
             // ---- the parent slot of the beam nodes: a beam node, a child of a beam node, the root, or none (frozen)
             nb = nbn; ne = nen;
-            if (rb) {
-                n_ps = (e_par == 0) ? PS_ROOT : PS_FROZEN;
+            {   // (wave-uniform loops: v_readlane)
+                if (rb) n_ps = (e_par == 0) ? PS_ROOT : PS_FROZEN;
                 for (int i = 0; i < nbn; ++i) {
                     const int bid = __builtin_amdgcn_readlane(e_id, i);
-                    if (e_par != 0 && bid == e_par) n_ps = i;
+                    if (rb && e_par != 0 && bid == e_par) n_ps = i;
                 }
-                if (n_ps == PS_FROZEN)
-                    for (int i = 0; i < nbn; ++i) {
-                        const int bid = __builtin_amdgcn_readlane(e_id, i);
-                        if (bid == e_gpar) n_ps = nbn + A * i + sym_plast(e_sym);
-                    }
+                const bool fz = rb && n_ps == PS_FROZEN;
+                for (int i = 0; i < nbn; ++i) {
+                    const int bid = __builtin_amdgcn_readlane(e_id, i);
+                    if (fz && bid == e_gpar) n_ps = nbn + A * i + sym_plast(e_sym);
+                }
             }
             e_ps = n_ps;
             // ---- G. a frozen parent that is an element again.  A beam node whose parent had left the table computed its
@@ -780,10 +787,10 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             // first form also wanted the beam scores still in order, and rebuilt the table for every permutation of the same
             // five nodes.)
             bool viol = (nb != W) || (mstep + 1 == nmain);
-            if (!viol && cand && s >= nb) {
+            if (!viol) {   // (wave-uniform: nb == W and not the last step)
                 double scmin = rg_readlane_d(sc, 0);
                 for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rg_readlane_d(sc, i));
-                viol = !(scmin > sc);
+                if (cand && s >= nb) viol = !(scmin > sc);
             }
             up = u; vp = v;
             mstep++;

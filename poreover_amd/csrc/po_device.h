@@ -10,6 +10,32 @@
 
 #define PO_NEG_INF (-__builtin_inf())
 
+// PO_EMU: the CPU lane-by-lane emulation used by tools/simt_emu (test infrastructure, never part of the shipped
+// library): the few inline-assembly helpers below get a plain C++ body there.
+#ifdef PO_EMU
+#define PO_FMA_PLAIN 1
+#define PO_NO_SLOAD 1
+#endif
+// v_max_f64 / v_min_f64 written out: the builtins add a canonicalisation of each operand in IEEE mode
+__device__ __forceinline__ double po_vmax(double a, double b) {
+#ifdef PO_EMU
+    return fmax(a, b);
+#else
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+__device__ __forceinline__ double po_vmin(double a, double b) {
+#ifdef PO_EMU
+    return fmin(a, b);
+#else
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+
 // Log.h:9-15 log_(): -inf for x <= 0 and for NaN
 __device__ __forceinline__ double po_log_(double x) { return (x > 0) ? log(x) : PO_NEG_INF; }
 
@@ -116,10 +142,7 @@ struct PoLaeFast {
         return lh + (w + u);
     }
     __device__ __forceinline__ double operator()(double x1, double x2) const {
-        // (v_max / v_min written out: the builtins add a canonicalisation of each operand in IEEE mode)
-        double hi, lo;
-        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x1), "v"(x2));
-        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x1), "v"(x2));
+        const double hi = po_vmax(x1, x2), lo = po_vmin(x1, x2);
         return hi + f(lo - hi);
     }
 };
@@ -186,7 +209,11 @@ __device__ __forceinline__ int po_lane() { return threadIdx.x & (PO_WAVE - 1); }
 // fire-and-forget global store into a full round trip.  Use this one when only LDS data is
 // exchanged across the barrier and global visibility is established later by __syncthreads().
 __device__ __forceinline__ void po_lds_barrier() {
+#ifdef PO_EMU
+    __syncthreads();
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // LDS hand-over inside a ONE-WAVE workgroup: a wave's LDS (and vector memory) operations are performed in program

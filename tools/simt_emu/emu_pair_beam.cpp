@@ -1,0 +1,49 @@
+// TEST INFRASTRUCTURE ONLY — the row_col pair beam search of the LDS-ring route (pre-pass, walk, beam2d_ring_kernel)
+// executed on the CPU by the SIMT emulator, behind one C entry point for ctypes (tools/simt_emu/check_ring.py compares
+// it with the oracle).  The kernels are the product's own sources, compiled with -DPO_EMU.
+#include <hip/hip_runtime.h>
+
+#include "../../poreover_amd/csrc/po_beam2d_pre.h"
+#include "../../poreover_amd/csrc/po_beam2d_ring.hip"
+
+extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
+                                  const int32_t* env, int n, int C, int A, uint32_t alphabet, int W, char* seq,
+                                  const int64_t* seq_off, int32_t* seq_len, int32_t* status, int blocks,
+                                  unsigned long long* upd_count) {
+    int64_t tr1 = y1_off[n] - y1_off[0], tr2 = y2_off[n] - y2_off[0], mr1 = 0, mr2 = 0;
+    for (int i = 0; i < n; ++i) {
+        mr1 = std::max<int64_t>(mr1, y1_off[i + 1] - y1_off[i]);
+        mr2 = std::max<int64_t>(mr2, y2_off[i + 1] - y2_off[i]);
+    }
+    if (blocks <= 0) blocks = 1;
+    X2Args a;
+    memset(&a, 0, sizeof(a));
+    a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
+    a.n = n; a.A = A; a.W = W; a.C = C; a.alphabet = alphabet;
+    a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status; a.use_pre_status = 0;
+    std::vector<int> queue(64, 0), nmain(n, 0), envt(2 * (size_t)tr2 + 2, 0);
+    std::vector<int2> meta(n);
+    std::vector<int4> sched((size_t)tr2 + 1);
+    std::vector<double> cum1((size_t)tr1 + 1), cum2((size_t)tr2 + 1);
+    const size_t pool_bytes = (size_t)4 << 20;
+    const int64_t WM = W > PO_A ? W : PO_A;
+    const size_t arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
+    std::vector<char> pool(pool_bytes * blocks, 0);
+    std::vector<int> arena(3 * arena_cap * blocks, 0);
+    std::vector<unsigned long long> wgstate(2 * (size_t)blocks, 0);
+    a.queue = queue.data(); a.meta = meta.data(); a.nmain = nmain.data(); a.sched = sched.data(); a.envt = envt.data();
+    a.cum1 = cum1.data(); a.cum2 = cum2.data();
+    a.pool = pool.data(); a.pool_bytes = pool_bytes; a.arena = arena.data(); a.arena_cap = (long long)arena_cap;
+    a.dbg = nullptr; a.upd_count = upd_count; a.defer_odd = 0; a.need_mono = 1; a.order = nullptr;
+    a.wgstate = wgstate.data(); a.magic = 0x1234567ull;
+    a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
+    a.ngl = po_ring_ngl();
+    for (int i = 0; i < n; ++i) status[i] = PO_OK;
+    hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), 0, nullptr, a);
+    hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, nullptr, a);
+    po_ring_launch(&a, blocks, nullptr);
+    int deferred = 0;
+    for (int i = 0; i < n; ++i)
+        if (meta[i].y == X2_DEFERRED) { deferred++; status[i] = -100; }   // (the product hands these to beam2d_kernel)
+    return deferred;
+}

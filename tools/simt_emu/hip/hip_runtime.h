@@ -1,0 +1,165 @@
+// TEST INFRASTRUCTURE ONLY: a host-side stand-in for <hip/hip_runtime.h> that lets a wave-synchronous HIP kernel of
+// this repo be compiled with g++ and executed on the CPU, one fibre per lane (tools/simt_emu/README.md).  It exists
+// because the development container has no GPU: kernel LOGIC (tables, cross-lane exchanges, LDS hand-overs) is
+// checked against the oracle here before a GPU-minute is spent.  Nothing under poreover_amd/ uses it; the product
+// library is built by hipcc from the same sources without PO_EMU.
+//
+// Model: a workgroup is a set of fibres scheduled round-robin on one OS thread.  A cross-lane operation (__shfl,
+// __ballot, readlane, wave barrier) is a rendezvous of the 64 fibres of a wave and must be reached by all of them from
+// the same source line (divergent use aborts with both line numbers); __syncthreads is a rendezvous of the block.
+// A fibre runs uninterrupted between rendezvous points, so plain loads / stores / "atomics" need no locking.
+#pragma once
+#define PO_EMU 1
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __noinline__ __attribute__((noinline))
+
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint3_ { unsigned x, y, z; };
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+#define hipSuccess 0
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 0; return 1; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n); return 0; }
+static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipMemcpyDeviceToHost 0
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+
+namespace emu {
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    bool done = false;
+    uint3_ tid{0, 0, 0};
+};
+struct Rv {   // rendezvous of a group of fibres
+    int arrived = 0, gen = 0, line = -1;
+};
+extern Fiber* g_cur;
+extern uint3_ g_bid, g_bdim, g_gdim;
+extern int g_nlive_block;
+extern unsigned long long g_xch[1024][2];
+void yield();
+void rendezvous_wave(int line);
+void rendezvous_block(int line);
+int wave_live(int wave);
+unsigned long long wave_group();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+long long clock_ticks();
+}  // namespace emu
+
+#define threadIdx (emu::g_cur->tid)
+#define blockIdx (emu::g_bid)
+#define blockDim (emu::g_bdim)
+#define gridDim (emu::g_gdim)
+
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); })
+
+// ---- cross-lane operations (wave = 64 consecutive threads of the block)
+namespace emu {
+template <class T>
+static inline T xch_get(int tid_in_block) { T v; memcpy(&v, &g_xch[tid_in_block][0], sizeof(T)); return v; }
+template <class T>
+static inline T shfl(T x, int src, int line) {
+    static_assert(sizeof(T) <= 16, "shfl payload");
+    const int me = (int)g_cur->tid.x, base = me & ~63;
+    memcpy(&g_xch[me][0], &x, sizeof(T));
+    rendezvous_wave(line);
+    if (!((wave_group() >> (src & 63)) & 1ull)) {
+        fprintf(stderr, "[simt_emu] line %d: thread %d reads lane %d, which is not executing this operation\n", line, me, src & 63);
+        abort();
+    }
+    const T r = xch_get<T>(base + (src & 63));
+    rendezvous_wave(line);
+    return r;
+}
+static inline unsigned long long ballot(bool p, int line) {
+    const int me = (int)g_cur->tid.x, base = me & ~63;
+    g_xch[me][0] = p ? 1ull : 0ull;
+    rendezvous_wave(line);
+    const unsigned long long grp = wave_group();   // (lanes outside the branch, or gone, do not vote)
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (((grp >> l) & 1ull) && g_xch[base + l][0]) m |= 1ull << l;
+    rendezvous_wave(line);
+    return m;
+}
+}  // namespace emu
+#define __shfl(v_, l_) emu::shfl((v_), (l_), __LINE__)
+static inline int emu_lane_() { return (int)(emu::g_cur->tid.x & 63); }
+#define __shfl_xor(v_, m_) emu::shfl((v_), (int)(emu_lane_() ^ (m_)), __LINE__)
+#define __ballot(p_) emu::ballot((p_), __LINE__)
+#define __builtin_amdgcn_readlane(v_, l_) emu::shfl((int)(v_), (l_), __LINE__)
+#define __builtin_amdgcn_readfirstlane(v_) emu::shfl((int)(v_), 0, __LINE__)
+#define __builtin_amdgcn_ds_bpermute(a_, v_) emu::shfl((int)(v_), ((a_) >> 2), __LINE__)
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() emu::rendezvous_wave(__LINE__)
+#define __builtin_amdgcn_s_sleep(n) emu::yield()
+#define __builtin_amdgcn_s_barrier() emu::rendezvous_block(__LINE__)
+#define __syncthreads() emu::rendezvous_block(__LINE__)
+static inline int emu_syncthreads_or(int p, int line) {
+    static int acc[2];
+    static int phase = 0;
+    const int ph = phase;
+    if (p) acc[ph] = 1;
+    emu::rendezvous_block(line);
+    const int r = acc[ph];
+    emu::rendezvous_block(line);
+    if (emu::g_cur->tid.x == 0) { acc[ph] = 0; phase ^= 1; }
+    emu::rendezvous_block(line);
+    return r;
+}
+#define __syncthreads_or(p_) emu_syncthreads_or((p_), __LINE__)
+
+// ---- scalar helpers
+static inline int __double2hiint(double x) { unsigned long long u; memcpy(&u, &x, 8); return (int)(unsigned)(u >> 32); }
+static inline int __double2loint(double x) { unsigned long long u; memcpy(&u, &x, 8); return (int)(unsigned)u; }
+static inline double __hiloint2double(int hi, int lo) {
+    const unsigned long long u = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    double x; memcpy(&x, &u, 8); return x;
+}
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline long long wall_clock64() { return emu::clock_ticks(); }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline long long min(long long a, long long b) { return a < b ? a : b; }
+static inline long long max(long long a, long long b) { return a > b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+static inline size_t min(size_t a, size_t b) { return a < b ? a : b; }
+static inline size_t max(size_t a, size_t b) { return a > b ? a : b; }
+
+// ---- "atomics": a fibre is never preempted between rendezvous points
+template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicAnd(T* p, T v) { const T o = *p; *p = o & v; return o; }
+template <class T> static inline T atomicExch(T* p, T v) { const T o = *p; *p = v; return o; }
+template <class T> static inline T atomicCAS(T* p, T c, T v) { const T o = *p; if (o == c) *p = v; return o; }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
