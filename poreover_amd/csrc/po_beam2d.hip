@@ -47,6 +47,7 @@
 #include <unordered_map>
 
 #include "po_device.h"
+#include "po_host.h"
 #include "po_beam2d_common.h"
 
 namespace {
@@ -2340,27 +2341,9 @@ inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 
 // device memory a pair-beam workspace may plan with (a fixed share of the board's memory: the size reported by
 // po_*_workspace_bytes and the size a launch expects must agree whatever else is allocated)
-size_t b2_mem_budget() {
-    static size_t tot = 0;
-    if (!tot) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) tot = p.totalGlobalMem;
-        if (!tot) tot = (size_t)288 << 30;
-    }
-    return tot / 4;
-}
+size_t b2_mem_budget() { return po_dev_info().mem / 4; }
 
-int b2_num_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+int b2_num_cus() { return po_dev_info().cus; }
 
 // resident workgroups per CU of one kernel instance (registers and LDS decide), asked once from the runtime
 template <int MODEL, int WMAX>
@@ -2372,16 +2355,13 @@ int b2_occ() {
     return nblk;
 }
 int b2_blocks_per_cu(int model, int wclass) {
-    static int cache[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    static PoPerDeviceCache<9> cache;
     const int mi = model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2), wi = wclass == 6 ? 0 : (wclass == 12 ? 1 : 2);
-    if (!cache[mi][wi]) {
-        int v = 0;
-        if (mi == 0) v = wi == 0 ? b2_occ<PO_MODEL_CTC, 6>() : (wi == 1 ? b2_occ<PO_MODEL_CTC, 12>() : b2_occ<PO_MODEL_CTC, 25>());
-        else if (mi == 1) v = wi == 0 ? b2_occ<PO_MODEL_MERGE, 6>() : (wi == 1 ? b2_occ<PO_MODEL_MERGE, 12>() : b2_occ<PO_MODEL_MERGE, 25>());
-        else v = wi == 0 ? b2_occ<PO_MODEL_FLIPFLOP, 6>() : (wi == 1 ? b2_occ<PO_MODEL_FLIPFLOP, 12>() : b2_occ<PO_MODEL_FLIPFLOP, 25>());
-        cache[mi][wi] = v;
-    }
-    return cache[mi][wi];
+    return cache.get(mi * 3 + wi, [=] {
+        if (mi == 0) return wi == 0 ? b2_occ<PO_MODEL_CTC, 6>() : (wi == 1 ? b2_occ<PO_MODEL_CTC, 12>() : b2_occ<PO_MODEL_CTC, 25>());
+        if (mi == 1) return wi == 0 ? b2_occ<PO_MODEL_MERGE, 6>() : (wi == 1 ? b2_occ<PO_MODEL_MERGE, 12>() : b2_occ<PO_MODEL_MERGE, 25>());
+        return wi == 0 ? b2_occ<PO_MODEL_FLIPFLOP, 6>() : (wi == 1 ? b2_occ<PO_MODEL_FLIPFLOP, 12>() : b2_occ<PO_MODEL_FLIPFLOP, 25>());
+    });
 }
 
 B2Geom b2_geometry(int n, int64_t mr1, int64_t mr2, int W, int model, int method, int max_blocks = 0) {
@@ -2530,17 +2510,16 @@ const void* x2_fn(int W) {
     return W <= 6 ? (const void*)beam2d_x2_kernel<MODEL, 32> : (const void*)beam2d_x2_kernel<MODEL, 64>;
 }
 int x2_blocks_per_cu(int model, int W) {
-    static int per_cu[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    static PoPerDeviceCache<6> per_cu;
     const int mi = model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2), wi = W <= 6 ? 0 : 1;
-    if (!per_cu[mi][wi]) {
+    return per_cu.get(mi * 2 + wi, [=] {
         int nblk = 0;
         const void* fn = mi == 0 ? x2_fn<PO_MODEL_CTC>(W) : (mi == 1 ? x2_fn<PO_MODEL_MERGE>(W) : x2_fn<PO_MODEL_FLIPFLOP>(W));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, 64, 0) != hipSuccess || nblk <= 0) nblk = 8;
         if (b2_route().debug_occ) fprintf(stderr, "[po] beam2d_x2_kernel model %d W %d: %d resident workgroups per CU\n", model, W, nblk);
         if (b2_route().x2_per_cu > 0 && b2_route().x2_per_cu < nblk) nblk = b2_route().x2_per_cu;  // experiment knob
-        per_cu[mi][wi] = nblk;
-    }
-    return per_cu[mi][wi];
+        return nblk;
+    });
 }
 X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model) {
     X2Geom g;

@@ -30,6 +30,7 @@
 #include <climits>
 
 #include "po_beam2d_common.h"
+#include "po_host.h"
 
 namespace {
 
@@ -753,7 +754,130 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
 
         // ---------------------------------------------------------------- the diagonal walk (BeamSearch.h:300-393)
         while (st == PO_OK && mstep < nmain) {
-            const int u = rec.x, v = rec.y, ce = rec.z, re = rec.w;
+            int u = rec.x, v = rec.y, ce = rec.z, re = rec.w;
+            double sc = PO_NEG_INF;
+            bool viol = false, run_viol = false;
+#ifndef PO_RING_NO_RUN
+            // ---- a RUN of main steps on the table as it stands.  After a step that kept the set of beam nodes, with every
+            // live lane's values ending at the same time and nothing to catch up, the next step is: the new times of the two
+            // windows (often none on a read: the envelope's window ends move a base at a time) in lockstep, the window maxima
+            // from what is carried, the score, the one comparison per child.  The general step below does the same through
+            // scan()'s prologue (which loop, which parent, which seed); here all of that is known.  The run ends at the first
+            // step that is not of this kind (it is then done below) or that changes the beam (it is ranked below).
+            if (!tbl_fresh && !tbl_uneven && nb == W && __ballot(live && e_ps == PS_ROOT) == 0ull) {
+                const int sym = sym_last(e_sym);
+                const double* const ringp = &sm.ring[r][0][c_plrow];
+                double* const ringm = &sm.ring[r][0][e_lrow];
+                const double* const yb_ = &sm.ybuf[r][0][0];
+                for (;;) {
+                    u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
+                    const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
+                    if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || ce - u > RG_RL - 1 || re - v > RG_RL - 1 || mstep + 1 >= nmain) break;
+                    const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
+                    const bool part2 = live && dr < we;
+                    if (__ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull) break;   // a frozen parent's older values: tier 2
+                    // ---- the carried part [ws, dr) of the window: its maximum is what the previous step left, unless that
+                    // time is now before the window start
+                    const bool has_c = live && dr > ws;
+                    double mx = PO_NEG_INF, cmx = PO_NEG_INF, self = v_self;
+                    int mt = -1, cmt = -1, td = has_c ? v_td : ws, tr = INT_MIN;
+                    bool rr_need = false;
+                    if (has_c) {
+                        if (v_mx == PO_NEG_INF || v_mt >= ws) { cmx = v_mx; cmt = v_mt; }
+                        else rr_need = true;
+                    }
+                    double rr4[4] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
+                    if (rr_need) {   // (window <= 31 times: these slots are not written in this step)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rr4[q] = ringm[((ws + q) & (RG_RL - 1)) * RG_NRP];
+                    }
+                    // ---- the new times [dr, we), everybody in lockstep
+                    const int n2 = we - dr;   // (half-uniform, >= 0)
+                    const int n2max = max(ce - d0, re - d1);
+                    if (n2max > 0) {
+                        if (n2 > 0 && !(dr >= yhi - RG_NY && we <= yhi)) { y_reload(dr); yhi = dr + RG_NY; }
+                        rg_sync();
+                        for (int k = 0; k < n2max; ++k) {
+                            const int t = dr + k;
+                            if (live && k < n2) {
+                                const double* yrow = yb_ + (t & (RG_NY - 1)) * RG_YC;
+                                const double ya = yrow[sym], yb = yrow[A];
+                                const int tm = t - 1;
+                                double pp = ringp[(tm & (RG_RL - 1)) * RG_NRP];
+                                if (e_ps < 0) pp = (tm == fz_t) ? fz_val : PO_NEG_INF;
+                                const double out = lae(pp + ya, self + yb);
+#ifdef PO_RING_TRACE_NODE
+                                if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g RUN ps %d fzt %d\n", e_id, r, t, out, pp, self, e_ps, fz_t);
+#endif
+                                ringm[(t & (RG_RL - 1)) * RG_NRP] = out;
+                                if (out > self) tr = t;
+                                self = out;
+                                mt = (out >= mx) ? t : mt;
+                                mx = po_vmax(mx, out);
+                            }
+                            rg_sync();
+                        }
+                        if (part2) { v_hiw = max(v_hiw, we); v_done = we; v_self = self; }
+                    }
+                    if (rr_need) {   // the carried part's maximum from the stored values (as scan()'s rr_resolve)
+                        const bool inring = (ws >= v_lo && ws >= v_hiw - RG_RL);
+                        if (td <= ws) {
+                            cmx = inring ? rr4[0] : read_own(ws);
+                            cmt = ws;
+                        } else {
+                            double pv = PO_NEG_INF;
+                            const int te = min(td + 1, dr);
+                            td = ws;
+                            int tq0 = ws;
+                            if (inring) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int tq = ws + q;
+                                    if (tq < te) {
+                                        if (rr4[q] >= cmx) { cmx = rr4[q]; cmt = tq; }
+                                        if (tq > ws && rr4[q] > pv) td = tq;
+                                        pv = rr4[q];
+                                    }
+                                }
+                                tq0 = ws + 4;
+                            }
+                            for (int tq = tq0; tq < te; ++tq) {
+                                const double vq = read_own(tq);
+                                if (vq >= cmx) { cmx = vq; cmt = tq; }
+                                if (tq > ws && vq > pv) td = tq;
+                                pv = vq;
+                            }
+                        }
+                    }
+                    if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
+                    if (live) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
+                    smx = live ? mx : PO_NEG_INF;
+                    if (a.upd_count != nullptr) {
+                        cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
+                        cnt_x += (unsigned)(__popcll(__ballot(live && r == 0)) * (ce - d0) + __popcll(__ballot(live && r == 1)) * (re - d1));
+                    }
+                    sc = smx + __shfl_xor(smx, 32);
+#ifdef PO_RING_TRACE
+                    if (pi == 0 && live && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
+#endif
+                    double scmin = rg_readlane_d(sc, 0);
+                    for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rg_readlane_d(sc, i));
+                    viol = live && s >= nb && !(scmin > sc);
+                    up = u; vp = v;
+                    mstep++;
+                    if ((mstep & 63) == 0) {
+                        rcur = rnxt;
+                        rnxt = sched[min(mstep + 64 + lane, max(nmain - 1, 0))];
+                    }
+                    rec = rec_at(min(mstep, nmain - 1));
+                    RTC(12, 1);
+                    if (__ballot(viol) != 0ull) { run_viol = true; break; }
+                }
+                RT(3);
+            }
+#endif
+            if (!run_viol) {
+            u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
             // ---- catch-up steps between the previous main step and this one (:314-336): only the beam nodes, one time
             // at a time; a time the last main step's window covered is a no-op (the bits are there)
             {
@@ -774,10 +898,9 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             }
             if (a.upd_count != nullptr) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
             // node_greater_max_sym: max over read 0's window + max over read 1's
-            const double sc = smx + __shfl_xor(smx, 32);
-            const bool cand = live;
+            sc = smx + __shfl_xor(smx, 32);
 #ifdef PO_RING_TRACE   // debugging builds only (scripts/trace_rowcol.py): every candidate's score before the prune
-            if (pi == 0 && cand && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
+            if (pi == 0 && live && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
 #endif
             // ---- prune (Beam.h:93-108).  Most steps keep the SET of beam nodes: iff every child is strictly below the smallest
             // beam score (a child AT it, ties included, goes the full way, as partial_sort decides them).  The order of the
@@ -786,11 +909,11 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             // the set changes ranks everybody — and for the label: the last main step is always ranked.  (Round 3, late: the
             // first form also wanted the beam scores still in order, and rebuilt the table for every permutation of the same
             // five nodes.)
-            bool viol = (nb != W) || (mstep + 1 == nmain);
+            viol = (nb != W) || (mstep + 1 == nmain);
             if (!viol) {   // (wave-uniform: nb == W and not the last step)
                 double scmin = rg_readlane_d(sc, 0);
                 for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rg_readlane_d(sc, i));
-                if (cand && s >= nb) viol = !(scmin > sc);
+                if (live && s >= nb) viol = !(scmin > sc);
             }
             up = u; vp = v;
             mstep++;
@@ -804,6 +927,8 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
             after_event = false;
 #endif
             if (__ballot(viol) == 0ull) continue;
+            }   // (!run_viol)
+            const bool cand = live;
             RT_SET(8);
             // ---- full ranking among the distinct candidates
             const unsigned cm = (unsigned)__ballot(cand && r == 0);
@@ -899,15 +1024,18 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
 
 // resident workgroups per CU (LDS decides: 8)
 extern "C" int po_ring_blocks_per_cu() {
-    static int per_cu = 0;
-    if (!per_cu) {
+#ifdef PO_EMU
+    return 8;
+#else
+    static PoPerDeviceCache<1> per_cu;
+    return per_cu.get(0, [] {
         int nblk = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_ring_kernel, 64, 0) != hipSuccess || nblk <= 0) nblk = 8;
         if (const char* e = getenv("PO_RING_PER_CU")) { const int v = atoi(e); if (v > 0 && v < nblk) nblk = v; }
         if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_ring_kernel: %d resident workgroups per CU, %zu B of LDS\n", nblk, sizeof(RingSmem));
-        per_cu = nblk;
-    }
-    return per_cu;
+        return nblk;
+    });
+#endif
 }
 extern "C" int po_ring_max_elements() { return RG_NRP; }
 extern "C" int po_ring_ngl() { return RG_NGL; }

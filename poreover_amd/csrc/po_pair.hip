@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "po_device.h"
+#include "po_host.h"
 
 namespace {
 
@@ -824,27 +825,9 @@ struct PPGeom {
 
 // device memory the workspaces may plan with: a fixed share of the board's memory, so that the size a caller
 // is told (po_*_workspace_bytes) and the size the launch expects agree whatever else is allocated
-size_t pp_total_mem() {
-    static size_t tot = 0;
-    if (!tot) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) tot = p.totalGlobalMem;
-        if (!tot) tot = (size_t)288 << 30;
-    }
-    return tot;
-}
+size_t pp_total_mem() { return po_dev_info().mem; }
 
-int pp_num_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+int pp_num_cus() { return po_dev_info().cus; }
 
 PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int C, const po_pair_options* opt) {
     PPGeom g;
