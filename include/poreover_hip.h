@@ -85,6 +85,7 @@ int po_device_info(int device, char* name, int name_cap, int* compute_units, int
 #define PO_ROUTE_X2 1
 #define PO_ROUTE_LEGACY 2
 #define PO_ROUTE_RING 3
+#define PO_ROUTE_REG 4   /* beam2d_reg_kernel: element state in registers, values in the tagged HBM store */
 int po_set_pair_route(int route, int defer_odd);
 /* test / tuning hook: legacy != 0 -> the banded aligner (align.pyx:100-178) runs the row-at-a-time kernel that stores the
  * score table instead of the skewed-wavefront kernel.  Process-wide; results are identical. */

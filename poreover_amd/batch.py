@@ -35,18 +35,32 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-_SCRATCH = {}
+_SCRATCH = None          # threading.local: a thread's buffers die with it
+_SCRATCH_KEEP = 1 << 30  # bytes a thread keeps between calls; a larger buffer is dropped by release_scratch()
 
 
 def _scratch(name, nbytes):
-    """A uint8 buffer of at least nbytes that survives the call (grow-only, one per thread and name)."""
+    """A uint8 buffer of at least nbytes that survives the call (grow-only, one per thread and name; freed with the
+    thread, or by release_scratch())."""
     import threading
-    key = (threading.get_ident(), name)
-    buf = _SCRATCH.get(key)
+    global _SCRATCH
+    if _SCRATCH is None:
+        _SCRATCH = threading.local()
+    bufs = _SCRATCH.__dict__.setdefault("bufs", {})
+    buf = bufs.get(name)
     if buf is None or buf.size < nbytes:
         buf = np.empty(int(nbytes * 1.25) + 4096, dtype=np.uint8)
-        _SCRATCH[key] = buf
+        bufs[name] = buf
     return buf[:nbytes]
+
+
+def release_scratch(keep_bytes=0):
+    """Drop this thread's text buffers larger than keep_bytes (a long-running process after one large job)."""
+    if _SCRATCH is None:
+        return
+    bufs = _SCRATCH.__dict__.get("bufs", {})
+    for k in [k for k, b in bufs.items() if b.size > keep_bytes]:
+        del bufs[k]
 
 
 _PENDING = -(2 ** 31)   # a status no decode returns: "not written yet" (pair_decode_stream)
@@ -279,6 +293,18 @@ def _multi(devices, wave_pairs=0, wave_rows=0, threads=0):
     return m
 
 
+_PIPE_LOCKS = {}
+
+
+def _pipeline_lock(handle):
+    import threading
+    key = int(handle) if not isinstance(handle, int) else handle
+    lk = _PIPE_LOCKS.get(key)
+    if lk is None:
+        lk = _PIPE_LOCKS.setdefault(key, threading.Lock())
+    return lk
+
+
 def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="row_col", padding=5, alignment="banded",
                        diagonal_envelope=False, diagonal_width=50, perm1=None, perm2=None, reverse2=False,
                        return_envelope=False, wave_pairs=0, wave_rows=0, threads=0, strict=True, stats=None,
@@ -381,31 +407,49 @@ def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="
                 "envelope": env[eo[i]:eo[i + 1]].astype(np.int64) if (code == 0 and return_envelope) else None})
 
     done = 0
-    if overlap:
-        import threading
-        st.fill(_PENDING)
-        box = []
-        th = threading.Thread(target=lambda: box.append(call()))
-        th.start()
-        err = None
-        while th.is_alive():
-            seg = st[done:]
-            pend = np.flatnonzero(seg == _PENDING)
-            k = int(pend[0]) if len(pend) else len(seg)
-            if k == 0 or err is not None:
-                _time.sleep(0.001)
-                continue
+    # one engine call at a time per pipeline: the cached pipeline (slots, staging buffers) is shared by every caller of
+    # this process that asks for the same geometry
+    plock = _pipeline_lock(pl)
+    plock.acquire()
+    try:
+        if overlap:
+            import threading
+            st.fill(_PENDING)
+            box = []
+
+            def run():   # (the engine keeps its error text per thread: read it where it was written)
+                rc = call()
+                box.append((rc, (lib.po_last_error() or b"").decode() if rc != L.OK else ""))
+            th = threading.Thread(target=run)
+            th.start()
+            err = None
             try:
-                records(done, done + k)
-            except L.EngineError as e:      # (strict: raised once the engine call has returned)
-                err = e
-            done += k
-        th.join()
-        L.check(box[0] if box else L.E_HIP, what)
-        if err is not None:
-            raise err
-    else:
-        L.check(call(), what)
+                while th.is_alive():
+                    seg = st[done:]
+                    pend = np.flatnonzero(seg == _PENDING)
+                    k = int(pend[0]) if len(pend) else len(seg)
+                    if k == 0 or err is not None:
+                        _time.sleep(0.001)
+                        continue
+                    try:
+                        records(done, done + k)
+                    except L.EngineError as e:      # (strict: raised once the engine call has returned)
+                        err = e
+                    done += k
+            finally:
+                # whatever ends the loop (KeyboardInterrupt, MemoryError, a decode error in records()): the engine call is
+                # still writing into this thread's buffers and driving the cached pipeline — wait for it before they can
+                # be handed to another call
+                th.join()
+            rc, detail = box[0] if box else (L.E_HIP, "the engine call did not return")
+            if rc != L.OK:
+                raise L.EngineError(rc, what, detail)
+            if err is not None:
+                raise err
+        else:
+            L.check(call(), what)
+    finally:
+        plock.release()
     if stats is not None:
         pk, wt, tot, wv, np_ = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_int()
         if multi:

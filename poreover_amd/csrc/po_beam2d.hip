@@ -2466,11 +2466,12 @@ constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over 
 // PO_ROUTE_LEGACY (always beam2d_kernel) — the last two exist for the tests, which run the pair path on both kernels,
 // and for A/B timing.  The environment variables PO_X2_FORCE / PO_B2_LEGACY / PO_X2_DEFER_ODD only give the INITIAL
 // value, read once when the library is first used, so that a workspace size and the launch that follows always agree.
-struct B2Route { int route, defer_odd, x2_per_cu, debug_occ, ring_auto, ring_small, no_order; };
+struct B2Route { int route, defer_odd, x2_per_cu, debug_occ, ring_auto, ring_small, no_order, reg_auto; };
 B2Route& b2_route() {
     static B2Route r = [] {
         B2Route x;
-        x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_X2_FORCE") ? PO_ROUTE_X2 : (getenv("PO_RING_FORCE") ? PO_ROUTE_RING : PO_ROUTE_AUTO));
+        x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_X2_FORCE") ? PO_ROUTE_X2 : (getenv("PO_RING_FORCE") ? PO_ROUTE_RING : (getenv("PO_REG_FORCE") ? PO_ROUTE_REG : PO_ROUTE_AUTO)));
+        x.reg_auto = getenv("PO_REG_NEVER") ? 0 : 1;      // beam2d_reg_kernel for launches beyond the ring kernel's range (the default)
         x.defer_odd = getenv("PO_X2_DEFER_ODD") ? 1 : 0;
         x.no_order = getenv("PO_B2_NO_ORDER") ? 1 : 0;   // A/B: pairs taken in input order
         x.debug_occ = getenv("PO_DEBUG_OCC") ? 1 : 0;
@@ -2573,14 +2574,29 @@ bool ring_eligible(int n, int W, int A, int model, int method) {
 struct RingGeom {
     int blocks;
     size_t pool_bytes, arena_cap;
-    size_t off_queue, off_state, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, total;
+    size_t off_queue, off_state, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_order, off_fb, fb_bytes, total;
     unsigned long long magic;
 };
-RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model) {
+// The register-state kernel (beam2d_reg_kernel, po_beam2d_reg.hip): the same pre-pass, walk and meta words; the engine's
+// choice for launches beyond the ring kernel's resident workgroups, where throughput counts (16 pairs per CU).
+extern "C" int po_reg_blocks_per_cu();
+extern "C" int po_reg_max_elements();
+extern "C" int po_reg_ngl();
+extern "C" void po_reg_launch(const void* x2args, int blocks, hipStream_t stream);
+bool reg_eligible(int n, int W, int A, int model, int method) {
+    const int rt = b2_route().route;
+    if (!(model == PO_MODEL_CTC && method == PO_METHOD_ROW_COL && W <= 6 && A >= 1 && W * (A + 1) <= po_reg_max_elements())) return false;
+    if (rt == PO_ROUTE_REG) return true;
+    if (rt != PO_ROUTE_AUTO) return false;
+    return b2_route().reg_auto && !ring_eligible(n, W, A, model, method);
+}
+RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model, bool reg = false) {
     RingGeom g;
-    g.blocks = b2_num_cus() * po_ring_blocks_per_cu();
+    g.blocks = b2_num_cus() * (reg ? po_reg_blocks_per_cu() : po_ring_blocks_per_cu());
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
-    g.pool_bytes = (size_t)4 << 20;   // tier 2: 128 row groups at R = 256 (windows up to 254 frames), 112 tracked
+    // ring kernel, tier 2: 128 row groups at R = 256 (windows up to 254 frames), 96 tracked; register-state kernel: the
+    // whole store, 2 MB = 128 groups at R = 128 (beam2d_kernel's W <= 6 geometry)
+    g.pool_bytes = (size_t)(reg ? 2 : 4) << 20;
     const int64_t WM = W > PO_A ? W : PO_A;
     g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
     {
@@ -2599,11 +2615,12 @@ RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2
     g.off_cum2 = o; o += al256(sizeof(double) * (size_t)tr2);
     g.off_pool = o; o += g.pool_bytes * g.blocks;
     g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * g.blocks);
+    g.off_order = o; o += al256(sizeof(int) * (size_t)std::max(n, 1));   // the queue's order (pair_order_kernel)
     g.off_fb = o;
     g.fb_bytes = b2_geometry(n, mr1, mr2, W, model, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
     o += al256(g.fb_bytes);
     g.total = o + 256;
-    g.magic = 0xa0761d6478bd642full ^ ((unsigned long long)g.pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)g.blocks << 40) ^
+    g.magic = (reg ? 0x51ed270b0a1f3c97ull : 0xa0761d6478bd642full) ^ ((unsigned long long)g.pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)g.blocks << 40) ^
               ((unsigned long long)g.off_pool * 0x9e3779b97f4a7c15ull);
     return g;
 }
@@ -2674,6 +2691,7 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
     (void)C;
     if (method == PO_METHOD_GRID) return grid_geometry(n, mr1, mr2, W, model, true).total;
     if (method == PO_METHOD_GRID_NOENV) return grid_geometry(n, mr1, mr2, W, model, false).total;
+    if (reg_eligible(n, W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return ring_geometry(n, tr1, tr2, mr1, mr2, W, model, true).total;
     if (ring_eligible(n, W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return ring_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     if (x2_eligible(n, W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total + b2_geometry(n, mr1, mr2, W, model, method, X2_FB_BLOCKS).total;
@@ -2709,7 +2727,7 @@ void (*g_b2_mark)(int begin, hipStream_t stream) = nullptr;   // profiling: brac
 }
 extern "C" void po_b2_set_mark(void (*f)(int, hipStream_t)) { g_b2_mark = f; g_b2_mark_fwd = f; }
 extern "C" int po_set_pair_route(int route, int defer_odd) {
-    if (route != PO_ROUTE_AUTO && route != PO_ROUTE_X2 && route != PO_ROUTE_LEGACY && route != PO_ROUTE_RING) return PO_E_ARG;
+    if (route != PO_ROUTE_AUTO && route != PO_ROUTE_X2 && route != PO_ROUTE_LEGACY && route != PO_ROUTE_RING && route != PO_ROUTE_REG) return PO_E_ARG;
     b2_route().route = route;
     b2_route().defer_odd = defer_odd ? 1 : 0;
     return PO_OK;
@@ -2866,8 +2884,9 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         else grid_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
         return PO_OK;
     }
-    if (ring_eligible(n, W, A, model, method)) {
-        const RingGeom g = ring_geometry(n, tr1, tr2, mr1, mr2, W, model);
+    const bool use_reg = reg_eligible(n, W, A, model, method);
+    if (use_reg || ring_eligible(n, W, A, model, method)) {
+        const RingGeom g = ring_geometry(n, tr1, tr2, mr1, mr2, W, model, use_reg);
         if (ws_bytes < g.total) return PO_E_CAP;
         char* w = (char*)ws;
         X2Args a;
@@ -2886,12 +2905,16 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
         a.need_mono = 1;
-        a.order = nullptr;   // (at most as many pairs as resident workgroups by default: all start at once)
+        a.order = nullptr;   // (the ring kernel by default gets at most as many pairs as resident workgroups: all start at once)
+        if (n > g.blocks && !b2_route().no_order) {   // more pairs than resident workgroups: longest first
+            a.order = (int*)(w + g.off_order);
+            hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
+        }
         a.wgstate = (unsigned long long*)(w + g.off_state);
         a.magic = g.magic;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
         const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
-        a.ngl = po_ring_ngl();
+        a.ngl = use_reg ? po_reg_ngl() : po_ring_ngl();
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
         // (the range this layout answers for ends where the nested workspace of the deferred-pairs pass begins)
         if (b2_ws_layout_changed(ws, g.off_state, g.off_fb, g.magic) &&
@@ -2900,7 +2923,8 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
         hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
         if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
-        po_ring_launch(&a, g.blocks, stream);
+        if (use_reg) po_reg_launch(&a, g.blocks, stream);
+        else po_ring_launch(&a, g.blocks, stream);
         if (g_b2_mark_fwd) g_b2_mark_fwd(0, stream);
         // pairs the pre-pass or the kernel deferred (tier-2 row groups exhausted, windows beyond the store's ring):
         // one small pass of beam2d_kernel, a no-op when there are none

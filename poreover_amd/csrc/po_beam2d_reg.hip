@@ -1,0 +1,909 @@
+// Pair (2-D) CTC beam search, method "row_col" with a monotone envelope, one-value model ("ctc"), W * (A + 1) <= 32:
+// the per-element state lives in REGISTERS (lane = (read, element slot), as beam2d_ring_kernel), every computed value
+// goes once into the tagged value store in HBM (as beam2d_kernel), and the kernel keeps almost nothing in LDS — so that
+// 16 pairs share a CU (4 waves per SIMD) instead of the ring kernel's 8.
+//
+// Replaces (like beam2d_kernel, which stays the general form): decoding_cpp.cpp_beam_search_2d (decoding_cpp.pyx:107-139)
+// -> beam_search_2d_by_row_col (BeamSearch.h:262-397) over PoreOverPrefixTree2D (PrefixTree.h:492-533) with
+// Beam<..., node_greater_max_sym> (Beam.h:35-38,93-108).
+//
+// Why a third kernel.  Round 3 measured the two ways of holding the window values: beam2d_kernel (HBM store, element
+// tables in LDS, 4 waves per SIMD) and beam2d_ring_kernel (LDS rings + registers, 2 waves per SIMD).  The ring kernel's
+// per-phase timers at full load (profiles/r04_ring_timing_*.txt) show a wave busy about half of the time with 2 waves
+// per SIMD — the device is latency-bound there, and the rings (13 KB of a pair's 20 KB of LDS) are what keeps more
+// pairs from being resident.  This kernel is the ring kernel's control structure without the rings:
+//   * VALUE STORE (HBM, L2-resident in practice): the reference's per-node maps (PrefixTree.h:76-145), entry =
+//     {tag(epoch, node, t), value}, ring rows of R entries, rows in groups of four per parent — beam2d_kernel's layout
+//     and recycling rule.  Every read of a value "at rest" is a tagged lookup: absent reads as -inf, exactly
+//     probability_at().  Written once per computed (node, read, time).
+//   * REGISTERS: a lane's element (ids, rows, parent slot), where its values end (v_done), its last value (v_self),
+//     the carried window maximum (value, time, last rise).  Within a scan a child takes its parent's previous value
+//     from the parent's LANE (ds_bpermute) — no exchange buffer, no LDS ring, no fence per iteration.
+//   * LDS (9.8 KB): 32 y rows per read, the staged windows of up to three parents for a step's new elements, the row
+//     group table, the logaddexp tables.
+//   * RUN loop: consecutive main steps that keep the set of beam nodes are one tight loop (the new times of the two
+//     windows in lockstep, the carried maxima, the score, one comparison per child); the window maximum of a decaying
+//     element needs one stored value per step, requested a step ahead.
+//   * NEW ELEMENTS (a node entered the beam: its children compute their whole windows, ~ 12 dependent logaddexp
+//     iterations on a few lanes): their parent's stored window is staged into LDS in one memory round trip, then the
+//     chain runs on LDS and registers only; everybody else continues where it was (the stored bits of the part they
+//     already have would be rewritten unchanged: every input is unchanged).
+// The walk comes precomputed (beam2d_walk_kernel), envelope checks / blank prefix sums / R from beam2d_prepass_kernel;
+// pairs this kernel cannot hold (row groups exhausted, non-monotone envelopes) go to beam2d_kernel through the meta
+// word.  Results are bit-identical to the other kernels': the same arithmetic in the same order within every chain.
+#include <climits>
+
+#include "po_beam2d_common.h"
+#include "po_host.h"
+
+namespace {
+
+constexpr int RK_NY = 32;     // y rows per read resident in LDS
+constexpr int RK_YC = 5;      // doubles per y row (A + 1 <= 5)
+constexpr int RK_NGL = 96;    // row groups tracked per pair
+constexpr int RK_PS = 3;      // parents whose stored window one step stages for its new elements
+constexpr int RK_PT = 64;     // times staged per parent and read
+constexpr int RK_FRESH = INT_MIN / 2;
+
+struct RegSmem {
+    double ybuf[2][RK_NY][RK_YC];
+    double pst[2][RK_PS][RK_PT];
+    int g_owner[RK_NGL], g_hi0[RK_NGL], g_hi1[RK_NGL];
+    int ord[32];              // prune with exact score ties: candidate slots in node-id order (po_stl_prune)
+    double csc[32];           // ... and their scores
+    int sh[8];
+    unsigned long long nupd, nupd_x;
+    PoLaeTables lae;
+};
+
+__device__ __forceinline__ void rk_sync() { b2_sync_lds<64>(); }
+__device__ __forceinline__ double rk_readlane_d(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+}  // namespace
+
+#ifndef PO_REG_WAVES
+#define PO_REG_WAVES 4
+#endif
+__global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) {
+    using Ent = Entry<1>;
+    __shared__ RegSmem sm;
+    const int lane = threadIdx.x, r = lane >> 5, s = lane & 31, hb = lane & 32;
+    const int A = a.A, W = a.W, C = a.C;
+    const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here
+    Ent* const pool = (Ent*)(a.pool + (size_t)blockIdx.x * a.pool_bytes);
+    const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
+    int* const apl = a.arena + (size_t)blockIdx.x * 3 * a.arena_cap;
+    int* const afc = apl + a.arena_cap;
+    int* const acrow = afc + a.arena_cap;
+    int* const g_hi = r ? sm.g_hi1 : sm.g_hi0;
+
+    // ---- epoch tags across pairs and launches (as beam2d_kernel): no memset of the store
+    unsigned epoch = 0;
+    auto clear_slice = [&]() {
+        for (long long i = lane; i < pool_entries; i += 64) pool[i].tag = 0ull;
+        __syncthreads();
+    };
+    {
+        unsigned long long* stp = a.wgstate + 2 * (size_t)blockIdx.x;
+        const unsigned long long w0 = stp[0], w1 = stp[1];
+        const bool ok = (w0 == (a.magic ^ (unsigned long long)blockIdx.x));
+        epoch = ok ? (unsigned)w1 : 0u;
+        if (!ok) clear_slice();
+    }
+    po_lae_tables_load(&sm.lae, lane, 64);
+    const PoLaeFast lae{&sm.lae};
+    if (lane == 0) { sm.nupd = 0; sm.nupd_x = 0; }
+    __syncthreads();
+
+    for (;;) {
+        // ---------------------------------------------------------------- next pair from the queue
+        int pi = 0;
+        if (lane == 0) {
+            const int q = atomicAdd(a.queue, 1);
+            pi = (a.order != nullptr && q < a.n) ? a.order[q] : q;   // longest pairs first (pair_order_kernel)
+        }
+        pi = __builtin_amdgcn_readfirstlane(pi);
+        if (pi >= a.n) break;
+        epoch++;
+        if ((epoch & 0xffffu) == 0) { clear_slice(); epoch++; }
+        const int2 m = a.meta[pi];
+        if (m.y == X2_DEFERRED) continue;                 // beam2d_kernel decodes it after this kernel
+        if (m.x != PO_OK || m.y < 0) {                    // refused by the pre-pass, or skipped upstream
+            if (lane == 0) {
+                a.seq_len[pi] = 0;
+                if (m.y >= 0) a.status[pi] = m.x;
+            }
+            continue;
+        }
+        const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
+        const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
+        const double* const yr = r ? a.y2 + o2 * C : a.y1 + o1 * C;      // this lane's read
+        const int Tr = r ? V : U;
+        const double* const cumr = r ? a.cum2 + (o2 - a.y2_off[0]) : a.cum1 + (o1 - a.y1_off[0]);
+        const int4* const sched = a.sched + (o2 - a.y2_off[0]);
+        const int nmain = a.nmain[pi];
+        const int R2 = m.y, Rm2 = R2 - 1;
+        const int NG = (int)min((long long)RK_NGL, pool_entries / ((long long)PO_A * 2 * R2));
+        int st = PO_OK;
+
+        // ---------------------------------------------------------------- the value store (this lane's read)
+        auto t2_entry = [&](int row2, int tq) -> const Ent* { return &pool[((size_t)row2 * 2 + r) * R2 + (tq & Rm2)]; };
+        auto t2_read = [&](int row2, int node, int tq) -> double {
+            double v = PO_NEG_INF;
+            if (tq >= 0 && row2 >= 0) {
+                const Ent e = *t2_entry(row2, tq);
+                if (e.tag == make_tag(epoch, node, tq)) v = e.v[0];
+            }
+            return v;
+        };
+        auto t2_write = [&](int row2, int node, int tq, double v) {
+            Ent e;
+            e.tag = make_tag(epoch, node, tq);
+            e.v[0] = v;
+            pool[((size_t)row2 * 2 + r) * R2 + (tq & Rm2)] = e;
+        };
+        // ---------------------------------------------------------------- per-lane element state (slot s, read r)
+        // table fields (the same in both halves of the wave)
+        int e_id = 0, e_row2 = -1, e_sym = 0, e_fc = -1, e_crow2 = -1, e_par = 0, e_gpar = -1, e_prow2 = -1,
+            e_depth = 0, e_ps = PS_ROOT, e_alias = -1;
+        bool live = false;
+        // values of this read: computed and stored up to v_done (exclusive); v_fresh: 1 = an element again, its last
+        // value is in the store; 2 = a node that never computed
+        int v_done = RK_FRESH, v_fresh = 0;
+        double v_self = PO_NEG_INF, v_mx = PO_NEG_INF;
+        int v_mt = -1, v_td = 0;
+        // a beam node whose parent is no element any more (FROZEN): the parent's last value and its time, taken when the
+        // parent left — later times are absent (-inf), earlier ones are in the store.  fz_t = INT_MAX: nothing captured.
+        double fz_val = PO_NEG_INF;
+        int fz_t = INT_MAX;
+        // the stored value the next step's carried maximum may need (a decaying element: its value at the window start),
+        // requested a step ahead: pf_t = its time (-1: none)
+        Ent pf_e; pf_e.tag = 0ull; pf_e.v[0] = 0.0;
+        int pf_t = -1;
+        int nb = A, ne = A;
+        int next_id = 1 + A;
+        int gcur = 1;               // row group allocation cursor
+        int yhi = 0;                // y rows [yhi - RK_NY, yhi) of this lane's read are in sm.ybuf
+        int sel[6] = {0, 1, 2, 3, 4, 5};
+
+        for (int q = lane; q < RK_NGL; q += 64) { sm.g_owner[q] = -1; sm.g_hi0[q] = 0; sm.g_hi1[q] = 0; }
+        rk_sync();
+        // root = node 0; its A children = nodes 1..A in row group 0 (BeamSearch.h:286-293), updated at t = 0 on both reads
+        if (lane == 0) {
+            apl[0] = po_pack_node(-1, A); afc[0] = 1; acrow[0] = 0;
+            sm.g_owner[0] = 0; sm.g_hi0[0] = 1; sm.g_hi1[0] = 1;
+        }
+        if (s < A) {
+            if (r == 0) { apl[1 + s] = po_pack_node(0, s); afc[1 + s] = -1; acrow[1 + s] = -1; }
+            e_id = 1 + s; e_row2 = s; e_sym = sym_pack(s, A, true); e_fc = -1; e_crow2 = -1;
+            e_par = 0; e_gpar = -1; e_prow2 = -1; e_depth = 1; e_ps = PS_ROOT; e_alias = -1;
+            live = true;
+            const double out = lae(0.0 + yr[s], PO_NEG_INF + yr[A]);   // update_prob(n, r, 0): parent = root at t = -1
+            t2_write(e_row2, e_id, 0, out);
+            v_done = 1; v_fresh = 0; v_self = out;
+            v_mx = out; v_mt = 0; v_td = 0;   // (the window maximum over [0, 1))
+        }
+        rk_sync();
+
+        int mstep = 0, up = -1, vp = -1;
+        // The walk's records, 64 at a time: lane l holds record 64 * batch + l of the current batch and of the next one
+        // (requested a batch ahead: the load's latency never shows), the step's own record comes out with v_readlane.
+        int4 rcur = sched[min(lane, max(nmain - 1, 0))], rnxt = sched[min(64 + lane, max(nmain - 1, 0))];
+        auto rec_at = [&](int i) -> int4 {   // record of main step i (uniform i within the current batch)
+            const int l = i & 63;
+            return make_int4(__builtin_amdgcn_readlane(rcur.x, l), __builtin_amdgcn_readlane(rcur.y, l),
+                             __builtin_amdgcn_readlane(rcur.z, l), __builtin_amdgcn_readlane(rcur.w, l));
+        };
+        int4 rec = rec_at(0);
+        bool have_children = false;   // the table has its children slots (false only before the first expansion)
+        bool tbl_fresh = true;        // the table has elements that have not computed yet (set by rebuild)
+        bool tbl_uneven = false;      // a catch-up scan moved the beam nodes beyond their children
+        unsigned long long cnt_ref = 0, cnt_x = 0;
+
+        auto read_own = [&](int tq) -> double { return t2_read(e_row2, e_id, tq); };
+
+        // ---------------------------------------------------------------- y rows [t0, t0 + RK_NY) of this read -> LDS
+        // (all of a lane's loads go out together: one memory round trip per reload)
+        auto y_reload = [&](int t0) {
+            constexpr int PER = (RK_NY * RK_YC + 31) / 32;   // elements per lane (C <= RK_YC)
+            double v[PER];
+            int slot[PER];
+            const int divC = (65536 + C - 1) / C;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int i = s + 32 * j;
+                const int q = (i * divC) >> 16, c = i - q * C;
+                const int t = t0 + q;
+                const bool ok = i < RK_NY * C && t < Tr;
+                slot[j] = ok ? (t & (RK_NY - 1)) * RK_YC + c : -1;
+                v[j] = ok ? yr[(int64_t)t * C + c] : 0.0;
+            }
+            double* const yb = &sm.ybuf[r][0][0];
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (slot[j] >= 0) yb[slot[j]] = v[j];
+        };
+
+        // ---------------------------------------------------------------- the carried part of a window's maximum
+        // [ws, start) is not recomputed: its maximum is what the previous step left (cmx at cmt), unless that time has
+        // left the window — then the stored values are looked at again.  A node past its peak decays frame by frame:
+        // if the values were non-increasing since before the window start (td <= ws), the maximum is the first one.
+        // pf: an entry requested a step ahead for exactly that time (pf_t), else the store is asked now.
+        auto carried_max = [&](int ws, int start, double& cmx, int& cmt, int& td) {
+            auto own = [&](int tq) -> double {
+                if (tq == pf_t) return (pf_e.tag == make_tag(epoch, e_id, tq)) ? pf_e.v[0] : PO_NEG_INF;
+                return read_own(tq);
+            };
+            if (td <= ws) { cmx = own(ws); cmt = ws; return; }
+            double pv = PO_NEG_INF;
+            const int te = min(td + 1, start);   // from td on the values fall
+            td = ws;
+            for (int tq = ws; tq < te; ++tq) {
+                const double v = own(tq);
+                if (v >= cmx) { cmx = v; cmt = tq; }
+                if (tq > ws && v > pv) td = tq;
+                pv = v;
+            }
+        };
+
+        // ---------------------------------------------------------------- one scan (the general form)
+        // Every participating lane computes [max(done, ws), we) of its read, all lanes of a read in lockstep on t: a child
+        // at t takes its parent's t - 1 from the parent's lane when the parent computed it one iteration earlier (or holds
+        // it as its last value), from the store otherwise.  MAIN steps (is_main) track the window maximum; catch-up scans
+        // (BeamSearch.h:314-336) move the beam nodes only.
+        double smx = PO_NEG_INF;   // out: max over this read's window (main steps)
+        auto scan = [&](bool is_main, int ws0, int we0, int ws1, int we1, int nlanes) {
+            const int ws = r ? ws1 : ws0, we = r ? we1 : we0;
+            const bool part = live && s < nlanes && we > ws;
+            // a window end that moves back cannot happen on a monotone envelope (the pre-pass hands the others to
+            // beam2d_kernel); should it, the pair goes the same way
+            if (is_main && part && v_fresh == 0 && v_done > we) st = PO_E_NOMEM;
+            int start = max(v_done, ws);
+            double self = PO_NEG_INF;
+            if (part) {
+                if (v_fresh != 0) {
+                    start = ws;
+                    self = (v_fresh == 1) ? read_own(start - 1) : PO_NEG_INF;
+                } else if (start > v_done) {
+                    // a gap (catch-ups went beyond the last window): the value at start - 1 was never computed
+                } else {
+                    self = v_self;
+                }
+            }
+            const bool part2 = part && start < we;
+            double mx = PO_NEG_INF, cmx = PO_NEG_INF;
+            int mt = -1, cmt = -1, td = ws, tr = INT_MIN;
+            const bool has_c = is_main && part && start > ws;
+            if (has_c) {
+                td = v_td;
+                if (v_mx == PO_NEG_INF || (v_mt >= ws && v_mt < start)) { cmx = v_mx; cmt = v_mt; }
+                else carried_max(ws, start, cmx, cmt, td);
+            }
+            const int sym = sym_last(e_sym);
+            // the parent's lane: where it starts and ends in this scan (its `self` is its value at p_start - 1 before the
+            // first iteration, then at the time it computed last)
+            const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
+            const int p_start = __shfl(part2 ? start : INT_MAX, plane), p_we = __shfl(part2 ? we : INT_MIN, plane);
+            int tm_ = part2 ? start : INT_MAX;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) tm_ = min(tm_, __shfl_xor(tm_, off));
+            const int tmin = tm_;                                   // (half-uniform)
+            const int span = (tmin == INT_MAX) ? 0 : we - tmin;
+            const int niter = max(__builtin_amdgcn_readlane(span, 0), __builtin_amdgcn_readlane(span, 32));
+            int k = 0;
+            while (k < niter) {
+                const int tcur = tmin + k;   // (garbage when this half has nothing to do: guarded by span)
+                const bool hw = k < span;    // this half still has times to compute
+                rk_sync();                   // (every lane is done with the rows a reload overwrites)
+                if (hw && !(tcur >= yhi - RK_NY && tcur < yhi)) { y_reload(tcur); yhi = tcur + RK_NY; }
+                rk_sync();
+                const int cend = hw ? (min(we, yhi) - tmin) : niter;
+                const int kend = min(__builtin_amdgcn_readlane(cend, 0), __builtin_amdgcn_readlane(cend, 32));
+                for (; k < kend; ++k) {
+                    const int t = tmin + k;
+                    const double ps_self = __shfl(self, plane);
+                    if (part2 && t >= start && t < we) {
+                        const double ya = sm.ybuf[r][t & (RK_NY - 1)][sym], yb = sm.ybuf[r][t & (RK_NY - 1)][A];
+                        const int tm = t - 1;
+                        double pp;
+                        if (e_ps >= 0) {
+                            if (tm >= p_start - 1 && tm < p_we && p_start != INT_MAX) pp = ps_self;
+                            else pp = t2_read(e_prow2, e_par, tm);
+                        } else if (e_ps == PS_ROOT) {
+                            pp = (tm < 0) ? 0.0 : cumr[tm];
+                        } else if (tm >= fz_t) {
+                            pp = (tm == fz_t) ? fz_val : PO_NEG_INF;                                 // frozen parent: its last value, then nothing
+                        } else {
+                            pp = t2_read(e_prow2, e_par, tm);
+                        }
+                        const double out = lae(pp + ya, self + yb);
+#ifdef PO_RING_TRACE_NODE
+                        if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g G ps %d fzt %d main %d\n", e_id, r, t, out, pp, self, e_ps, fz_t, (int)is_main);
+#endif
+                        t2_write(e_row2, e_id, t, out);
+                        if (out > self) tr = t;   // the last time a value rose
+                        self = out;
+                        mt = (out >= mx) ? t : mt;
+                        mx = po_vmax(mx, out);
+                    }
+                }
+            }
+            if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
+            if (part2) { v_done = we; v_self = self; v_fresh = 0; }
+            if (is_main) {
+                if (part) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
+                smx = part ? mx : PO_NEG_INF;
+            }
+            pf_t = -1;
+            if (a.upd_count != nullptr) {
+                const int lenx = part2 ? we - start : 0;
+                int tot = lenx;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+                cnt_x += (unsigned)tot;
+            }
+        };
+
+        // ---------------------------------------------------------------- a main step with NEW elements
+        // After a rebuild: the continuing elements (all ending at the same time dr, as in a run) only need the new times
+        // [dr, we); the fresh ones — children of a node that entered the beam — need their whole window [ws, we).  Over
+        // [ws, dr) their parent does not move: its values are at rest in the store, so they are STAGED into LDS in one
+        // memory round trip (with the fresh lanes' own seeds), and phase 1 runs the fresh lanes' chains on LDS and registers
+        // only; phase 2 is the run loop's lockstep over the new times for everybody.  Returns false (nothing done) when
+        // the step is not of this kind: scan() takes it.
+        auto scan_new = [&](int u, int ce, int v, int re) -> bool {
+            const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);   // (beam slot 0 always continues)
+            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || ce - d0 > RK_NY || re - d1 > RK_NY || d0 - u > RK_PT || d1 - v > RK_PT) return false;
+            const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
+            const bool fresh = live && v_fresh != 0;
+            const bool cont = live && v_fresh == 0;
+            // everybody who continues ends at dr; fresh lanes hang under a continuing lane; no root, no older frozen values
+            const bool bad = (cont && v_done != dr) || (live && e_ps == PS_ROOT) || (fresh && e_ps < 0) ||
+                             (cont && e_ps == PS_FROZEN && dr < we && dr - 1 < fz_t);
+            const bool pfresh = __shfl((int)fresh, hb | max(e_ps, 0)) != 0;
+#ifdef PO_EMU_DEBUG
+            if (__ballot(bad || (fresh && pfresh)) != 0ull) {
+                const int w0 = (int)(__ballot(cont && v_done != dr) != 0), w1 = (int)(__ballot(live && e_ps == PS_ROOT) != 0), w2 = (int)(__ballot(fresh && e_ps < 0) != 0);
+                const int w3 = (int)(__ballot(cont && e_ps == PS_FROZEN && dr < we && dr - 1 < fz_t) != 0), w4 = (int)(__ballot(fresh && pfresh) != 0);
+                if (lane == 0) printf("WHY cont_done %d root %d freshfrozen %d frozenold %d pfresh %d\n", w0, w1, w2, w3, w4);
+                return false;
+            }
+#else
+            if (__ballot(bad || (fresh && pfresh)) != 0ull) return false;
+#endif
+            // ---- the parents to stage (beam slots with fresh children): at most RK_PS
+            int pj[RK_PS], nps = 0;
+#pragma unroll
+            for (int k = 0; k < RK_PS; ++k) pj[k] = -1;
+            bool many = false;
+            for (int jj = 0; jj < nb; ++jj) {   // (wave-uniform)
+                if (__ballot(fresh && e_ps == jj) == 0ull) continue;
+                if (nps < RK_PS) {
+#pragma unroll
+                    for (int k = 0; k < RK_PS; ++k) if (k == nps) pj[k] = jj;
+                    nps++;
+                } else many = true;
+            }
+            if (many) return false;
+            int myk = 0;
+#pragma unroll
+            for (int k = 1; k < RK_PS; ++k) myk = (e_ps == pj[k]) ? k : myk;
+            // ---- staging: lane i of a read asks for the parent's value at ws - 1 + i (and + 32); the fresh lanes' seeds go
+            // out with them
+            const int n1 = dr - ws;   // (half-uniform, >= 0): times the fresh lanes compute before everybody else starts
+            Ent se; se.tag = 0ull; se.v[0] = 0.0;
+            const bool want_seed = fresh && v_fresh == 1 && ws - 1 >= 0;
+            if (want_seed) se = *t2_entry(e_row2, ws - 1);
+            for (int k = 0; k < nps; ++k) {   // (wave-uniform)
+                int jk = pj[0];
+#pragma unroll
+                for (int q = 1; q < RK_PS; ++q) jk = (k == q) ? pj[q] : jk;
+                const int prow = __builtin_amdgcn_readlane(e_row2, jk), pid = __builtin_amdgcn_readlane(e_id, jk);
+#pragma unroll
+                for (int h = 0; h < RK_PT / 32; ++h) {
+                    const int i = s + 32 * h, tq = ws - 1 + i;
+                    if (i < n1) {
+                        double val = PO_NEG_INF;
+                        if (tq >= 0) {
+                            const Ent e = *t2_entry(prow, tq);
+                            if (e.tag == make_tag(epoch, pid, tq)) val = e.v[0];
+                        }
+                        sm.pst[r][k][i] = val;
+                    }
+                }
+            }
+            // ---- the carried part [ws, dr) of the continuing lanes' windows
+            const bool has_c = cont && dr > ws;
+            double mx = PO_NEG_INF, cmx = PO_NEG_INF;
+            double self = cont ? v_self : PO_NEG_INF;
+            if (want_seed && se.tag == make_tag(epoch, e_id, ws - 1)) self = se.v[0];
+            int mt = -1, cmt = -1, td = has_c ? v_td : ws, tr = INT_MIN;
+            if (has_c) {
+                if (v_mx == PO_NEG_INF || v_mt >= ws) { cmx = v_mx; cmt = v_mt; }
+                else carried_max(ws, dr, cmx, cmt, td);
+            }
+            const int sym = sym_last(e_sym);
+            const double* const yb_ = &sm.ybuf[r][0][0];
+            // the y rows [lo, hi) of this read in LDS (hi - lo <= RK_NY; half-uniform arguments, wave-uniform call)
+            auto y_need = [&](int lo, int hi) {
+                rk_sync();   // (every lane is done with the rows a reload overwrites, and with the staging writes)
+                if (hi > lo && !(lo >= yhi - RK_NY && hi <= yhi)) { y_reload(lo); yhi = lo + RK_NY; }
+                rk_sync();
+            };
+            // ---- phase 1: the fresh lanes over [ws, dr) — every operand is at rest
+            const int n1max = max(d0 - u, d1 - v);
+            if (n1max > 0) {
+                const double* const ps_ = &sm.pst[r][myk][0];
+                for (int k = 0; k < n1max; ++k) {
+                    if ((k & (RK_NY - 1)) == 0) y_need(ws + k, min(ws + k + RK_NY, dr));
+                    if (fresh && k < n1) {
+                        const int t = ws + k;
+                        const double* yrow = yb_ + (t & (RK_NY - 1)) * RK_YC;
+                        const double ya = yrow[sym], yb = yrow[A];
+                        const double pp = ps_[k];
+                        const double out = lae(pp + ya, self + yb);
+#ifdef PO_RING_TRACE_NODE
+                        if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P1\n", e_id, r, t, out, pp, self);
+#endif
+                        t2_write(e_row2, e_id, t, out);
+                        if (out > self) tr = t;
+                        self = out;
+                        mt = (out >= mx) ? t : mt;
+                        mx = po_vmax(mx, out);
+                    }
+                }
+            }
+            // ---- phase 2: everybody over [dr, we), in lockstep
+            const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
+            const int n2 = we - dr;
+            const int n2max = max(ce - d0, re - d1);
+            y_need(dr, we);
+            for (int k = 0; k < n2max; ++k) {
+                const int t = dr + k;
+                const double ps_self = __shfl(self, plane);
+                if (live && k < n2) {
+                    const double* yrow = yb_ + (t & (RK_NY - 1)) * RK_YC;
+                    const double ya = yrow[sym], yb = yrow[A];
+                    const int tm = t - 1;
+                    double pp = ps_self;
+                    if (e_ps < 0) pp = (tm == fz_t) ? fz_val : PO_NEG_INF;
+                    const double out = lae(pp + ya, self + yb);
+#ifdef PO_RING_TRACE_NODE
+                    if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P2 ps %d fzt %d\n", e_id, r, t, out, pp, self, e_ps, fz_t);
+#endif
+                    t2_write(e_row2, e_id, t, out);
+                    if (out > self) tr = t;
+                    self = out;
+                    mt = (out >= mx) ? t : mt;
+                    mx = po_vmax(mx, out);
+                }
+            }
+            if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
+            if (live) {
+                if (fresh || dr < we) { v_done = we; v_self = self; }
+                v_fresh = 0;
+                v_mx = mx; v_mt = mt; v_td = max(td, tr);
+            }
+            smx = live ? mx : PO_NEG_INF;
+            pf_t = -1;
+            if (a.upd_count != nullptr) {
+                int tot = live ? (n2 + (fresh ? n1 : 0)) : 0;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+                cnt_x += (unsigned)tot;
+            }
+            return true;
+        };
+
+        // ---------------------------------------------------------------- the next element table
+        // Given the new beam (sel[0 .. nbn): slots of the present table, in rank order), builds the table of the next main
+        // step: expansion of the beam nodes (BeamSearch.h:342-360: node ids in beam order), children slots, which old
+        // element continues in which new slot (its carried maxima and times move with it).
+        auto rebuild = [&](int nbn, int nu, int nv, int nce, int nre) {
+            const int nbo = nb;
+            const int nen = nbn * (A + 1);
+            // ---- A. new beam lanes take their fields from the old slot sel[s]
+            int mysel = sel[0];
+#pragma unroll
+            for (int i = 1; i < 6; ++i) mysel = (s == i) ? sel[i] : mysel;
+            const bool rb = s < nbn;                       // this lane is a beam slot of the new table
+            const bool rc = !rb && s < nen;                // ... a child slot
+            const int j = rc ? (((s - nbn) * divA) >> 16) : 0, c = rc ? (s - nbn) - j * A : 0;
+            int pj = sel[0];
+#pragma unroll
+            for (int i = 1; i < 6; ++i) pj = (j == i) ? sel[i] : pj;
+            const int srcb = rb ? mysel : 0;
+            int n_id = __shfl(e_id, hb | srcb), n_row2 = __shfl(e_row2, hb | srcb), n_sym = __shfl(e_sym, hb | srcb);
+            int n_fc = __shfl(e_fc, hb | srcb), n_crow2 = __shfl(e_crow2, hb | srcb), n_par = __shfl(e_par, hb | srcb);
+            int n_gpar = __shfl(e_gpar, hb | srcb), n_prow2 = __shfl(e_prow2, hb | srcb), n_depth = __shfl(e_depth, hb | srcb);
+            // ---- every old element marks its row group with the times it has written there
+            if (live && v_fresh == 0) atomicMax(&g_hi[e_row2 >> 2], v_done);
+            // ---- B. expansion of the new beam nodes
+            if (rb && n_fc == -2) { n_fc = afc[n_id]; n_crow2 = acrow[n_id]; }   // a node whose parent re-entered: the arena knows
+            rk_sync();
+            bool isnew = false, need_group = false;
+            if (rb) {
+                isnew = n_fc < 0;
+                need_group = isnew || n_crow2 < 0 || n_crow2 >= NG || sm.g_owner[n_crow2] != n_id;   // (old rows recycled: all dead)
+            }
+            {
+                const unsigned bn = (unsigned)__ballot(isnew && r == 0);
+                if (isnew) {
+                    n_fc = next_id + A * __popc(bn & ((1u << s) - 1u));
+                    if (r == 0) afc[n_id] = n_fc;
+                }
+                next_id += A * __popc(bn);
+                if (rb && !need_group) { atomicMax(&sm.g_hi0[n_crow2], nce); atomicMax(&sm.g_hi1[n_crow2], nre); }
+                rk_sync();
+                unsigned hg = (unsigned)__ballot(need_group && r == 0);
+                while (hg != 0) {   // (uniform: every lane walks the group table, lane 0 writes)
+                    const int jj = __builtin_ctz(hg);
+                    hg &= hg - 1;
+                    const int owner = __builtin_amdgcn_readlane(n_id, jj);
+                    int gg = -1;
+                    for (int tries = 0; tries < NG; ++tries) {
+                        const int cc = gcur;
+                        gcur = (gcur + 1 == NG) ? 0 : gcur + 1;
+                        if (sm.g_owner[cc] < 0 || (sm.g_hi0[cc] <= nu - 1 && sm.g_hi1[cc] <= nv - 1)) { gg = cc; break; }
+                    }
+                    if (gg < 0) { st = PO_E_NOMEM; gg = 0; }
+                    rk_sync();   // (every lane has walked the table before lane 0 changes it)
+                    if (lane == 0) { sm.g_owner[gg] = owner; sm.g_hi0[gg] = nce; sm.g_hi1[gg] = nre; acrow[owner] = gg; }
+                    if (s == jj) n_crow2 = gg;
+                    rk_sync();
+                }
+            }
+            // ---- C. children slots take their parent's (new) fields
+            const int p_id = __shfl(n_id, hb | j), p_fc = __shfl(n_fc, hb | j), p_crow2 = __shfl(n_crow2, hb | j);
+            const int p_sym = __shfl(n_sym, hb | j), p_par = __shfl(n_par, hb | j), p_row2 = __shfl(n_row2, hb | j);
+            const int p_depth = __shfl(n_depth, hb | j);
+            const bool p_isnew = __shfl((int)isnew, hb | j) != 0;
+            int n_alias = -1, n_ps = PS_FROZEN;
+            if (rc) {
+                n_id = p_fc + c; n_row2 = p_crow2 * PO_A + c; n_sym = sym_pack(c, sym_last(p_sym), false);
+                n_par = p_id; n_gpar = p_par; n_prow2 = p_row2; n_depth = p_depth + 1; n_ps = j;
+                n_fc = p_isnew ? -1 : -2; n_crow2 = p_isnew ? -1 : -2;
+                if (p_isnew && r == 0) { apl[n_id] = po_pack_node(p_id, c); afc[n_id] = -1; acrow[n_id] = -1; }
+            }
+            // a child slot whose node is also a beam slot is the same node pushed twice (Beam::prune's std::unique)
+            for (int i = 0; i < nbn; ++i) {
+                const int bid = __builtin_amdgcn_readlane(n_id, i);
+                if (rc && bid == n_id) n_alias = i;
+            }
+            // ---- D. which old slot continues here
+            int src = -1;
+            if (rb) src = mysel;
+            else if (rc && n_alias < 0 && pj < nbo) {   // the parent was a beam node: its children were elements (or aliases of beam slots)
+                if (have_children) src = nbo + A * pj + c;
+            }
+            {   // the parent enters the beam: a child of it was an element only as a beam node
+                const bool look = !rb && rc && n_alias < 0 && pj >= nbo;
+                for (int i = 0; i < nbo; ++i) {   // (wave-uniform loop: v_readlane)
+                    const int oid = __builtin_amdgcn_readlane(e_id, i);
+                    if (look && oid == n_id) src = i;
+                }
+            }
+            {   // (an old child slot that was an alias hands over to the beam slot that held the node)
+                const int oa = __shfl(e_alias, hb | max(src, 0));
+                if (!rb && src >= nbo && oa >= 0) src = oa;
+            }
+            const bool nlive = (rb || (rc && n_alias < 0));
+            // ---- F. the lanes take their new identity
+            const int gsrc = hb | max(src, 0);
+            const int g_done = __shfl(v_done, gsrc), g_fresh = __shfl(v_fresh, gsrc), g_mt = __shfl(v_mt, gsrc), g_td = __shfl(v_td, gsrc);
+            const double g_self = __shfl(v_self, gsrc), g_mx = __shfl(v_mx, gsrc);
+            const int g_fc = __shfl(e_fc, gsrc), g_crow2 = __shfl(e_crow2, gsrc);
+            // the last value of the node's parent as the old table knew it: of the parent's lane if it was an element,
+            // else what was captured when it stopped being one
+            double c_val;
+            int c_t;
+            const int op = __shfl(e_ps, gsrc);                     // the parent's slot in the old table (or ROOT / FROZEN)
+            {
+                const int opl = hb | max(op, 0);
+                const int o_done = __shfl(v_done, opl), o_fresh = __shfl(v_fresh, opl);
+                const double o_last = __shfl(v_self, opl);
+                const double q_val = __shfl(fz_val, gsrc);
+                const int q_t = __shfl(fz_t, gsrc);
+                c_val = (op >= 0) ? o_last : q_val;
+                c_t = (op >= 0) ? ((o_fresh == 0) ? o_done - 1 : INT_MAX) : q_t;
+            }
+            e_id = n_id; e_row2 = n_row2; e_sym = n_sym; e_par = n_par; e_gpar = n_gpar; e_prow2 = n_prow2; e_depth = n_depth;
+            e_alias = rc ? n_alias : -1;
+            e_fc = n_fc; e_crow2 = n_crow2;
+            if (rc && src >= 0) { e_fc = g_fc; e_crow2 = g_crow2; }   // a continuing child keeps what is known about its own children
+            live = nlive;
+            fz_val = c_val; fz_t = (nlive && src >= 0) ? c_t : INT_MAX;
+            if (nlive && src >= 0) {
+                v_done = g_done; v_fresh = g_fresh; v_mt = g_mt; v_td = g_td; v_self = g_self; v_mx = g_mx;
+            } else {
+                v_done = RK_FRESH; v_fresh = (rc && p_isnew) ? 2 : 1;
+                v_self = PO_NEG_INF; v_mx = PO_NEG_INF; v_mt = -1; v_td = 0;
+            }
+            // ---- the parent slot of the beam nodes: a beam node, a child of a beam node, the root, or none (frozen)
+            nb = nbn; ne = nen;
+            {   // (wave-uniform loops: v_readlane)
+                if (rb) n_ps = (e_par == 0) ? PS_ROOT : PS_FROZEN;
+                for (int i = 0; i < nbn; ++i) {
+                    const int bid = __builtin_amdgcn_readlane(e_id, i);
+                    if (rb && e_par != 0 && bid == e_par) n_ps = i;
+                }
+                const bool fz = rb && n_ps == PS_FROZEN;
+                for (int i = 0; i < nbn; ++i) {
+                    const int bid = __builtin_amdgcn_readlane(e_id, i);
+                    if (fz && bid == e_gpar) n_ps = nbn + A * i + sym_plast(e_sym);
+                }
+            }
+            e_ps = n_ps;
+            // ---- G. a frozen parent that is an element again.  A beam node whose parent had left the table computed its
+            // newest values against "absent" (-inf beyond the parent's last time).  When the grandparent enters the beam the
+            // parent comes back as one of its children, computes its whole window — times it never had — and the
+            // reference's step, which recomputes every window in full, then gives the node (and everything below it)
+            // different values over the part of the window it already had.  Those elements go back to the window start;
+            // the part before it is what both sides keep.  (Everybody else's inputs are unchanged: skipping their old
+            // times rewrites nothing.)
+            {
+                bool rew = rb && nlive && src >= 0 && op == PS_FROZEN && n_ps >= 0;
+                if (__ballot(rew) != 0ull) {
+                    for (int it = 0; it < W; ++it) {   // ... and their descendants in the table, generation by generation
+                        const bool prew = __shfl((int)rew, hb | max(e_ps, 0)) != 0;
+                        if (live && e_ps >= 0 && prew) rew = true;
+                    }
+                    const int wsn = r ? nv : nu;
+                    if (rew && live && v_fresh == 0 && v_done > wsn) {
+                        v_self = read_own(wsn - 1);
+                        v_done = wsn;
+                    }
+                }
+            }
+            tbl_fresh = __ballot(live && v_fresh != 0) != 0ull;
+            have_children = true;
+            pf_t = -1;
+            rk_sync();
+        };
+
+        // the first table: the root's children are the beam, their children come from the first expansion
+        rebuild(A, rec.x, rec.y, rec.z, rec.w);
+
+        // ---------------------------------------------------------------- the diagonal walk (BeamSearch.h:300-393)
+        while (st == PO_OK && mstep < nmain) {
+            int u = rec.x, v = rec.y, ce = rec.z, re = rec.w;
+            double sc = PO_NEG_INF;
+            bool viol = false, run_viol = false;
+            // ---- a RUN of main steps on the table as it stands.  After a step that kept the set of beam nodes, with every
+            // live lane's values ending at the same time and nothing to catch up, the next step is: the new times of the two
+            // windows (often none on a read: the envelope's window ends move a base at a time) in lockstep, the window maxima
+            // from what is carried, the score, the one comparison per child.  The run ends at the first step that is not of
+            // this kind (it is then done below) or that changes the beam (it is ranked below).
+            if (!tbl_fresh && !tbl_uneven && nb == W && __ballot(live && e_ps == PS_ROOT) == 0ull) {
+                const int sym = sym_last(e_sym);
+                const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
+                const double* const yb_ = &sm.ybuf[r][0][0];
+                for (;;) {
+                    u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
+                    const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
+                    if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || ce - d0 > RK_NY || re - d1 > RK_NY || mstep + 1 >= nmain) break;
+                    const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
+                    const bool part2 = live && dr < we;
+                    if (__ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull) break;   // a frozen parent's older values: the store
+                    // ---- the carried part [ws, dr) of the window
+                    const bool has_c = live && dr > ws;
+                    double mx = PO_NEG_INF, cmx = PO_NEG_INF, self = v_self;
+                    int mt = -1, cmt = -1, td = has_c ? v_td : ws, tr = INT_MIN;
+                    if (has_c) {
+                        if (v_mx == PO_NEG_INF || v_mt >= ws) { cmx = v_mx; cmt = v_mt; }
+                        else carried_max(ws, dr, cmx, cmt, td);
+                    }
+                    // ---- the new times [dr, we), everybody in lockstep: the parent's previous value comes from its lane
+                    const int n2 = we - dr;   // (half-uniform, >= 0)
+                    const int n2max = max(ce - d0, re - d1);
+                    if (n2max > 0) {
+                        if (n2 > 0 && !(dr >= yhi - RK_NY && we <= yhi)) { y_reload(dr); yhi = dr + RK_NY; }
+                        rk_sync();
+                        for (int k = 0; k < n2max; ++k) {
+                            const int t = dr + k;
+                            const double ps_self = __shfl(self, plane);
+                            if (live && k < n2) {
+                                const double* yrow = yb_ + (t & (RK_NY - 1)) * RK_YC;
+                                const double ya = yrow[sym], yb = yrow[A];
+                                const int tm = t - 1;
+                                double pp = ps_self;
+                                if (e_ps < 0) pp = (tm == fz_t) ? fz_val : PO_NEG_INF;
+                                const double out = lae(pp + ya, self + yb);
+#ifdef PO_RING_TRACE_NODE
+                                if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g RUN ps %d fzt %d\n", e_id, r, t, out, pp, self, e_ps, fz_t);
+#endif
+                                t2_write(e_row2, e_id, t, out);
+                                if (out > self) tr = t;
+                                self = out;
+                                mt = (out >= mx) ? t : mt;
+                                mx = po_vmax(mx, out);
+                            }
+                        }
+                        if (part2) { v_done = we; v_self = self; }
+                    }
+                    if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
+                    if (live) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
+                    smx = live ? mx : PO_NEG_INF;
+                    if (a.upd_count != nullptr) {
+                        cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
+                        cnt_x += (unsigned)(__popcll(__ballot(live && r == 0)) * (ce - d0) + __popcll(__ballot(live && r == 1)) * (re - d1));
+                    }
+                    sc = smx + __shfl_xor(smx, 32);
+#ifdef PO_RING_TRACE
+                    if (pi == 0 && live && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
+#endif
+                    double scmin = rk_readlane_d(sc, 0);
+                    for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rk_readlane_d(sc, i));
+                    viol = live && s >= nb && !(scmin > sc);
+                    up = u; vp = v;
+                    mstep++;
+                    if ((mstep & 63) == 0) {
+                        rcur = rnxt;
+                        rnxt = sched[min(mstep + 64 + lane, max(nmain - 1, 0))];
+                    }
+                    rec = rec_at(min(mstep, nmain - 1));
+                    {   // the stored value the next step's carried maximum will ask for, if any: requested now
+                        const int wsn = r ? rec.y : rec.x;
+                        pf_t = -1;
+                        if (live && v_done > wsn && v_mx != PO_NEG_INF && v_mt < wsn) { pf_t = wsn; pf_e = *t2_entry(e_row2, wsn); }
+                    }
+#ifdef PO_EMU_DEBUG
+                    if (lane == 0) printf("STEP run\n");
+#endif
+                    if (__ballot(viol) != 0ull) { run_viol = true; break; }
+                }
+            }
+            if (!run_viol) {
+            u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
+            // ---- catch-up steps between the previous main step and this one (:314-336): only the beam nodes, one time
+            // at a time; a time the last main step's window covered is a no-op (the bits are there)
+            {
+                const int nbe = min(W, nb);
+                const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
+                if (a.upd_count != nullptr) cnt_ref += (unsigned)((max(u - up - 1, 0) + max(v - vp - 1, 0)) * nbe);
+                if (u - 1 >= max(up + 1, d0)) { scan(false, up + 1, u, 0, 0, nbe); tbl_uneven = true; }
+                if (v - 1 >= max(vp + 1, d1)) { scan(false, 0, 0, vp + 1, v, nbe); tbl_uneven = true; }
+            }
+            // ---- MAIN step at (u, v): windows [u, ce) x [v, re)  (:342-375)
+#ifdef PO_EMU_DEBUG
+            {
+                const bool tf = tbl_fresh, tu = tbl_uneven;
+                const bool done_new = tbl_fresh && !tbl_uneven && scan_new(u, ce, v, re);
+                if (!done_new) scan(true, u, ce, v, re, 32);
+                if (lane == 0) printf("STEP %s fresh %d uneven %d w %d %d\n", done_new ? "new" : "general", (int)tf, (int)tu, ce - u, re - v);
+            }
+#else
+            if (!(tbl_fresh && !tbl_uneven && scan_new(u, ce, v, re))) scan(true, u, ce, v, re, 32);
+#endif
+            tbl_fresh = false; tbl_uneven = false;
+            if (a.upd_count != nullptr) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
+            // node_greater_max_sym: max over read 0's window + max over read 1's
+            sc = smx + __shfl_xor(smx, 32);
+#ifdef PO_RING_TRACE   // debugging builds only: every candidate's score before the prune
+            if (pi == 0 && live && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
+#endif
+            // ---- prune (Beam.h:93-108).  Most steps keep the SET of beam nodes: iff every child is strictly below the smallest
+            // beam score (a child AT it, ties included, goes the full way, as partial_sort decides them).  The order of the
+            // beam nodes among themselves is not looked at: nothing is created while the set stays (every beam node has its
+            // children), ties are decided on node ids, and the order matters only where nodes are created — the step in which
+            // the set changes ranks everybody — and for the label: the last main step is always ranked.
+            viol = (nb != W) || (mstep + 1 == nmain);
+            if (!viol) {   // (wave-uniform: nb == W and not the last step)
+                double scmin = rk_readlane_d(sc, 0);
+                for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rk_readlane_d(sc, i));
+                if (live && s >= nb) viol = !(scmin > sc);
+            }
+            up = u; vp = v;
+            mstep++;
+            if ((mstep & 63) == 0) {   // the next batch becomes the current one, the one after it is requested
+                rcur = rnxt;
+                rnxt = sched[min(mstep + 64 + lane, max(nmain - 1, 0))];
+            }
+            rec = rec_at(min(mstep, nmain - 1));
+            if (__ballot(viol) == 0ull) continue;
+            }   // (!run_viol)
+            const bool cand = live;
+            // ---- full ranking among the distinct candidates
+            const unsigned cm = (unsigned)__ballot(cand && r == 0);
+            const int ncand = __popc(cm);
+            // Only the beam nodes and the children that reach the smallest beam score can be among the W best (every
+            // other child has W candidates above it), and nothing outside that set outranks a member of it: the ranks
+            // are taken within it (a handful of candidates instead of W * (A + 1)).
+            unsigned smask = cm;
+            if (nb == W) {
+                double thr = rk_readlane_d(sc, 0);
+                for (int i = 1; i < nb; ++i) thr = fmin(thr, rk_readlane_d(sc, i));
+                smask = (unsigned)__ballot(cand && r == 0 && (s < nb || sc >= thr));
+            }
+            int rank = 0, neq = 0;
+            for (unsigned mm = smask; mm != 0u; mm &= mm - 1u) {
+                const int o = __builtin_ctz(mm);
+                const double so = rk_readlane_d(sc, o);
+                const int io = __builtin_amdgcn_readlane(e_id, o);
+                rank += ((so > sc) | (!(sc > so) & (io < e_id))) ? 1 : 0;
+                neq += (so == sc) ? 1 : 0;
+            }
+            if (!((smask >> s) & 1u)) { rank = 64; neq = 0; }
+            const int nbn = min(W, ncand);
+#pragma unroll
+            for (int jx = 0; jx < 6; ++jx) {
+                const unsigned long long bj = __ballot(cand && r == 0 && rank == jx);
+                sel[jx] = (bj != 0ull) ? (int)__builtin_ctzll(bj) : 0;
+            }
+            if (__ballot(cand && neq > 1 && rank < W) != 0ull) {
+                // exact ties reaching into the beam: what libstdc++'s partial_sort / sort leave on the candidates in
+                // creation order (po_device.h), replayed by one lane
+                int pos = 0;   // (the replay runs over ALL candidates in creation order)
+                for (int o = 0; o < ne; ++o) {
+                    const int io = __builtin_amdgcn_readlane(e_id, o);
+                    pos += (int)((cm >> o) & 1u) & ((io < e_id) ? 1 : 0);
+                }
+                if (cand && r == 0) { sm.ord[pos] = s; sm.csc[s] = sc; }
+                rk_sync();
+                if (lane == 0) {
+                    const double* cp = sm.csc;
+                    po_stl_prune<6>(sm.ord, ncand, W, [&](int slot) { return cp[slot]; });
+                }
+                rk_sync();
+#pragma unroll
+                for (int jx = 0; jx < 6; ++jx) sel[jx] = (jx < nbn) ? sm.ord[jx] : 0;
+                rk_sync();
+            }
+            rebuild(nbn, rec.x, rec.y, rec.z, rec.w);
+        }
+
+        // ---------------------------------------------------------------- label of the top node
+        if (st == PO_E_NOMEM && lane == 0) {   // out of row groups (or a window end moved back): beam2d_kernel takes the pair
+            a.meta[pi] = make_int2(PO_OK, X2_DEFERRED);
+        } else if (lane == 0) {
+            int nout = 0;
+            if (st == PO_OK) {
+                int node = e_id;
+                nout = e_depth;
+                char* out = a.seq + a.seq_off[pi];
+                const int cap = (int)(a.seq_off[pi + 1] - a.seq_off[pi]);
+                if (nout > cap) { st = PO_E_CAP; nout = 0; }
+                else
+                    for (int i = nout - 1; i >= 0; --i) {
+                        const int pk = apl[node];
+                        out[i] = (char)((a.alphabet >> (8 * (po_node_last(pk) & 3))) & 0xffu);
+                        node = po_node_parent(pk);
+                    }
+            }
+            a.seq_len[pi] = nout;
+            a.status[pi] = st;
+        }
+        if (a.upd_count != nullptr && lane == 0) { sm.nupd += cnt_ref; sm.nupd_x += cnt_x; }
+        rk_sync();
+    }
+    if (lane == 0) {   // the next launch on this workspace continues from here
+        unsigned long long* stp = a.wgstate + 2 * (size_t)blockIdx.x;
+        stp[0] = a.magic ^ (unsigned long long)blockIdx.x;
+        stp[1] = (unsigned long long)epoch;
+        if (a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
+    }
+}
+
+// resident workgroups per CU (registers and LDS decide: 16)
+extern "C" int po_reg_blocks_per_cu() {
+#ifdef PO_EMU
+    return 16;
+#else
+    static PoPerDeviceCache<1> per_cu;
+    return per_cu.get(0, [] {
+        int nblk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel, 64, 0) != hipSuccess || nblk <= 0) nblk = 16;
+        if (const char* e = getenv("PO_REG_PER_CU")) { const int v = atoi(e); if (v > 0 && v < nblk) nblk = v; }
+        if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_reg_kernel: %d resident workgroups per CU, %zu B of LDS\n", nblk, sizeof(RegSmem));
+        return nblk;
+    });
+#endif
+}
+extern "C" int po_reg_max_elements() { return 32; }
+extern "C" int po_reg_ngl() { return RK_NGL; }
+extern "C" void po_reg_launch(const void* x2args, int blocks, hipStream_t stream) {
+    const X2Args a = *(const X2Args*)x2args;
+    hipLaunchKernelGGL(beam2d_reg_kernel, dim3(blocks), dim3(64), 0, stream, a);
+}

@@ -178,12 +178,28 @@ void pack_items(const void* const* src, const int64_t* rows, int first, int n, s
 }
 }  // namespace
 
+namespace {
+// binds the calling thread to `device` for a scope and gives it back the device it had
+struct DeviceScope {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == device) prev = -1;
+        else ok = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
 extern "C" {
 
 po_pipeline* po_pipeline_create(int device, int wave_pairs, int64_t wave_rows, int threads) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { po_set_error("po_pipeline_create: no such device"); return nullptr; }
-    if (hipSetDevice(device) != hipSuccess) { po_set_error("po_pipeline_create: hipSetDevice failed"); return nullptr; }
+    // the caller's thread keeps the device it had: a pipeline's own work sets its device where it runs
+    DeviceScope bind(device);
+    if (!bind.ok) { po_set_error("po_pipeline_create: hipSetDevice failed"); return nullptr; }
     po_pipeline* p = new po_pipeline();
     p->device = device;
     if (wave_pairs > 0) p->wave_pairs = wave_pairs;
@@ -203,7 +219,7 @@ po_pipeline* po_pipeline_create(int device, int wave_pairs, int64_t wave_rows, i
 
 void po_pipeline_destroy(po_pipeline* p) {
     if (!p) return;
-    (void)hipSetDevice(p->device);
+    DeviceScope bind(p->device);
     for (auto& s : p->slot) {
         if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
     }
@@ -405,7 +421,8 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
                identity_h, env_out_h, seq_h, seq_off_h, seq_len_h, status_h, nullptr};
     std::string why;
     if (check_call(c, &why) != PO_OK) return fail(p, PO_E_ARG, "po_pipeline_pair_decode: " + why);
-    PCHK(hipSetDevice(p->device));
+    DeviceScope bind(p->device);   // (the caller's thread gets its own device back on every exit)
+    if (!bind.ok) return fail(p, PO_E_HIP, "po_pipeline_pair_decode: hipSetDevice failed");
     std::vector<int64_t> env_row0;
     if (env_out_h) {
         env_row0.resize((size_t)n + 1, 0);

@@ -32,6 +32,31 @@ def jagged(rng, U, V, style, pad):
     return env
 
 
+def write_summary(args, mode, **counts):
+    """profiles/rNN_fuzz_*.json: what ran, on which binary, with what result (the verdict of round 3 asked for artefacts)"""
+    if not args.json:
+        return
+    import hashlib
+    import json
+    from poreover_amd import _lib
+    lib_path = os.environ.get("POREOVER_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "libporeover_hip.so")
+    try:
+        sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
+    except OSError:
+        sha = None
+    rec = dict(mode=mode, seed=args.seed, seconds=args.seconds, route=args.route, focus=bool(args.focus), git_head=args.head,
+               lib=os.path.relpath(lib_path), lib_sha256=sha, when=time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), **counts)
+    os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
+    prev = []
+    if os.path.exists(args.json):
+        try:
+            prev = json.load(open(args.json))
+        except ValueError:
+            prev = []
+    with open(args.json, "w") as f:
+        json.dump(prev + [rec], f, indent=1)
+
+
 def _oracle_one(job):
     from oracle import po_oracle as O
     y1, y2, env, W, model, method = job
@@ -54,8 +79,10 @@ def _oracle_pipeline(job):
 
 def pipeline_mode(args, pool):
     """the whole stage chain (Viterbi x2, banded NW, skips, envelope, pair beam) against the oracle's"""
-    from poreover_amd import batch
+    from poreover_amd import batch, _lib as _L
     from poreover_amd.synth import synth_pair
+    _L.load()
+    _L.set_pair_route(args.route)
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     rounds = pairs = bad = 0
@@ -96,6 +123,7 @@ def pipeline_mode(args, pool):
         rounds += 1; pairs += n
     pool.terminate()
     print("fuzz pipeline: %d rounds, %d pairs, %d mismatches" % (rounds, pairs, bad))
+    write_summary(args, "pipeline", rounds=rounds, pairs=pairs, mismatches=bad)
     sys.exit(1 if bad else 0)
 
 
@@ -144,6 +172,7 @@ def oned_mode(args, pool):
         rounds += 1; reads += n
     pool.terminate()
     print("fuzz 1-D: %d rounds, %d reads, %d mismatches" % (rounds, reads, bad))
+    write_summary(args, "oned", rounds=rounds, reads=reads, mismatches=bad)
     sys.exit(1 if bad else 0)
 
 
@@ -154,6 +183,11 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--procs", type=int, default=min(32, os.cpu_count() or 1))
+    ap.add_argument("--route", default="auto", help="pin the pair beam kernel: auto | legacy | x2 | ring | reg")
+    ap.add_argument("--focus", action="store_true", help="pair mode: only what the ring / register-state kernels serve "
+                    "(ctc, row_col, W <= 6, monotone envelope styles)")
+    ap.add_argument("--json", default="", help="append a summary record to this JSON file (profiles/rNN_fuzz_*.json)")
+    ap.add_argument("--head", default="", help="git head of the tree under test (the GPU box has no .git)")
     args = ap.parse_args()
     from oracle import po_oracle as O
     O.build()
@@ -163,19 +197,27 @@ def main():
         return pipeline_mode(args, pool)
     if args.oned:
         return oned_mode(args, pool)
-    from poreover_amd import batch
+    from poreover_amd import batch, _lib
+    _lib.load()
+    _lib.set_pair_route(args.route)
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     rounds = pairs = bad = refused = 0
+    by_style = {}
     while time.time() < t_end:
         model, ff = [("ctc", False), ("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)][rng.integers(4)]
         method = ["row_col", "row_col", "row_col", "row", "grid"][rng.integers(5)]
         W = int([1, 2, 3, 4, 5, 5, 5, 6, 7, 9, 10, 12, 13, 16, 25][rng.integers(15)])
+        if args.focus:
+            model, ff, method = "ctc", False, "row_col"
+            W = int([1, 2, 3, 4, 5, 5, 5, 5, 6][rng.integers(9)])
         # (grid with the other models in a narrow band: every score -inf — the reference's own order is heap-address
         #  order there; engine and oracle both replay libstdc++ on creation order and agree)
         tmax = 260 if method == "grid" else 1400
         n = int(rng.integers(4, 40))
         style = ["pipeline", "diag", "stairs", "wobble", "bursts"][rng.integers(5)]
+        if args.focus and rng.random() < 0.5:
+            n = int(rng.integers(40, 400))
         y1s, y2s, envs = [], [], []
         for i in range(n):
             T = int(rng.integers(30, tmax))
@@ -214,9 +256,11 @@ def main():
                     np.savez_compressed("gpurun_out/fuzz_fail_%d_%d.npz" % (args.seed, bad), y1=y1s[i], y2=y2s[i], env=envs[i], W=W,
                                         model=model, method=method, got=g, want=ws, status=np.array([c, wc]), index=i, n=n)
         rounds += 1; pairs += n
+        by_style[style] = by_style.get(style, 0) + n
     pool.terminate()
     print("fuzz: %d rounds, %d pairs, %d mismatches, %d refused by the engine (PO_E_NOMEM / PO_E_UNSUPPORTED) where the "
           "oracle decodes" % (rounds, pairs, bad, refused))
+    write_summary(args, "pair_beam", rounds=rounds, pairs=pairs, mismatches=bad, refused=refused, pairs_by_envelope_style=by_style)
     sys.exit(1 if bad else 0)
 
 

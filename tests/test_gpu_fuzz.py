@@ -56,7 +56,7 @@ def test_fuzz_pair_beam_kernels(eng, oracle):
             except oracle.OracleError as e:
                 wants.append(("", e.code))
         # the engine's choice, beam2d_kernel always, and the LDS-ring kernel where it can run (one-value model, row_col, W * (A + 1) <= 26)
-        for route in (("auto", "ring", "legacy") if (kind == "poreover" and method == "row_col" and W <= 5) else ("auto", "legacy")):
+        for route in (("auto", "ring", "reg", "legacy") if (kind == "poreover" and method == "row_col" and W <= 5) else ("auto", "legacy")):
             _lib.set_pair_route(route)
             try:
                 got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=MODELS[kind], method=method, return_status=True)
@@ -300,7 +300,7 @@ def test_saved_fuzz_cases_on_every_route(eng, oracle):
             W, model, method = int(d["W"]), str(d["model"]), str(d["method"])
             want = oracle.cpp_beam_search_2d(y1, y2, env, W, model_=model, method_=method)
             assert want == str(d["want"])
-            for route in ("auto", "legacy", "x2", "ring"):
+            for route in ("auto", "legacy", "x2", "ring", "reg"):
                 _lib.set_pair_route(route)
                 got = batch.beam_search_2d_batch([y1], [y2], [env], W, model=model, method=method)
                 assert got[0] == want, (os.path.basename(f), route)

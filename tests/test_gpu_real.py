@@ -88,7 +88,7 @@ def test_beam1d_real(eng, real):
         assert eng.beam_search_batch([y1], W)[0] == g["beam1d_read1"][str(W)], W
 
 
-@pytest.mark.parametrize("method,route", [("row_col", "auto"), ("row_col", "ring"), ("row", "auto")])
+@pytest.mark.parametrize("method,route", [("row_col", "auto"), ("row_col", "ring"), ("row_col", "reg"), ("row", "auto")])
 def test_pair_decode_real_revcomp(eng, real, method, route):
     """the reference's float64 log-probabilities in, every stage output compared (row_col on both one-pair-per-wave
     kernels: 62 000 x 75 600 frames, windows up to 257 wide — far beyond the LDS ring of the `ring` route)"""

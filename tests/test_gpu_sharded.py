@@ -97,7 +97,7 @@ def test_shard_of_the_strong_scaling_job(oracle):
     y1s = [base[i % 50][0] for i in range(1250)]
     y2s = [base[i % 50][1] for i in range(1250)]
     want = [oracle.pair_decode(a, b, "poreover", 5, "row_col")["consensus"] for a, b in base]
-    for route in ("auto", "ring"):
+    for route in ("auto", "ring", "reg"):
         _lib.set_pair_route(route)
         try:
             got = batch.pair_decode_stream(y1s, y2s, "poreover", 5, "row_col", devices=_devices())

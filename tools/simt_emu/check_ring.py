@@ -40,7 +40,8 @@ def make_case(job):
 
 
 def run_emu(job):
-    case, W, lib_path = job
+    case, W, lib_path = job[:3]
+    kernel = job[3] if len(job) > 3 else 0
     y1, y2, env, want, code = case
     lib = C.CDLL(lib_path)
     n = 1
@@ -54,7 +55,7 @@ def run_emu(job):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     alphabet = int.from_bytes(b"ACGT", "little")
     t0 = time.time()
-    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, 5, 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), 1, p(upd))
+    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, 5, 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), 1, p(upd), kernel)
     got = bytes(seq[: sl[0]]).decode()
     return got, int(st[0]), deferred, time.time() - t0, int(upd[1])
 
@@ -68,6 +69,7 @@ def main():
     ap.add_argument("--W", type=int, default=5)
     ap.add_argument("--lib", default=os.path.join(HERE, "_build", "libemu_pair_beam.so"))
     ap.add_argument("--styles", default="pipeline,stairs,wobble,bursts")
+    ap.add_argument("--kernel", default="ring", help="ring | reg")
     args = ap.parse_args()
     styles = args.styles.split(",")
     rng = np.random.default_rng(args.seed)
@@ -80,7 +82,7 @@ def main():
     with ProcessPoolExecutor(args.procs) as pool:
         cases = list(pool.map(make_case, jobs))
         keep = [(c, j) for c, j in zip(cases, jobs) if c is not None]
-        res = list(pool.map(run_emu, [(c, j[2], args.lib) for c, j in keep]))
+        res = list(pool.map(run_emu, [(c, j[2], args.lib, 1 if args.kernel == "reg" else 0) for c, j in keep]))
     bad = 0
     tot_t = 0.0
     for (c, j), (got, st, deferred, dt, upd) in zip(keep, res):

@@ -5,11 +5,12 @@
 
 #include "../../poreover_amd/csrc/po_beam2d_pre.h"
 #include "../../poreover_amd/csrc/po_beam2d_ring.hip"
+#include "../../poreover_amd/csrc/po_beam2d_reg.hip"
 
 extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
                                   const int32_t* env, int n, int C, int A, uint32_t alphabet, int W, char* seq,
                                   const int64_t* seq_off, int32_t* seq_len, int32_t* status, int blocks,
-                                  unsigned long long* upd_count) {
+                                  unsigned long long* upd_count, int kernel) {
     int64_t tr1 = y1_off[n] - y1_off[0], tr2 = y2_off[n] - y2_off[0], mr1 = 0, mr2 = 0;
     for (int i = 0; i < n; ++i) {
         mr1 = std::max<int64_t>(mr1, y1_off[i + 1] - y1_off[i]);
@@ -25,7 +26,7 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     std::vector<int2> meta(n);
     std::vector<int4> sched((size_t)tr2 + 1);
     std::vector<double> cum1((size_t)tr1 + 1), cum2((size_t)tr2 + 1);
-    const size_t pool_bytes = (size_t)4 << 20;
+    const size_t pool_bytes = (size_t)(kernel == 1 ? 2 : 4) << 20;
     const int64_t WM = W > PO_A ? W : PO_A;
     const size_t arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
     std::vector<char> pool(pool_bytes * blocks, 0);
@@ -37,11 +38,12 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     a.dbg = nullptr; a.upd_count = upd_count; a.defer_odd = 0; a.need_mono = 1; a.order = nullptr;
     a.wgstate = wgstate.data(); a.magic = 0x1234567ull;
     a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
-    a.ngl = po_ring_ngl();
+    a.ngl = kernel == 1 ? po_reg_ngl() : po_ring_ngl();
     for (int i = 0; i < n; ++i) status[i] = PO_OK;
     hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), 0, nullptr, a);
     hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, nullptr, a);
-    po_ring_launch(&a, blocks, nullptr);
+    if (kernel == 1) po_reg_launch(&a, blocks, nullptr);
+    else po_ring_launch(&a, blocks, nullptr);
     int deferred = 0;
     for (int i = 0; i < n; ++i)
         if (meta[i].y == X2_DEFERRED) { deferred++; status[i] = -100; }   // (the product hands these to beam2d_kernel)

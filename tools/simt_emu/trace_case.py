@@ -14,7 +14,7 @@ job = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
 if len(sys.argv) > 5 and sys.argv[5] == "emu":
     import check_ring as cr
     c = cr.make_case(job)
-    r = cr.run_emu((c, job[2], os.path.join(HERE, "_build_trace", "libemu_pair_beam.so")))
+    r = cr.run_emu((c, job[2], os.path.join(HERE, "_build_trace", "libemu_pair_beam.so"), 1 if os.environ.get("EMU_KERNEL") == "reg" else 0))
     sys.stdout.flush()
     print("\nRESULT", r[0])
     sys.exit(0)
