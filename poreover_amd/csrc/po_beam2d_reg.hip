@@ -41,13 +41,14 @@ namespace {
 constexpr int RK_NY = 32;     // y rows per read resident in LDS
 constexpr int RK_YC = 5;      // doubles per y row (A + 1 <= 5)
 constexpr int RK_NGL = 96;    // row groups tracked per pair
-constexpr int RK_PS = 3;      // parents whose stored window one step stages for its new elements
-constexpr int RK_PT = 64;     // times staged per parent and read
+constexpr int RK_PS = 6;      // parents whose stored window one step can stage for its new elements (W <= 6)
+constexpr int RK_PT = 64;     // most times staged per parent and read ...
+constexpr int RK_PCAP = 192;  // ... and per read in all: parents x times (3 x 64, 6 x 32)
 constexpr int RK_FRESH = INT_MIN / 2;
 
 struct RegSmem {
     double ybuf[2][RK_NY][RK_YC];
-    double pst[2][RK_PS][RK_PT];
+    double pst[2][RK_PCAP];
     int g_owner[RK_NGL], g_hi0[RK_NGL], g_hi1[RK_NGL];
     int ord[32];              // prune with exact score ties: candidate slots in node-id order (po_stl_prune)
     double csc[32];           // ... and their scores
@@ -96,6 +97,16 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
     const PoLaeFast lae{&sm.lae};
     if (lane == 0) { sm.nupd = 0; sm.nupd_x = 0; }
     __syncthreads();
+#ifdef PO_REG_TIMING
+    // phase timers of workgroup 0 (wall_clock64: 100 MHz) and counts: see po_reg_launch for the names
+    long long tk[24], tlast = wall_clock64();
+    for (int i = 0; i < 24; ++i) tk[i] = 0;
+#define KT(i) do { const long long n_ = wall_clock64(); tk[(i)] += n_ - tlast; tlast = n_; } while (0)
+#define KC(i, n) do { tk[(i)] += (n); } while (0)
+#else
+#define KT(i) do {} while (0)
+#define KC(i, n) do {} while (0)
+#endif
 
     for (;;) {
         // ---------------------------------------------------------------- next pair from the queue
@@ -129,20 +140,29 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         int st = PO_OK;
 
         // ---------------------------------------------------------------- the value store (this lane's read)
-        auto t2_entry = [&](int row2, int tq) -> const Ent* { return &pool[((size_t)row2 * 2 + r) * R2 + (tq & Rm2)]; };
+        // (entry index and byte offset stay within 32 bits: a workgroup's slice is a few MB — one v_lshl_add per access
+        //  instead of 64-bit address arithmetic; the tag's words are put together from per-call constants the same way)
+        const char* const poolb = (const char*)pool;
+        const unsigned tag_ep = (epoch & 0xffffu) << 16;
+        auto t2_off = [&](int row2, int tq) -> unsigned { return (unsigned)(((row2 * 2 + r) * R2 + (tq & Rm2)) << 4); };
+        auto t2_entry = [&](int row2, int tq) -> const Ent* { return (const Ent*)(poolb + (size_t)t2_off(row2, tq)); };
+        auto tag_of = [&](int node, int tq) -> unsigned long long {   // == make_tag(epoch, node, tq) for 0 <= tq < 2^24
+            const unsigned hi = tag_ep | (((unsigned)node >> 8) & 0xffffu), lo = ((unsigned)node << 24) | ((unsigned)tq & 0xffffffu);
+            return ((unsigned long long)hi << 32) | lo;
+        };
         auto t2_read = [&](int row2, int node, int tq) -> double {
             double v = PO_NEG_INF;
             if (tq >= 0 && row2 >= 0) {
                 const Ent e = *t2_entry(row2, tq);
-                if (e.tag == make_tag(epoch, node, tq)) v = e.v[0];
+                if (e.tag == tag_of(node, tq)) v = e.v[0];
             }
             return v;
         };
         auto t2_write = [&](int row2, int node, int tq, double v) {
             Ent e;
-            e.tag = make_tag(epoch, node, tq);
+            e.tag = tag_of(node, tq);
             e.v[0] = v;
-            pool[((size_t)row2 * 2 + r) * R2 + (tq & Rm2)] = e;
+            *(Ent*)(const_cast<char*>(poolb) + (size_t)t2_off(row2, tq)) = e;
         };
         // ---------------------------------------------------------------- per-lane element state (slot s, read r)
         // table fields (the same in both halves of the wave)
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         // pf: an entry requested a step ahead for exactly that time (pf_t), else the store is asked now.
         auto carried_max = [&](int ws, int start, double& cmx, int& cmt, int& td) {
             auto own = [&](int tq) -> double {
-                if (tq == pf_t) return (pf_e.tag == make_tag(epoch, e_id, tq)) ? pf_e.v[0] : PO_NEG_INF;
+                if (tq == pf_t) return (pf_e.tag == tag_of(e_id, tq)) ? pf_e.v[0] : PO_NEG_INF;
                 return read_own(tq);
             };
             if (td <= ws) { cmx = own(ws); cmt = ws; return; }
@@ -337,6 +357,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 smx = part ? mx : PO_NEG_INF;
             }
             pf_t = -1;
+            KT(is_main ? 4 : 5); KC(is_main ? 16 : 17, 1); KC(18, niter);
             if (a.upd_count != nullptr) {
                 const int lenx = part2 ? we - start : 0;
                 int tot = lenx;
@@ -355,18 +376,23 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         // the step is not of this kind: scan() takes it.
         auto scan_new = [&](int u, int ce, int v, int re) -> bool {
             const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);   // (beam slot 0 always continues)
-            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || ce - d0 > RK_NY || re - d1 > RK_NY || d0 - u > RK_PT || d1 - v > RK_PT) return false;
+#ifdef PO_EMU_DEBUG
+            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || d0 - u > RK_PT || d1 - v > RK_PT) {
+                if (lane == 0) printf("WHY0 u %d d0 %d ce %d v %d d1 %d re %d\n", u, d0, ce, v, d1, re);
+                return false;
+            }
+#endif
+            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || d0 - u > RK_PT || d1 - v > RK_PT) return false;
             const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
             const bool fresh = live && v_fresh != 0;
             const bool cont = live && v_fresh == 0;
             // everybody who continues ends at dr; fresh lanes hang under a continuing lane; no root, no older frozen values
-            const bool bad = (cont && v_done != dr) || (live && e_ps == PS_ROOT) || (fresh && e_ps < 0) ||
-                             (cont && e_ps == PS_FROZEN && dr < we && dr - 1 < fz_t);
+            const bool bad = (cont && v_done != dr) || (live && e_ps == PS_ROOT) || (fresh && e_ps < 0);
             const bool pfresh = __shfl((int)fresh, hb | max(e_ps, 0)) != 0;
 #ifdef PO_EMU_DEBUG
             if (__ballot(bad || (fresh && pfresh)) != 0ull) {
                 const int w0 = (int)(__ballot(cont && v_done != dr) != 0), w1 = (int)(__ballot(live && e_ps == PS_ROOT) != 0), w2 = (int)(__ballot(fresh && e_ps < 0) != 0);
-                const int w3 = (int)(__ballot(cont && e_ps == PS_FROZEN && dr < we && dr - 1 < fz_t) != 0), w4 = (int)(__ballot(fresh && pfresh) != 0);
+                const int w3 = 0, w4 = (int)(__ballot(fresh && pfresh) != 0);
                 if (lane == 0) printf("WHY cont_done %d root %d freshfrozen %d frozenold %d pfresh %d\n", w0, w1, w2, w3, w4);
                 return false;
             }
@@ -386,13 +412,16 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                     nps++;
                 } else many = true;
             }
-            if (many) return false;
+#ifdef PO_EMU_DEBUG
+            if (many && lane == 0) printf("WHY many\n");
+#endif
+            const int n1 = dr - ws;   // (half-uniform, >= 0): times the fresh lanes compute before everybody else starts
+            if (many || nps * max(d0 - u, d1 - v) > RK_PCAP) return false;
             int myk = 0;
 #pragma unroll
-            for (int k = 1; k < RK_PS; ++k) myk = (e_ps == pj[k]) ? k : myk;
+            for (int k = 1; k < RK_PS; ++k) myk = (e_ps == pj[k] && pj[k] >= 0) ? k : myk;
             // ---- staging: lane i of a read asks for the parent's value at ws - 1 + i (and + 32); the fresh lanes' seeds go
             // out with them
-            const int n1 = dr - ws;   // (half-uniform, >= 0): times the fresh lanes compute before everybody else starts
             Ent se; se.tag = 0ull; se.v[0] = 0.0;
             const bool want_seed = fresh && v_fresh == 1 && ws - 1 >= 0;
             if (want_seed) se = *t2_entry(e_row2, ws - 1);
@@ -408,22 +437,15 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                         double val = PO_NEG_INF;
                         if (tq >= 0) {
                             const Ent e = *t2_entry(prow, tq);
-                            if (e.tag == make_tag(epoch, pid, tq)) val = e.v[0];
+                            if (e.tag == tag_of(pid, tq)) val = e.v[0];
                         }
-                        sm.pst[r][k][i] = val;
+                        sm.pst[r][k * n1 + i] = val;
                     }
                 }
             }
-            // ---- the carried part [ws, dr) of the continuing lanes' windows
-            const bool has_c = cont && dr > ws;
-            double mx = PO_NEG_INF, cmx = PO_NEG_INF;
-            double self = cont ? v_self : PO_NEG_INF;
-            if (want_seed && se.tag == make_tag(epoch, e_id, ws - 1)) self = se.v[0];
-            int mt = -1, cmt = -1, td = has_c ? v_td : ws, tr = INT_MIN;
-            if (has_c) {
-                if (v_mx == PO_NEG_INF || v_mt >= ws) { cmx = v_mx; cmt = v_mt; }
-                else carried_max(ws, dr, cmx, cmt, td);
-            }
+            double mx = PO_NEG_INF, self = PO_NEG_INF;
+            if (want_seed && se.tag == tag_of(e_id, ws - 1)) self = se.v[0];
+            int mt = -1, tr = INT_MIN;
             const int sym = sym_last(e_sym);
             const double* const yb_ = &sm.ybuf[r][0][0];
             // the y rows [lo, hi) of this read in LDS (hi - lo <= RK_NY; half-uniform arguments, wave-uniform call)
@@ -434,10 +456,15 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
             };
             // ---- phase 1: the fresh lanes over [ws, dr) — every operand is at rest
             const int n1max = max(d0 - u, d1 - v);
+            KT(1); KC(13, 1); KC(14, n1max);
             if (n1max > 0) {
-                const double* const ps_ = &sm.pst[r][myk][0];
-                for (int k = 0; k < n1max; ++k) {
-                    if ((k & (RK_NY - 1)) == 0) y_need(ws + k, min(ws + k + RK_NY, dr));
+                const double* const ps_ = &sm.pst[r][myk * n1];
+                // (the y rows come in blocks of RK_NY times, loaded BETWEEN the chain loops: a load inside the loop would make
+                //  the compiler wait for vmcnt(0) there — i.e. for every value-store write of the iteration before)
+                for (int k0 = 0; k0 < n1max; k0 += RK_NY) {
+                y_need(ws + k0, min(ws + k0 + RK_NY, dr));
+                const int k1 = min(n1max, k0 + RK_NY);
+                for (int k = k0; k < k1; ++k) {
                     if (fresh && k < n1) {
                         const int t = ws + k;
                         const double* yrow = yb_ + (t & (RK_NY - 1)) * RK_YC;
@@ -454,42 +481,17 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                         mx = po_vmax(mx, out);
                     }
                 }
-            }
-            // ---- phase 2: everybody over [dr, we), in lockstep
-            const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
-            const int n2 = we - dr;
-            const int n2max = max(ce - d0, re - d1);
-            y_need(dr, we);
-            for (int k = 0; k < n2max; ++k) {
-                const int t = dr + k;
-                const double ps_self = __shfl(self, plane);
-                if (live && k < n2) {
-                    const double* yrow = yb_ + (t & (RK_NY - 1)) * RK_YC;
-                    const double ya = yrow[sym], yb = yrow[A];
-                    const int tm = t - 1;
-                    double pp = ps_self;
-                    if (e_ps < 0) pp = (tm == fz_t) ? fz_val : PO_NEG_INF;
-                    const double out = lae(pp + ya, self + yb);
-#ifdef PO_RING_TRACE_NODE
-                    if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P2 ps %d fzt %d\n", e_id, r, t, out, pp, self, e_ps, fz_t);
-#endif
-                    t2_write(e_row2, e_id, t, out);
-                    if (out > self) tr = t;
-                    self = out;
-                    mt = (out >= mx) ? t : mt;
-                    mx = po_vmax(mx, out);
                 }
             }
-            if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
-            if (live) {
-                if (fresh || dr < we) { v_done = we; v_self = self; }
-                v_fresh = 0;
-                v_mx = mx; v_mt = mt; v_td = max(td, tr);
+            // the fresh lanes are ordinary continuing lanes now, ending at dr like everybody else: the run loop does the step
+            if (fresh) {
+                v_done = dr; v_self = self; v_fresh = 0;
+                v_mx = mx; v_mt = mt; v_td = max(ws, tr);
             }
-            smx = live ? mx : PO_NEG_INF;
             pf_t = -1;
+            KT(2);
             if (a.upd_count != nullptr) {
-                int tot = live ? (n2 + (fresh ? n1 : 0)) : 0;
+                int tot = fresh ? n1 : 0;
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
                 cnt_x += (unsigned)tot;
@@ -661,16 +663,19 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
             have_children = true;
             pf_t = -1;
             rk_sync();
+            KT(8);
         };
 
         // the first table: the root's children are the beam, their children come from the first expansion
         rebuild(A, rec.x, rec.y, rec.z, rec.w);
 
         // ---------------------------------------------------------------- the diagonal walk (BeamSearch.h:300-393)
+        KT(9);
         while (st == PO_OK && mstep < nmain) {
             int u = rec.x, v = rec.y, ce = rec.z, re = rec.w;
             double sc = PO_NEG_INF;
             bool viol = false, run_viol = false;
+            KT(6);
             // ---- a RUN of main steps on the table as it stands.  After a step that kept the set of beam nodes, with every
             // live lane's values ending at the same time and nothing to catch up, the next step is: the new times of the two
             // windows (often none on a read: the envelope's window ends move a base at a time) in lockstep, the window maxima
@@ -683,11 +688,19 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 for (;;) {
                     u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
                     const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
-                    if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || ce - d0 > RK_NY || re - d1 > RK_NY || mstep + 1 >= nmain) break;
+#ifdef PO_EMU_DEBUG
+                    if ((!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re)) && lane == 0) printf("RUNBRK u %d d0 %d ce %d v %d d1 %d re %d\n", u, d0, ce, v, d1, re);
+#endif
+                    if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || mstep + 1 >= nmain) break;
                     const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
                     const bool part2 = live && dr < we;
+#ifdef PO_EMU_DEBUG
+                    if (__ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull) { if (lane == 0) printf("RUNBRK frozenold\n"); break; }
+#endif
                     if (__ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull) break;   // a frozen parent's older values: the store
-                    // ---- the carried part [ws, dr) of the window
+                    // ---- the carried part [ws, dr) of the window: its maximum is what the previous step left while that time
+                    // is inside the window; else the stored values are looked at (the one most steps need — a decaying
+                    // element's value at the window start — was requested a step ago: pf)
                     const bool has_c = live && dr > ws;
                     double mx = PO_NEG_INF, cmx = PO_NEG_INF, self = v_self;
                     int mt = -1, cmt = -1, td = has_c ? v_td : ws, tr = INT_MIN;
@@ -698,10 +711,15 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                     // ---- the new times [dr, we), everybody in lockstep: the parent's previous value comes from its lane
                     const int n2 = we - dr;   // (half-uniform, >= 0)
                     const int n2max = max(ce - d0, re - d1);
-                    if (n2max > 0) {
-                        if (n2 > 0 && !(dr >= yhi - RK_NY && we <= yhi)) { y_reload(dr); yhi = dr + RK_NY; }
-                        rk_sync();
-                        for (int k = 0; k < n2max; ++k) {
+                    for (int k0 = 0; k0 < n2max; k0 += RK_NY) {   // (blocks of RK_NY times: the y rows are loaded between the loops)
+                        {
+                            const int lo = dr + k0, hi = min(lo + RK_NY, we);
+                            rk_sync();
+                            if (hi > lo && !(lo >= yhi - RK_NY && hi <= yhi)) { y_reload(lo); yhi = lo + RK_NY; }
+                            rk_sync();
+                        }
+                        const int k1 = min(n2max, k0 + RK_NY);
+                        for (int k = k0; k < k1; ++k) {
                             const int t = dr + k;
                             const double ps_self = __shfl(self, plane);
                             if (live && k < n2) {
@@ -721,8 +739,8 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                                 mx = po_vmax(mx, out);
                             }
                         }
-                        if (part2) { v_done = we; v_self = self; }
                     }
+                    if (part2) { v_done = we; v_self = self; }
                     if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
                     if (live) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
                     smx = live ? mx : PO_NEG_INF;
@@ -752,8 +770,10 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
 #ifdef PO_EMU_DEBUG
                     if (lane == 0) printf("STEP run\n");
 #endif
+                    KC(12, 1); KC(19, n2max);
                     if (__ballot(viol) != 0ull) { run_viol = true; break; }
                 }
+                KT(0);
             }
             if (!run_viol) {
             u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
@@ -767,16 +787,18 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 if (v - 1 >= max(vp + 1, d1)) { scan(false, 0, 0, vp + 1, v, nbe); tbl_uneven = true; }
             }
             // ---- MAIN step at (u, v): windows [u, ce) x [v, re)  (:342-375)
+            // (new elements first: their windows up to where everybody else stands — then the step is an ordinary one)
+            if (tbl_fresh && !tbl_uneven && scan_new(u, ce, v, re)) {
 #ifdef PO_EMU_DEBUG
-            {
-                const bool tf = tbl_fresh, tu = tbl_uneven;
-                const bool done_new = tbl_fresh && !tbl_uneven && scan_new(u, ce, v, re);
-                if (!done_new) scan(true, u, ce, v, re, 32);
-                if (lane == 0) printf("STEP %s fresh %d uneven %d w %d %d\n", done_new ? "new" : "general", (int)tf, (int)tu, ce - u, re - v);
-            }
-#else
-            if (!(tbl_fresh && !tbl_uneven && scan_new(u, ce, v, re))) scan(true, u, ce, v, re, 32);
+                if (lane == 0) printf("STEP new\n");
 #endif
+                tbl_fresh = false;
+                continue;
+            }
+#ifdef PO_EMU_DEBUG
+            if (lane == 0) printf("STEP general fresh %d uneven %d w %d %d\n", (int)tbl_fresh, (int)tbl_uneven, ce - u, re - v);
+#endif
+            scan(true, u, ce, v, re, 32);
             tbl_fresh = false; tbl_uneven = false;
             if (a.upd_count != nullptr) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
             // node_greater_max_sym: max over read 0's window + max over read 1's
@@ -802,6 +824,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 rnxt = sched[min(mstep + 64 + lane, max(nmain - 1, 0))];
             }
             rec = rec_at(min(mstep, nmain - 1));
+            KT(6);
             if (__ballot(viol) == 0ull) continue;
             }   // (!run_viol)
             const bool cand = live;
@@ -851,8 +874,10 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 for (int jx = 0; jx < 6; ++jx) sel[jx] = (jx < nbn) ? sm.ord[jx] : 0;
                 rk_sync();
             }
+            KT(7);
             rebuild(nbn, rec.x, rec.y, rec.z, rec.w);
         }
+        KT(6);
 
         // ---------------------------------------------------------------- label of the top node
         if (st == PO_E_NOMEM && lane == 0) {   // out of row groups (or a window end moved back): beam2d_kernel takes the pair
@@ -877,7 +902,12 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         }
         if (a.upd_count != nullptr && lane == 0) { sm.nupd += cnt_ref; sm.nupd_x += cnt_x; }
         rk_sync();
+        KT(9);
     }
+#ifdef PO_REG_TIMING
+    if (lane == 0 && a.dbg && blockIdx.x == 0)
+        for (int i = 0; i < 24; ++i) a.dbg[i] = tk[i];
+#endif
     if (lane == 0) {   // the next launch on this workspace continues from here
         unsigned long long* stp = a.wgstate + 2 * (size_t)blockIdx.x;
         stp[0] = a.magic ^ (unsigned long long)blockIdx.x;
@@ -904,6 +934,25 @@ extern "C" int po_reg_blocks_per_cu() {
 extern "C" int po_reg_max_elements() { return 32; }
 extern "C" int po_reg_ngl() { return RK_NGL; }
 extern "C" void po_reg_launch(const void* x2args, int blocks, hipStream_t stream) {
-    const X2Args a = *(const X2Args*)x2args;
+    X2Args a = *(const X2Args*)x2args;
+#ifdef PO_REG_TIMING
+    static long long* dbg = nullptr;
+    if (!dbg) { (void)hipMalloc((void**)&dbg, 24 * sizeof(long long)); }
+    (void)hipMemsetAsync(dbg, 0, 24 * sizeof(long long), stream);
+    a.dbg = dbg;
+#endif
     hipLaunchKernelGGL(beam2d_reg_kernel, dim3(blocks), dim3(64), 0, stream, a);
+#ifdef PO_REG_TIMING
+    {
+        long long h[24];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[po_reg_timing] workgroup 0, 10 ns ticks\n");
+        fprintf(stderr, "   run loop %lld (%lld steps, %lld new-time iterations)\n", h[0], h[12], h[19]);
+        fprintf(stderr, "   steps with new elements: %lld steps; staging + carried maxima %lld, phase 1 %lld (%lld iterations), phase 2 + state %lld (%lld iterations)\n",
+                h[13], h[1], h[2], h[14], h[3], h[15]);
+        fprintf(stderr, "   general scans: main %lld ticks (%lld), catch-up %lld ticks (%lld); iterations %lld\n", h[4], h[16], h[5], h[17], h[18]);
+        fprintf(stderr, "   step top + score + prune test %lld, ranking %lld, rebuild %lld, pair setup + label %lld\n", h[6], h[7], h[8], h[9]);
+    }
+#endif
 }
