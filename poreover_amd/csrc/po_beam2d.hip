@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2
         x2_sync();
         TK(2);  // expansion
         if (dm && h.sh[4] != PO_OK) {  // out of row groups: hand the pair to beam2d_kernel
-            if (s == 0) a.meta[pi] = make_int2(PO_OK, X2_DEFERRED);
+            if (s == 0) { a.meta[pi] = make_int2(PO_OK, X2_DEFERRED); a.queue[16] = 1; }
             have = false; fin = true;
         }
         const bool dmm = dm && !fin;
@@ -2929,7 +2929,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         // pairs the pre-pass or the kernel deferred (tier-2 row groups exhausted, windows beyond the store's ring):
         // one small pass of beam2d_kernel, a no-op when there are none
         return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off,
-                                seq_len, status, use_pre_status, w + g.off_fb, g.fb_bytes, stream, X2_FB_BLOCKS, a.meta);
+                                seq_len, status, use_pre_status, w + g.off_fb, g.fb_bytes, stream, X2_FB_BLOCKS, a.meta, 0, a.queue + 16);
     }
     if (x2_eligible(n, W, model, method)) {
         const X2Geom g = x2_geometry(n, tr1, tr2, mr1, mr2, W, model);
@@ -2984,7 +2984,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         // pairs the pre-pass or the kernel deferred (window too wide for its store geometry, row groups
         // exhausted): one small pass of beam2d_kernel, a no-op when there are none
         return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off,
-                                seq_len, status, use_pre_status, w + g.off_fb, g.fb_bytes, stream, X2_FB_BLOCKS, a.meta);
+                                seq_len, status, use_pre_status, w + g.off_fb, g.fb_bytes, stream, X2_FB_BLOCKS, a.meta, 0, a.queue + 16);
     }
     return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off, seq_len,
                             status, use_pre_status, ws, ws_bytes, stream, 0, nullptr);

@@ -129,7 +129,11 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             if (t < Tn) cw[t] = mine;
         }
     }
-    if (tid == 0) { a.meta[pi] = make_int2(st, R); a.nmain[pi] = 0; }
+    if (tid == 0) {
+        a.meta[pi] = make_int2(st, R);
+        a.nmain[pi] = 0;
+        if (st == PO_OK && R == X2_DEFERRED) a.queue[16] = 1;   // the pass over the deferred pairs has something to do
+    }
 }
 
 // ---- the diagonal walk itself (BeamSearch.h:300-341) depends on the envelope only: one wave per pair replays it

@@ -42,8 +42,7 @@ constexpr int RK_NY = 32;     // y rows per read resident in LDS
 constexpr int RK_YC = 5;      // doubles per y row (A + 1 <= 5)
 constexpr int RK_NGL = 96;    // row groups tracked per pair
 constexpr int RK_PS = 6;      // parents whose stored window one step can stage for its new elements (W <= 6)
-constexpr int RK_PT = 64;     // most times staged per parent and read ...
-constexpr int RK_PCAP = 192;  // ... and per read in all: parents x times (3 x 64, 6 x 32)
+constexpr int RK_PCAP = RK_PS * RK_NY;   // staged values per read: a block of RK_NY times of every parent
 constexpr int RK_FRESH = INT_MIN / 2;
 
 struct RegSmem {
@@ -377,12 +376,12 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         auto scan_new = [&](int u, int ce, int v, int re) -> bool {
             const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);   // (beam slot 0 always continues)
 #ifdef PO_EMU_DEBUG
-            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || d0 - u > RK_PT || d1 - v > RK_PT) {
+            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re)) {
                 if (lane == 0) printf("WHY0 u %d d0 %d ce %d v %d d1 %d re %d\n", u, d0, ce, v, d1, re);
                 return false;
             }
 #endif
-            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || d0 - u > RK_PT || d1 - v > RK_PT) return false;
+            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re)) return false;
             const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
             const bool fresh = live && v_fresh != 0;
             const bool cont = live && v_fresh == 0;
@@ -416,60 +415,56 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
             if (many && lane == 0) printf("WHY many\n");
 #endif
             const int n1 = dr - ws;   // (half-uniform, >= 0): times the fresh lanes compute before everybody else starts
-            if (many || nps * max(d0 - u, d1 - v) > RK_PCAP) return false;
+            if (many) return false;
             int myk = 0;
 #pragma unroll
             for (int k = 1; k < RK_PS; ++k) myk = (e_ps == pj[k] && pj[k] >= 0) ? k : myk;
-            // ---- staging: lane i of a read asks for the parent's value at ws - 1 + i (and + 32); the fresh lanes' seeds go
-            // out with them
+            // the fresh lanes' own seeds (an element again: its last value is in the store)
             Ent se; se.tag = 0ull; se.v[0] = 0.0;
             const bool want_seed = fresh && v_fresh == 1 && ws - 1 >= 0;
             if (want_seed) se = *t2_entry(e_row2, ws - 1);
-            for (int k = 0; k < nps; ++k) {   // (wave-uniform)
-                int jk = pj[0];
+            double mx = PO_NEG_INF, self = PO_NEG_INF;
+            int mt = -1, tr = INT_MIN;
+            const int sym = sym_last(e_sym);
+            const double* const yb_ = &sm.ybuf[r][0][0];
+            // ---- phase 1: the fresh lanes over [ws, dr) — every operand is at rest.  In blocks of RK_NY times: the parents'
+            // stored values of the block are STAGED (lane i of a read asks for time ws - 1 + k0 + i of each parent: one memory
+            // round trip for all of them, with the y rows of the block), then the chains run on LDS and registers only — a
+            // load inside the chain loop would make the compiler wait for vmcnt(0) there, i.e. for every value-store write
+            // of the iteration before.
+            const int n1max = max(d0 - u, d1 - v);
+            KT(1); KC(13, 1); KC(14, n1max);
+            const double* const ps_ = &sm.pst[r][myk * RK_NY];
+            for (int k0 = 0; k0 < n1max; k0 += RK_NY) {
+                rk_sync();   // (every lane is done with the rows and staged values of the block before)
+                {
+                    const int lo = ws + k0, hi = min(lo + RK_NY, dr);
+                    if (hi > lo && !(lo >= yhi - RK_NY && hi <= yhi)) { y_reload(lo); yhi = lo + RK_NY; }
+                }
+                for (int k = 0; k < nps; ++k) {   // (wave-uniform)
+                    int jk = pj[0];
 #pragma unroll
-                for (int q = 1; q < RK_PS; ++q) jk = (k == q) ? pj[q] : jk;
-                const int prow = __builtin_amdgcn_readlane(e_row2, jk), pid = __builtin_amdgcn_readlane(e_id, jk);
-#pragma unroll
-                for (int h = 0; h < RK_PT / 32; ++h) {
-                    const int i = s + 32 * h, tq = ws - 1 + i;
+                    for (int q = 1; q < RK_PS; ++q) jk = (k == q) ? pj[q] : jk;
+                    const int prow = __builtin_amdgcn_readlane(e_row2, jk), pid = __builtin_amdgcn_readlane(e_id, jk);
+                    const int i = k0 + s, tq = ws - 1 + i;
                     if (i < n1) {
                         double val = PO_NEG_INF;
                         if (tq >= 0) {
                             const Ent e = *t2_entry(prow, tq);
                             if (e.tag == tag_of(pid, tq)) val = e.v[0];
                         }
-                        sm.pst[r][k * n1 + i] = val;
+                        sm.pst[r][k * RK_NY + s] = val;
                     }
                 }
-            }
-            double mx = PO_NEG_INF, self = PO_NEG_INF;
-            if (want_seed && se.tag == tag_of(e_id, ws - 1)) self = se.v[0];
-            int mt = -1, tr = INT_MIN;
-            const int sym = sym_last(e_sym);
-            const double* const yb_ = &sm.ybuf[r][0][0];
-            // the y rows [lo, hi) of this read in LDS (hi - lo <= RK_NY; half-uniform arguments, wave-uniform call)
-            auto y_need = [&](int lo, int hi) {
-                rk_sync();   // (every lane is done with the rows a reload overwrites, and with the staging writes)
-                if (hi > lo && !(lo >= yhi - RK_NY && hi <= yhi)) { y_reload(lo); yhi = lo + RK_NY; }
+                if (k0 == 0 && want_seed && se.tag == tag_of(e_id, ws - 1)) self = se.v[0];
                 rk_sync();
-            };
-            // ---- phase 1: the fresh lanes over [ws, dr) — every operand is at rest
-            const int n1max = max(d0 - u, d1 - v);
-            KT(1); KC(13, 1); KC(14, n1max);
-            if (n1max > 0) {
-                const double* const ps_ = &sm.pst[r][myk * n1];
-                // (the y rows come in blocks of RK_NY times, loaded BETWEEN the chain loops: a load inside the loop would make
-                //  the compiler wait for vmcnt(0) there — i.e. for every value-store write of the iteration before)
-                for (int k0 = 0; k0 < n1max; k0 += RK_NY) {
-                y_need(ws + k0, min(ws + k0 + RK_NY, dr));
                 const int k1 = min(n1max, k0 + RK_NY);
                 for (int k = k0; k < k1; ++k) {
                     if (fresh && k < n1) {
                         const int t = ws + k;
                         const double* yrow = yb_ + (t & (RK_NY - 1)) * RK_YC;
                         const double ya = yrow[sym], yb = yrow[A];
-                        const double pp = ps_[k];
+                        const double pp = ps_[k - k0];
                         const double out = lae(pp + ya, self + yb);
 #ifdef PO_RING_TRACE_NODE
                         if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P1\n", e_id, r, t, out, pp, self);
@@ -481,8 +476,8 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                         mx = po_vmax(mx, out);
                     }
                 }
-                }
             }
+            if (n1max == 0 && want_seed && se.tag == tag_of(e_id, ws - 1)) self = se.v[0];
             // the fresh lanes are ordinary continuing lanes now, ending at dr like everybody else: the run loop does the step
             if (fresh) {
                 v_done = dr; v_self = self; v_fresh = 0;
@@ -882,6 +877,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         // ---------------------------------------------------------------- label of the top node
         if (st == PO_E_NOMEM && lane == 0) {   // out of row groups (or a window end moved back): beam2d_kernel takes the pair
             a.meta[pi] = make_int2(PO_OK, X2_DEFERRED);
+            a.queue[16] = 1;
         } else if (lane == 0) {
             int nout = 0;
             if (st == PO_OK) {

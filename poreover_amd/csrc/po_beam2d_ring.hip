@@ -988,6 +988,7 @@ __global__ __launch_bounds__(64, 2) void beam2d_ring_kernel(X2Args a) {
         // ---------------------------------------------------------------- label of the top node
         if (st == PO_E_NOMEM && lane == 0) {   // out of tier-2 row groups: beam2d_kernel takes the pair
             a.meta[pi] = make_int2(PO_OK, X2_DEFERRED);
+            a.queue[16] = 1;
         } else if (lane == 0) {
             int nout = 0;
             if (st == PO_OK) {
