@@ -2578,7 +2578,9 @@ struct RingGeom {
     unsigned long long magic;
 };
 // The register-state kernel (beam2d_reg_kernel, po_beam2d_reg.hip): the same pre-pass, walk and meta words; the engine's
-// choice for launches beyond the ring kernel's resident workgroups, where throughput counts (16 pairs per CU).
+// choice (PO_ROUTE_AUTO) at every batch size since round 4 — 16 pairs per CU instead of the ring kernel's 8, and the
+// lower latency of the two for a single pair as well (16.6 vs 17.3 ms; 1 250 pairs 24.9 vs 25.3 ms; 10 000 pairs 74.4 vs
+// 106 ms, beam2d_kernel 89.1).  PO_REG_NEVER gives the round-3 routing back (ring up to 2 048 pairs, beam2d_kernel beyond).
 extern "C" int po_reg_blocks_per_cu();
 extern "C" int po_reg_max_elements();
 extern "C" int po_reg_ngl();
@@ -2588,7 +2590,7 @@ bool reg_eligible(int n, int W, int A, int model, int method) {
     if (!(model == PO_MODEL_CTC && method == PO_METHOD_ROW_COL && W <= 6 && A >= 1 && W * (A + 1) <= po_reg_max_elements())) return false;
     if (rt == PO_ROUTE_REG) return true;
     if (rt != PO_ROUTE_AUTO) return false;
-    return b2_route().reg_auto && !ring_eligible(n, W, A, model, method);
+    return b2_route().reg_auto != 0;
 }
 RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model, bool reg = false) {
     RingGeom g;

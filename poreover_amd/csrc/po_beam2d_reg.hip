@@ -743,7 +743,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                         cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
                         cnt_x += (unsigned)(__popcll(__ballot(live && r == 0)) * (ce - d0) + __popcll(__ballot(live && r == 1)) * (re - d1));
                     }
-                    sc = smx + __shfl_xor(smx, 32);
+                    sc = smx + po_xor32(smx, r != 0);
 #ifdef PO_RING_TRACE
                     if (pi == 0 && live && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
 #endif
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
             tbl_fresh = false; tbl_uneven = false;
             if (a.upd_count != nullptr) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
             // node_greater_max_sym: max over read 0's window + max over read 1's
-            sc = smx + __shfl_xor(smx, 32);
+            sc = smx + po_xor32(smx, r != 0);
 #ifdef PO_RING_TRACE   // debugging builds only: every candidate's score before the prune
             if (pi == 0 && live && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
 #endif

@@ -204,6 +204,22 @@ struct PoLaePoly {
 
 __device__ __forceinline__ int po_lane() { return threadIdx.x & (PO_WAVE - 1); }
 
+// The value of lane ^ 32 (the other half of the wave): v_permlane32_swap_b32 (gfx950) exchanges the upper half of one
+// register with the lower half of another inside the VALU — two of them and two selects per double, instead of two
+// ds_bpermute_b32 round trips through the LDS crossbar.
+__device__ __forceinline__ int po_xor32_i(int x, bool upper) {
+#ifdef PO_EMU
+    (void)upper;
+    return __shfl_xor(x, 32);
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return (int)(upper ? r[0] : r[1]);
+#endif
+}
+__device__ __forceinline__ double po_xor32(double x, bool upper) {   // upper: this lane is one of 32..63
+    return __hiloint2double(po_xor32_i(__double2hiint(x), upper), po_xor32_i(__double2loint(x), upper));
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
 // outstanding global access (s_waitcnt vmcnt(0)); inside a dependent loop that turns each
 // fire-and-forget global store into a full round trip.  Use this one when only LDS data is

@@ -5,7 +5,7 @@
 #      (--no_secondary --no_strong: every launch of it is a 10 000-pair launch, so AverageNs IS roofline.avg_launch_ms)
 #   3. HBM counters, separate --pmc passes, 10 000 and 1250 pairs       -> pmc_hbm_TAG_10000.json, pmc_hbm_TAG_1250.json
 #   4. SQ instruction / wait counters, 10 000 pairs                     -> pmc_sq_TAG.json
-#   5. the same for the LDS-ring route (PO_RING_AUTO=1)                 -> *_TAG_ring*
+#   5. the same for round 3's routing (PO_REG_NEVER=1: beam2d_kernel)   -> *_TAG_legacy*
 #   6. the 1-D beam search (config 2): kernel stats + SQ counters       -> beam1d_TAG.txt
 tag=${1:-rXX}
 root=${GRAFT_REPO_ROOT:-/root/repo}
@@ -45,11 +45,10 @@ prof_one ""
 cd $root && scripts/pmc_hbm.sh ${tag}_10000 10000 > gpurun_out/pmc_hbm_${tag}_10000.txt 2>&1; tail -16 gpurun_out/pmc_hbm_${tag}_10000.txt
 scripts/pmc_hbm.sh ${tag}_1250 1250 > gpurun_out/pmc_hbm_${tag}_1250.txt 2>&1
 cd /tmp; sq_one ""
-export PO_RING_AUTO=1
-prof_one "_ring"
-cd $root && scripts/pmc_hbm.sh ${tag}_ring_10000 10000 > gpurun_out/pmc_hbm_${tag}_ring_10000.txt 2>&1; tail -12 gpurun_out/pmc_hbm_${tag}_ring_10000.txt
-cd /tmp; sq_one "_ring"
-unset PO_RING_AUTO
+export PO_REG_NEVER=1
+prof_one "_legacy"
+cd /tmp; sq_one "_legacy"
+unset PO_REG_NEVER
 # 1-D beam search
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/b1_$tag -- python3 $root/scripts/quick_time_1d.py 1000 > $root/gpurun_out/beam1d_$tag.txt 2>&1
