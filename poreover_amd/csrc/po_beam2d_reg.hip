@@ -40,8 +40,14 @@ namespace {
 
 constexpr int RK_NY = 32;     // y rows per read resident in LDS
 constexpr int RK_YC = 5;      // doubles per y row (A + 1 <= 5)
-constexpr int RK_NGL = 96;    // row groups tracked per pair
-constexpr int RK_PS = 6;      // parents whose stored window one step can stage for its new elements (W <= 6)
+#ifndef PO_REG_NGL
+#define PO_REG_NGL 96
+#endif
+#ifndef PO_REG_PS
+#define PO_REG_PS 6
+#endif
+constexpr int RK_NGL = PO_REG_NGL;    // row groups tracked per pair
+constexpr int RK_PS = PO_REG_PS;      // parents whose stored window one step can stage for its new elements (W <= 6)
 constexpr int RK_PCAP = RK_PS * RK_NY;   // staged values per read: a block of RK_NY times of every parent
 constexpr int RK_FRESH = INT_MIN / 2;
 
@@ -459,12 +465,21 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 if (k0 == 0 && want_seed && se.tag == tag_of(e_id, ws - 1)) self = se.v[0];
                 rk_sync();
                 const int k1 = min(n1max, k0 + RK_NY);
+                // (the operands of an iteration are asked for one iteration ahead: a lone wave then waits for the LDS only
+                //  inside logaddexp's own table lookups)
+                double nya = 0.0, nyb = 0.0, npp = 0.0;
+                if (fresh && k0 < n1) {
+                    const double* yrow = yb_ + ((ws + k0) & (RK_NY - 1)) * RK_YC;
+                    nya = yrow[sym]; nyb = yrow[A]; npp = ps_[0];
+                }
                 for (int k = k0; k < k1; ++k) {
                     if (fresh && k < n1) {
                         const int t = ws + k;
-                        const double* yrow = yb_ + (t & (RK_NY - 1)) * RK_YC;
-                        const double ya = yrow[sym], yb = yrow[A];
-                        const double pp = ps_[k - k0];
+                        const double ya = nya, yb = nyb, pp = npp;
+                        {   // (one past the end of the block: read, never used — the slots exist)
+                            const double* yrow = yb_ + ((t + 1) & (RK_NY - 1)) * RK_YC;
+                            nya = yrow[sym]; nyb = yrow[A]; npp = ps_[min(k - k0 + 1, RK_NY - 1)];
+                        }
                         const double out = lae(pp + ya, self + yb);
 #ifdef PO_RING_TRACE_NODE
                         if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P1\n", e_id, r, t, out, pp, self);
@@ -689,10 +704,8 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                     if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || mstep + 1 >= nmain) break;
                     const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
                     const bool part2 = live && dr < we;
-#ifdef PO_EMU_DEBUG
-                    if (__ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull) { if (lane == 0) printf("RUNBRK frozenold\n"); break; }
-#endif
-                    if (__ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull) break;   // a frozen parent's older values: the store
+                    // (a frozen parent's older values would have to come from the store: only asked when there are new times)
+                    if ((ce > d0 || re > d1) && __ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull) break;
                     // ---- the carried part [ws, dr) of the window: its maximum is what the previous step left while that time
                     // is inside the window; else the stored values are looked at (the one most steps need — a decaying
                     // element's value at the window start — was requested a step ago: pf)

@@ -91,8 +91,7 @@ struct WavePlanner {
     int64_t wave_rows;
     int next = 0;
     int handed = 0;      // waves handed out so far
-    int ramp = 0;        // > 0: the first waves are short (ramp, 2 * ramp, ... up to wave_pairs).  Measured on the 10 000-pair job
-                         // (1024, 2048, 4096, ...): no gain — the short waves decode at small-batch rates — so nobody sets it
+    int ramp = 0;        // > 0: the first waves are short (ramp, 2 * ramp, ... up to wave_pairs): see PO_WAVE_RAMP
     bool bad = false;
     std::mutex mu;
     bool take(int* first, int* wn, int64_t* r1, int64_t* r2, int64_t* m1, int64_t* m2) {
@@ -122,7 +121,11 @@ constexpr int PO_MAX_SLOTS = 4;
 // 3 x 3 334 63.4k; 5 x 2 048 (the LDS-ring kernel's range) 50.8k; a short first wave (ramp) 54 - 59k.  The first wave is what
 // the device waits for (pack + upload: 22 ms at 2 500 pairs, 35 ms at 4 096), even waves keep the last one from being a
 // tail, and a third slot lets wave k + 2 upload while k decodes and k + 1 waits.  A job of at most 4 096 pairs stays one wave.
-constexpr int PO_WAVE_TARGET = 2500, PO_WAVE_MAX = 4096;
+// Round 4 (beam2d_reg_kernel: 16 pairs per CU, a launch of 3 334 pairs decodes at ~ 110k pairs/s where 2 500 pairs reach
+// ~ 85k), same job, same box: waves of 2 500 73.9k pairs/s end to end, 3 334 82.1k, 5 000 on two or three slots 75k, 2 000 x 5
+// 69k, four slots 68k; and now a SHORT FIRST WAVE pays (1 250 pairs, then 2 500, then full waves: the device starts ~ 10 ms
+// earlier and the short wave no longer decodes much slower per pair): 3 334 with that ramp 84.4k (2 500 with it 77.6k).
+constexpr int PO_WAVE_TARGET = 3334, PO_WAVE_MAX = 4096, PO_WAVE_RAMP = 1250;
 static int auto_wave_pairs(int n) {
     if (n <= PO_WAVE_MAX) return PO_WAVE_MAX;
     const int waves = (n + PO_WAVE_TARGET - 1) / PO_WAVE_TARGET;
@@ -432,7 +435,8 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
     WavePlanner plan;
     plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n; plan.wave_rows = p->wave_rows;
     plan.wave_pairs = p->wave_pairs > 0 ? p->wave_pairs : auto_wave_pairs(n);
-    if (const char* e = getenv("PO_WAVE_RAMP")) plan.ramp = std::max(0, atoi(e));   // experiment: first wave of this many pairs, doubling
+    plan.ramp = (p->wave_pairs <= 0 && n > PO_WAVE_MAX) ? PO_WAVE_RAMP : 0;   // a job of several waves starts with a short one, doubling
+    if (const char* e = getenv("PO_WAVE_RAMP")) plan.ramp = std::max(0, atoi(e));
     // (Tried: a job within the latency-bound regime of the pair beam kernel — <= 2 048 pairs, one GPU's share of a multi-GPU
     //  job — cut into two waves whose kernels run side by side while the second uploads: 36.8 vs 36.9 ms for 1 250 pairs,
     //  three waves on the two slots 60 ms.  The upload is not what such a job waits for.  PO_PIPELINE_SPLIT=1 still does it.)
