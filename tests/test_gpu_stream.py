@@ -169,7 +169,7 @@ def test_alternating_wave_geometries_on_one_pipeline(eng, kind):
 
 
 def test_stream_large_job_records_built_while_decoding(eng, oracle):
-    """More than 4 096 pairs: even waves on three slots, and the Python records of finished waves are built while the later
+    """More than 4 096 pairs: several waves on three slots, and the Python records of finished waves are built while the later
     waves decode (the engine writes a pair's status last; batch._PENDING marks "not yet").  4 700 pairs — 14 distinct ones,
     one of them with a read too short to align (skipped, consensus None) — every record in its place, against the oracle;
     strict=True raises for an engine error only after the call has come back."""
@@ -183,7 +183,7 @@ def test_stream_large_job_records_built_while_decoding(eng, oracle):
     idx = rng.integers(len(base), size=4700)
     st = {}
     got = eng.pair_decode_stream([base[i][0] for i in idx], [base[i][1] for i in idx], "poreover", 5, "row_col", strict=False, stats=st)
-    assert st["waves"] == 2 and len(got) == len(idx)
+    assert st["waves"] >= 2 and len(got) == len(idx)   # (round 4: a short first wave, then full ones)
     for k, i in enumerate(idx):
         w = base[i][2]
         assert got[k]["seq1"] == w["seq1"] and got[k]["seq2"] == w["seq2"], k
