@@ -2581,10 +2581,17 @@ struct RingGeom {
 // choice (PO_ROUTE_AUTO) at every batch size since round 4 — 16 pairs per CU instead of the ring kernel's 8, and the
 // lower latency of the two for a single pair as well (16.6 vs 17.3 ms; 1 250 pairs 24.9 vs 25.3 ms; 10 000 pairs 74.4 vs
 // 106 ms, beam2d_kernel 89.1).  PO_REG_NEVER gives the round-3 routing back (ring up to 2 048 pairs, beam2d_kernel beyond).
-extern "C" int po_reg_blocks_per_cu();
+extern "C" int po_reg_slots_per_cu(int board);
 extern "C" int po_reg_max_elements();
 extern "C" int po_reg_ngl();
-extern "C" void po_reg_launch(const void* x2args, int blocks, hipStream_t stream);
+extern "C" void po_reg_launch(const void* x2args, int slots, int board, hipStream_t stream);
+// The job-board form of the kernel (7 pair waves + a chain wave per workgroup) pays where the device is full: launches
+// beyond the one-wave form's resident pairs.  PO_REG_BOARD=0 / 1 pins it off / on at every size (A/B).
+bool reg_use_board(int n) {
+    static const int env = [] { const char* e = getenv("PO_REG_BOARD"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env != 0;
+    return false;
+}
 bool reg_eligible(int n, int W, int A, int model, int method) {
     const int rt = b2_route().route;
     if (!(model == PO_MODEL_CTC && method == PO_METHOD_ROW_COL && W <= 6 && A >= 1 && W * (A + 1) <= po_reg_max_elements())) return false;
@@ -2594,7 +2601,7 @@ bool reg_eligible(int n, int W, int A, int model, int method) {
 }
 RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model, bool reg = false) {
     RingGeom g;
-    g.blocks = b2_num_cus() * (reg ? po_reg_blocks_per_cu() : po_ring_blocks_per_cu());
+    g.blocks = b2_num_cus() * (reg ? po_reg_slots_per_cu(reg_use_board(n) ? 1 : 0) : po_ring_blocks_per_cu());
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
     // ring kernel, tier 2: 128 row groups at R = 256 (windows up to 254 frames), 96 tracked; register-state kernel: the
     // whole store, 2 MB = 128 groups at R = 128 (beam2d_kernel's W <= 6 geometry)
@@ -2925,7 +2932,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
         hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
         if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
-        if (use_reg) po_reg_launch(&a, g.blocks, stream);
+        if (use_reg) po_reg_launch(&a, g.blocks, reg_use_board(n) ? 1 : 0, stream);
         else po_ring_launch(&a, g.blocks, stream);
         if (g_b2_mark_fwd) g_b2_mark_fwd(0, stream);
         // pairs the pre-pass or the kernel deferred (tier-2 row groups exhausted, windows beyond the store's ring):

@@ -51,7 +51,7 @@ constexpr int RK_PS = PO_REG_PS;      // parents whose stored window one step ca
 constexpr int RK_PCAP = RK_PS * RK_NY;   // staged values per read: a block of RK_NY times of every parent
 constexpr int RK_FRESH = INT_MIN / 2;
 
-struct RegSmem {
+struct RegSmem {              // per pair wave
     double ybuf[2][RK_NY][RK_YC];
     double pst[2][RK_PCAP];
     int g_owner[RK_NGL], g_hi0[RK_NGL], g_hi1[RK_NGL];
@@ -59,7 +59,28 @@ struct RegSmem {
     double csc[32];           // ... and their scores
     int sh[8];
     unsigned long long nupd, nupd_x;
+};
+
+// ---- the job board (NPW > 1): NPW pair waves and one CHAIN wave per workgroup.  A step's new elements are a few lanes
+// running ~ 20 dependent logaddexp iterations while the rest of their wave idles — 40 % of the kernel's vector
+// instructions (profiles/r04_pmc_sq.json) at 8 - 16 busy lanes of 64.  Over that range every operand of a chain is at
+// rest: the y rows and the parent's staged values sit in the poster's LDS, the seed is a number, the results go to the value
+// store and to four numbers per chain.  So the pair wave POSTS its chains of a block (<= 32 times each) and sleeps; the
+// chain wave runs the chains of ALL the workgroup's pair waves, one per lane, each lane at its own time — lanes pick up new
+// chains whenever they are free — and reports back.  Same arithmetic in the same order within every chain: bit-identical.
+constexpr int RK_JOBS = 48;   // chains one pair wave can post per block: 2 reads x W x A fresh children
+struct RegJob { int code /* wave | read << 4 | staged parent << 5 | symbol << 8 */, t0, n, rowbase, node, pad_; double seed; };
+struct RegRes { double self, mx; int mt, tr; };
+union RegSlot { RegJob j; RegRes r; };
+template <int NPW>
+struct RegGroup {
+    RegSmem w[NPW];
     PoLaeTables lae;
+    RegSlot slot[NPW > 1 ? NPW : 1][NPW > 1 ? RK_JOBS : 1];
+    unsigned posted[8], taken[8], done[8];   // running totals per pair wave: chains posted / picked up / finished
+    int pc_rm2[8];                           // per pair wave, for the pair it decodes: store ring mask ...
+    unsigned pc_tagep[8];                    // ... and the epoch bits of its tags
+    int exited;                              // pair waves that have left the kernel
 };
 
 __device__ __forceinline__ void rk_sync() { b2_sync_lds<64>(); }
@@ -72,36 +93,137 @@ __device__ __forceinline__ double rk_readlane_d(double x, int l) {
 #ifndef PO_REG_WAVES
 #define PO_REG_WAVES 4
 #endif
-__global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) {
+template <int NPW>
+__global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) {
     using Ent = Entry<1>;
-    __shared__ RegSmem sm;
-    const int lane = threadIdx.x, r = lane >> 5, s = lane & 31, hb = lane & 32;
+    __shared__ RegGroup<NPW> gsm;
+    const int wave = (NPW == 1) ? 0 : (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = lane >> 5, s = lane & 31, hb = lane & 32;
+    RegSmem& sm = gsm.w[(wave < NPW) ? wave : 0];
+    const int slotid = blockIdx.x * NPW + wave;      // this pair wave's slice of the workspace
+    const bool use_board = (NPW > 1) && a.reg_board != 0;
     const int A = a.A, W = a.W, C = a.C;
     const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here
-    Ent* const pool = (Ent*)(a.pool + (size_t)blockIdx.x * a.pool_bytes);
+    Ent* const pool = (Ent*)(a.pool + (size_t)slotid * a.pool_bytes);
     const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
-    int* const apl = a.arena + (size_t)blockIdx.x * 3 * a.arena_cap;
+    int* const apl = a.arena + (size_t)slotid * 3 * a.arena_cap;
     int* const afc = apl + a.arena_cap;
     int* const acrow = afc + a.arena_cap;
     int* const g_hi = r ? sm.g_hi1 : sm.g_hi0;
+    const bool is_pair_wave = wave < NPW && slotid < a.reg_slots;
 
     // ---- epoch tags across pairs and launches (as beam2d_kernel): no memset of the store
     unsigned epoch = 0;
     auto clear_slice = [&]() {
         for (long long i = lane; i < pool_entries; i += 64) pool[i].tag = 0ull;
-        __syncthreads();
+        rk_sync();
     };
-    {
-        unsigned long long* stp = a.wgstate + 2 * (size_t)blockIdx.x;
+    if (is_pair_wave) {
+        unsigned long long* stp = a.wgstate + 2 * (size_t)slotid;
         const unsigned long long w0 = stp[0], w1 = stp[1];
-        const bool ok = (w0 == (a.magic ^ (unsigned long long)blockIdx.x));
+        const bool ok = (w0 == (a.magic ^ (unsigned long long)slotid));
         epoch = ok ? (unsigned)w1 : 0u;
         if (!ok) clear_slice();
     }
-    po_lae_tables_load(&sm.lae, lane, 64);
-    const PoLaeFast lae{&sm.lae};
-    if (lane == 0) { sm.nupd = 0; sm.nupd_x = 0; }
+    po_lae_tables_load(&gsm.lae, (int)threadIdx.x, (int)blockDim.x);
+    const PoLaeFast lae{&gsm.lae};
+    if (lane == 0 && wave < NPW) { sm.nupd = 0; sm.nupd_x = 0; }
+    if (threadIdx.x < 8) { gsm.posted[threadIdx.x] = 0u; gsm.taken[threadIdx.x] = 0u; gsm.done[threadIdx.x] = 0u; }
+    if (threadIdx.x == 0) gsm.exited = 0;
     __syncthreads();
+    unsigned posted_total = 0u;   // chains this pair wave has posted so far (the board keeps running totals)
+    if constexpr (NPW > 1) {
+        if (wave == NPW) {
+            // ================================================================ the CHAIN wave
+            // (seven pair waves wait for what this wave computes: it goes first whenever it can issue)
+#ifndef PO_EMU
+            __builtin_amdgcn_s_setprio(3);
+#endif
+            bool busy = false, fin = false;
+            int jw = 0, jslot = 0, t = 0, k = 0, n = 0, rowbase = 0, node = 0, symo = 0, mt = -1, tr = INT_MIN, rm2 = 0;
+            unsigned tagep = 0u;
+            double self = PO_NEG_INF, mx = PO_NEG_INF;
+            const double* yb = &gsm.w[0].ybuf[0][0][0];
+            const double* ps = &gsm.w[0].pst[0][0];
+            char* pl = a.pool;
+            for (;;) {
+#ifdef PO_EMU
+                { static long itc2 = 0; static const bool dbg2_ = getenv("EMU_CHAIN_DEBUG") != nullptr; if (dbg2_ && lane == 0 && (++itc2 % 2000) == 0) { fprintf(stderr, "[chain loop %ld] exited %d", itc2, gsm.exited); for (int w2 = 0; w2 < NPW; ++w2) fprintf(stderr, "  w%d p%u t%u d%u", w2, gsm.posted[w2], gsm.taken[w2], gsm.done[w2]); fprintf(stderr, "\n"); } }
+#endif
+                // ---- free lanes pick up posted chains (totals: posted - taken chains of a pair wave are waiting)
+                if (__ballot(!busy) != 0ull) {
+                    // lane w looks at pair wave w's totals: one LDS round trip tells which pair waves have chains waiting
+                    const int lw = lane & 7;
+                    const unsigned po_l = ((volatile unsigned*)gsm.posted)[lw], tk_l = gsm.taken[lw];   // (taken: this wave's own)
+                    unsigned wm = (unsigned)__ballot(lane < NPW && (int)(po_l - tk_l) > 0);
+                    while (wm != 0u) {   // (wave-uniform)
+                        const int w2 = __builtin_ctz(wm);
+                        wm &= wm - 1u;
+                        const unsigned po = (unsigned)__builtin_amdgcn_readlane((int)po_l, w2), tk = (unsigned)__builtin_amdgcn_readlane((int)tk_l, w2);
+                        const int avail = (int)(po - tk);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const unsigned long long fm = __ballot(!busy);
+                        const int nf = __popcll(fm);
+                        if (nf == 0) break;
+                        const int give = min(avail, nf);
+                        const int myrank = __popcll(fm & ((1ull << lane) - 1ull));
+                        if (!busy && myrank < give) {
+                            const int si = (int)((tk + (unsigned)myrank) % (unsigned)RK_JOBS);
+                            const RegJob j = gsm.slot[w2][si].j;
+                            busy = true; jw = w2; jslot = si;
+                            const int rr = (j.code >> 4) & 1, myk = (j.code >> 5) & 7;
+                            symo = (j.code >> 8) & 7;
+                            t = j.t0; n = j.n; k = 0; rowbase = j.rowbase; node = j.node; self = j.seed;
+                            mx = PO_NEG_INF; mt = -1; tr = INT_MIN;
+                            yb = &gsm.w[w2].ybuf[rr][0][0]; ps = &gsm.w[w2].pst[rr][myk * RK_NY];
+                            rm2 = gsm.pc_rm2[w2]; tagep = gsm.pc_tagep[w2];
+                            pl = a.pool + (size_t)(blockIdx.x * NPW + w2) * a.pool_bytes;
+                        }
+                        rk_sync();
+                        if (lane == 0) gsm.taken[w2] = tk + (unsigned)give;
+                        rk_sync();
+                    }
+                }
+                // ---- one iteration of every running chain (update_prob: PrefixTree.h:518-531)
+                if (busy) {
+                    const double* yrow = yb + (t & (RK_NY - 1)) * RK_YC;
+                    const double ya = yrow[symo], ybl = yrow[A];
+                    const double pp = ps[k];
+                    const double out = lae(pp + ya, self + ybl);
+                    Ent e;
+                    e.tag = ((unsigned long long)(tagep | (((unsigned)node >> 8) & 0xffffu)) << 32) | (((unsigned)node << 24) | ((unsigned)t & 0xffffffu));
+                    e.v[0] = out;
+                    *(Ent*)(pl + (size_t)(unsigned)((rowbase + (t & rm2)) << 4)) = e;
+                    if (out > self) tr = t;
+                    self = out;
+                    mt = (out >= mx) ? t : mt;
+                    mx = po_vmax(mx, out);
+                    ++t; ++k;
+                    if (k == n) { busy = false; fin = true; }
+                }
+                // ---- finished chains: their poster reads the values back through the store, so the writes must have landed
+                // before it is told (one wait for all the chains that finish in this iteration)
+                if (__ballot(fin) != 0ull) {
+                    if (fin) { RegRes rr_; rr_.self = self; rr_.mx = mx; rr_.mt = mt; rr_.tr = tr; gsm.slot[jw][jslot].r = rr_; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the stores to the value store and the result, before the count)
+                    if (fin) { atomicAdd(&gsm.done[jw], 1u); fin = false; }
+                } else if (__ballot(busy) == 0ull) {
+#ifdef PO_EMU
+                    { static long itc = 0; static const bool dbg_ = getenv("EMU_CHAIN_DEBUG") != nullptr; if (dbg_ && lane == 0 && (++itc % 200000) == 0) { fprintf(stderr, "[chain idle] exited %d", gsm.exited); for (int w2 = 0; w2 < NPW; ++w2) fprintf(stderr, "  w%d p%u t%u d%u", w2, gsm.posted[w2], gsm.taken[w2], gsm.done[w2]); fprintf(stderr, "\n"); } }
+#endif
+                    bool idle = ((volatile int*)&gsm.exited)[0] >= NPW;
+                    for (int w2 = 0; w2 < NPW; ++w2) idle = idle && (((volatile unsigned*)gsm.posted)[w2] == gsm.taken[w2]);
+                    if (__builtin_amdgcn_readfirstlane((int)idle) != 0) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            return;
+        }
+    }
+    if (!is_pair_wave) {
+        if (NPW > 1 && lane == 0) atomicAdd(&gsm.exited, 1);
+        return;
+    }
 #ifdef PO_REG_TIMING
     // phase timers of workgroup 0 (wall_clock64: 100 MHz) and counts: see po_reg_launch for the names
     long long tk[24], tlast = wall_clock64();
@@ -135,9 +257,10 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         }
         const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
         const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
-        const double* const yr = r ? a.y2 + o2 * C : a.y1 + o1 * C;      // this lane's read
-        const int Tr = r ? V : U;
-        const double* const cumr = r ? a.cum2 + (o2 - a.y2_off[0]) : a.cum1 + (o1 - a.y1_off[0]);
+        // (this lane's read: its rows, length and blank prefix sums are put together where they are used — a y reload every
+        //  ~ 16 steps, the root's children at the start of a pair — rather than held in six registers across the walk)
+        auto yr_ = [&]() -> const double* { return r ? a.y2 + o2 * C : a.y1 + o1 * C; };
+        auto cumr_ = [&]() -> const double* { return r ? a.cum2 + (o2 - a.y2_off[0]) : a.cum1 + (o1 - a.y1_off[0]); };
         const int4* const sched = a.sched + (o2 - a.y2_off[0]);
         const int nmain = a.nmain[pi];
         const int R2 = m.y, Rm2 = R2 - 1;
@@ -149,6 +272,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         //  instead of 64-bit address arithmetic; the tag's words are put together from per-call constants the same way)
         const char* const poolb = (const char*)pool;
         const unsigned tag_ep = (epoch & 0xffffu) << 16;
+        if (NPW > 1 && lane == 0) { gsm.pc_rm2[wave] = Rm2; gsm.pc_tagep[wave] = tag_ep; }
         auto t2_off = [&](int row2, int tq) -> unsigned { return (unsigned)(((row2 * 2 + r) * R2 + (tq & Rm2)) << 4); };
         auto t2_entry = [&](int row2, int tq) -> const Ent* { return (const Ent*)(poolb + (size_t)t2_off(row2, tq)); };
         auto tag_of = [&](int node, int tq) -> unsigned long long {   // == make_tag(epoch, node, tq) for 0 <= tq < 2^24
@@ -185,8 +309,8 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         int fz_t = INT_MAX;
         // the stored value the next step's carried maximum may need (a decaying element: its value at the window start),
         // requested a step ahead: pf_t = its time (-1: none)
-        Ent pf_e; pf_e.tag = 0ull; pf_e.v[0] = 0.0;
-        int pf_t = -1;
+        // (pf_val / pf_t live in the run loop only: a long-lived entry in registers is what the allocator spills first, and a
+        //  spilled prefetch is a wait at the point of issue)
         int nb = A, ne = A;
         int next_id = 1 + A;
         int gcur = 1;               // row group allocation cursor
@@ -205,6 +329,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
             e_id = 1 + s; e_row2 = s; e_sym = sym_pack(s, A, true); e_fc = -1; e_crow2 = -1;
             e_par = 0; e_gpar = -1; e_prow2 = -1; e_depth = 1; e_ps = PS_ROOT; e_alias = -1;
             live = true;
+            const double* const yr = yr_();
             const double out = lae(0.0 + yr[s], PO_NEG_INF + yr[A]);   // update_prob(n, r, 0): parent = root at t = -1
             t2_write(e_row2, e_id, 0, out);
             v_done = 1; v_fresh = 0; v_self = out;
@@ -215,11 +340,18 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         int mstep = 0, up = -1, vp = -1;
         // The walk's records, 64 at a time: lane l holds record 64 * batch + l of the current batch and of the next one
         // (requested a batch ahead: the load's latency never shows), the step's own record comes out with v_readlane.
-        int4 rcur = sched[min(lane, max(nmain - 1, 0))], rnxt = sched[min(64 + lane, max(nmain - 1, 0))];
+        // (kept PACKED, two words per record — time | window length << 24; times stay below 2^24 and a window below the
+        //  store's ring length of <= 256 — : four registers for the two batches instead of eight)
+        auto rec_load = [&](int i) -> int2 {
+            const int4 q = sched[min(i, max(nmain - 1, 0))];
+            return make_int2(q.x | ((q.z - q.x) << 24), q.y | ((q.w - q.y) << 24));
+        };
+        int2 rcur = rec_load(lane), rnxt = rec_load(64 + lane);
         auto rec_at = [&](int i) -> int4 {   // record of main step i (uniform i within the current batch)
             const int l = i & 63;
-            return make_int4(__builtin_amdgcn_readlane(rcur.x, l), __builtin_amdgcn_readlane(rcur.y, l),
-                             __builtin_amdgcn_readlane(rcur.z, l), __builtin_amdgcn_readlane(rcur.w, l));
+            const int px = __builtin_amdgcn_readlane(rcur.x, l), py = __builtin_amdgcn_readlane(rcur.y, l);
+            const int uu = px & 0xffffff, vv = py & 0xffffff;
+            return make_int4(uu, vv, uu + (int)((unsigned)px >> 24), vv + (int)((unsigned)py >> 24));
         };
         int4 rec = rec_at(0);
         bool have_children = false;   // the table has its children slots (false only before the first expansion)
@@ -235,6 +367,8 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
             constexpr int PER = (RK_NY * RK_YC + 31) / 32;   // elements per lane (C <= RK_YC)
             double v[PER];
             int slot[PER];
+            const double* const yr = yr_();
+            const int Tr = r ? V : U;
             const int divC = (65536 + C - 1) / C;
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -256,9 +390,9 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         // left the window — then the stored values are looked at again.  A node past its peak decays frame by frame:
         // if the values were non-increasing since before the window start (td <= ws), the maximum is the first one.
         // pf: an entry requested a step ahead for exactly that time (pf_t), else the store is asked now.
-        auto carried_max = [&](int ws, int start, double& cmx, int& cmt, int& td) {
+        auto carried_max = [&](int ws, int start, double& cmx, int& cmt, int& td, int pf_t = -1, double pf_val = 0.0) {
             auto own = [&](int tq) -> double {
-                if (tq == pf_t) return (pf_e.tag == tag_of(e_id, tq)) ? pf_e.v[0] : PO_NEG_INF;
+                if (tq == pf_t) return pf_val;
                 return read_own(tq);
             };
             if (td <= ws) { cmx = own(ws); cmt = ws; return; }
@@ -337,7 +471,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                             if (tm >= p_start - 1 && tm < p_we && p_start != INT_MAX) pp = ps_self;
                             else pp = t2_read(e_prow2, e_par, tm);
                         } else if (e_ps == PS_ROOT) {
-                            pp = (tm < 0) ? 0.0 : cumr[tm];
+                            pp = (tm < 0) ? 0.0 : cumr_()[tm];
                         } else if (tm >= fz_t) {
                             pp = (tm == fz_t) ? fz_val : PO_NEG_INF;                                 // frozen parent: its last value, then nothing
                         } else {
@@ -361,7 +495,6 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 if (part) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
                 smx = part ? mx : PO_NEG_INF;
             }
-            pf_t = -1;
             KT(is_main ? 4 : 5); KC(is_main ? 16 : 17, 1); KC(18, niter);
             if (a.upd_count != nullptr) {
                 const int lenx = part2 ? we - start : 0;
@@ -465,6 +598,36 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 if (k0 == 0 && want_seed && se.tag == tag_of(e_id, ws - 1)) self = se.v[0];
                 rk_sync();
                 const int k1 = min(n1max, k0 + RK_NY);
+                if (use_board) {
+                    // ---- the chains of this block go to the chain wave
+                    const int nblk = fresh ? max(min(n1 - k0, RK_NY), 0) : 0;
+                    const bool has = nblk > 0;
+                    const unsigned long long hm = __ballot(has);
+                    const int cnt = __popcll(hm);
+                    if (cnt > 0) {
+                        const int rank = __popcll(hm & ((1ull << lane) - 1ull));
+                        if (has) {
+                            RegJob j;
+                            j.code = wave | (r << 4) | (myk << 5) | (sym << 8); j.t0 = ws + k0; j.n = nblk;
+                            j.rowbase = (e_row2 * 2 + r) * R2; j.node = e_id; j.pad_ = 0; j.seed = self;
+                            gsm.slot[wave][(posted_total + (unsigned)rank) % (unsigned)RK_JOBS].j = j;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        rk_sync();
+                        if (lane == 0) ((volatile unsigned*)gsm.posted)[wave] = posted_total + (unsigned)cnt;
+                        posted_total += (unsigned)cnt;
+                        while ((int)(((volatile unsigned*)gsm.done)[wave] - posted_total) < 0) __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        if (has) {
+                            const RegRes rr_ = gsm.slot[wave][(posted_total - (unsigned)cnt + (unsigned)rank) % (unsigned)RK_JOBS].r;
+                            self = rr_.self;
+                            mt = (rr_.mx >= mx) ? rr_.mt : mt;   // (later times win ties)
+                            mx = po_vmax(mx, rr_.mx);
+                            if (rr_.tr != INT_MIN) tr = rr_.tr;
+                        }
+                    }
+                    continue;
+                }
                 // (the operands of an iteration are asked for one iteration ahead: a lone wave then waits for the LDS only
                 //  inside logaddexp's own table lookups)
                 double nya = 0.0, nyb = 0.0, npp = 0.0;
@@ -498,7 +661,6 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 v_done = dr; v_self = self; v_fresh = 0;
                 v_mx = mx; v_mt = mt; v_td = max(ws, tr);
             }
-            pf_t = -1;
             KT(2);
             if (a.upd_count != nullptr) {
                 int tot = fresh ? n1 : 0;
@@ -671,7 +833,6 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
             }
             tbl_fresh = __ballot(live && v_fresh != 0) != 0ull;
             have_children = true;
-            pf_t = -1;
             rk_sync();
             KT(8);
         };
@@ -695,6 +856,8 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                 const int sym = sym_last(e_sym);
                 const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
                 const double* const yb_ = &sm.ybuf[r][0][0];
+                Ent pf_e; pf_e.tag = 0ull; pf_e.v[0] = 0.0;   // the entry requested at the end of the previous step of this run
+                int pf_t = -1;
                 for (;;) {
                     u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
                     const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
@@ -714,7 +877,10 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                     int mt = -1, cmt = -1, td = has_c ? v_td : ws, tr = INT_MIN;
                     if (has_c) {
                         if (v_mx == PO_NEG_INF || v_mt >= ws) { cmx = v_mx; cmt = v_mt; }
-                        else carried_max(ws, dr, cmx, cmt, td);
+                        else {
+                            const double pf_val = (pf_t >= 0 && pf_e.tag == tag_of(e_id, pf_t)) ? pf_e.v[0] : PO_NEG_INF;
+                            carried_max(ws, dr, cmx, cmt, td, pf_t, pf_val);
+                        }
                     }
                     // ---- the new times [dr, we), everybody in lockstep: the parent's previous value comes from its lane
                     const int n2 = we - dr;   // (half-uniform, >= 0)
@@ -767,7 +933,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
                     mstep++;
                     if ((mstep & 63) == 0) {
                         rcur = rnxt;
-                        rnxt = sched[min(mstep + 64 + lane, max(nmain - 1, 0))];
+                        rnxt = rec_load(mstep + 64 + lane);
                     }
                     rec = rec_at(min(mstep, nmain - 1));
                     {   // the stored value the next step's carried maximum will ask for, if any: requested now
@@ -829,7 +995,7 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
             mstep++;
             if ((mstep & 63) == 0) {   // the next batch becomes the current one, the one after it is requested
                 rcur = rnxt;
-                rnxt = sched[min(mstep + 64 + lane, max(nmain - 1, 0))];
+                rnxt = rec_load(mstep + 64 + lane);
             }
             rec = rec_at(min(mstep, nmain - 1));
             KT(6);
@@ -914,49 +1080,67 @@ __global__ __launch_bounds__(64, PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) 
         KT(9);
     }
 #ifdef PO_REG_TIMING
-    if (lane == 0 && a.dbg && blockIdx.x == 0)
+    if (lane == 0 && a.dbg && slotid == 0)
         for (int i = 0; i < 24; ++i) a.dbg[i] = tk[i];
 #endif
     if (lane == 0) {   // the next launch on this workspace continues from here
-        unsigned long long* stp = a.wgstate + 2 * (size_t)blockIdx.x;
-        stp[0] = a.magic ^ (unsigned long long)blockIdx.x;
+        unsigned long long* stp = a.wgstate + 2 * (size_t)slotid;
+        stp[0] = a.magic ^ (unsigned long long)slotid;
         stp[1] = (unsigned long long)epoch;
         if (a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
+        if (NPW > 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); atomicAdd(&gsm.exited, 1); }
     }
 }
 
-// resident workgroups per CU (registers and LDS decide: 16)
-extern "C" int po_reg_blocks_per_cu() {
+// The board variant: 7 pair waves + 1 chain wave per workgroup (512 threads; two workgroups per CU: 14 pair slots).
+constexpr int RK_BOARD_NPW = 7;
+
+// pair slots per CU (registers and LDS decide): 16 one-wave workgroups, or 2 x 7 pair waves with the job board
+extern "C" int po_reg_slots_per_cu(int board) {
 #ifdef PO_EMU
-    return 16;
+    return board ? 2 * RK_BOARD_NPW : 16;
 #else
-    static PoPerDeviceCache<1> per_cu;
-    return per_cu.get(0, [] {
+    static PoPerDeviceCache<2> per_cu;
+    return per_cu.get(board ? 1 : 0, [board] {
         int nblk = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel, 64, 0) != hipSuccess || nblk <= 0) nblk = 16;
+        if (board) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel<RK_BOARD_NPW>, 64 * (RK_BOARD_NPW + 1), 0) != hipSuccess || nblk <= 0) nblk = 2;
+            if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_reg_kernel<%d> (job board): %d resident workgroups per CU, %zu B of LDS\n", RK_BOARD_NPW, nblk, sizeof(RegGroup<RK_BOARD_NPW>));
+            return nblk * RK_BOARD_NPW;
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel<1>, 64, 0) != hipSuccess || nblk <= 0) nblk = 16;
         if (const char* e = getenv("PO_REG_PER_CU")) { const int v = atoi(e); if (v > 0 && v < nblk) nblk = v; }
-        if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_reg_kernel: %d resident workgroups per CU, %zu B of LDS\n", nblk, sizeof(RegSmem));
+        if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_reg_kernel: %d resident workgroups per CU, %zu B of LDS\n", nblk, sizeof(RegGroup<1>));
         return nblk;
     });
 #endif
 }
+extern "C" int po_reg_blocks_per_cu() { return po_reg_slots_per_cu(0); }
 extern "C" int po_reg_max_elements() { return 32; }
 extern "C" int po_reg_ngl() { return RK_NGL; }
-extern "C" void po_reg_launch(const void* x2args, int blocks, hipStream_t stream) {
+// `slots` pair slots (each with its own store slice and arena); board != 0: workgroups of RK_BOARD_NPW pair waves + a chain wave
+extern "C" void po_reg_launch(const void* x2args, int slots, int board, hipStream_t stream) {
     X2Args a = *(const X2Args*)x2args;
+    a.reg_slots = slots;
+    a.reg_board = board ? 1 : 0;
 #ifdef PO_REG_TIMING
     static long long* dbg = nullptr;
     if (!dbg) { (void)hipMalloc((void**)&dbg, 24 * sizeof(long long)); }
     (void)hipMemsetAsync(dbg, 0, 24 * sizeof(long long), stream);
     a.dbg = dbg;
 #endif
-    hipLaunchKernelGGL(beam2d_reg_kernel, dim3(blocks), dim3(64), 0, stream, a);
+    if (board) {
+        const int wgs = (slots + RK_BOARD_NPW - 1) / RK_BOARD_NPW;
+        hipLaunchKernelGGL(beam2d_reg_kernel<RK_BOARD_NPW>, dim3(wgs), dim3(64 * (RK_BOARD_NPW + 1)), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(beam2d_reg_kernel<1>, dim3(slots), dim3(64), 0, stream, a);
+    }
 #ifdef PO_REG_TIMING
     {
         long long h[24];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[po_reg_timing] workgroup 0, 10 ns ticks\n");
+        fprintf(stderr, "[po_reg_timing] pair slot 0, 10 ns ticks\n");
         fprintf(stderr, "   run loop %lld (%lld steps, %lld new-time iterations)\n", h[0], h[12], h[19]);
         fprintf(stderr, "   steps with new elements: %lld steps; staging + carried maxima %lld, phase 1 %lld (%lld iterations), phase 2 + state %lld (%lld iterations)\n",
                 h[13], h[1], h[2], h[14], h[3], h[15]);

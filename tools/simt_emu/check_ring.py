@@ -55,9 +55,31 @@ def run_emu(job):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     alphabet = int.from_bytes(b"ACGT", "little")
     t0 = time.time()
-    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, 5, 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), 1, p(upd), kernel)
+    nblocks = int(os.environ.get("EMU_SLOTS", "1"))
+    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, 5, 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), nblocks, p(upd), kernel)
     got = bytes(seq[: sl[0]]).decode()
     return got, int(st[0]), deferred, time.time() - t0, int(upd[1])
+
+
+def run_emu_batch(job):
+    """several pairs in ONE emulated launch (pair waves of one workgroup working side by side)"""
+    cases, W, lib_path, kernel, slots = job
+    lib = C.CDLL(lib_path)
+    n = len(cases)
+    y1 = np.ascontiguousarray(np.concatenate([c[0] for c in cases]), dtype=np.float64)
+    y2 = np.ascontiguousarray(np.concatenate([c[1] for c in cases]), dtype=np.float64)
+    env = np.ascontiguousarray(np.concatenate([c[2] for c in cases]), dtype=np.int32)
+    o1 = np.zeros(n + 1, dtype=np.int64); o2 = np.zeros(n + 1, dtype=np.int64); so = np.zeros(n + 1, dtype=np.int64)
+    for i, c in enumerate(cases):
+        o1[i + 1] = o1[i] + len(c[0]); o2[i + 1] = o2[i] + len(c[1]); so[i + 1] = so[i] + len(c[0]) + len(c[1]) + 8
+    seq = np.zeros(int(so[-1]), dtype=np.uint8)
+    sl = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32); upd = np.zeros(2, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    alphabet = int.from_bytes(b"ACGT", "little")
+    t0 = time.time()
+    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, 5, 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), slots, p(upd), kernel)
+    dt = time.time() - t0
+    return [(bytes(seq[so[i]: so[i] + sl[i]]).decode(), int(st[i]), deferred if st[i] == -100 else 0, dt / n, 0) for i in range(n)]
 
 
 def main():
@@ -69,7 +91,8 @@ def main():
     ap.add_argument("--W", type=int, default=5)
     ap.add_argument("--lib", default=os.path.join(HERE, "_build", "libemu_pair_beam.so"))
     ap.add_argument("--styles", default="pipeline,stairs,wobble,bursts")
-    ap.add_argument("--kernel", default="ring", help="ring | reg")
+    ap.add_argument("--batch", type=int, default=1, help="pairs per emulated launch (with as many pair slots)")
+    ap.add_argument("--kernel", default="ring", help="ring | reg | board (the register-state kernel with its job board)")
     args = ap.parse_args()
     styles = args.styles.split(",")
     rng = np.random.default_rng(args.seed)
@@ -82,7 +105,22 @@ def main():
     with ProcessPoolExecutor(args.procs) as pool:
         cases = list(pool.map(make_case, jobs))
         keep = [(c, j) for c, j in zip(cases, jobs) if c is not None]
-        res = list(pool.map(run_emu, [(c, j[2], args.lib, 1 if args.kernel == "reg" else 0) for c, j in keep]))
+        kid = {"ring": 0, "reg": 1, "board": 2}[args.kernel]
+        if args.batch <= 1:
+            res = list(pool.map(run_emu, [(c, j[2], args.lib, kid) for c, j in keep]))
+        else:   # batches of equal beam width
+            res = [None] * len(keep)
+            groups = {}
+            for i, (c, j) in enumerate(keep):
+                groups.setdefault(j[2], []).append(i)
+            jobs2, where = [], []
+            for W_, idx in groups.items():
+                for b in range(0, len(idx), args.batch):
+                    part = idx[b:b + args.batch]
+                    jobs2.append(([keep[i][0] for i in part], W_, args.lib, kid, len(part))); where.append(part)
+            for part, out in zip(where, pool.map(run_emu_batch, jobs2)):
+                for i, o in zip(part, out):
+                    res[i] = o
     bad = 0
     tot_t = 0.0
     for (c, j), (got, st, deferred, dt, upd) in zip(keep, res):

@@ -13,6 +13,7 @@ static std::vector<Fiber> g_fibers;
 static void* g_main_sp = nullptr;
 static const std::function<void()>* g_body = nullptr;
 static Rv g_block_rv;
+static long g_spin_limit = getenv("EMU_SPIN_LIMIT") ? atol(getenv("EMU_SPIN_LIMIT")) : 20000000L;
 static int g_wave_livecnt[16];
 static constexpr size_t STACK = 512 << 10;
 
@@ -103,7 +104,7 @@ void rendezvous_wave(int line) {
     long spins = 0;
     while (r.wline[l] >= 0) {
         yield();
-        if (++spins > 20000000L) { fprintf(stderr, "[simt_emu] stuck in a wave-level operation at line %d (thread %u)\n", line, g_cur->tid.x); abort(); }
+        if (++spins > g_spin_limit) { fprintf(stderr, "[simt_emu] stuck in a wave-level operation at line %d (thread %u)\n", line, g_cur->tid.x); abort(); }
     }
 }
 static void rendezvous(Rv& rv, int need, int line, const char* what) {

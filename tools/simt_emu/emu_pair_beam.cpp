@@ -26,7 +26,7 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     std::vector<int2> meta(n);
     std::vector<int4> sched((size_t)tr2 + 1);
     std::vector<double> cum1((size_t)tr1 + 1), cum2((size_t)tr2 + 1);
-    const size_t pool_bytes = (size_t)(kernel == 1 ? 2 : 4) << 20;
+    const size_t pool_bytes = (size_t)(kernel >= 1 ? 2 : 4) << 20;
     const int64_t WM = W > PO_A ? W : PO_A;
     const size_t arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
     std::vector<char> pool(pool_bytes * blocks, 0);
@@ -38,11 +38,15 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     a.dbg = nullptr; a.upd_count = upd_count; a.defer_odd = 0; a.need_mono = 1; a.order = nullptr;
     a.wgstate = wgstate.data(); a.magic = 0x1234567ull;
     a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
-    a.ngl = kernel == 1 ? po_reg_ngl() : po_ring_ngl();
+    a.ngl = kernel >= 1 ? po_reg_ngl() : po_ring_ngl();
     for (int i = 0; i < n; ++i) status[i] = PO_OK;
+    const bool vb = getenv("EMU_VERBOSE") != nullptr;
+    if (vb) fprintf(stderr, "[emu] prepass\n");
     hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), 0, nullptr, a);
+    if (vb) fprintf(stderr, "[emu] walk\n");
     hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, nullptr, a);
-    if (kernel == 1) po_reg_launch(&a, blocks, nullptr);
+    if (vb) fprintf(stderr, "[emu] main kernel\n");
+    if (kernel >= 1) po_reg_launch(&a, blocks, kernel == 2 ? 1 : 0, nullptr);   // kernel 2: the job-board form
     else po_ring_launch(&a, blocks, nullptr);
     int deferred = 0;
     for (int i = 0; i < n; ++i)
