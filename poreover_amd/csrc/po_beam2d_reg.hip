@@ -264,6 +264,10 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         const int4* const sched = a.sched + (o2 - a.y2_off[0]);
         const int nmain = a.nmain[pi];
         const int R2 = m.y, Rm2 = R2 - 1;
+        if (R2 > 256) {   // windows of 255 frames and more: the packed walk records below keep a window's length in 8 bits
+            if (lane == 0) { a.meta[pi] = make_int2(PO_OK, X2_DEFERRED); a.queue[16] = 1; }
+            continue;
+        }
         const int NG = (int)min((long long)RK_NGL, pool_entries / ((long long)PO_A * 2 * R2));
         int st = PO_OK;
 
@@ -418,7 +422,11 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             const bool part = live && s < nlanes && we > ws;
             // a window end that moves back cannot happen on a monotone envelope (the pre-pass hands the others to
             // beam2d_kernel); should it, the pair goes the same way
-            if (is_main && part && v_fresh == 0 && v_done > we) st = PO_E_NOMEM;
+            // (st stays wave-uniform: the walk loop's condition reads it)
+            if (is_main && __ballot(part && v_fresh == 0 && v_done > we) != 0ull) st = PO_E_NOMEM;
+#ifdef PO_EMU_DEBUG
+            if (is_main && part && v_fresh == 0 && v_done > we) printf("BACK lane %d id %d done %d ws %d we %d mstep %d nmain %d\n", lane, e_id, v_done, ws, we, mstep, nmain);
+#endif
             int start = max(v_done, ws);
             double self = PO_NEG_INF;
             if (part) {
@@ -882,6 +890,17 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                             carried_max(ws, dr, cmx, cmt, td, pf_t, pf_val);
                         }
                     }
+                    {   // the stored value the NEXT step's carried maximum will ask for, if any, requested now — a whole step
+                        // ahead (its record is in the registers already).  Whether the lane will need it is decided on its
+                        // state before this step: should this step's new values bring a new maximum, the entry goes unused.
+                        const int i1 = min(mstep + 1, nmain - 1), l1 = i1 & 63;
+                        const bool nb_ = (l1 == 0) && (i1 != mstep);   // the next step opens the next batch: its record is rnxt's first
+                        const int cx = __builtin_amdgcn_readlane(rcur.x, l1), cy = __builtin_amdgcn_readlane(rcur.y, l1);
+                        const int nx = __builtin_amdgcn_readlane(rnxt.x, 0), ny = __builtin_amdgcn_readlane(rnxt.y, 0);
+                        const int wsn = (r ? (nb_ ? ny : cy) : (nb_ ? nx : cx)) & 0xffffff;
+                        pf_t = -1;
+                        if (live && v_done > wsn && v_mx != PO_NEG_INF && v_mt < wsn) { pf_t = wsn; pf_e = *t2_entry(e_row2, wsn); }
+                    }
                     // ---- the new times [dr, we), everybody in lockstep: the parent's previous value comes from its lane
                     const int n2 = we - dr;   // (half-uniform, >= 0)
                     const int n2max = max(ce - d0, re - d1);
@@ -936,11 +955,6 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                         rnxt = rec_load(mstep + 64 + lane);
                     }
                     rec = rec_at(min(mstep, nmain - 1));
-                    {   // the stored value the next step's carried maximum will ask for, if any: requested now
-                        const int wsn = r ? rec.y : rec.x;
-                        pf_t = -1;
-                        if (live && v_done > wsn && v_mx != PO_NEG_INF && v_mt < wsn) { pf_t = wsn; pf_e = *t2_entry(e_row2, wsn); }
-                    }
 #ifdef PO_EMU_DEBUG
                     if (lane == 0) printf("STEP run\n");
 #endif
@@ -1052,7 +1066,6 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             rebuild(nbn, rec.x, rec.y, rec.z, rec.w);
         }
         KT(6);
-
         // ---------------------------------------------------------------- label of the top node
         if (st == PO_E_NOMEM && lane == 0) {   // out of row groups (or a window end moved back): beam2d_kernel takes the pair
             a.meta[pi] = make_int2(PO_OK, X2_DEFERRED);

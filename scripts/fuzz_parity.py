@@ -176,6 +176,46 @@ def oned_mode(args, pool):
     sys.exit(1 if bad else 0)
 
 
+def draw_round(rng, focus):
+    """one round of the pair mode: a configuration and its batch (shared with tools/simt_emu, which replays the same rounds)"""
+    from oracle import po_oracle as O
+    from poreover_amd.synth import synth_pair
+    model, ff = [("ctc", False), ("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)][rng.integers(4)]
+    method = ["row_col", "row_col", "row_col", "row", "grid"][rng.integers(5)]
+    W = int([1, 2, 3, 4, 5, 5, 5, 6, 7, 9, 10, 12, 13, 16, 25][rng.integers(15)])
+    if focus:
+        model, ff, method = "ctc", False, "row_col"
+        W = int([1, 2, 3, 4, 5, 5, 5, 5, 6][rng.integers(9)])
+    # (grid with the other models in a narrow band: every score -inf — the reference's own order is heap-address
+    #  order there; engine and oracle both replay libstdc++ on creation order and agree)
+    tmax = 260 if method == "grid" else 1400
+    n = int(rng.integers(4, 40))
+    style = ["pipeline", "diag", "stairs", "wobble", "bursts"][rng.integers(5)]
+    if focus and rng.random() < 0.5:
+        n = int(rng.integers(40, 400))
+    y1s, y2s, envs = [], [], []
+    for i in range(n):
+        T = int(rng.integers(30, tmax))
+        y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=T, flipflop=ff)
+        if rng.random() < 0.15:
+            y2 = y2[: max(2, (2 * len(y2)) // 3)]
+        U, V = len(y1), len(y2)
+        if style == "pipeline":
+            kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
+            try:
+                env = np.asarray(O.pair_decode(y1, y2, kind, 5, "row_col")["envelope"])
+            except Exception:
+                env = np.asarray(O.diagonal_envelope(U, V, 12))
+            if env is None or len(env) != U:
+                env = np.asarray(O.diagonal_envelope(U, V, 12))
+        elif style == "diag":
+            env = np.asarray(O.diagonal_envelope(U, V, int(rng.integers(3, 30))))
+        else:
+            env = jagged(rng, U, V, style, int(rng.integers(2, 14)))
+        y1s.append(y1); y2s.append(y2); envs.append(env)
+    return model, method, W, style, y1s, y2s, envs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--oned", action="store_true", help="fuzz the 1-D entry points (Viterbi, beam search, forward, acceptor)")
@@ -187,6 +227,8 @@ def main():
     ap.add_argument("--focus", action="store_true", help="pair mode: only what the ring / register-state kernels serve "
                     "(ctc, row_col, W <= 6, monotone envelope styles)")
     ap.add_argument("--json", default="", help="append a summary record to this JSON file (profiles/rNN_fuzz_*.json)")
+    ap.add_argument("--dump", default="", help="pair mode: save every round's inputs here before the GPU call (a GPU fault kills "
+                    "the process: the file then holds the round that did it)")
     ap.add_argument("--head", default="", help="git head of the tree under test (the GPU box has no .git)")
     args = ap.parse_args()
     from oracle import po_oracle as O
@@ -205,39 +247,14 @@ def main():
     rounds = pairs = bad = refused = 0
     by_style = {}
     while time.time() < t_end:
-        model, ff = [("ctc", False), ("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)][rng.integers(4)]
-        method = ["row_col", "row_col", "row_col", "row", "grid"][rng.integers(5)]
-        W = int([1, 2, 3, 4, 5, 5, 5, 6, 7, 9, 10, 12, 13, 16, 25][rng.integers(15)])
-        if args.focus:
-            model, ff, method = "ctc", False, "row_col"
-            W = int([1, 2, 3, 4, 5, 5, 5, 5, 6][rng.integers(9)])
-        # (grid with the other models in a narrow band: every score -inf — the reference's own order is heap-address
-        #  order there; engine and oracle both replay libstdc++ on creation order and agree)
-        tmax = 260 if method == "grid" else 1400
-        n = int(rng.integers(4, 40))
-        style = ["pipeline", "diag", "stairs", "wobble", "bursts"][rng.integers(5)]
-        if args.focus and rng.random() < 0.5:
-            n = int(rng.integers(40, 400))
-        y1s, y2s, envs = [], [], []
-        for i in range(n):
-            T = int(rng.integers(30, tmax))
-            y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=T, flipflop=ff)
-            if rng.random() < 0.15:
-                y2 = y2[: max(2, (2 * len(y2)) // 3)]
-            U, V = len(y1), len(y2)
-            if style == "pipeline":
-                kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
-                try:
-                    env = np.asarray(O.pair_decode(y1, y2, kind, 5, "row_col")["envelope"])
-                except Exception:
-                    env = np.asarray(O.diagonal_envelope(U, V, 12))
-                if env is None or len(env) != U:
-                    env = np.asarray(O.diagonal_envelope(U, V, 12))
-            elif style == "diag":
-                env = np.asarray(O.diagonal_envelope(U, V, int(rng.integers(3, 30))))
-            else:
-                env = jagged(rng, U, V, style, int(rng.integers(2, 14)))
-            y1s.append(y1); y2s.append(y2); envs.append(env)
+        model, method, W, style, y1s, y2s, envs = draw_round(rng, args.focus)
+        n = len(y1s)
+        if args.dump:   # the round about to run, for a replay should the GPU fault (a fault kills the process)
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump)), exist_ok=True)
+            np.savez_compressed(args.dump, model=model, method=method, W=W, style=style, round=rounds, seed=args.seed,
+                                **{"y1_%d" % i: a for i, a in enumerate(y1s)}, **{"y2_%d" % i: a for i, a in enumerate(y2s)},
+                                **{"env_%d" % i: a for i, a in enumerate(envs)})
+            print("round", rounds, dict(model=model, method=method, W=W, style=style, n=n), flush=True)
         want = pool.map(_oracle_one, [(a, b, e, W, model, method) for a, b, e in zip(y1s, y2s, envs)])
         got, st = batch.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method=method, return_status=True)
         for i, ((ws, wc), g, c) in enumerate(zip(want, got, st.tolist())):

@@ -96,6 +96,14 @@ static void wave_try_release(int w) {
     r.group = g;
 }
 unsigned long long wave_group() { return g_wrv[g_cur->tid.x >> 6].group; }
+void dump_wave_lines() {   // where the lanes of the current wave wait (-1: released / running)
+    const WaveRv& r = g_wrv[g_cur->tid.x >> 6];
+    fprintf(stderr, "[simt_emu] released group %016llx; lanes waiting at source lines:", r.group);
+    for (int l = 0; l < 64; ++l) fprintf(stderr, " %d", r.wline[l]);
+    fprintf(stderr, "\n[simt_emu] live count %d, waiting %d; finished lanes:", g_wave_livecnt[g_cur->tid.x >> 6], r.nwait);
+    for (int l = 0; l < 64; ++l) if (g_fibers[(g_cur->tid.x & ~63u) + l].done) fprintf(stderr, " %d", l);
+    fprintf(stderr, "\n");
+}
 void rendezvous_wave(int line) {
     const int w = (int)(g_cur->tid.x >> 6), l = (int)(g_cur->tid.x & 63);
     WaveRv& r = g_wrv[w];

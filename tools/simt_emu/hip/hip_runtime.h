@@ -63,6 +63,7 @@ extern int g_nlive_block;
 extern unsigned long long g_xch[1024][2];
 void yield();
 void rendezvous_wave(int line);
+void dump_wave_lines();
 void rendezvous_block(int line);
 int wave_live(int wave);
 unsigned long long wave_group();
@@ -89,6 +90,7 @@ static inline T shfl(T x, int src, int line) {
     rendezvous_wave(line);
     if (!((wave_group() >> (src & 63)) & 1ull)) {
         fprintf(stderr, "[simt_emu] line %d: thread %d reads lane %d, which is not executing this operation\n", line, me, src & 63);
+        dump_wave_lines();
         abort();
     }
     const T r = xch_get<T>(base + (src & 63));
