@@ -33,6 +33,7 @@
 // word.  Results are bit-identical to the other kernels': the same arithmetic in the same order within every chain.
 #include <climits>
 
+#define PO_LAE_EARLY_TABLE 1   // (po_device.h: the exp table entry is requested before the polynomial — a lone wave's chain is latency)
 #include "po_beam2d_common.h"
 #include "po_host.h"
 
@@ -226,11 +227,17 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
     }
 #ifdef PO_REG_TIMING
     // phase timers of workgroup 0 (wall_clock64: 100 MHz) and counts: see po_reg_launch for the names
-    long long tk[24], tlast = wall_clock64();
-    for (int i = 0; i < 24; ++i) tk[i] = 0;
+    long long tk[40], tlast = wall_clock64();
+    for (int i = 0; i < 40; ++i) tk[i] = 0;
 #define KT(i) do { const long long n_ = wall_clock64(); tk[(i)] += n_ - tlast; tlast = n_; } while (0)
 #define KC(i, n) do { tk[(i)] += (n); } while (0)
+#ifdef PO_REG_TIMING2   // finer buckets inside the run loop and the table build (their time leaves buckets 0 and 8)
+#define KT2(i) KT(i)
 #else
+#define KT2(i) do {} while (0)
+#endif
+#else
+#define KT2(i) do {} while (0)
 #define KT(i) do {} while (0)
 #define KC(i, n) do {} while (0)
 #endif
@@ -700,6 +707,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             int n_id = __shfl(e_id, hb | srcb), n_row2 = __shfl(e_row2, hb | srcb), n_sym = __shfl(e_sym, hb | srcb);
             int n_fc = __shfl(e_fc, hb | srcb), n_crow2 = __shfl(e_crow2, hb | srcb), n_par = __shfl(e_par, hb | srcb);
             int n_gpar = __shfl(e_gpar, hb | srcb), n_prow2 = __shfl(e_prow2, hb | srcb), n_depth = __shfl(e_depth, hb | srcb);
+            KT2(32);
             // ---- every old element marks its row group with the times it has written there
             if (live && v_fresh == 0) atomicMax(&g_hi[e_row2 >> 2], v_done);
             // ---- B. expansion of the new beam nodes
@@ -737,6 +745,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     rk_sync();
                 }
             }
+            KT2(33);
             // ---- C. children slots take their parent's (new) fields
             const int p_id = __shfl(n_id, hb | j), p_fc = __shfl(n_fc, hb | j), p_crow2 = __shfl(n_crow2, hb | j);
             const int p_sym = __shfl(n_sym, hb | j), p_par = __shfl(n_par, hb | j), p_row2 = __shfl(n_row2, hb | j);
@@ -772,6 +781,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 if (!rb && src >= nbo && oa >= 0) src = oa;
             }
             const bool nlive = (rb || (rc && n_alias < 0));
+            KT2(34);
             // ---- F. the lanes take their new identity
             const int gsrc = hb | max(src, 0);
             const int g_done = __shfl(v_done, gsrc), g_fresh = __shfl(v_fresh, gsrc), g_mt = __shfl(v_mt, gsrc), g_td = __shfl(v_td, gsrc);
@@ -803,6 +813,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 v_done = RK_FRESH; v_fresh = (rc && p_isnew) ? 2 : 1;
                 v_self = PO_NEG_INF; v_mx = PO_NEG_INF; v_mt = -1; v_td = 0;
             }
+            KT2(35);
             // ---- the parent slot of the beam nodes: a beam node, a child of a beam node, the root, or none (frozen)
             nb = nbn; ne = nen;
             {   // (wave-uniform loops: v_readlane)
@@ -818,6 +829,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 }
             }
             e_ps = n_ps;
+            KT2(36);
             // ---- G. a frozen parent that is an element again.  A beam node whose parent had left the table computed its
             // newest values against "absent" (-inf beyond the parent's last time).  When the grandparent enters the beam the
             // parent comes back as one of its children, computes its whole window — times it never had — and the
@@ -880,16 +892,42 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     // ---- the carried part [ws, dr) of the window: its maximum is what the previous step left while that time
                     // is inside the window; else the stored values are looked at (the one most steps need — a decaying
                     // element's value at the window start — was requested a step ago: pf)
+                    // A CHILD keeps its old maximum when that time has left the window: the maximum over an older, larger
+                    // window is an upper bound, and a child only has to stay below the smallest beam score — its exact
+                    // maximum is looked up below, if the bound does not settle that.  (40 of 50 lanes never ask the store.)
+#ifdef PO_REG_TIMING2
+                    KT2(22);
+#ifndef PO_EMU
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (timing builds: what the drain of the wave's memory queue costs here)
+#endif
+                    KT2(23);
+#endif
                     const bool has_c = live && dr > ws;
+                    const bool child = s >= nb;
+                    const bool bnd = has_c && child && !(v_mx == PO_NEG_INF || v_mt >= ws);
                     double mx = PO_NEG_INF, cmx = PO_NEG_INF, self = v_self;
                     int mt = -1, cmt = -1, td = has_c ? v_td : ws, tr = INT_MIN;
                     if (has_c) {
-                        if (v_mx == PO_NEG_INF || v_mt >= ws) { cmx = v_mx; cmt = v_mt; }
+                        if (v_mx == PO_NEG_INF || v_mt >= ws || child) { cmx = v_mx; cmt = v_mt; }
                         else {
                             const double pf_val = (pf_t >= 0 && pf_e.tag == tag_of(e_id, pf_t)) ? pf_e.v[0] : PO_NEG_INF;
                             carried_max(ws, dr, cmx, cmt, td, pf_t, pf_val);
                         }
                     }
+#ifdef PO_REG_TIMING2
+                    {   // which way the carried maxima went (counts of steps; the longest rescan of the step)
+                        const bool need = has_c && !child && !(v_mx == PO_NEG_INF || v_mt >= ws);
+                        const bool one = need && v_td <= ws;
+                        const int len = (need && !one) ? min(v_td + 1, dr) - ws : 0;
+                        int lm = len;
+                        for (int off = 32; off >= 1; off >>= 1) lm = max(lm, __shfl_xor(lm, off));
+                        KC(37, __ballot(one && pf_t != ws) != 0ull ? 1 : 0);
+                        KC(38, lm > 0 ? 1 : 0);
+                        KC(39, lm);
+                        KC(30, __ballot(one && pf_t == ws) != 0ull ? 1 : 0);
+                    }
+#endif
+                    KT2(24);
                     {   // the stored value the NEXT step's carried maximum will ask for, if any, requested now — a whole step
                         // ahead (its record is in the registers already).  Whether the lane will need it is decided on its
                         // state before this step: should this step's new values bring a new maximum, the entry goes unused.
@@ -899,8 +937,9 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                         const int nx = __builtin_amdgcn_readlane(rnxt.x, 0), ny = __builtin_amdgcn_readlane(rnxt.y, 0);
                         const int wsn = (r ? (nb_ ? ny : cy) : (nb_ ? nx : cx)) & 0xffffff;
                         pf_t = -1;
-                        if (live && v_done > wsn && v_mx != PO_NEG_INF && v_mt < wsn) { pf_t = wsn; pf_e = *t2_entry(e_row2, wsn); }
+                        if (live && !child && v_done > wsn && v_mx != PO_NEG_INF && v_mt < wsn) { pf_t = wsn; pf_e = *t2_entry(e_row2, wsn); }
                     }
+                    KT2(25);
                     // ---- the new times [dr, we), everybody in lockstep: the parent's previous value comes from its lane
                     const int n2 = we - dr;   // (half-uniform, >= 0)
                     const int n2max = max(ce - d0, re - d1);
@@ -911,6 +950,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                             if (hi > lo && !(lo >= yhi - RK_NY && hi <= yhi)) { y_reload(lo); yhi = lo + RK_NY; }
                             rk_sync();
                         }
+                        KT2(26);
                         const int k1 = min(n2max, k0 + RK_NY);
                         for (int k = k0; k < k1; ++k) {
                             const int t = dr + k;
@@ -932,8 +972,11 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                                 mx = po_vmax(mx, out);
                             }
                         }
+                        KT2(27);
                     }
                     if (part2) { v_done = we; v_self = self; }
+                    const double nmx = mx;   // the maximum over the new times alone
+                    const int nmt = mt;
                     if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
                     if (live) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
                     smx = live ? mx : PO_NEG_INF;
@@ -942,12 +985,28 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                         cnt_x += (unsigned)(__popcll(__ballot(live && r == 0)) * (ce - d0) + __popcll(__ballot(live && r == 1)) * (re - d1));
                     }
                     sc = smx + po_xor32(smx, r != 0);
+                    double scmin = rk_readlane_d(sc, 0);
+                    for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rk_readlane_d(sc, i));
+                    viol = live && child && !(scmin > sc);
+                    // a child that reaches the smallest beam score on a bound: its exact maximum now (the stored values are
+                    // looked at), then the score and the test again — the decision is the one exact maxima give
+                    if (__ballot(viol && bnd && !(nmx >= cmx)) != 0ull) {
+                        if (viol && bnd && !(nmx >= cmx)) {
+                            double cx = PO_NEG_INF;
+                            int ct = -1, td2 = td;
+                            carried_max(ws, dr, cx, ct, td2);
+                            const bool keep = (nmx >= cx);
+                            v_mx = keep ? nmx : cx; v_mt = keep ? nmt : ct; v_td = max(td2, tr);
+                            smx = v_mx;
+                        }
+                        sc = smx + po_xor32(smx, r != 0);
+                        viol = live && child && !(scmin > sc);
+                        KC(31, 1);
+                    }
 #ifdef PO_RING_TRACE
                     if (pi == 0 && live && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
 #endif
-                    double scmin = rk_readlane_d(sc, 0);
-                    for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rk_readlane_d(sc, i));
-                    viol = live && s >= nb && !(scmin > sc);
+                    KT2(28);
                     up = u; vp = v;
                     mstep++;
                     if ((mstep & 63) == 0) {
@@ -959,6 +1018,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     if (lane == 0) printf("STEP run\n");
 #endif
                     KC(12, 1); KC(19, n2max);
+                    KT2(29);
                     if (__ballot(viol) != 0ull) { run_viol = true; break; }
                 }
                 KT(0);
@@ -1094,7 +1154,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
     }
 #ifdef PO_REG_TIMING
     if (lane == 0 && a.dbg && slotid == 0)
-        for (int i = 0; i < 24; ++i) a.dbg[i] = tk[i];
+        for (int i = 0; i < 40; ++i) a.dbg[i] = tk[i];
 #endif
     if (lane == 0) {   // the next launch on this workspace continues from here
         unsigned long long* stp = a.wgstate + 2 * (size_t)slotid;
@@ -1138,8 +1198,8 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int board, hipStrea
     a.reg_board = board ? 1 : 0;
 #ifdef PO_REG_TIMING
     static long long* dbg = nullptr;
-    if (!dbg) { (void)hipMalloc((void**)&dbg, 24 * sizeof(long long)); }
-    (void)hipMemsetAsync(dbg, 0, 24 * sizeof(long long), stream);
+    if (!dbg) { (void)hipMalloc((void**)&dbg, 40 * sizeof(long long)); }
+    (void)hipMemsetAsync(dbg, 0, 40 * sizeof(long long), stream);
     a.dbg = dbg;
 #endif
     if (board) {
@@ -1150,7 +1210,7 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int board, hipStrea
     }
 #ifdef PO_REG_TIMING
     {
-        long long h[24];
+        long long h[40];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         fprintf(stderr, "[po_reg_timing] pair slot 0, 10 ns ticks\n");
@@ -1159,6 +1219,15 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int board, hipStrea
                 h[13], h[1], h[2], h[14], h[3], h[15]);
         fprintf(stderr, "   general scans: main %lld ticks (%lld), catch-up %lld ticks (%lld); iterations %lld\n", h[4], h[16], h[5], h[17], h[18]);
         fprintf(stderr, "   step top + score + prune test %lld, ranking %lld, rebuild %lld, pair setup + label %lld\n", h[6], h[7], h[8], h[9]);
+#ifdef PO_REG_TIMING2
+        fprintf(stderr, "   inside the run loop: top + carried maxima %lld, prefetch %lld, y rows + syncs %lld, new-time iterations %lld, maxima + score + test %lld, record advance %lld (rest %lld)\n",
+                h[24], h[25], h[26], h[27], h[28], h[29], h[0]);
+        fprintf(stderr, "   run loop top before the carried maxima %lld, waiting for the memory queue to drain there %lld\n", h[22], h[23]);
+        fprintf(stderr, "   steps in which a child's bound had to be made exact: %lld\n", h[31]);
+        fprintf(stderr, "   carried maxima in the run loop: steps with a prefetched entry used %lld, with a value asked for on the spot %lld, with a rescan %lld (longest rescans summed: %lld reads)\n", h[30], h[37], h[38], h[39]);
+        fprintf(stderr, "   inside the table build: A fields %lld, B expansion + groups %lld, C + D children / sources %lld, F identity %lld, parent slots %lld (rest: G + end %lld)\n",
+                h[32], h[33], h[34], h[35], h[36], h[8]);
+#endif
     }
 #endif
 }

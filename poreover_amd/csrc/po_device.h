@@ -116,6 +116,13 @@ struct PoLaeFast {
             const double kf = tm - 0x1.8p52;
             const int k = __double2loint(tm);
             const int j = k & 63;
+#if defined(PO_LAE_EARLY_TABLE) && !defined(PO_EMU)
+            // The table entry is asked for as soon as its index exists and nothing is scheduled across that point: left
+            // alone, the scheduler sinks the LDS read below the polynomial and a lone wave waits a full LDS round trip
+            // per logaddexp in its dependent chain (same instructions, same result bits).
+            const double th = t->exp_t[j][0], tl = t->exp_t[j][1];
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             double r = __builtin_fma(-kf, PO_LN2_64_HI, d);
             r = __builtin_fma(-kf, PO_LN2_64_LO, r);
             double p = po_fma_c(r, 1.0 / 720, 1.0 / 120);
@@ -123,7 +130,9 @@ struct PoLaeFast {
             p = po_fma_c(r, p, 1.0 / 6);
             p = po_fma_c(r, p, 0.5);
             p = __builtin_fma(r * r, p, r);
+#if !(defined(PO_LAE_EARLY_TABLE) && !defined(PO_EMU))
             const double th = t->exp_t[j][0], tl = t->exp_t[j][1];
+#endif
             const double x = th + __builtin_fma(th, p, tl);
             e = __hiloint2double(__double2hiint(x) + ((k >> 6) << 20), __double2loint(x));
         }
