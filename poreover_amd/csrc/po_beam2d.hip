@@ -39,6 +39,7 @@
 //   * One workgroup per pair, thread = (read, element slot); the LDS layout is a compile-time struct
 //     per beam-width class (W <= 6 / 12 / 25 -> 64 / 128 / 256 threads).  Workgroups are persistent
 //     and pull pairs from an atomic queue.
+#define PO_LAE_EARLY_TABLE 1   // (po_device.h; A/B in round 4: W = 10 -0.7 %, Bonito W = 5 -3 %, beam2d_kernel -1 %)
 #include <algorithm>
 #include <climits>
 #include <cstdio>
@@ -2914,6 +2915,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
         a.need_mono = 1;
+        a.no_cum = use_reg ? 1 : 0;
         a.order = nullptr;   // (the ring kernel by default gets at most as many pairs as resident workgroups: all start at once)
         if (n > g.blocks && !b2_route().no_order) {   // more pairs than resident workgroups: longest first
             a.order = (int*)(w + g.off_order);
@@ -2960,6 +2962,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
         a.need_mono = 0;
+        a.no_cum = 0;
         a.order = nullptr;
         if (n > g.blocks * g.npw && !b2_route().no_order) {   // more pairs than resident half-waves: longest first
             a.order = (int*)(w + g.off_order);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
     }
     // blank prefix sums = the CTC root's alpha (PrefixTree.h:509-515): serial in t so the rounding is the
     // reference's; one wave per read loads 64 frames at a time (coalesced) and adds them in lane order
-    if (st == PO_OK && MODEL == PO_MODEL_CTC && wave < 2) {
+    if (st == PO_OK && MODEL == PO_MODEL_CTC && wave < 2 && !a.no_cum) {
         const int rr = wave;
         const double* yr = rr ? a.y2 + o2 * C : a.y1 + o1 * C;
         double* cw = rr ? a.cum2 + (o2 - b2) : a.cum1 + (o1 - b1);
@@ -170,10 +170,20 @@ __global__ __launch_bounds__(64) void beam2d_walk_kernel(X2Args a) {
         if (lane < run) sc[m + lane] = make_int4(ul, vl, ece, ere);
         m += run; u += run; v += run;
         if (run < 64 && ((haveb >> run) & 1ull)) {   // the position after the run is in range and is not a main step
+            // Catch-ups come in runs too (a base of one read against a stretch of the other: 10 - 30 in a row, as many
+            // positions as main steps on the bench's pairs), and a run of them is resolved at once:
+            //  * read 1 (:314-322): row u starts beyond v — every (u, v') up to the row's start is the same case;
+            //  * read 0 (:328-336): column v starts beyond u — (u', v) is the same case while u' stays before the column's
+            //    start and row u' does not start beyond v (that would be a read-1 catch-up, which is tested first).
             const unsigned long long c1 = __ballot(!row_ok && vl < ers), c0 = __ballot(!col_ok && ul < ecs);
-            if ((c1 >> run) & 1ull) v++;              // catch-up on read 1 (:314-322)
-            else if ((c0 >> run) & 1ull) u++;         // catch-up on read 0 (:328-336)
-            else { werr = 1; break; }                  // uninitialised bounds upstream (:309)
+            if ((c1 >> run) & 1ull) v = __builtin_amdgcn_readlane(ers, run);
+            else if ((c0 >> run) & 1ull) {
+                const int cs = __builtin_amdgcn_readlane(ecs, run);
+                const int rw = u + 1 + lane, ir = rw - ubase;            // lane l looks at row u + 1 + l
+                const int rws = __shfl(erc.x, ir & 63);
+                const unsigned long long same = __ballot(ir < 64 && rw < cs && rw < U && !(v < rws));
+                u += 1 + ((~same == 0ull) ? 64 : __builtin_ctzll(~same));
+            } else { werr = 1; break; }                // uninitialised bounds upstream (:309)
         }
         // (a run that ends where the caches or the reads end is simply continued by the next round)
     }

@@ -34,6 +34,7 @@
 #include <climits>
 
 #define PO_LAE_EARLY_TABLE 1   // (po_device.h: the exp table entry is requested before the polynomial — a lone wave's chain is latency)
+#define PO_LAE_BRANCHLESS 1    // (... and exp's small-argument test is a select, not a branch: 10 000 pairs 68.3 -> 67.0 ms)
 #include "po_beam2d_common.h"
 #include "po_host.h"
 
@@ -59,6 +60,10 @@ struct RegSmem {              // per pair wave
     int ord[32];              // prune with exact score ties: candidate slots in node-id order (po_stl_prune)
     double csc[32];           // ... and their scores
     int sh[8];
+    double rootcum[2];        // the root's alpha (blank prefix sum, PrefixTree.h:509-515) of each read at time rootT: added up as the
+    int rootT[2];             // scans pass the times, while children of the root are in the table (the start of a pair)
+    double pf0[2][8];         // a run's first step: the beam lanes' values at the window start, fetched with the staging of the
+    int pf0_t[2][8];          // step before (their times; -1: none)
     unsigned long long nupd, nupd_x;
 };
 
@@ -267,7 +272,6 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         // (this lane's read: its rows, length and blank prefix sums are put together where they are used — a y reload every
         //  ~ 16 steps, the root's children at the start of a pair — rather than held in six registers across the walk)
         auto yr_ = [&]() -> const double* { return r ? a.y2 + o2 * C : a.y1 + o1 * C; };
-        auto cumr_ = [&]() -> const double* { return r ? a.cum2 + (o2 - a.y2_off[0]) : a.cum1 + (o1 - a.y1_off[0]); };
         const int4* const sched = a.sched + (o2 - a.y2_off[0]);
         const int nmain = a.nmain[pi];
         const int R2 = m.y, Rm2 = R2 - 1;
@@ -345,14 +349,20 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             t2_write(e_row2, e_id, 0, out);
             v_done = 1; v_fresh = 0; v_self = out;
             v_mx = out; v_mt = 0; v_td = 0;   // (the window maximum over [0, 1))
+            if (s == 0) { sm.rootcum[r] = 0.0 + yr[A]; sm.rootT[r] = 0; }   // (serial in t from 0.0, as the reference adds)
         }
         rk_sync();
 
         int mstep = 0, up = -1, vp = -1;
+        int pf0_step = -1;   // the main step sm.pf0 was filled for
         // The walk's records, 64 at a time: lane l holds record 64 * batch + l of the current batch and of the next one
         // (requested a batch ahead: the load's latency never shows), the step's own record comes out with v_readlane.
         // (kept PACKED, two words per record — time | window length << 24; times stay below 2^24 and a window below the
         //  store's ring length of <= 256 — : four registers for the two batches instead of eight)
+        // (The walk INSIDE this kernel — the wave putting its own next 64 records together — was built and measured in
+        //  round 4: 10 000 pairs 68.3 instead of 66.7 ms, a single pair 15.5 instead of 15.4: the walk is ~ 2 800 dependent
+        //  rounds per pair, serial on this wave whether it runs here or in front; as a kernel of its own its waves fill the
+        //  device 8 - 10 to a SIMD.  It stays a kernel, and got catch-up runs resolved in one round instead.)
         auto rec_load = [&](int i) -> int2 {
             const int4 q = sched[min(i, max(nmain - 1, 0))];
             return make_int2(q.x | ((q.z - q.x) << 24), q.y | ((q.w - q.y) << 24));
@@ -401,20 +411,46 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         // left the window — then the stored values are looked at again.  A node past its peak decays frame by frame:
         // if the values were non-increasing since before the window start (td <= ws), the maximum is the first one.
         // pf: an entry requested a step ahead for exactly that time (pf_t), else the store is asked now.
-        auto carried_max = [&](int ws, int start, double& cmx, int& cmt, int& td, int pf_t = -1, double pf_val = 0.0) {
-            auto own = [&](int tq) -> double {
-                if (tq == pf_t) return pf_val;
-                return read_own(tq);
-            };
-            if (td <= ws) { cmx = own(ws); cmt = ws; return; }
-            double pv = PO_NEG_INF;
-            const int te = min(td + 1, start);   // from td on the values fall
-            td = ws;
-            for (int tq = ws; tq < te; ++tq) {
-                const double v = own(tq);
-                if (v >= cmx) { cmx = v; cmt = tq; }
-                if (tq > ws && v > pv) td = tq;
-                pv = v;
+        // Two parts.  carried_one (per lane): the single value of a decaying element; returns true when the lane needs the
+        // rescan.  rescan_wave (the whole wave, uniform control flow): the lanes that need one are served in turn, each by
+        // all 64 lanes — lane i asks for the stored value at ws + i of THAT lane's row (one memory round trip for the
+        // range instead of one per time), the maximum comes from po_wave_max, its latest time and the last rise from
+        // ballots.  (Done lane by lane and time by time, a late bump in an otherwise falling window was rescanned at
+        // every step until the window start had passed it: ~ 10 dependent reads in each of 30 % of the run-loop steps.)
+        auto carried_one = [&](int ws, double& cmx, int& cmt, int td, int pf_t = -1, double pf_val = 0.0) -> bool {
+            if (td > ws) return true;
+            cmx = (ws == pf_t) ? pf_val : read_own(ws);
+            cmt = ws;
+            return false;
+        };
+        auto rescan_wave = [&](bool need, int ws, int start, double& cmx, int& cmt, int& td) {
+            unsigned long long m = __ballot(need);
+            while (m != 0ull) {   // (wave-uniform)
+                const int L = (int)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const int wsL = __builtin_amdgcn_readlane(ws, L), teL = __builtin_amdgcn_readlane(min(td + 1, start), L);
+                const int rowL = __builtin_amdgcn_readlane(e_row2, L), idL = __builtin_amdgcn_readlane(e_id, L);
+                const int rowbase = (rowL * 2 + (L >> 5)) * R2;
+                double bmx = PO_NEG_INF, pvc = PO_NEG_INF;
+                int bmt = -1, btd = wsL;
+                for (int base = wsL; base < teL; base += 64) {
+                    const int tq = base + lane;
+                    const bool valid = tq < teL;
+                    double val = PO_NEG_INF;
+                    if (valid) {
+                        const Ent e = *(const Ent*)(poolb + (size_t)(unsigned)((rowbase + (tq & Rm2)) << 4));
+                        if (e.tag == tag_of(idL, tq)) val = e.v[0];
+                    }
+                    const double mxv = po_wave_max(val);
+                    const unsigned long long eq = __ballot(valid && val == mxv);   // (later times win ties: the highest lane)
+                    if (mxv >= bmx && eq != 0ull) { bmx = mxv; bmt = base + 63 - (int)__builtin_clzll(eq); }
+                    double prev = __shfl(val, (lane + 63) & 63);
+                    if (lane == 0) prev = pvc;
+                    const unsigned long long rs = __ballot(valid && tq > wsL && val > prev);
+                    if (rs != 0ull) btd = base + 63 - (int)__builtin_clzll(rs);
+                    pvc = rk_readlane_d(val, 63);
+                }
+                if (lane == L) { cmx = bmx; cmt = bmt; td = btd; }
             }
         };
 
@@ -450,12 +486,16 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             double mx = PO_NEG_INF, cmx = PO_NEG_INF;
             int mt = -1, cmt = -1, td = ws, tr = INT_MIN;
             const bool has_c = is_main && part && start > ws;
+            bool rsc = false;
             if (has_c) {
                 td = v_td;
                 if (v_mx == PO_NEG_INF || (v_mt >= ws && v_mt < start)) { cmx = v_mx; cmt = v_mt; }
-                else carried_max(ws, start, cmx, cmt, td);
+                else rsc = carried_one(ws, cmx, cmt, td);
             }
+            rescan_wave(rsc, ws, start, cmx, cmt, td);
             const int sym = sym_last(e_sym);
+            const bool has_root = __ballot(live && e_ps == PS_ROOT) != 0ull;
+            bool bad_root = false;
             // the parent's lane: where it starts and ends in this scan (its `self` is its value at p_start - 1 before the
             // first iteration, then at the time it computed last)
             const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
@@ -486,7 +526,8 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                             if (tm >= p_start - 1 && tm < p_we && p_start != INT_MAX) pp = ps_self;
                             else pp = t2_read(e_prow2, e_par, tm);
                         } else if (e_ps == PS_ROOT) {
-                            pp = (tm < 0) ? 0.0 : cumr_()[tm];
+                            pp = 0.0;
+                            if (tm >= 0) { pp = sm.rootcum[r]; bad_root = bad_root || (tm != sm.rootT[r]); }
                         } else if (tm >= fz_t) {
                             pp = (tm == fz_t) ? fz_val : PO_NEG_INF;                                 // frozen parent: its last value, then nothing
                         } else {
@@ -502,8 +543,14 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                         mt = (out >= mx) ? t : mt;
                         mx = po_vmax(mx, out);
                     }
+                    if (has_root) {   // the root's alpha moves on with the times this read's scans pass (every one of them, in order)
+                        rk_sync();
+                        if (s == 0 && k < span && t == sm.rootT[r] + 1) { sm.rootcum[r] += sm.ybuf[r][t & (RK_NY - 1)][A]; sm.rootT[r] = t; }
+                        rk_sync();
+                    }
                 }
             }
+            if (__ballot(bad_root) != 0ull) st = PO_E_NOMEM;   // (a time the sums have not reached: cannot happen — beam2d_kernel would take the pair)
             if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
             if (part2) { v_done = we; v_self = self; v_fresh = 0; }
             if (is_main) {
@@ -576,7 +623,11 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             // the fresh lanes' own seeds (an element again: its last value is in the store)
             Ent se; se.tag = 0ull; se.v[0] = 0.0;
             const bool want_seed = fresh && v_fresh == 1 && ws - 1 >= 0;
+            // (the same registers, other lanes: a continuing beam lane whose window maximum has left the window and whose
+            //  values fall — the run that follows this step asks for its value at ws first thing)
+            const bool want_pf = cont && s < nb && v_done > ws && v_mx != PO_NEG_INF && v_mt < ws && v_td <= ws;
             if (want_seed) se = *t2_entry(e_row2, ws - 1);
+            else if (want_pf) se = *t2_entry(e_row2, ws);
             double mx = PO_NEG_INF, self = PO_NEG_INF;
             int mt = -1, tr = INT_MIN;
             const int sym = sym_last(e_sym);
@@ -650,6 +701,9 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     const double* yrow = yb_ + ((ws + k0) & (RK_NY - 1)) * RK_YC;
                     nya = yrow[sym]; nyb = yrow[A]; npp = ps_[0];
                 }
+#ifdef PO_REG_UNROLL2
+#pragma unroll 2
+#endif
                 for (int k = k0; k < k1; ++k) {
                     if (fresh && k < n1) {
                         const int t = ws + k;
@@ -671,6 +725,11 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 }
             }
             if (n1max == 0 && want_seed && se.tag == tag_of(e_id, ws - 1)) self = se.v[0];
+            if (s < 8) {
+                sm.pf0_t[r][s] = want_pf ? ws : -1;
+                if (want_pf) sm.pf0[r][s] = (se.tag == tag_of(e_id, ws)) ? se.v[0] : PO_NEG_INF;
+            }
+            pf0_step = mstep;
             // the fresh lanes are ordinary continuing lanes now, ending at dr like everybody else: the run loop does the step
             if (fresh) {
                 v_done = dr; v_self = self; v_fresh = 0;
@@ -878,6 +937,10 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 const double* const yb_ = &sm.ybuf[r][0][0];
                 Ent pf_e; pf_e.tag = 0ull; pf_e.v[0] = 0.0;   // the entry requested at the end of the previous step of this run
                 int pf_t = -1;
+                if (pf0_step == mstep && s < 8) {   // ... or with the staging of the new elements' step just before this run
+                    pf_t = sm.pf0_t[r][s];
+                    if (pf_t >= 0) { pf_e.tag = tag_of(e_id, pf_t); pf_e.v[0] = sm.pf0[r][s]; }
+                }
                 for (;;) {
                     u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
                     const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
@@ -907,13 +970,13 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     const bool bnd = has_c && child && !(v_mx == PO_NEG_INF || v_mt >= ws);
                     double mx = PO_NEG_INF, cmx = PO_NEG_INF, self = v_self;
                     int mt = -1, cmt = -1, td = has_c ? v_td : ws, tr = INT_MIN;
+                    const double pf_val = (pf_t >= 0 && pf_e.tag == tag_of(e_id, pf_t)) ? pf_e.v[0] : PO_NEG_INF;
+                    bool rsc = false;
                     if (has_c) {
                         if (v_mx == PO_NEG_INF || v_mt >= ws || child) { cmx = v_mx; cmt = v_mt; }
-                        else {
-                            const double pf_val = (pf_t >= 0 && pf_e.tag == tag_of(e_id, pf_t)) ? pf_e.v[0] : PO_NEG_INF;
-                            carried_max(ws, dr, cmx, cmt, td, pf_t, pf_val);
-                        }
+                        else rsc = carried_one(ws, cmx, cmt, td, pf_t, pf_val);
                     }
+                    rescan_wave(rsc, ws, dr, cmx, cmt, td);
 #ifdef PO_REG_TIMING2
                     {   // which way the carried maxima went (counts of steps; the longest rescan of the step)
                         const bool need = has_c && !child && !(v_mx == PO_NEG_INF || v_mt >= ws);
@@ -928,17 +991,6 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     }
 #endif
                     KT2(24);
-                    {   // the stored value the NEXT step's carried maximum will ask for, if any, requested now — a whole step
-                        // ahead (its record is in the registers already).  Whether the lane will need it is decided on its
-                        // state before this step: should this step's new values bring a new maximum, the entry goes unused.
-                        const int i1 = min(mstep + 1, nmain - 1), l1 = i1 & 63;
-                        const bool nb_ = (l1 == 0) && (i1 != mstep);   // the next step opens the next batch: its record is rnxt's first
-                        const int cx = __builtin_amdgcn_readlane(rcur.x, l1), cy = __builtin_amdgcn_readlane(rcur.y, l1);
-                        const int nx = __builtin_amdgcn_readlane(rnxt.x, 0), ny = __builtin_amdgcn_readlane(rnxt.y, 0);
-                        const int wsn = (r ? (nb_ ? ny : cy) : (nb_ ? nx : cx)) & 0xffffff;
-                        pf_t = -1;
-                        if (live && !child && v_done > wsn && v_mx != PO_NEG_INF && v_mt < wsn) { pf_t = wsn; pf_e = *t2_entry(e_row2, wsn); }
-                    }
                     KT2(25);
                     // ---- the new times [dr, we), everybody in lockstep: the parent's previous value comes from its lane
                     const int n2 = we - dr;   // (half-uniform, >= 0)
@@ -990,11 +1042,13 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     viol = live && child && !(scmin > sc);
                     // a child that reaches the smallest beam score on a bound: its exact maximum now (the stored values are
                     // looked at), then the score and the test again — the decision is the one exact maxima give
-                    if (__ballot(viol && bnd && !(nmx >= cmx)) != 0ull) {
-                        if (viol && bnd && !(nmx >= cmx)) {
-                            double cx = PO_NEG_INF;
-                            int ct = -1, td2 = td;
-                            carried_max(ws, dr, cx, ct, td2);
+                    const bool hot = viol && bnd && !(nmx >= cmx);
+                    if (__ballot(hot) != 0ull) {
+                        double cx = PO_NEG_INF;
+                        int ct = -1, td2 = td;
+                        const bool rs2 = hot && carried_one(ws, cx, ct, td2, pf_t, pf_val);
+                        rescan_wave(rs2, ws, dr, cx, ct, td2);
+                        if (hot) {
                             const bool keep = (nmx >= cx);
                             v_mx = keep ? nmx : cx; v_mt = keep ? nmt : ct; v_td = max(td2, tr);
                             smx = v_mx;
@@ -1014,6 +1068,12 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                         rnxt = rec_load(mstep + 64 + lane);
                     }
                     rec = rec_at(min(mstep, nmain - 1));
+                    {   // the stored value the next step's carried maximum will ask for, if any, requested now: the beam lanes,
+                        // and a child whose bound has just had to be made exact (it will be again)
+                        const int wsn = r ? rec.y : rec.x;
+                        pf_t = -1;
+                        if (live && (!child || hot) && v_done > wsn && v_mx != PO_NEG_INF && v_mt < wsn) { pf_t = wsn; pf_e = *t2_entry(e_row2, wsn); }
+                    }
 #ifdef PO_EMU_DEBUG
                     if (lane == 0) printf("STEP run\n");
 #endif

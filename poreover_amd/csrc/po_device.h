@@ -111,7 +111,11 @@ struct PoLaeFast {
     // rint / ldexp formulation on 2e7 random and structured arguments (scripts/check_lae.c).
     __device__ __forceinline__ double f(double d) const {
         double e = 0.0;
+#ifdef PO_LAE_BRANCHLESS   // (every lane computes, the small arguments are selected away below: no exec-mask branch in a lone wave's chain)
+        {
+#else
         if (d > -40.0) {  // below: exp(d) < 2^-57, 1 + e == 1
+#endif
             const double tm = __builtin_fma(d, PO_64_LN2, 0x1.8p52);
             const double kf = tm - 0x1.8p52;
             const int k = __double2loint(tm);
@@ -135,6 +139,9 @@ struct PoLaeFast {
 #endif
             const double x = th + __builtin_fma(th, p, tl);
             e = __hiloint2double(__double2hiint(x) + ((k >> 6) << 20), __double2loint(x));
+#ifdef PO_LAE_BRANCHLESS
+            e = (d > -40.0) ? e : 0.0;   // (also d = NaN and -inf, whose e above is garbage; the table index j is in range for any k)
+#endif
         }
         const double z = 1.0 + e;
         const unsigned i = ((unsigned)__double2hiint(z) - 0x3FF00000u + 0x2000u) >> 14;
@@ -227,6 +234,26 @@ __device__ __forceinline__ int po_xor32_i(int x, bool upper) {
 }
 __device__ __forceinline__ double po_xor32(double x, bool upper) {   // upper: this lane is one of 32..63
     return __hiloint2double(po_xor32_i(__double2hiint(x), upper), po_xor32_i(__double2loint(x), upper));
+}
+
+// The maximum of x over the wave, in every lane (all 64 lanes must be executing): four DPP exchanges inside the rows of 16
+// (quad xor 1, quad xor 2, half-row mirror, row mirror — a maximum does not care which partner it sees), then the four
+// rows through v_readlane.  No LDS round trips: ~ 25 instructions.
+__device__ __forceinline__ double po_wave_max(double x) {
+#ifdef PO_EMU
+    for (int off = 32; off >= 1; off >>= 1) x = po_vmax(x, __shfl_xor(x, off));
+    return x;
+#else
+#define PO_DPP_D(ctrl) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), (ctrl), 0xf, 0xf, false), \
+                                        __builtin_amdgcn_update_dpp(0, __double2loint(x), (ctrl), 0xf, 0xf, false))
+    x = po_vmax(x, PO_DPP_D(0xB1));    // quad_perm [1,0,3,2]
+    x = po_vmax(x, PO_DPP_D(0x4E));    // quad_perm [2,3,0,1]
+    x = po_vmax(x, PO_DPP_D(0x141));   // row_half_mirror
+    x = po_vmax(x, PO_DPP_D(0x140));   // row_mirror
+#undef PO_DPP_D
+    auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l)); };
+    return po_vmax(po_vmax(rl(0), rl(16)), po_vmax(rl(32), rl(48)));
+#endif
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every

@@ -39,6 +39,7 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     a.wgstate = wgstate.data(); a.magic = 0x1234567ull;
     a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
     a.ngl = kernel >= 1 ? po_reg_ngl() : po_ring_ngl();
+    a.no_cum = kernel >= 1 ? 1 : 0;
     for (int i = 0; i < n; ++i) status[i] = PO_OK;
     const bool vb = getenv("EMU_VERBOSE") != nullptr;
     if (vb) fprintf(stderr, "[emu] prepass\n");
