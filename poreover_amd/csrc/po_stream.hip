@@ -92,6 +92,8 @@ struct WavePlanner {
     int next = 0;
     int handed = 0;      // waves handed out so far
     int ramp = 0;        // > 0: the first waves are short (ramp, 2 * ramp, ... up to wave_pairs): see PO_WAVE_RAMP
+    int tail = 0;        // > 0: the LAST wave has at most this many pairs (what follows it is serial: its download, the
+                         // copy into the caller's arrays, the caller's own work on its results): see PO_WAVE_TAIL
     bool bad = false;
     std::mutex mu;
     bool take(int* first, int* wn, int64_t* r1, int64_t* r2, int64_t* m1, int64_t* m2) {
@@ -100,6 +102,10 @@ struct WavePlanner {
         int limit = wave_pairs;
         if (ramp > 0 && handed < 8) limit = std::min<long long>(wave_pairs, (long long)ramp << handed);
         ++handed;
+        {
+            const int remaining = n - next;
+            if (tail > 0 && remaining > tail && remaining <= limit) limit = remaining - tail;
+        }
         int k = 0;
         int64_t a1 = 0, a2 = 0, x1 = 0, x2 = 0;
         while (next + k < n && k < limit) {
@@ -125,7 +131,11 @@ constexpr int PO_MAX_SLOTS = 4;
 // ~ 85k), same job, same box: waves of 2 500 73.9k pairs/s end to end, 3 334 82.1k, 5 000 on two or three slots 75k, 2 000 x 5
 // 69k, four slots 68k; and now a SHORT FIRST WAVE pays (1 250 pairs, then 2 500, then full waves: the device starts ~ 10 ms
 // earlier and the short wave no longer decodes much slower per pair): 3 334 with that ramp 84.4k (2 500 with it 77.6k).
-constexpr int PO_WAVE_TARGET = 3334, PO_WAVE_MAX = 4096, PO_WAVE_RAMP = 1250;
+// ... and a SHORT LAST WAVE (round 4, after the pair beam got faster: 10 000 pairs resident 67 ms): what follows the last wave
+// is serial — its download, the copy into the caller's arrays, the Python records of its pairs (~ 4.7 us each: 15 ms for
+// 3 334 pairs).  The last wave is cut to 800 pairs (the rest of it goes before): 90.9k -> 98.4k pairs/s end to end (tail
+// 500: 90.6k, 1 250: 75 - 84k; waves of 4 000 / 3 000 with the tail 87.8k / 86.3k).
+constexpr int PO_WAVE_TARGET = 3334, PO_WAVE_MAX = 4096, PO_WAVE_RAMP = 1250, PO_WAVE_TAIL = 800;
 static int auto_wave_pairs(int n) {
     if (n <= PO_WAVE_MAX) return PO_WAVE_MAX;
     const int waves = (n + PO_WAVE_TARGET - 1) / PO_WAVE_TARGET;
@@ -437,6 +447,8 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
     plan.wave_pairs = p->wave_pairs > 0 ? p->wave_pairs : auto_wave_pairs(n);
     plan.ramp = (p->wave_pairs <= 0 && n > PO_WAVE_MAX) ? PO_WAVE_RAMP : 0;   // a job of several waves starts with a short one, doubling
     if (const char* e = getenv("PO_WAVE_RAMP")) plan.ramp = std::max(0, atoi(e));
+    plan.tail = (p->wave_pairs <= 0 && n > PO_WAVE_MAX) ? PO_WAVE_TAIL : 0;
+    if (const char* e = getenv("PO_WAVE_TAIL")) plan.tail = std::max(0, atoi(e));
     // (Tried: a job within the latency-bound regime of the pair beam kernel — <= 2 048 pairs, one GPU's share of a multi-GPU
     //  job — cut into two waves whose kernels run side by side while the second uploads: 36.8 vs 36.9 ms for 1 250 pairs,
     //  three waves on the two slots 60 ms.  The upload is not what such a job waits for.  PO_PIPELINE_SPLIT=1 still does it.)
@@ -468,6 +480,7 @@ int po_wave_plan(const int64_t* rows1, const int64_t* rows2, int n, int wave_pai
     const int wp = wave_pairs > 0 ? wave_pairs : auto_wave_pairs(n);
     plan.wave_pairs = (ndev > 1) ? std::max(1, std::min(wp, (n + 2 * ndev - 1) / (2 * ndev))) : wp;
     plan.wave_rows = wave_rows > 0 ? wave_rows : ((int64_t)64 << 20);
+    if (ndev == 1 && wave_pairs <= 0 && n > PO_WAVE_MAX) { plan.ramp = PO_WAVE_RAMP; plan.tail = PO_WAVE_TAIL; }   // (po_pipeline_pair_decode's own plan)
     int k = 0, f = 0, c = 0;
     int64_t r1, r2, m1, m2;
     while (plan.take(&f, &c, &r1, &r2, &m1, &m2)) {

@@ -83,6 +83,26 @@ def test_workspace_bounded_for_long_reads():
     assert small < 48 * 2**30      # (the bench configuration keeps its full occupancy: ~16 GB of DP slices + ~15 GB for the pair beam)
 
 
+def test_wave_plan_single_device_short_first_and_last_wave():
+    """the plan po_pipeline_pair_decode makes by itself for a job of several waves: a short first wave (the device starts
+    early), doubling up to the full size, and a short LAST one (what follows it — download, copies, the caller's records — is
+    serial)"""
+    from poreover_amd import _lib
+    lib = _lib.load(require_gpu=False)
+    n = 10000
+    r1 = np.full(n, 4000, dtype=np.int64); r2 = np.full(n, 3900, dtype=np.int64)
+    first = np.zeros(32, dtype=np.int32); count = np.zeros(32, dtype=np.int32)
+    k = lib.po_wave_plan(r1.ctypes.data_as(_lib._i64p), r2.ctypes.data_as(_lib._i64p), n, 0, 0, 1,
+                         first.ctypes.data_as(_lib._i32p), count.ctypes.data_as(_lib._i32p), 32)
+    c = count[:k].tolist()
+    assert sum(c) == n and first[:k].tolist() == np.concatenate([[0], np.cumsum(c)[:-1]]).tolist()
+    assert c[0] == 1250 and c[1] == 2500 and max(c) <= 3334 and c[-1] <= 800 and k == 5, c
+    # a job of one wave is left alone
+    k = lib.po_wave_plan(r1.ctypes.data_as(_lib._i64p), r2.ctypes.data_as(_lib._i64p), 4000, 0, 0, 1,
+                         first.ctypes.data_as(_lib._i32p), count.ctypes.data_as(_lib._i32p), 32)
+    assert k == 1 and count[0] == 4000
+
+
 def test_wave_plan_covers_every_pair_in_order():
     """the planner of the multi-device pipeline (po_wave_plan: what po_multi_pair_decode hands out): every pair in
     exactly one wave, waves in input order, no wave beyond the pair / frame limits, and with several devices at
