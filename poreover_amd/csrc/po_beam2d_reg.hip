@@ -425,6 +425,9 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         };
         auto rescan_wave = [&](bool need, int ws, int start, double& cmx, int& cmt, int& td) {
             unsigned long long m = __ballot(need);
+            KC(21, __popcll(m)); KC(10, m != 0ull ? 1 : 0);
+            // (two lanes per round, their loads issued together, measured in round 4: a single pair 14.57 -> 14.36 ms, but
+            //  1 250 pairs 20.2 -> 20.5 and 4 096 pairs 30.6 -> 31.3 ms — twice the reduction code; one lane at a time stays)
             while (m != 0ull) {   // (wave-uniform)
                 const int L = (int)__builtin_ctzll(m);
                 m &= m - 1ull;
@@ -642,16 +645,33 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             const double* const ps_ = &sm.pst[r][myk * RK_NY];
             for (int k0 = 0; k0 < n1max; k0 += RK_NY) {
                 rk_sync();   // (every lane is done with the rows and staged values of the block before)
+                // (the first two parents' entries are asked for BEFORE the y rows: one memory round trip for the rows and the
+                //  staged values of the usual step — one or two nodes entered the beam — instead of one after the other)
+                const int i = k0 + s, tq = ws - 1 + i;
+                Ent e01[2];
+                int pid01[2] = {0, 0};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    e01[k].tag = 0ull; e01[k].v[0] = 0.0;
+                    if (k < nps) {   // (wave-uniform)
+                        const int jk = pj[k];
+                        const int prow = __builtin_amdgcn_readlane(e_row2, jk);
+                        pid01[k] = __builtin_amdgcn_readlane(e_id, jk);
+                        if (i < n1 && tq >= 0) e01[k] = *t2_entry(prow, tq);
+                    }
+                }
                 {
                     const int lo = ws + k0, hi = min(lo + RK_NY, dr);
                     if (hi > lo && !(lo >= yhi - RK_NY && hi <= yhi)) { y_reload(lo); yhi = lo + RK_NY; }
                 }
-                for (int k = 0; k < nps; ++k) {   // (wave-uniform)
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (k < nps && i < n1) sm.pst[r][k * RK_NY + s] = (tq >= 0 && e01[k].tag == tag_of(pid01[k], tq)) ? e01[k].v[0] : PO_NEG_INF;
+                for (int k = 2; k < nps; ++k) {   // (wave-uniform; three and more parents: rare)
                     int jk = pj[0];
 #pragma unroll
                     for (int q = 1; q < RK_PS; ++q) jk = (k == q) ? pj[q] : jk;
                     const int prow = __builtin_amdgcn_readlane(e_row2, jk), pid = __builtin_amdgcn_readlane(e_id, jk);
-                    const int i = k0 + s, tq = ws - 1 + i;
                     if (i < n1) {
                         double val = PO_NEG_INF;
                         if (tq >= 0) {
@@ -770,6 +790,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             // ---- every old element marks its row group with the times it has written there
             if (live && v_fresh == 0) atomicMax(&g_hi[e_row2 >> 2], v_done);
             // ---- B. expansion of the new beam nodes
+            KC(20, __ballot(rb && n_fc == -2) != 0ull ? 1 : 0);
             if (rb && n_fc == -2) { n_fc = afc[n_id]; n_crow2 = acrow[n_id]; }   // a node whose parent re-entered: the arena knows
             rk_sync();
             bool isnew = false, need_group = false;
@@ -1283,6 +1304,7 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int board, hipStrea
         fprintf(stderr, "   inside the run loop: top + carried maxima %lld, prefetch %lld, y rows + syncs %lld, new-time iterations %lld, maxima + score + test %lld, record advance %lld (rest %lld)\n",
                 h[24], h[25], h[26], h[27], h[28], h[29], h[0]);
         fprintf(stderr, "   run loop top before the carried maxima %lld, waiting for the memory queue to drain there %lld\n", h[22], h[23]);
+        fprintf(stderr, "   table builds that ask the arena for a node's children: %lld; window rescans: %lld lanes in %lld calls\n", h[20], h[21], h[10]);
         fprintf(stderr, "   steps in which a child's bound had to be made exact: %lld\n", h[31]);
         fprintf(stderr, "   carried maxima in the run loop: steps with a prefetched entry used %lld, with a value asked for on the spot %lld, with a rescan %lld (longest rescans summed: %lld reads)\n", h[30], h[37], h[38], h[39]);
         fprintf(stderr, "   inside the table build: A fields %lld, B expansion + groups %lld, C + D children / sources %lld, F identity %lld, parent slots %lld (rest: G + end %lld)\n",
