@@ -29,3 +29,24 @@ def test_emulated_kernel_matches_oracle(emu_lib, oracle, kernel, sched):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "0 mismatches" in out.stdout
+
+
+def test_emulated_kernel_hands_a_wide_window_on(emu_lib, oracle):
+    """the fuzz case that faulted the GPU in round 4 (a 311-frame window at W = 1: the packed walk records keep a window
+    length in 8 bits): the register-state kernel must DEFER the pair (beam2d_kernel decodes it), not decode it wrong"""
+    import ctypes as C
+
+    import numpy as np
+    d = np.load(os.path.join(REPO, "tests", "golden", "fuzz_cases", "seed411_pipeline_W1_window311.npz"))
+    y1 = np.ascontiguousarray(d["y1"], dtype=np.float64); y2 = np.ascontiguousarray(d["y2"], dtype=np.float64)
+    env = np.ascontiguousarray(d["env"], dtype=np.int32)
+    assert int((env[:, 1] - env[:, 0]).max()) < 255      # (rows are narrow: the wide window is a COLUMN's)
+    lib = C.CDLL(emu_lib)
+    o1 = np.array([0, len(y1)], dtype=np.int64); o2 = np.array([0, len(y2)], dtype=np.int64)
+    cap = len(y1) + len(y2) + 8
+    seq = np.zeros(cap, dtype=np.uint8); so = np.array([0, cap], dtype=np.int64)
+    sl = np.zeros(1, dtype=np.int32); st = np.zeros(1, dtype=np.int32); upd = np.zeros(2, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), 1, 5, 4, C.c_uint32(int.from_bytes(b"ACGT", "little")),
+                                      int(d["W"]), p(seq), p(so), p(sl), p(st), 1, p(upd), 1)
+    assert deferred == 1 and int(st[0]) == -100
