@@ -338,6 +338,62 @@ def main():
         except FileNotFoundError:
             parity = None
 
+    # ---- strong scaling / end to end: ONE job of P pairs, host float32 logit matrices (the form the .npy files hold)
+    # in -> Python strings out through the pipelined host layer (pack -> H2D -> device ingest -> decode -> D2H, two
+    # slots), this rank's share [slo, shi) on its own device; the clock is the slowest rank's
+    # (This leg runs BEFORE the secondary configurations since round 4: after them — ~ 20 s of other kernels, their host
+    #  lists and device buffers — the same job measured 69 - 71k pairs/s where it reaches 85 - 93k on a fresh process
+    #  (gpurun_out/r04_g38: packing 31 instead of 20 ms, H2D 11 instead of 14 GB/s); what is measured is the pipeline, not the
+    #  state the other legs leave the host in.)
+    strong = None
+    if not args.no_strong:
+        from poreover_amd import batch as pobatch
+        torch.cuda.empty_cache()
+        if rank == 0:
+            l1s = [y1[o1[i]:o1[i + 1]].astype(np.float32) for i in range(slo, shi)]
+            l2s = [y2[o2[i]:o2[i + 1]].astype(np.float32) for i in range(slo, shi)]
+        else:
+            l1s = [q[0].astype(np.float32) for q in strong_pairs]
+            l2s = [q[1].astype(np.float32) for q in strong_pairs]
+            strong_pairs = None
+        ns = len(l1s)
+        wp = args.e2e_wave_pairs
+        nwarm = min(ns, max(256, wp))
+        pobatch.pair_decode_stream(l1s[:nwarm], l2s[:nwarm], "poreover", args.beam_width, "row_col", wave_pairs=wp)   # buffers + first-use costs
+        runs, stt, res = [], {}, None
+        for _ in range(3):   # the MEDIAN of three repetitions is reported, with the spread beside it
+            barrier()
+            t0 = time.perf_counter()
+            res = pobatch.pair_decode_stream(l1s, l2s, "poreover", args.beam_width, "row_col", stats=stt, wave_pairs=wp)
+            dt_local = time.perf_counter() - t0
+            sb = sum(len(r["consensus"] or "") for r in res)
+            dt, (tb,) = podist.job_aggregate(dist, dt_local, [sb], dev)
+            runs.append((dt, tb))
+        runs.sort()
+        best = runs[len(runs) // 2]
+        in_bytes = 4.0 * Cc * (tr1 + tr2) * (1.0 if world == 1 else 1.0)   # float32 logits of the whole job (rank 0's inputs ARE the job)
+        strong = {"pairs": P, "n_gpus": world, "seconds": round(best[0], 4), "pairs_per_s": round(P / best[0], 1),
+                  "repetitions": len(runs), "seconds_min": round(runs[0][0], 4), "seconds_max": round(runs[-1][0], 4),
+                  "pairs_per_s_min": round(P / runs[-1][0], 1), "pairs_per_s_max": round(P / runs[0][0], 1),
+                  "mbases_per_s": round(best[1] / best[0] / 1e6, 3),
+                  "h2d_gbps": round(in_bytes / best[0] / 1e9, 2),
+                  "mode": "one process per GPU (this launch), each rank its 1/N share of the same %d host arrays" % P,
+                  "input": "list of host float32 logit matrices (T x 5), 80 KB per read over PCIe", "output": "Python strings",
+                  "pipeline_rank0": dict(stt)}
+        if world == 1 and args.inprocess_devices:
+            devs = [int(x) for x in args.inprocess_devices.split(",") if x.strip() != ""]
+            pobatch.pair_decode_stream(l1s[:nwarm], l2s[:nwarm], "poreover", args.beam_width, "row_col", wave_pairs=wp, devices=devs)
+            bi, sti = None, {}
+            for _ in range(2):
+                t0 = time.perf_counter()
+                pobatch.pair_decode_stream(l1s, l2s, "poreover", args.beam_width, "row_col", stats=sti, wave_pairs=wp, devices=devs)
+                dt = time.perf_counter() - t0
+                bi = dt if bi is None else min(bi, dt)
+            strong["inprocess"] = {"devices": devs, "seconds": round(bi, 4), "pairs_per_s": round(P / bi, 1),
+                                   "mode": "ONE process, a pipeline and a host thread per device (po_multi_pair_decode)",
+                                   "per_device": sti.get("per_device")}
+        del l1s, l2s, res
+
     sec = {}
     if secondary:
         def timed(fn, reps=3):
@@ -444,62 +500,6 @@ def main():
             del yf1, yf2
         torch.cuda.empty_cache()
 
-    # ---- strong scaling / end to end: ONE job of P pairs, host float32 logit matrices (the form the .npy files hold)
-    # in -> Python strings out through the pipelined host layer (pack -> H2D -> device ingest -> decode -> D2H, two
-    # slots), this rank's share [slo, shi) on its own device; the clock is the slowest rank's
-    strong = None
-    if not args.no_strong:
-        from poreover_amd import batch as pobatch
-        try:
-            del d_ws
-        except NameError:
-            pass
-        torch.cuda.empty_cache()
-        if rank == 0:
-            l1s = [y1[o1[i]:o1[i + 1]].astype(np.float32) for i in range(slo, shi)]
-            l2s = [y2[o2[i]:o2[i + 1]].astype(np.float32) for i in range(slo, shi)]
-        else:
-            l1s = [q[0].astype(np.float32) for q in strong_pairs]
-            l2s = [q[1].astype(np.float32) for q in strong_pairs]
-            strong_pairs = None
-        ns = len(l1s)
-        wp = args.e2e_wave_pairs
-        nwarm = min(ns, max(256, wp))
-        pobatch.pair_decode_stream(l1s[:nwarm], l2s[:nwarm], "poreover", args.beam_width, "row_col", wave_pairs=wp)   # buffers + first-use costs
-        runs, stt, res = [], {}, None
-        for _ in range(3):   # the MEDIAN of three repetitions is reported, with the spread beside it
-            barrier()
-            t0 = time.perf_counter()
-            res = pobatch.pair_decode_stream(l1s, l2s, "poreover", args.beam_width, "row_col", stats=stt, wave_pairs=wp)
-            dt_local = time.perf_counter() - t0
-            sb = sum(len(r["consensus"] or "") for r in res)
-            dt, (tb,) = podist.job_aggregate(dist, dt_local, [sb], dev)
-            runs.append((dt, tb))
-        runs.sort()
-        best = runs[len(runs) // 2]
-        in_bytes = 4.0 * Cc * (tr1 + tr2) * (1.0 if world == 1 else 1.0)   # float32 logits of the whole job (rank 0's inputs ARE the job)
-        strong = {"pairs": P, "n_gpus": world, "seconds": round(best[0], 4), "pairs_per_s": round(P / best[0], 1),
-                  "repetitions": len(runs), "seconds_min": round(runs[0][0], 4), "seconds_max": round(runs[-1][0], 4),
-                  "pairs_per_s_min": round(P / runs[-1][0], 1), "pairs_per_s_max": round(P / runs[0][0], 1),
-                  "mbases_per_s": round(best[1] / best[0] / 1e6, 3),
-                  "h2d_gbps": round(in_bytes / best[0] / 1e9, 2),
-                  "mode": "one process per GPU (this launch), each rank its 1/N share of the same %d host arrays" % P,
-                  "input": "list of host float32 logit matrices (T x 5), 80 KB per read over PCIe", "output": "Python strings",
-                  "pipeline_rank0": dict(stt)}
-        if world == 1 and args.inprocess_devices:
-            devs = [int(x) for x in args.inprocess_devices.split(",") if x.strip() != ""]
-            pobatch.pair_decode_stream(l1s[:nwarm], l2s[:nwarm], "poreover", args.beam_width, "row_col", wave_pairs=wp, devices=devs)
-            bi, sti = None, {}
-            for _ in range(2):
-                t0 = time.perf_counter()
-                pobatch.pair_decode_stream(l1s, l2s, "poreover", args.beam_width, "row_col", stats=sti, wave_pairs=wp, devices=devs)
-                dt = time.perf_counter() - t0
-                bi = dt if bi is None else min(bi, dt)
-            strong["inprocess"] = {"devices": devs, "seconds": round(bi, 4), "pairs_per_s": round(P / bi, 1),
-                                   "mode": "ONE process, a pipeline and a host thread per device (po_multi_pair_decode)",
-                                   "per_device": sti.get("per_device")}
-        del l1s, l2s, res
-
     # whole-job aggregate: max time over ranks, sum of units
     tmax, (tot_pairs, tot_bases) = podist.job_aggregate(dist, elapsed, [P * args.steps, bases * args.steps], dev)
 
@@ -591,7 +591,11 @@ def main():
                                            "independent chains per lane, same table-driven logaddexp); "
                                            "reference_schedule_* counts what the reference's schedule evaluates for this "
                                            "input (every element over its full windows in every step) — the kernel skips "
-                                           "the ones whose result is provably already stored (bit-identical output)"}
+                                           "the ones whose result is provably already stored (bit-identical output).  "
+                                           "beam2d_reg_kernel (round 4) executes about HALF of what round 3's "
+                                           "beam2d_kernel did on the same pairs (3.6e9 against 7.3e9 per 10 000 pairs: "
+                                           "continuing elements compute new times only), so `frac` fell while the kernel "
+                                           "got faster; reference_schedule_frac compares like with like across rounds"}
         if parity is not None:
             out["parity_check"] = parity
         if sec:
