@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         auto t2_off = [&](int row2, int tq) -> unsigned { return (unsigned)(((row2 * 2 + r) * R2 + (tq & Rm2)) << 4); };
         auto t2_entry = [&](int row2, int tq) -> const Ent* { return (const Ent*)(poolb + (size_t)t2_off(row2, tq)); };
         auto tag_of = [&](int node, int tq) -> unsigned long long {   // == make_tag(epoch, node, tq) for 0 <= tq < 2^24
-            const unsigned hi = tag_ep | (((unsigned)node >> 8) & 0xffffu), lo = ((unsigned)node << 24) | ((unsigned)tq & 0xffffffu);
+            const unsigned hi = tag_ep | (((unsigned)node >> 8) & 0xffffu), lo = ((unsigned)node << 24) | (unsigned)tq;   // (0 <= tq < 2^24: the pre-pass)
             return ((unsigned long long)hi << 32) | lo;
         };
         auto t2_read = [&](int row2, int node, int tq) -> double {

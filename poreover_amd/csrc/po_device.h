@@ -109,9 +109,22 @@ struct PoLaeFast {
     // is read off the low word of d * 64/ln2 + 1.5 * 2^52; 2^m is added into the exponent field (m >= -58: no
     // subnormals); the interval of z in [1, 2] is its top six mantissa bits, rounded.  Same result bits as the
     // rint / ldexp formulation on 2e7 random and structured arguments (scripts/check_lae.c).
-    __device__ __forceinline__ double f(double d) const {
+    __device__ __forceinline__ double f(double d0) const {
+#ifdef PO_LAE_BRANCHLESS
+        // every lane computes; the small arguments are CLAMPED instead of tested: below -40, exp(d) < 2^-57 and 1 + e == 1
+        // exactly, and that is as true of exp(-40.5) as of 0 — one v_max_f64 (which also turns d = NaN, from (-inf) - (-inf),
+        // and -inf into -40.5: IEEE maxNum) instead of a compare and two selects; the table index is in range for any argument
+#ifdef PO_EMU
+        const double d = fmax(d0, -40.5);
+#else
+        double d;
+        asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(d0), "s"(-40.5));
+#endif
+#else
+        const double d = d0;
+#endif
         double e = 0.0;
-#ifdef PO_LAE_BRANCHLESS   // (every lane computes, the small arguments are selected away below: no exec-mask branch in a lone wave's chain)
+#ifdef PO_LAE_BRANCHLESS
         {
 #else
         if (d > -40.0) {  // below: exp(d) < 2^-57, 1 + e == 1
@@ -139,9 +152,6 @@ struct PoLaeFast {
 #endif
             const double x = th + __builtin_fma(th, p, tl);
             e = __hiloint2double(__double2hiint(x) + ((k >> 6) << 20), __double2loint(x));
-#ifdef PO_LAE_BRANCHLESS
-            e = (d > -40.0) ? e : 0.0;   // (also d = NaN and -inf, whose e above is garbage; the table index j is in range for any k)
-#endif
         }
         const double z = 1.0 + e;
         const unsigned i = ((unsigned)__double2hiint(z) - 0x3FF00000u + 0x2000u) >> 14;
