@@ -261,8 +261,6 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    d_upd = torch.zeros(2, dtype=torch.int64, device=dev)   # update_prob evaluations: reference schedule, executed
-    lib.po_profile_update_counter(d_upd.data_ptr())
     lib.po_profile_enable(1)
     lib.po_profile_reset()
     t0 = time.perf_counter()
@@ -271,8 +269,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     lib.po_profile_enable(0)
+    # update_prob evaluations (reference schedule, executed) of ONE more step, outside the timed region: with the counter
+    # attached the kernels count per step (ballots, a wave reduction per scan) — diagnostics the product path does not run
+    d_upd = torch.zeros(2, dtype=torch.int64, device=dev)
+    lib.po_profile_update_counter(d_upd.data_ptr())
+    step()
+    barrier()
     lib.po_profile_update_counter(None)
-    n_upd, n_upd_exec = (int(x) for x in d_upd.cpu().tolist())
+    n_upd, n_upd_exec = (int(x) * args.steps for x in d_upd.cpu().tolist())   # (every step decodes the same pairs)
 
     def _kernel_ms(k):
         ms, cnt = C.c_double(), C.c_int64()

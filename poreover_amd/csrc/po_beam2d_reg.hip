@@ -99,7 +99,9 @@ __device__ __forceinline__ double rk_readlane_d(double x, int l) {
 #ifndef PO_REG_WAVES
 #define PO_REG_WAVES 4
 #endif
-template <int NPW>
+// COUNT: the instantiation po_profile_update_counter asks for (update_prob evaluations of the reference's schedule and executed
+// ones, added up per step: ballots, a wave reduction per scan); the product path carries none of it.
+template <int NPW, bool COUNT = false>
 __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void beam2d_reg_kernel(X2Args a) {
     using Ent = Entry<1>;
     __shared__ RegGroup<NPW> gsm;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 smx = part ? mx : PO_NEG_INF;
             }
             KT(is_main ? 4 : 5); KC(is_main ? 16 : 17, 1); KC(18, niter);
-            if (a.upd_count != nullptr) {
+            if constexpr (COUNT) {
                 const int lenx = part2 ? we - start : 0;
                 int tot = lenx;
 #pragma unroll
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 v_mx = mx; v_mt = mt; v_td = max(ws, tr);
             }
             KT(2);
-            if (a.upd_count != nullptr) {
+            if constexpr (COUNT) {
                 int tot = fresh ? n1 : 0;
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
@@ -1053,7 +1055,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
                     if (live) { v_mx = mx; v_mt = mt; v_td = max(td, tr); }
                     smx = live ? mx : PO_NEG_INF;
-                    if (a.upd_count != nullptr) {
+                    if constexpr (COUNT) {
                         cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
                         cnt_x += (unsigned)(__popcll(__ballot(live && r == 0)) * (ce - d0) + __popcll(__ballot(live && r == 1)) * (re - d1));
                     }
@@ -1111,7 +1113,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             {
                 const int nbe = min(W, nb);
                 const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
-                if (a.upd_count != nullptr) cnt_ref += (unsigned)((max(u - up - 1, 0) + max(v - vp - 1, 0)) * nbe);
+                if constexpr (COUNT) cnt_ref += (unsigned)((max(u - up - 1, 0) + max(v - vp - 1, 0)) * nbe);
                 if (u - 1 >= max(up + 1, d0)) { scan(false, up + 1, u, 0, 0, nbe); tbl_uneven = true; }
                 if (v - 1 >= max(vp + 1, d1)) { scan(false, 0, 0, vp + 1, v, nbe); tbl_uneven = true; }
             }
@@ -1129,7 +1131,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
 #endif
             scan(true, u, ce, v, re, 32);
             tbl_fresh = false; tbl_uneven = false;
-            if (a.upd_count != nullptr) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
+            if constexpr (COUNT) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
             // node_greater_max_sym: max over read 0's window + max over read 1's
             sc = smx + po_xor32(smx, r != 0);
 #ifdef PO_RING_TRACE   // debugging builds only: every candidate's score before the prune
@@ -1229,7 +1231,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             a.seq_len[pi] = nout;
             a.status[pi] = st;
         }
-        if (a.upd_count != nullptr && lane == 0) { sm.nupd += cnt_ref; sm.nupd_x += cnt_x; }
+        if (COUNT && lane == 0) { sm.nupd += cnt_ref; sm.nupd_x += cnt_x; }
         rk_sync();
         KT(9);
     }
@@ -1241,7 +1243,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         unsigned long long* stp = a.wgstate + 2 * (size_t)slotid;
         stp[0] = a.magic ^ (unsigned long long)slotid;
         stp[1] = (unsigned long long)epoch;
-        if (a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
+        if (COUNT && a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
         if (NPW > 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); atomicAdd(&gsm.exited, 1); }
     }
 }
@@ -1258,11 +1260,11 @@ extern "C" int po_reg_slots_per_cu(int board) {
     return per_cu.get(board ? 1 : 0, [board] {
         int nblk = 0;
         if (board) {
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel<RK_BOARD_NPW>, 64 * (RK_BOARD_NPW + 1), 0) != hipSuccess || nblk <= 0) nblk = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel<RK_BOARD_NPW, true>, 64 * (RK_BOARD_NPW + 1), 0) != hipSuccess || nblk <= 0) nblk = 2;
             if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_reg_kernel<%d> (job board): %d resident workgroups per CU, %zu B of LDS\n", RK_BOARD_NPW, nblk, sizeof(RegGroup<RK_BOARD_NPW>));
             return nblk * RK_BOARD_NPW;
         }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel<1>, 64, 0) != hipSuccess || nblk <= 0) nblk = 16;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel<1, false>, 64, 0) != hipSuccess || nblk <= 0) nblk = 16;
         if (const char* e = getenv("PO_REG_PER_CU")) { const int v = atoi(e); if (v > 0 && v < nblk) nblk = v; }
         if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_reg_kernel: %d resident workgroups per CU, %zu B of LDS\n", nblk, sizeof(RegGroup<1>));
         return nblk;
@@ -1285,9 +1287,10 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int board, hipStrea
 #endif
     if (board) {
         const int wgs = (slots + RK_BOARD_NPW - 1) / RK_BOARD_NPW;
-        hipLaunchKernelGGL(beam2d_reg_kernel<RK_BOARD_NPW>, dim3(wgs), dim3(64 * (RK_BOARD_NPW + 1)), 0, stream, a);
+        hipLaunchKernelGGL((beam2d_reg_kernel<RK_BOARD_NPW, true>), dim3(wgs), dim3(64 * (RK_BOARD_NPW + 1)), 0, stream, a);
     } else {
-        hipLaunchKernelGGL(beam2d_reg_kernel<1>, dim3(slots), dim3(64), 0, stream, a);
+        if (a.upd_count != nullptr) hipLaunchKernelGGL((beam2d_reg_kernel<1, true>), dim3(slots), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((beam2d_reg_kernel<1, false>), dim3(slots), dim3(64), 0, stream, a);
     }
 #ifdef PO_REG_TIMING
     {
