@@ -90,6 +90,25 @@ struct RegGroup {
 };
 
 __device__ __forceinline__ void rk_sync() { b2_sync_lds<64>(); }
+// the smallest of x over lanes 0 .. n - 1 (n <= 16: the beam slots sit in row 0 of the wave), wave-uniform: four row_shr steps
+// in the VALU and one pair of v_readlane instead of 2 n v_readlane and n - 1 minima
+__device__ __forceinline__ double rk_row0_min(double x, int n, int lane) {
+#ifdef PO_EMU
+    double m_ = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 0), __builtin_amdgcn_readlane(__double2loint(x), 0));
+    for (int i = 1; i < n; ++i)
+        m_ = fmin(m_, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), i), __builtin_amdgcn_readlane(__double2loint(x), i)));
+    (void)lane;
+    return m_;
+#else
+    x = (lane < n) ? x : __builtin_inf();
+#define RK_STEP(ctrl)                                                                                                     \
+    x = po_vmin(x, __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), ctrl, 0xf, 0xf, false), \
+                                    __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), ctrl, 0xf, 0xf, false)))
+    RK_STEP(0x111); RK_STEP(0x112); RK_STEP(0x114); RK_STEP(0x118);
+#undef RK_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 15), __builtin_amdgcn_readlane(__double2loint(x), 15));
+#endif
+}
 __device__ __forceinline__ double rk_readlane_d(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
@@ -259,10 +278,10 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         pi = __builtin_amdgcn_readfirstlane(pi);
         if (pi >= a.n) break;
         epoch++;
-        if ((epoch & 0xffffu) == 0) { clear_slice(); epoch++; }
+        if (__builtin_expect((epoch & 0xffffu) == 0, 0)) { clear_slice(); epoch++; }
         const int2 m = a.meta[pi];
-        if (m.y == X2_DEFERRED) continue;                 // beam2d_kernel decodes it after this kernel
-        if (m.x != PO_OK || m.y < 0) {                    // refused by the pre-pass, or skipped upstream
+        if (__builtin_expect(m.y == X2_DEFERRED, 0)) continue;                 // beam2d_kernel decodes it after this kernel
+        if (__builtin_expect(m.x != PO_OK || m.y < 0, 0)) {                    // refused by the pre-pass, or skipped upstream
             if (lane == 0) {
                 a.seq_len[pi] = 0;
                 if (m.y >= 0) a.status[pi] = m.x;
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         const int4* const sched = a.sched + (o2 - a.y2_off[0]);
         const int nmain = a.nmain[pi];
         const int R2 = m.y, Rm2 = R2 - 1;
-        if (R2 > 256) {   // windows of 255 frames and more: the packed walk records below keep a window's length in 8 bits
+        if (__builtin_expect(R2 > 256, 0)) {   // windows of 255 frames and more: the packed walk records below keep a window's length in 8 bits
             if (lane == 0) { a.meta[pi] = make_int2(PO_OK, X2_DEFERRED); a.queue[16] = 1; }
             continue;
         }
@@ -587,7 +606,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 return false;
             }
 #endif
-            if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re)) return false;
+            if (__builtin_expect(!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re), 0)) return false;
             const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
             const bool fresh = live && v_fresh != 0;
             const bool cont = live && v_fresh == 0;
@@ -602,7 +621,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 return false;
             }
 #else
-            if (__ballot(bad || (fresh && pfresh)) != 0ull) return false;
+            if (__builtin_expect(__ballot(bad || (fresh && pfresh)) != 0ull, 0)) return false;
 #endif
             // ---- the parents to stage (beam slots with fresh children): at most RK_PS
             int pj[RK_PS], nps = 0;
@@ -621,7 +640,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             if (many && lane == 0) printf("WHY many\n");
 #endif
             const int n1 = dr - ws;   // (half-uniform, >= 0): times the fresh lanes compute before everybody else starts
-            if (many) return false;
+            if (__builtin_expect(many, 0)) return false;
             int myk = 0;
 #pragma unroll
             for (int k = 1; k < RK_PS; ++k) myk = (e_ps == pj[k] && pj[k] >= 0) ? k : myk;
@@ -669,7 +688,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
                     if (k < nps && i < n1) sm.pst[r][k * RK_NY + s] = (tq >= 0 && e01[k].tag == tag_of(pid01[k], tq)) ? e01[k].v[0] : PO_NEG_INF;
-                for (int k = 2; k < nps; ++k) {   // (wave-uniform; three and more parents: rare)
+                for (int k = 2; __builtin_expect(k < nps, 0); ++k) {   // (wave-uniform; three and more parents: rare)
                     int jk = pj[0];
 #pragma unroll
                     for (int q = 1; q < RK_PS; ++q) jk = (k == q) ? pj[q] : jk;
@@ -793,7 +812,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             if (live && v_fresh == 0) atomicMax(&g_hi[e_row2 >> 2], v_done);
             // ---- B. expansion of the new beam nodes
             KC(20, __ballot(rb && n_fc == -2) != 0ull ? 1 : 0);
-            if (rb && n_fc == -2) { n_fc = afc[n_id]; n_crow2 = acrow[n_id]; }   // a node whose parent re-entered: the arena knows
+            if (__builtin_expect(rb && n_fc == -2, 0)) { n_fc = afc[n_id]; n_crow2 = acrow[n_id]; }   // a node whose parent re-entered: the arena knows
             rk_sync();
             bool isnew = false, need_group = false;
             if (rb) {
@@ -921,7 +940,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             // times rewrites nothing.)
             {
                 bool rew = rb && nlive && src >= 0 && op == PS_FROZEN && n_ps >= 0;
-                if (__ballot(rew) != 0ull) {
+                if (__builtin_expect(__ballot(rew) != 0ull, 0)) {
                     for (int it = 0; it < W; ++it) {   // ... and their descendants in the table, generation by generation
                         const bool prew = __shfl((int)rew, hb | max(e_ps, 0)) != 0;
                         if (live && e_ps >= 0 && prew) rew = true;
@@ -954,7 +973,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             // windows (often none on a read: the envelope's window ends move a base at a time) in lockstep, the window maxima
             // from what is carried, the score, the one comparison per child.  The run ends at the first step that is not of
             // this kind (it is then done below) or that changes the beam (it is ranked below).
-            if (!tbl_fresh && !tbl_uneven && nb == W && __ballot(live && e_ps == PS_ROOT) == 0ull) {
+            if (__builtin_expect(!tbl_fresh && !tbl_uneven && nb == W && __ballot(live && e_ps == PS_ROOT) == 0ull, 1)) {
                 const int sym = sym_last(e_sym);
                 const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
                 const double* const yb_ = &sm.ybuf[r][0][0];
@@ -974,7 +993,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     const int ws = r ? v : u, we = r ? re : ce, dr = r ? d1 : d0;
                     const bool part2 = live && dr < we;
                     // (a frozen parent's older values would have to come from the store: only asked when there are new times)
-                    if ((ce > d0 || re > d1) && __ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull) break;
+                    if (__builtin_expect((ce > d0 || re > d1) && __ballot(part2 && e_ps == PS_FROZEN && dr - 1 < fz_t) != 0ull, 0)) break;
                     // ---- the carried part [ws, dr) of the window: its maximum is what the previous step left while that time
                     // is inside the window; else the stored values are looked at (the one most steps need — a decaying
                     // element's value at the window start — was requested a step ago: pf)
@@ -1018,11 +1037,15 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     // ---- the new times [dr, we), everybody in lockstep: the parent's previous value comes from its lane
                     const int n2 = we - dr;   // (half-uniform, >= 0)
                     const int n2max = max(ce - d0, re - d1);
+                    // (a frozen parent's captured value can only be asked for by the first new time — the test above — : one select
+                    //  per iteration instead of two compares and two)
+                    const bool fzl = e_ps < 0;
+                    double pp_fz = (fzl && dr - 1 == fz_t) ? fz_val : PO_NEG_INF;
                     for (int k0 = 0; k0 < n2max; k0 += RK_NY) {   // (blocks of RK_NY times: the y rows are loaded between the loops)
                         {
                             const int lo = dr + k0, hi = min(lo + RK_NY, we);
                             rk_sync();
-                            if (hi > lo && !(lo >= yhi - RK_NY && hi <= yhi)) { y_reload(lo); yhi = lo + RK_NY; }
+                            if (__builtin_expect(hi > lo && !(lo >= yhi - RK_NY && hi <= yhi), 0)) { y_reload(lo); yhi = lo + RK_NY; }
                             rk_sync();
                         }
                         KT2(26);
@@ -1033,9 +1056,8 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                             if (live && k < n2) {
                                 const double* yrow = yb_ + (t & (RK_NY - 1)) * RK_YC;
                                 const double ya = yrow[sym], yb = yrow[A];
-                                const int tm = t - 1;
-                                double pp = ps_self;
-                                if (e_ps < 0) pp = (tm == fz_t) ? fz_val : PO_NEG_INF;
+                                const double pp = fzl ? pp_fz : ps_self;
+                                pp_fz = PO_NEG_INF;
                                 const double out = lae(pp + ya, self + yb);
 #ifdef PO_RING_TRACE_NODE
                                 if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g RUN ps %d fzt %d\n", e_id, r, t, out, pp, self, e_ps, fz_t);
@@ -1060,13 +1082,12 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                         cnt_x += (unsigned)(__popcll(__ballot(live && r == 0)) * (ce - d0) + __popcll(__ballot(live && r == 1)) * (re - d1));
                     }
                     sc = smx + po_xor32(smx, r != 0);
-                    double scmin = rk_readlane_d(sc, 0);
-                    for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rk_readlane_d(sc, i));
+                    const double scmin = rk_row0_min(sc, nb, lane);
                     viol = live && child && !(scmin > sc);
                     // a child that reaches the smallest beam score on a bound: its exact maximum now (the stored values are
                     // looked at), then the score and the test again — the decision is the one exact maxima give
                     const bool hot = viol && bnd && !(nmx >= cmx);
-                    if (__ballot(hot) != 0ull) {
+                    if (__builtin_expect(__ballot(hot) != 0ull, 0)) {
                         double cx = PO_NEG_INF;
                         int ct = -1, td2 = td;
                         const bool rs2 = hot && carried_one(ws, cx, ct, td2, pf_t, pf_val);
@@ -1086,7 +1107,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                     KT2(28);
                     up = u; vp = v;
                     mstep++;
-                    if ((mstep & 63) == 0) {
+                    if (__builtin_expect((mstep & 63) == 0, 0)) {
                         rcur = rnxt;
                         rnxt = rec_load(mstep + 64 + lane);
                     }
@@ -1114,12 +1135,12 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 const int nbe = min(W, nb);
                 const int d0 = __builtin_amdgcn_readlane(v_done, 0), d1 = __builtin_amdgcn_readlane(v_done, 32);
                 if constexpr (COUNT) cnt_ref += (unsigned)((max(u - up - 1, 0) + max(v - vp - 1, 0)) * nbe);
-                if (u - 1 >= max(up + 1, d0)) { scan(false, up + 1, u, 0, 0, nbe); tbl_uneven = true; }
-                if (v - 1 >= max(vp + 1, d1)) { scan(false, 0, 0, vp + 1, v, nbe); tbl_uneven = true; }
+                if (__builtin_expect(u - 1 >= max(up + 1, d0), 0)) { scan(false, up + 1, u, 0, 0, nbe); tbl_uneven = true; }
+                if (__builtin_expect(v - 1 >= max(vp + 1, d1), 0)) { scan(false, 0, 0, vp + 1, v, nbe); tbl_uneven = true; }
             }
             // ---- MAIN step at (u, v): windows [u, ce) x [v, re)  (:342-375)
             // (new elements first: their windows up to where everybody else stands — then the step is an ordinary one)
-            if (tbl_fresh && !tbl_uneven && scan_new(u, ce, v, re)) {
+            if (__builtin_expect(tbl_fresh && !tbl_uneven && scan_new(u, ce, v, re), 1)) {
 #ifdef PO_EMU_DEBUG
                 if (lane == 0) printf("STEP new\n");
 #endif
@@ -1150,7 +1171,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             }
             up = u; vp = v;
             mstep++;
-            if ((mstep & 63) == 0) {   // the next batch becomes the current one, the one after it is requested
+            if (__builtin_expect((mstep & 63) == 0, 0)) {   // the next batch becomes the current one, the one after it is requested
                 rcur = rnxt;
                 rnxt = rec_load(mstep + 64 + lane);
             }
@@ -1186,7 +1207,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 const unsigned long long bj = __ballot(cand && r == 0 && rank == jx);
                 sel[jx] = (bj != 0ull) ? (int)__builtin_ctzll(bj) : 0;
             }
-            if (__ballot(cand && neq > 1 && rank < W) != 0ull) {
+            if (__builtin_expect(__ballot(cand && neq > 1 && rank < W) != 0ull, 0)) {
                 // exact ties reaching into the beam: what libstdc++'s partial_sort / sort leave on the candidates in
                 // creation order (po_device.h), replayed by one lane
                 int pos = 0;   // (the replay runs over ALL candidates in creation order)
