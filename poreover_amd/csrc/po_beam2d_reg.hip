@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                         cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
                         cnt_x += (unsigned)(__popcll(__ballot(live && r == 0)) * (ce - d0) + __popcll(__ballot(live && r == 1)) * (re - d1));
                     }
-                    sc = smx + po_xor32(smx, r != 0);
+                    sc = po_sum32(smx);
                     const double scmin = rk_row0_min(sc, nb, lane);
                     viol = live && child && !(scmin > sc);
                     // a child that reaches the smallest beam score on a bound: its exact maximum now (the stored values are
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                             v_mx = keep ? nmx : cx; v_mt = keep ? nmt : ct; v_td = max(td2, tr);
                             smx = v_mx;
                         }
-                        sc = smx + po_xor32(smx, r != 0);
+                        sc = po_sum32(smx);
                         viol = live && child && !(scmin > sc);
                         KC(31, 1);
                     }
@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             tbl_fresh = false; tbl_uneven = false;
             if constexpr (COUNT) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
             // node_greater_max_sym: max over read 0's window + max over read 1's
-            sc = smx + po_xor32(smx, r != 0);
+            sc = po_sum32(smx);
 #ifdef PO_RING_TRACE   // debugging builds only: every candidate's score before the prune
             if (pi == 0 && live && r == 0) printf("T %d %d %d %.17g\n", u, v, e_id, sc);
 #endif
@@ -1165,8 +1165,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             // the set changes ranks everybody — and for the label: the last main step is always ranked.
             viol = (nb != W) || (mstep + 1 == nmain);
             if (!viol) {   // (wave-uniform: nb == W and not the last step)
-                double scmin = rk_readlane_d(sc, 0);
-                for (int i = 1; i < nb; ++i) scmin = fmin(scmin, rk_readlane_d(sc, i));
+                const double scmin = rk_row0_min(sc, nb, lane);
                 if (live && s >= nb) viol = !(scmin > sc);
             }
             up = u; vp = v;
@@ -1188,8 +1187,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             // are taken within it (a handful of candidates instead of W * (A + 1)).
             unsigned smask = cm;
             if (nb == W) {
-                double thr = rk_readlane_d(sc, 0);
-                for (int i = 1; i < nb; ++i) thr = fmin(thr, rk_readlane_d(sc, i));
+                const double thr = rk_row0_min(sc, nb, lane);
                 smask = (unsigned)__ballot(cand && r == 0 && (s < nb || sc >= thr));
             }
             int rank = 0, neq = 0;

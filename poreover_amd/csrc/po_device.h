@@ -242,6 +242,17 @@ __device__ __forceinline__ int po_xor32_i(int x, bool upper) {
     return (int)(upper ? r[0] : r[1]);
 #endif
 }
+// x + (x of lane ^ 32): after swapping the upper half of one copy with the lower half of another, every lane holds its own
+// value in one of the two and the other half's in the other — their sum needs no select (a + b == b + a bit for bit)
+__device__ __forceinline__ double po_sum32(double x) {
+#ifdef PO_EMU
+    return x + __shfl_xor(x, 32);
+#else
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+#endif
+}
 __device__ __forceinline__ double po_xor32(double x, bool upper) {   // upper: this lane is one of 32..63
     return __hiloint2double(po_xor32_i(__double2hiint(x), upper), po_xor32_i(__double2loint(x), upper));
 }
