@@ -34,6 +34,7 @@
 #include <climits>
 
 #define PO_LAE_EARLY_TABLE 1   // (po_device.h: the exp table entry is requested before the polynomial — a lone wave's chain is latency)
+#define PO_LAE_TRIM 1          // (... two instructions fewer: -|x1 - x2| through source modifiers, the exponent add in two)
 #define PO_LAE_BRANCHLESS 1    // (... and exp's small-argument test is a select, not a branch: 10 000 pairs 68.3 -> 67.0 ms)
 #include "po_beam2d_common.h"
 #include "po_host.h"
@@ -80,8 +81,8 @@ struct RegRes { double self, mx; int mt, tr; };
 union RegSlot { RegJob j; RegRes r; };
 template <int NPW>
 struct RegGroup {
+    PoLaeTables lae;   // (first: at LDS address 0 the tables' offsets fit the immediate fields of ds_read2_b64 — one address per entry)
     RegSmem w[NPW];
-    PoLaeTables lae;
     RegSlot slot[NPW > 1 ? NPW : 1][NPW > 1 ? RK_JOBS : 1];
     unsigned posted[8], taken[8], done[8];   // running totals per pair wave: chains posted / picked up / finished
     int pc_rm2[8];                           // per pair wave, for the pair it decodes: store ring mask ...

@@ -109,8 +109,17 @@ struct PoLaeFast {
     // is read off the low word of d * 64/ln2 + 1.5 * 2^52; 2^m is added into the exponent field (m >= -58: no
     // subnormals); the interval of z in [1, 2] is its top six mantissa bits, rounded.  Same result bits as the
     // rint / ldexp formulation on 2e7 random and structured arguments (scripts/check_lae.c).
+    // (PO_LAE_TRIM, with PO_LAE_BRANCHLESS: d0 is x1 - x2 with either sign and the clamp takes -|d0| as its operand — the
+    //  source modifiers are free, and lo - hi == -|x1 - x2| bit for bit: a - b and b - a round to exact negatives)
     __device__ __forceinline__ double f(double d0) const {
-#ifdef PO_LAE_BRANCHLESS
+#if defined(PO_LAE_BRANCHLESS) && defined(PO_LAE_TRIM)
+#ifdef PO_EMU
+        const double d = fmax(-fabs(d0), -40.5);
+#else
+        double d;
+        asm("v_max_f64 %0, -|%1|, %2" : "=v"(d) : "v"(d0), "s"(-40.5));
+#endif
+#elif defined(PO_LAE_BRANCHLESS)
         // every lane computes; the small arguments are CLAMPED instead of tested: below -40, exp(d) < 2^-57 and 1 + e == 1
         // exactly, and that is as true of exp(-40.5) as of 0 — one v_max_f64 (which also turns d = NaN, from (-inf) - (-inf),
         // and -inf into -40.5: IEEE maxNum) instead of a compare and two selects; the table index is in range for any argument
@@ -151,7 +160,19 @@ struct PoLaeFast {
             const double th = t->exp_t[j][0], tl = t->exp_t[j][1];
 #endif
             const double x = th + __builtin_fma(th, p, tl);
+#ifdef PO_LAE_TRIM   // (the same integer, mod 2^32, in two instructions instead of three: v_and, v_lshl_add)
+#ifdef PO_EMU
+            e = __hiloint2double(__double2hiint(x) + (int)((unsigned)(k & ~63) << 14), __double2loint(x));
+#else
+            {
+                int xh;   // (written out: the compiler turns the expression back into shift, mask and add)
+                asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(xh) : "v"(k & ~63), "v"(__double2hiint(x)));
+                e = __hiloint2double(xh, __double2loint(x));
+            }
+#endif
+#else
             e = __hiloint2double(__double2hiint(x) + ((k >> 6) << 20), __double2loint(x));
+#endif
         }
         const double z = 1.0 + e;
         const unsigned i = ((unsigned)__double2hiint(z) - 0x3FF00000u + 0x2000u) >> 14;
@@ -168,8 +189,13 @@ struct PoLaeFast {
         return lh + (w + u);
     }
     __device__ __forceinline__ double operator()(double x1, double x2) const {
+#if defined(PO_LAE_BRANCHLESS) && defined(PO_LAE_TRIM)
+        const double hi = po_vmax(x1, x2);
+        return hi + f(x1 - x2);
+#else
         const double hi = po_vmax(x1, x2), lo = po_vmin(x1, x2);
         return hi + f(lo - hi);
+#endif
     }
 };
 
