@@ -47,7 +47,7 @@ constexpr int RK_YC = 5;      // doubles per y row (A + 1 <= 5)
 #define PO_REG_NGL 96
 #endif
 #ifndef PO_REG_PS
-#define PO_REG_PS 6
+#define PO_REG_PS 4
 #endif
 constexpr int RK_NGL = PO_REG_NGL;    // row groups tracked per pair
 constexpr int RK_PS = PO_REG_PS;      // parents whose stored window one step can stage for its new elements (W <= 6)
@@ -58,6 +58,9 @@ struct RegSmem {              // per pair wave
     double ybuf[2][RK_NY][RK_YC];
     double pst[2][RK_PCAP];
     int g_owner[RK_NGL], g_hi0[RK_NGL], g_hi1[RK_NGL];
+    // the table fields only the table build (and the rare general scan) looks at, per element slot — the same in both halves of
+    // the wave: in LDS they cost no register between two table builds (seven VGPRs of 128, in a kernel that spills)
+    int f_fc[32], f_crow2[32], f_par[32], f_gpar[32], f_prow2[32], f_depth[32], f_alias[32];
     int ord[32];              // prune with exact score ties: candidate slots in node-id order (po_stl_prune)
     double csc[32];           // ... and their scores
     int sh[8];
@@ -332,8 +335,12 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         };
         // ---------------------------------------------------------------- per-lane element state (slot s, read r)
         // table fields (the same in both halves of the wave)
-        int e_id = 0, e_row2 = -1, e_sym = 0, e_fc = -1, e_crow2 = -1, e_par = 0, e_gpar = -1, e_prow2 = -1,
-            e_depth = 0, e_ps = PS_ROOT, e_alias = -1;
+        int e_id = 0, e_row2 = -1, e_sym = 0, e_ps = PS_ROOT;   // (first child, children's row group, parent, grandparent, the
+                                                                  //  parent's row, depth, alias: sm.f_*)
+        if (r == 0) {
+            sm.f_fc[s] = -1; sm.f_crow2[s] = -1; sm.f_par[s] = 0; sm.f_gpar[s] = -1; sm.f_prow2[s] = -1;
+            sm.f_depth[s] = (s < A) ? 1 : 0; sm.f_alias[s] = -1;
+        }
         bool live = false;
         // values of this read: computed and stored up to v_done (exclusive); v_fresh: 1 = an element again, its last
         // value is in the store; 2 = a node that never computed
@@ -363,8 +370,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
         }
         if (s < A) {
             if (r == 0) { apl[1 + s] = po_pack_node(0, s); afc[1 + s] = -1; acrow[1 + s] = -1; }
-            e_id = 1 + s; e_row2 = s; e_sym = sym_pack(s, A, true); e_fc = -1; e_crow2 = -1;
-            e_par = 0; e_gpar = -1; e_prow2 = -1; e_depth = 1; e_ps = PS_ROOT; e_alias = -1;
+            e_id = 1 + s; e_row2 = s; e_sym = sym_pack(s, A, true); e_ps = PS_ROOT;
             live = true;
             const double* const yr = yr_();
             const double out = lae(0.0 + yr[s], PO_NEG_INF + yr[A]);   // update_prob(n, r, 0): parent = root at t = -1
@@ -549,14 +555,14 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                         double pp;
                         if (e_ps >= 0) {
                             if (tm >= p_start - 1 && tm < p_we && p_start != INT_MAX) pp = ps_self;
-                            else pp = t2_read(e_prow2, e_par, tm);
+                            else pp = t2_read(sm.f_prow2[s], sm.f_par[s], tm);
                         } else if (e_ps == PS_ROOT) {
                             pp = 0.0;
                             if (tm >= 0) { pp = sm.rootcum[r]; bad_root = bad_root || (tm != sm.rootT[r]); }
                         } else if (tm >= fz_t) {
                             pp = (tm == fz_t) ? fz_val : PO_NEG_INF;                                 // frozen parent: its last value, then nothing
                         } else {
-                            pp = t2_read(e_prow2, e_par, tm);
+                            pp = t2_read(sm.f_prow2[s], sm.f_par[s], tm);
                         }
                         const double out = lae(pp + ya, self + yb);
 #ifdef PO_RING_TRACE_NODE
@@ -806,8 +812,8 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             for (int i = 1; i < 6; ++i) pj = (j == i) ? sel[i] : pj;
             const int srcb = rb ? mysel : 0;
             int n_id = __shfl(e_id, hb | srcb), n_row2 = __shfl(e_row2, hb | srcb), n_sym = __shfl(e_sym, hb | srcb);
-            int n_fc = __shfl(e_fc, hb | srcb), n_crow2 = __shfl(e_crow2, hb | srcb), n_par = __shfl(e_par, hb | srcb);
-            int n_gpar = __shfl(e_gpar, hb | srcb), n_prow2 = __shfl(e_prow2, hb | srcb), n_depth = __shfl(e_depth, hb | srcb);
+            int n_fc = sm.f_fc[srcb], n_crow2 = sm.f_crow2[srcb], n_par = sm.f_par[srcb];
+            int n_gpar = sm.f_gpar[srcb], n_prow2 = sm.f_prow2[srcb], n_depth = sm.f_depth[srcb];
             KT2(32);
             // ---- every old element marks its row group with the times it has written there
             if (live && v_fresh == 0) atomicMax(&g_hi[e_row2 >> 2], v_done);
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 }
             }
             {   // (an old child slot that was an alias hands over to the beam slot that held the node)
-                const int oa = __shfl(e_alias, hb | max(src, 0));
+                const int oa = sm.f_alias[max(src, 0)];
                 if (!rb && src >= nbo && oa >= 0) src = oa;
             }
             const bool nlive = (rb || (rc && n_alias < 0));
@@ -888,7 +894,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             const int gsrc = hb | max(src, 0);
             const int g_done = __shfl(v_done, gsrc), g_fresh = __shfl(v_fresh, gsrc), g_mt = __shfl(v_mt, gsrc), g_td = __shfl(v_td, gsrc);
             const double g_self = __shfl(v_self, gsrc), g_mx = __shfl(v_mx, gsrc);
-            const int g_fc = __shfl(e_fc, gsrc), g_crow2 = __shfl(e_crow2, gsrc);
+            const int g_fc = sm.f_fc[max(src, 0)], g_crow2 = sm.f_crow2[max(src, 0)];
             // the last value of the node's parent as the old table knew it: of the parent's lane if it was an element,
             // else what was captured when it stopped being one
             double c_val;
@@ -903,10 +909,13 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
                 c_val = (op >= 0) ? o_last : q_val;
                 c_t = (op >= 0) ? ((o_fresh == 0) ? o_done - 1 : INT_MAX) : q_t;
             }
-            e_id = n_id; e_row2 = n_row2; e_sym = n_sym; e_par = n_par; e_gpar = n_gpar; e_prow2 = n_prow2; e_depth = n_depth;
-            e_alias = rc ? n_alias : -1;
-            e_fc = n_fc; e_crow2 = n_crow2;
-            if (rc && src >= 0) { e_fc = g_fc; e_crow2 = g_crow2; }   // a continuing child keeps what is known about its own children
+            e_id = n_id; e_row2 = n_row2; e_sym = n_sym;
+            if (rc && src >= 0) { n_fc = g_fc; n_crow2 = g_crow2; }   // a continuing child keeps what is known about its own children
+            rk_sync();   // (every lane has read the old table's fields)
+            if (r == 0) {
+                sm.f_fc[s] = n_fc; sm.f_crow2[s] = n_crow2; sm.f_par[s] = n_par; sm.f_gpar[s] = n_gpar; sm.f_prow2[s] = n_prow2;
+                sm.f_depth[s] = n_depth; sm.f_alias[s] = rc ? n_alias : -1;
+            }
             live = nlive;
             fz_val = c_val; fz_t = (nlive && src >= 0) ? c_t : INT_MAX;
             if (nlive && src >= 0) {
@@ -919,15 +928,15 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             // ---- the parent slot of the beam nodes: a beam node, a child of a beam node, the root, or none (frozen)
             nb = nbn; ne = nen;
             {   // (wave-uniform loops: v_readlane)
-                if (rb) n_ps = (e_par == 0) ? PS_ROOT : PS_FROZEN;
+                if (rb) n_ps = (n_par == 0) ? PS_ROOT : PS_FROZEN;
                 for (int i = 0; i < nbn; ++i) {
                     const int bid = __builtin_amdgcn_readlane(e_id, i);
-                    if (rb && e_par != 0 && bid == e_par) n_ps = i;
+                    if (rb && n_par != 0 && bid == n_par) n_ps = i;
                 }
                 const bool fz = rb && n_ps == PS_FROZEN;
                 for (int i = 0; i < nbn; ++i) {
                     const int bid = __builtin_amdgcn_readlane(e_id, i);
-                    if (fz && bid == e_gpar) n_ps = nbn + A * i + sym_plast(e_sym);
+                    if (fz && bid == n_gpar) n_ps = nbn + A * i + sym_plast(e_sym);
                 }
             }
             e_ps = n_ps;
@@ -1237,7 +1246,7 @@ __global__ __launch_bounds__(NPW == 1 ? 64 : 64 * (NPW + 1), PO_REG_WAVES) void 
             int nout = 0;
             if (st == PO_OK) {
                 int node = e_id;
-                nout = e_depth;
+                nout = sm.f_depth[0];
                 char* out = a.seq + a.seq_off[pi];
                 const int cap = (int)(a.seq_off[pi + 1] - a.seq_off[pi]);
                 if (nout > cap) { st = PO_E_CAP; nout = 0; }
