@@ -20,6 +20,11 @@
 // candidate slot s (slots [0,Wc) = beam nodes in rank order, slot Wc + 4*j + c = child c of
 // beam node j), strided when 5W > 64.  Prune = dedupe by node id + rank by (score desc, id asc)
 // + keep the top W (Beam.h:93-108; tie rule: see DESIGN.md).
+// (po_device.h's logaddexp variants, A/B in round 4 on 1 000 reads: CTC W = 10 4.82 -> 4.68 ms, flip-flop W = 10 7.17 -> 7.10 ms,
+//  W = 25 17.4 -> 17.3 / 23.1 -> 23.4 ms; same result bits)
+#define PO_LAE_EARLY_TABLE 1
+#define PO_LAE_BRANCHLESS 1
+#define PO_LAE_TRIM 1
 #include "po_device.h"
 
 namespace {

@@ -40,6 +40,8 @@
 //     per beam-width class (W <= 6 / 12 / 25 -> 64 / 128 / 256 threads).  Workgroups are persistent
 //     and pull pairs from an atomic queue.
 #define PO_LAE_EARLY_TABLE 1   // (po_device.h; A/B in round 4: W = 10 -0.7 %, Bonito W = 5 -3 %, beam2d_kernel -1 %)
+#define PO_LAE_BRANCHLESS 1    // (... the clamp instead of the small-argument test, and the two-instruction forms: Bonito W = 5
+#define PO_LAE_TRIM 1          //  another -3 %, the others unchanged)
 #include <algorithm>
 #include <climits>
 #include <cstdio>
