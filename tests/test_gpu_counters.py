@@ -1,0 +1,44 @@
+"""GPU: the diagnostic counters of the pair beam search (po_profile_update_counter: update_prob evaluations the reference's
+schedule makes for the decoded pairs, and those the kernel executed).  With a counter attached the register-state kernel
+runs an instantiation of its own (beam2d_reg_kernel<1, true>, round 4): it must decode the same strings as the product
+path, and what it counts must make sense."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from poreover_amd.synth import synth_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_counting_instantiation_decodes_the_same(oracle):
+    torch = pytest.importorskip("torch")
+    from poreover_amd import _lib, batch
+    lib = _lib.load()
+    y1s, y2s, envs = [], [], []
+    for i in range(24):
+        a, b = synth_pair(7300 + i, T=500 + 90 * (i % 7))
+        y1s.append(a); y2s.append(b)
+        envs.append(np.asarray(oracle.pair_decode(a, b, "poreover", 5, "row_col")["envelope"]))
+    want = [oracle.cpp_beam_search_2d(a, b, e, 5, model_="ctc", method_="row_col") for a, b, e in zip(y1s, y2s, envs)]
+    plain = batch.beam_search_2d_batch(y1s, y2s, envs, 5, model="ctc", method="row_col")
+    assert plain == want
+    counts = {}
+    for route in ("reg", "legacy"):
+        _lib.set_pair_route(route)
+        d_upd = torch.zeros(2, dtype=torch.int64, device="cuda")
+        try:
+            assert lib.po_profile_update_counter(C.c_void_p(d_upd.data_ptr())) == 0
+            counted = batch.beam_search_2d_batch(y1s, y2s, envs, 5, model="ctc", method="row_col")
+            torch.cuda.synchronize()
+        finally:
+            lib.po_profile_update_counter(None)
+            _lib.set_pair_route("auto")
+        assert counted == want, route
+        counts[route] = [int(x) for x in d_upd.cpu().tolist()]
+    for route, (ref, exe) in counts.items():
+        assert 0 < exe <= ref, (route, ref, exe)
+    # both kernels count the schedule of the reference (to a few no-op catch-ups); the register-state kernel executes less of it
+    assert abs(counts["reg"][0] - counts["legacy"][0]) <= 0.02 * counts["legacy"][0], counts
+    assert counts["reg"][1] <= counts["legacy"][1], counts
