@@ -12,10 +12,20 @@ from poreover_amd.synth import synth_pair
 pytestmark = pytest.mark.gpu
 
 
+def _hip():
+    """the HIP runtime the engine itself is linked against, for sixteen bytes of device memory (the C-ABI allocates none)"""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    return hip
+
+
 def test_counting_instantiation_decodes_the_same(oracle):
-    torch = pytest.importorskip("torch")
     from poreover_amd import _lib, batch
     lib = _lib.load()
+    hip = _hip()
     y1s, y2s, envs = [], [], []
     for i in range(24):
         a, b = synth_pair(7300 + i, T=500 + 90 * (i % 7))
@@ -27,16 +37,20 @@ def test_counting_instantiation_decodes_the_same(oracle):
     counts = {}
     for route in ("reg", "legacy"):
         _lib.set_pair_route(route)
-        d_upd = torch.zeros(2, dtype=torch.int64, device="cuda")
+        d_upd = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d_upd), 16) == 0 and hip.hipMemset(d_upd, 0, 16) == 0
+        host = (C.c_uint64 * 2)()
         try:
-            assert lib.po_profile_update_counter(C.c_void_p(d_upd.data_ptr())) == 0
+            assert lib.po_profile_update_counter(d_upd) == 0
             counted = batch.beam_search_2d_batch(y1s, y2s, envs, 5, model="ctc", method="row_col")
-            torch.cuda.synchronize()
+            assert hip.hipDeviceSynchronize() == 0
+            assert hip.hipMemcpy(host, d_upd, 16, 2) == 0     # hipMemcpyDeviceToHost
         finally:
             lib.po_profile_update_counter(None)
             _lib.set_pair_route("auto")
+            hip.hipFree(d_upd)
         assert counted == want, route
-        counts[route] = [int(x) for x in d_upd.cpu().tolist()]
+        counts[route] = [int(host[0]), int(host[1])]
     for route, (ref, exe) in counts.items():
         assert 0 < exe <= ref, (route, ref, exe)
     # both kernels count the schedule of the reference (to a few no-op catch-ups); the register-state kernel executes less of it
