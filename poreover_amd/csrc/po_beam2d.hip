@@ -2584,31 +2584,29 @@ struct RingGeom {
 // choice (PO_ROUTE_AUTO) at every batch size since round 4 — 16 pairs per CU instead of the ring kernel's 8, and the
 // lower latency of the two for a single pair as well (16.6 vs 17.3 ms; 1 250 pairs 24.9 vs 25.3 ms; 10 000 pairs 74.4 vs
 // 106 ms, beam2d_kernel 89.1).  PO_REG_NEVER gives the round-3 routing back (ring up to 2 048 pairs, beam2d_kernel beyond).
-extern "C" int po_reg_slots_per_cu(int board);
-extern "C" int po_reg_max_elements();
-extern "C" int po_reg_ngl();
-extern "C" void po_reg_launch(const void* x2args, int slots, int board, hipStream_t stream);
-// The job-board form of the kernel (7 pair waves + a chain wave per workgroup) pays where the device is full: launches
-// beyond the one-wave form's resident pairs.  PO_REG_BOARD=0 / 1 pins it off / on at every size (A/B).
-bool reg_use_board(int n) {
-    static const int env = [] { const char* e = getenv("PO_REG_BOARD"); return e ? atoi(e) : -1; }();
-    if (env >= 0) return env != 0;
-    return false;
-}
+extern "C" int po_reg_slots_per_cu(int model, int wide);
+extern "C" int po_reg_max_elements(int wide);
+extern "C" int po_reg_ngl(int wide);
+extern "C" size_t po_reg_pool_bytes(int model, int wide);
+extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide, hipStream_t stream);
+// the 64-slot layout of the kernel (lane = element slot, the two reads one after the other): 7 <= W <= 12
+inline int reg_wide(int W) { return W > 6 ? 1 : 0; }
 bool reg_eligible(int n, int W, int A, int model, int method) {
     const int rt = b2_route().route;
-    if (!(model == PO_MODEL_CTC && method == PO_METHOD_ROW_COL && W <= 6 && A >= 1 && W * (A + 1) <= po_reg_max_elements())) return false;
+    // (every tree model since round 5: the kernel is templated on the model's values per entry)
+    if (!(method == PO_METHOD_ROW_COL && W <= 12 && A >= 1 && W * (A + 1) <= po_reg_max_elements(reg_wide(W)))) return false;
+    if (model != PO_MODEL_CTC && model != PO_MODEL_MERGE && model != PO_MODEL_FLIPFLOP) return false;
     if (rt == PO_ROUTE_REG) return true;
     if (rt != PO_ROUTE_AUTO) return false;
     return b2_route().reg_auto != 0;
 }
 RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model, bool reg = false) {
     RingGeom g;
-    g.blocks = b2_num_cus() * (reg ? po_reg_slots_per_cu(reg_use_board(n) ? 1 : 0) : po_ring_blocks_per_cu());
+    g.blocks = b2_num_cus() * (reg ? po_reg_slots_per_cu(model, reg_wide(W)) : po_ring_blocks_per_cu());
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
     // ring kernel, tier 2: 128 row groups at R = 256 (windows up to 254 frames), 96 tracked; register-state kernel: the
     // whole store, 2 MB = 128 groups at R = 128 (beam2d_kernel's W <= 6 geometry)
-    g.pool_bytes = (size_t)(reg ? 2 : 4) << 20;
+    g.pool_bytes = reg ? po_reg_pool_bytes(model, reg_wide(W)) : ((size_t)4 << 20);
     const int64_t WM = W > PO_A ? W : PO_A;
     g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
     {
@@ -2927,16 +2925,18 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.magic = g.magic;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
         const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
-        a.ngl = use_reg ? po_reg_ngl() : po_ring_ngl();
+        a.ngl = use_reg ? po_reg_ngl(reg_wide(W)) : po_ring_ngl();
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
         // (the range this layout answers for ends where the nested workspace of the deferred-pairs pass begins)
         if (b2_ws_layout_changed(ws, g.off_state, g.off_fb, g.magic) &&
             hipMemsetAsync(w + g.off_state, 0, sizeof(unsigned long long) * 2 * (size_t)g.blocks, stream) != hipSuccess)
             return PO_E_HIP;
-        hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
+        if (model == PO_MODEL_CTC) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
+        else if (model == PO_MODEL_MERGE) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(256), plds, stream, a);
+        else hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(256), plds, stream, a);
         hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
         if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
-        if (use_reg) po_reg_launch(&a, g.blocks, reg_use_board(n) ? 1 : 0, stream);
+        if (use_reg) po_reg_launch(&a, g.blocks, model, reg_wide(W), stream);
         else po_ring_launch(&a, g.blocks, stream);
         if (g_b2_mark_fwd) g_b2_mark_fwd(0, stream);
         // pairs the pre-pass or the kernel deferred (tier-2 row groups exhausted, windows beyond the store's ring):

@@ -142,7 +142,6 @@ struct X2Args {
     unsigned long long* wgstate;      // beam2d_ring_kernel: per workgroup {magic, epoch counter} (see beam2d_kernel)
     unsigned long long magic;
     int reg_slots;                    // beam2d_reg_kernel: pair slots (waves that decode pairs) of the launch, each with its own store slice
-    int reg_board;                    // ... its new elements' chains go through the workgroup's job board (several pair waves + a chain wave)
     int no_cum;                       // pre-pass: leave the blank prefix sums out (beam2d_reg_kernel adds the root's alpha up as it goes)
 };
 

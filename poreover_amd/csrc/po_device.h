@@ -478,30 +478,29 @@ __device__ __forceinline__ void po_update(const double* sp, const double* pp, do
     if (MODEL == PO_MODEL_CTC) {
         out[0] = po_lae(pp[0] + ya, sp[0] + yb);
     } else if (MODEL == PO_MODEL_MERGE) {
+        // (ONE logaddexp whatever `same` says: the operand is selected, not the branch — lanes of one wave differ in it,
+        //  and two calls behind a divergent branch run one after the other)
         const double gap = sp[0] + yb;
-        double ng;
-        if (first) ng = ya;
-        else if (same) ng = po_lae(pp[1] + ya, sp[2] + ya);
-        else ng = po_lae(pp[0] + ya, sp[2] + ya);
+        const double x = same ? pp[1] : pp[0];
+        const double lg = po_lae(x + ya, sp[2] + ya);
+        const double ng = first ? ya : lg;
         out[0] = po_lae(gap, ng);
         out[1] = gap;
         out[2] = ng;
     } else {
+        // Three logaddexp per update, not four: the reference's `else` case (parent->last != last) computes
+        // emit_flip = logaddexp(p.flip, p.flop) + y and flop = logaddexp(-inf, stay_flop) — and logaddexp(-inf, x) is x for
+        // every x (x + log(1 + exp(-inf)) = x + 0; (-inf, -inf) gives -inf either way: Log.h:9-23, and the same holds for the
+        // table-driven form) — while the `same` case needs a logaddexp for flop and none for the emission.  One call serves
+        // both, its operands selected per lane.
         const double stay_flip = sp[1] + ya;
         const double stay_flop = sp[2] + yb;
-        double ef, eo;
-        if (first) {
-            ef = ya;
-            eo = yb;
-        } else if (same) {
-            ef = pp[2] + ya;
-            eo = pp[1] + yb;
-        } else {
-            ef = po_lae(pp[1], pp[2]) + ya;
-            eo = PO_NEG_INF;
-        }
+        const bool fs = first || same;
+        const double eo_fs = first ? yb : pp[1] + yb;
+        const double l2 = po_lae(fs ? eo_fs : pp[1], fs ? stay_flop : pp[2]);
+        const double ef = first ? ya : (same ? pp[2] + ya : l2 + ya);
         const double flip = po_lae(ef, stay_flip);
-        const double flop = po_lae(eo, stay_flop);
+        const double flop = fs ? l2 : stay_flop;
         out[0] = po_lae(flip, flop);
         out[1] = flip;
         out[2] = flop;

@@ -59,9 +59,12 @@ struct GrowBuf {   // grow-only buffer: device memory or pinned host memory
     }
     bool ensure(size_t bytes) {
         if (bytes <= cap) return true;
+        static const bool trace = getenv("PO_PIPE_TRACE") != nullptr;
+        const double t0 = trace ? now_ms() : 0.0;
         release();
         const size_t want = al256(bytes + bytes / 8);   // head-room: waves differ a little in size
         const hipError_t e = host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (trace) fprintf(stderr, "[po_pipe] %s %.1f MB: %.2f ms\n", host ? "hipHostMalloc" : "hipMalloc", want / 1048576.0, now_ms() - t0);
         if (e != hipSuccess) { p = nullptr; return false; }
         cap = want;
         return true;

@@ -2,7 +2,7 @@
 # LDS-side counters of the pair beam kernel: scripts/pmc_lds.sh VARIANT [n] [W]
 v=$1; n=${2:-5120}; W=${3:-5}
 root=${GRAFT_REPO_ROOT:-/root/repo}
-if [ "$v" = base ]; then export POREOVER_HIP_LIB=$root/poreover_amd/libporeover_hip.so; else export POREOVER_HIP_LIB=$root/scripts/_timing/libporeover_hip_$v.so; fi
+if [ "$v" = base ]; then export POREOVER_HIP_LIB=$root/poreover_amd/libporeover_hip.so; else export POREOVER_HIP_LIB=$root/scripts/variants/libporeover_hip_$v.so; fi
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $root/gpurun_out/pl_$v -- python3 $root/scripts/quick_time_2d.py $n $W > $root/gpurun_out/pl_$v.log 2>&1
 python3 - <<PY

@@ -2,7 +2,7 @@
 # SQ + LDS counters of the x2 kernel at a given residency: scripts/pmc_occ.sh VARIANT PER_CU N
 v=$1; k=$2; n=$3
 root=${GRAFT_REPO_ROOT:-/root/repo}
-if [ "$v" = base ]; then export POREOVER_HIP_LIB=$root/poreover_amd/libporeover_hip.so; else export POREOVER_HIP_LIB=$root/scripts/_timing/libporeover_hip_$v.so; fi
+if [ "$v" = base ]; then export POREOVER_HIP_LIB=$root/poreover_amd/libporeover_hip.so; else export POREOVER_HIP_LIB=$root/scripts/variants/libporeover_hip_$v.so; fi
 export PO_X2_PER_CU=$k
 cd /tmp && export TMPDIR=/tmp
 for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_WAVES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_BUSY_CU_CYCLES"; do

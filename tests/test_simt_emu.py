@@ -48,5 +48,5 @@ def test_emulated_kernel_hands_a_wide_window_on(emu_lib, oracle):
     sl = np.zeros(1, dtype=np.int32); st = np.zeros(1, dtype=np.int32); upd = np.zeros(2, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), 1, 5, 4, C.c_uint32(int.from_bytes(b"ACGT", "little")),
-                                      int(d["W"]), p(seq), p(so), p(sl), p(st), 1, p(upd), 1)
+                                      int(d["W"]), p(seq), p(so), p(sl), p(st), 1, p(upd), 1, 0)
     assert deferred == 1 and int(st[0]) == -100

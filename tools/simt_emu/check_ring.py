@@ -17,22 +17,27 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 
+MODELS = {"ctc": (0, "poreover", "ctc"), "merge": (1, "bonito", "ctc_merge_repeats"), "flipflop": (2, "flipflop", "ctc_flipflop")}
+MODEL = [os.environ.get("EMU_MODEL", "ctc")]
+
+
 def make_case(job):
     seed, T, W, style = job
     from oracle import po_oracle as O
     from poreover_amd.synth import synth_pair
     from fuzz_parity import jagged
+    _, kind, model_ = MODELS[MODEL[0]]
     rng = np.random.default_rng(seed)
-    y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=T)
+    y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=T, flipflop=(kind == "flipflop"))
     if style == "pipeline":
-        r = O.pair_decode(y1, y2, "poreover", W, "row_col")
+        r = O.pair_decode(y1, y2, kind, W, "row_col")
         if r["status"] != 0 or r.get("envelope") is None:
             return None
         env = np.asarray(r["envelope"], dtype=np.int32)
     else:
         env = jagged(rng, len(y1), len(y2), style, int(rng.integers(2, 12))).astype(np.int32)
     try:
-        want = O.cpp_beam_search_2d(y1, y2, env, W, model_="ctc", method_="row_col")
+        want = O.cpp_beam_search_2d(y1, y2, env, W, model_=model_, method_="row_col")
         code = 0
     except O.OracleError as e:
         want, code = "", e.code
@@ -56,7 +61,7 @@ def run_emu(job):
     alphabet = int.from_bytes(b"ACGT", "little")
     t0 = time.time()
     nblocks = int(os.environ.get("EMU_SLOTS", "1"))
-    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, 5, 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), nblocks, p(upd), kernel)
+    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, y1.shape[1], 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), nblocks, p(upd), kernel, MODELS[MODEL[0]][0])
     got = bytes(seq[: sl[0]]).decode()
     return got, int(st[0]), deferred, time.time() - t0, int(upd[1])
 
@@ -77,7 +82,7 @@ def run_emu_batch(job):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     alphabet = int.from_bytes(b"ACGT", "little")
     t0 = time.time()
-    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, 5, 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), slots, p(upd), kernel)
+    deferred = lib.emu_ring_pair_beam(p(y1), p(o1), p(y2), p(o2), p(env), n, y1.shape[1], 4, C.c_uint32(alphabet), W, p(seq), p(so), p(sl), p(st), slots, p(upd), kernel, MODELS[MODEL[0]][0])
     dt = time.time() - t0
     return [(bytes(seq[so[i]: so[i] + sl[i]]).decode(), int(st[i]), deferred if st[i] == -100 else 0, dt / n, 0) for i in range(n)]
 
@@ -92,8 +97,11 @@ def main():
     ap.add_argument("--lib", default=os.path.join(HERE, "_build", "libemu_pair_beam.so"))
     ap.add_argument("--styles", default="pipeline,stairs,wobble,bursts")
     ap.add_argument("--batch", type=int, default=1, help="pairs per emulated launch (with as many pair slots)")
-    ap.add_argument("--kernel", default="ring", help="ring | reg | board (the register-state kernel with its job board)")
+    ap.add_argument("--kernel", default="ring", help="ring | reg")
+    ap.add_argument("--model", default=MODEL[0], help="ctc | merge | flipflop (the register-state kernel serves all three)")
     args = ap.parse_args()
+    MODEL[0] = args.model
+    os.environ["EMU_MODEL"] = args.model   # (the pool's workers read it)
     styles = args.styles.split(",")
     rng = np.random.default_rng(args.seed)
     jobs = []
@@ -105,7 +113,7 @@ def main():
     with ProcessPoolExecutor(args.procs) as pool:
         cases = list(pool.map(make_case, jobs))
         keep = [(c, j) for c, j in zip(cases, jobs) if c is not None]
-        kid = {"ring": 0, "reg": 1, "board": 2}[args.kernel]
+        kid = {"ring": 0, "reg": 1}[args.kernel]
         if args.batch <= 1:
             res = list(pool.map(run_emu, [(c, j[2], args.lib, kid) for c, j in keep]))
         else:   # batches of equal beam width

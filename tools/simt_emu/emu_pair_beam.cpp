@@ -10,7 +10,7 @@
 extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
                                   const int32_t* env, int n, int C, int A, uint32_t alphabet, int W, char* seq,
                                   const int64_t* seq_off, int32_t* seq_len, int32_t* status, int blocks,
-                                  unsigned long long* upd_count, int kernel) {
+                                  unsigned long long* upd_count, int kernel, int model) {
     int64_t tr1 = y1_off[n] - y1_off[0], tr2 = y2_off[n] - y2_off[0], mr1 = 0, mr2 = 0;
     for (int i = 0; i < n; ++i) {
         mr1 = std::max<int64_t>(mr1, y1_off[i + 1] - y1_off[i]);
@@ -26,7 +26,8 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     std::vector<int2> meta(n);
     std::vector<int4> sched((size_t)tr2 + 1);
     std::vector<double> cum1((size_t)tr1 + 1), cum2((size_t)tr2 + 1);
-    const size_t pool_bytes = (size_t)(kernel >= 1 ? 2 : 4) << 20;
+    const int wide = (W > 6) ? 1 : 0;
+    const size_t pool_bytes = kernel >= 1 ? po_reg_pool_bytes(model, wide) : ((size_t)4 << 20);
     const int64_t WM = W > PO_A ? W : PO_A;
     const size_t arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
     std::vector<char> pool(pool_bytes * blocks, 0);
@@ -38,16 +39,18 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     a.dbg = nullptr; a.upd_count = upd_count; a.defer_odd = 0; a.need_mono = 1; a.order = nullptr;
     a.wgstate = wgstate.data(); a.magic = 0x1234567ull;
     a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
-    a.ngl = kernel >= 1 ? po_reg_ngl() : po_ring_ngl();
+    a.ngl = kernel >= 1 ? po_reg_ngl(wide) : po_ring_ngl();
     a.no_cum = kernel >= 1 ? 1 : 0;
     for (int i = 0; i < n; ++i) status[i] = PO_OK;
     const bool vb = getenv("EMU_VERBOSE") != nullptr;
     if (vb) fprintf(stderr, "[emu] prepass\n");
-    hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), 0, nullptr, a);
+    if (model == PO_MODEL_CTC) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), 0, nullptr, a);
+    else if (model == PO_MODEL_MERGE) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(256), 0, nullptr, a);
+    else hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(256), 0, nullptr, a);
     if (vb) fprintf(stderr, "[emu] walk\n");
     hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, nullptr, a);
     if (vb) fprintf(stderr, "[emu] main kernel\n");
-    if (kernel >= 1) po_reg_launch(&a, blocks, kernel == 2 ? 1 : 0, nullptr);   // kernel 2: the job-board form
+    if (kernel >= 1) po_reg_launch(&a, blocks, model, wide, nullptr);
     else po_ring_launch(&a, blocks, nullptr);
     int deferred = 0;
     for (int i = 0; i < n; ++i)

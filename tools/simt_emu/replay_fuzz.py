@@ -40,7 +40,7 @@ def main():
     args = ap.parse_args()
     from fuzz_parity import draw_round
     from check_ring import run_emu_batch
-    kid = {"ring": 0, "reg": 1, "board": 2}[args.kernel]
+    kid = {"ring": 0, "reg": 1}[args.kernel]
     rng = np.random.default_rng(args.seed)
     bad = 0
     with ProcessPoolExecutor(args.procs) as pool:
