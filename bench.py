@@ -41,11 +41,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 # the pair beam search kernel this workload runs on (row_col, ctc, W = 5): name prefix in the profiles
 # (profiles before the row_col-only instantiation existed call it beam2d_kernel<0, 6>, later ones beam2d_kernel<0, 6, true>;
 #  PO_RING_AUTO=1 makes the LDS-ring kernel the engine's choice: an A/B switch)
-#  round 4: the register-state kernel beam2d_reg_kernel is the engine's choice at every batch size; PO_REG_NEVER=1 gives
-#  the round-3 routing back — beam2d_kernel for this launch size — for the A/B)
-RING = bool(os.environ.get("PO_RING_AUTO")) and bool(os.environ.get("PO_REG_NEVER"))
-LEGACY = bool(os.environ.get("PO_REG_NEVER")) and not RING
-MAIN_KERNEL = "beam2d_ring_kernel" if RING else ("beam2d_kernel<0, 6" if LEGACY else "beam2d_reg_kernel")
+#  since round 4 the register-state kernel beam2d_reg_kernel is the engine's choice at every batch size; PO_REG_NEVER=1
+#  sends the launch to beam2d_kernel for the A/B)
+LEGACY = bool(os.environ.get("PO_REG_NEVER"))
+MAIN_KERNEL = "beam2d_kernel<0, 6" if LEGACY else "beam2d_reg_kernel"
 
 
 def _cpu_pair_worker(args):

@@ -77,14 +77,13 @@ const char* po_last_error(void);
 int po_device_info(int device, char* name, int name_cap, int* compute_units, int* clock_khz,
                    size_t* total_mem);
 
-/* test / tuning hook: which kernel serves the pair beam search.  PO_ROUTE_AUTO = the engine's choice;
- * PO_ROUTE_X2 = the two-pairs-per-wave kernel wherever it can run; PO_ROUTE_LEGACY = always beam2d_kernel;
- * defer_odd != 0: the x2 path hands every odd pair to beam2d_kernel (exercises the hand-over).  Process-wide; results
- * are identical on every route. */
+/* test / tuning hook: which kernel serves the pair beam search.  PO_ROUTE_AUTO = the engine's choice (DESIGN.md §3.3:
+ * beam2d_reg_kernel for row_col with an envelope, every tree model, W <= 12; beam2d_kernel elsewhere); PO_ROUTE_REG = the
+ * same, named; PO_ROUTE_LEGACY = always beam2d_kernel; defer_odd != 0: the register-state kernel hands every odd pair to
+ * beam2d_kernel (exercises the hand-over).  Process-wide; results are identical on every route.
+ * (Values 1 and 3 named the two-pairs-per-wave and LDS-ring kernels of rounds 1 - 4, retired in round 5: PO_E_ARG.) */
 #define PO_ROUTE_AUTO 0
-#define PO_ROUTE_X2 1
 #define PO_ROUTE_LEGACY 2
-#define PO_ROUTE_RING 3
 #define PO_ROUTE_REG 4   /* beam2d_reg_kernel: element state in registers, values in the tagged HBM store */
 int po_set_pair_route(int route, int defer_odd);
 /* test / tuning hook: legacy != 0 -> the banded aligner (align.pyx:100-178) runs the row-at-a-time kernel that stores the

@@ -182,7 +182,7 @@ def current_device():
     return int(os.environ.get("POREOVER_DEVICE", "0") or 0)
 
 
-ROUTES = {"auto": 0, "x2": 1, "legacy": 2, "ring": 3, "reg": 4}
+ROUTES = {"auto": 0, "legacy": 2, "reg": 4}
 
 
 def set_pair_route(route="auto", defer_odd=False):

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libporeover_hip.so")
-SOURCES = ["po_capi.hip", "po_viterbi.hip", "po_beam1d.hip", "po_beam2d.hip", "po_beam2d_ring.hip", "po_beam2d_reg.hip", "po_pair.hip", "po_lattice.hip", "po_prefix.hip", "po_ingest.hip", "po_gamma.hip", "po_stream.hip"]
+SOURCES = ["po_capi.hip", "po_viterbi.hip", "po_beam1d.hip", "po_beam2d.hip", "po_beam2d_reg.hip", "po_pair.hip", "po_lattice.hip", "po_prefix.hip", "po_ingest.hip", "po_gamma.hip", "po_stream.hip"]
 HEADERS = ["po_device.h", os.path.join("..", "..", "include", "poreover_hip.h")]
 
 

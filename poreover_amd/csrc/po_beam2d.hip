@@ -202,7 +202,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
         epoch++;
         if ((epoch & 0xffffu) == 0) { clear_slice(); epoch++; }   // (epoch 0 is what a cleared tag reads as)
         TK_START();
-        if (a.only_meta && a.only_meta[pi].y != X2_DEFERRED) continue;  // done by beam2d_x2_kernel
+        if (a.only_meta && a.only_meta[pi].y != X2_DEFERRED) continue;  // done by beam2d_reg_kernel
         if (a.retry_nomem) {
             if (a.status[pi] != PO_E_NOMEM) continue;                  // decoded (or refused for good) by the first pass
         } else
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
         auto scan = [&](bool is_main, bool reuse, int nelem, int skip_lo, int skip_hi, int t00, int len0_, int t01, int len1_) {
             // the window bounds come from (wave-uniform) vector loads: pin them to SGPRs so the iteration
             // loop is a scalar loop
-            // INCREMENTAL main step (as in beam2d_x2_kernel, restricted to the simplest case): the previous prune left
+            // INCREMENTAL main step (restricted to the simplest case): the previous prune left
             // the beam exactly as it was and nothing is created or re-allocated now, so every element sits in the slot
             // it had, and over the part of its windows the previous main step covered it would recompute the stored
             // bits.  Only the times beyond the previous window ends are computed (seeded from the store); the window
@@ -1199,808 +1199,8 @@ __global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <
 #endif
 }
 
-// =================================================================================================
-// row_col with an envelope, W <= 6, any tree model: TWO PAIRS PER WAVE (beam2d_x2_kernel).
-//
-// With one pair per wave and lane = (read, slot), a step costs max(len0, len1) iterations and at most
-// 25 + 25 of 64 lanes work; the per-step bookkeeping (expansion, prune) uses <= 30 lanes.  Here a
-// half-wave (32 lanes, lane = element slot) owns a pair and walks its two windows one after the
-// other (len0 + len1 iterations, the second seeded through the same LDS exchange slot); the two
-// halves run different pairs through the same instruction stream, so the bookkeeping is shared by
-// two pairs, catch-up steps of one pair overlap the other's, and the iteration count per step is
-// max over the two pairs of len0 + len1 — for two pairs.  Every per-pair quantity is half-uniform
-// (a VGPR); halves pull pairs from the queue independently.  The per-pair pre-pass (envelope check
-// and transpose, widest window, blank prefix sums) is a separate, fully parallel kernel.
-// Results are identical to beam2d_kernel's (same arithmetic, same order within every chain).
-namespace {
-#ifndef X2_NGL_
-#define X2_NGL_ 128
-#endif
-constexpr int X2_NGL = X2_NGL_;   // row groups tracked per pair
-#ifndef X2_YD_
-#define X2_YD_ 256
-#endif
-constexpr int X2_YD = X2_YD_;    // doubles in the per-pair y window buffer (256: 51 rows of 5, 32 rows of 8)
-
-
-struct alignas(16) X2Cand { double sc; int id; int dup; };
-// SG = lanes (element slots) per pair: 32 -> two pairs per wave (W <= 6), 64 -> one pair per wave (W <= 12)
-template <int K, int SG>
-struct X2Half {
-    static constexpr int WB = (SG == 32) ? 6 : 12;   // beam slots
-    static constexpr int NGL = (SG == 32) ? X2_NGL : 2 * X2_NGL;  // row groups tracked per pair
-    int e[F_COUNT][SG];
-    static constexpr int WBP = (SG == 32) ? 8 : 16;  // beam-slot arrays, padded
-    int bps[WBP];            // beam slot -> slot of its parent in the beam, or -1
-    int sel[WBP];
-    int newfc[WBP];          // bit 0: children created in this step; bit 1: children got a new row group
-    int stay[WBP];           // beam slot was a beam slot in the previous main step (so its children were elements)
-    int g_owner[NGL], g_hi0[NGL], g_hi1[NGL];
-    int sh[8];
-    X2Cand cand[SG];         // prune candidates: score, node id, duplicate flag — one 16-byte read per comparison
-    int ord[SG];             // prune with exact score ties: candidate slots in node-id order (po_stl_prune)
-    double xch[2][SG][K];
-    // doubles in the y window buffer: 192 (38 rows of 5) for the two-pairs-per-wave one-value kernel, so that 12
-    // workgroups fit a CU's LDS; 256 (32 rows of 8) elsewhere (those kernels are register-bound anyway)
-    static constexpr int YD = (K == 1 && SG == 32) ? (X2_YD < 192 ? X2_YD : 192) : X2_YD;
-    double ybuf[YD];         // the y rows of the current step's windows
-    // between two scans the buffer keeps, per element slot, the maxima of the step's two windows and their times
-    static_assert(YD >= 3 * SG, "y buffer too small for the carried maxima");
-    __device__ double* stg_v() { return ybuf; }                    // [2][SG]
-    __device__ int* stg_t() { return (int*)(ybuf + 2 * SG); }      // [2][SG]
-    unsigned long long nupd;   // profiling: update_prob evaluations the reference's schedule makes for these pairs
-    unsigned long long nupd_x; // ... and those this kernel executed (incremental steps, no-op catch-ups)
-};
-template <int K, int SG>
-struct X2Smem {
-    X2Half<K, SG> h[64 / SG];
-    PoLaeTables lae;
-};
-__device__ __forceinline__ void x2_sync() { b2_sync_lds<64>(); }
-}  // namespace
-
+// (the pre-pass and the diagonal walk of the register-state kernel: po_beam2d_reg.hip; they are launched from this file)
 #include "po_beam2d_pre.h"
-
-template <int MODEL, int SG>
-__global__ __launch_bounds__(64, (MODEL == PO_MODEL_CTC) ? 3 : 2) void beam2d_x2_kernel(X2Args a) {
-    constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
-    constexpr int NPW = 64 / SG;                 // pairs per wave
-    constexpr int WB = X2Half<K, SG>::WB, HNGL = X2Half<K, SG>::NGL;
-    using Ent = Entry<K>;
-    __shared__ X2Smem<K, SG> sm;
-    const int lane = threadIdx.x, g = lane / SG, s = lane & (SG - 1);
-    X2Half<K, SG>& h = sm.h[g];
-    const int A = a.A, W = a.W, C = a.C;
-    const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here (x < 1024, A <= 8)
-    const int hid = blockIdx.x * NPW + g;
-    Ent* const pool = (Ent*)(a.pool + (size_t)hid * a.pool_bytes);
-    const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
-    int* const apl = a.arena + (size_t)hid * 3 * a.arena_cap;
-    int* const afc = apl + a.arena_cap;
-    int* const acrow = afc + a.arena_cap;
-#ifdef PO_LAE_POLY
-    const PoLaePoly lae;
-#else
-    po_lae_tables_load(&sm.lae, lane, 64);
-    const PoLaeFast lae{&sm.lae};
-#endif
-    x2_sync();
-
-    // ---- half-uniform state of the pair in flight
-    if (s == 0) { h.nupd = 0; h.nupd_x = 0; }  // update_prob evaluations of this half-wave's pairs (profiling only; kept in LDS)
-    bool have = false, done = false;
-    int pi = 0, U = 1, V = 1, u = 0, v = 0, nb = 0, R = 32, Rm = 31, NG = 0, st = PO_OK;
-    int nbq = 0;                   // beam nodes in the previous main step (its element slots name the carried maxima)
-    bool steadyH = false;          // the previous prune left the beam exactly as it was (same nodes, same order)
-    int dupf = 0;                  // a child slot whose node is also a beam slot is the same node pushed twice
-    unsigned epoch = 0;
-    const double *yA = a.y1, *yB = a.y2, *cumA = a.cum1, *cumB = a.cum2;
-    const int4* sched = a.sched;   // this pair's main steps {u, v, column-window end, row-window end}
-    int mstep = 0, nmain = 0;      // next main step, their number
-    int up = -1, vp = -1;          // the previous main step
-    int4 rec = make_int4(0, 0, 0, 0), rec_n = rec;  // the next main step's record and the one after
-
-    auto root_at = [&](const double* cump, int t, double* out) {
-        if (MODEL == PO_MODEL_CTC) {
-            out[0] = (t < 0) ? 0.0 : cump[t];
-        } else {
-            double tmp[3];
-            root_values<MODEL>(t, 0.0, tmp);
-#pragma unroll
-            for (int k = 0; k < K; ++k) out[k] = tmp[k];
-        }
-    };
-    auto st_read = [&](const Ent* rowp, int t, unsigned long long tagbase, double* out) {
-        bool hit = false;
-        if (t >= 0) {
-            const Ent e = rowp[t & Rm];
-            hit = (e.tag == tagbase + (unsigned)t);
-#pragma unroll
-            for (int k = 0; k < K; ++k) out[k] = e.v[k];
-        }
-        if (!hit) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) out[k] = PO_NEG_INF;
-        }
-    };
-    auto alloc_group = [&](int owner, int lo0, int lo1) -> int {
-        int cur = h.sh[3];
-        int gg = -1;
-        for (int tries = 0; tries < NG; ++tries) {
-            const int c = cur;
-            cur = (cur + 1 == NG) ? 0 : cur + 1;
-            if (h.g_owner[c] < 0 || (h.g_hi0[c] <= lo0 && h.g_hi1[c] <= lo1)) { gg = c; break; }
-        }
-        h.sh[3] = cur;
-        if (gg < 0) { h.sh[4] = PO_E_NOMEM; gg = 0; }
-        h.g_owner[gg] = owner;
-        h.g_hi0[gg] = 0; h.g_hi1[gg] = 0;
-        return gg;
-    };
-
-#ifdef PO_B2_TIMING
-    long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
-    const int tko = 0;
-#endif
-    for (;;) {
-        // ------------------------------------------------------------ a half without a pair pulls one
-        if (!have && !done) {
-            int p = 0;
-            if (s == 0) {
-                p = atomicAdd(a.queue, 1);
-                if (a.order != nullptr && p < a.n) p = a.order[p];   // longest pairs first (pair_order_kernel)
-            }
-            p = __shfl(p, lane & ~(SG - 1));
-            if (p >= a.n) {
-                done = true;
-            } else {
-                pi = p;
-                epoch++;
-                const int2 m = a.meta[pi];
-                if (m.y == X2_DEFERRED) {
-                    // beam2d_kernel decodes it after this kernel
-                } else if (m.x != PO_OK || m.y < 0) {  // refused by the pre-pass, or skipped upstream
-                    if (s == 0) {
-                        a.seq_len[pi] = 0;
-                        if (m.y >= 0) a.status[pi] = m.x;
-                    }
-                } else {
-                    const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
-                    U = (int)(a.y1_off[pi + 1] - o1); V = (int)(a.y2_off[pi + 1] - o2);
-                    yA = a.y1 + o1 * C; yB = a.y2 + o2 * C;
-                    cumA = a.cum1 + (o1 - a.y1_off[0]); cumB = a.cum2 + (o2 - a.y2_off[0]);
-                    sched = a.sched + (o2 - a.y2_off[0]);
-                    nmain = a.nmain[pi]; mstep = 0; up = -1; vp = -1; steadyH = false;
-                    rec = sched[0]; rec_n = sched[min(1, max(nmain - 1, 0))];   // (read-1 rows >= 1: in bounds)
-                    R = m.y; Rm = R - 1;
-                    NG = (int)min((long long)HNGL, pool_entries / ((long long)PO_A * 2 * R));
-                    st = PO_OK; u = 0; v = 0;
-                    for (int q = s; q < HNGL; q += SG) { h.g_owner[q] = -1; h.g_hi0[q] = 0; h.g_hi1[q] = 0; }
-                    x2_sync();
-                    // root = node 0; its A children = nodes 1..A in row group 0 (BeamSearch.h:286-293)
-                    if (s == 0) {
-                        apl[0] = po_pack_node(-1, A); afc[0] = 1; acrow[0] = 0;
-                        h.g_owner[0] = 0; h.g_hi0[0] = 1; h.g_hi1[0] = 1;
-                        h.sh[2] = 1 + A;  // next node id
-                        h.sh[3] = 1;      // group allocation cursor
-                        h.sh[4] = PO_OK;
-                        h.sh[5] = INT_MIN; h.sh[6] = INT_MIN;  // window ends of the previous main step: none yet
-                    }
-                    if (s < X2Half<K, SG>::WBP) h.stay[s] = 0;
-                    if (s < A) {
-                        apl[1 + s] = po_pack_node(0, s); afc[1 + s] = -1; acrow[1 + s] = -1;
-                        h.e[F_ID][s] = 1 + s; h.e[F_ROW][s] = s; h.e[F_PROW][s] = -1; h.e[F_PAR][s] = 0;
-                        h.e[F_GPAR][s] = -1; h.e[F_SYM][s] = sym_pack(s, A, true); h.e[F_DEPTH][s] = 1;
-                        h.e[F_FC][s] = -1; h.e[F_CROW][s] = -1;
-                        h.bps[s] = -1;
-                        const double sp[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
-                        const unsigned long long tg = make_tag(epoch, 1 + s, 0);
-#pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) {  // update_prob(n, rr, 0)
-                            const double* yr = rr ? yB : yA;
-                            double pp[3], out[3];
-                            root_at(rr ? cumB : cumA, -1, pp);
-                            const double ya = yr[s], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr[s + A] : yr[A];
-                            po_update<MODEL>(sp, pp, ya, yb, false, true, out, lae);
-                            Ent e;
-                            e.tag = tg;
-#pragma unroll
-                            for (int k = 0; k < K; ++k) e.v[k] = out[k];
-                            pool[((size_t)s * 2 + rr) * R] = e;
-                        }
-                    }
-                    nb = A;
-                    have = true;
-                    x2_sync();
-                }
-            }
-        }
-        if (__ballot(have) == 0) {
-            if (__ballot(!done) == 0) break;
-            continue;
-        }
-
-        TK(0);  // queue + per-pair setup
-        // ------------------------------------------------------------ catch-up steps (BeamSearch.h:314-336)
-        // Between two main steps only one of u, v advances at a time and only the beam nodes are updated, at
-        // that one time, from t-1 values in the store.  The pre-pass has replayed the walk: the record of the
-        // next main step says where it is.  A catch-up at a time the previous main step's window already
-        // covered is a no-op (every beam node was an element of that step: (node, t) is stored with exactly
-        // the bits the update would write), so only times from that window's end on are computed — rare.
-        bool fin = !have;
-        if (have && mstep >= nmain) fin = true;   // no main step left: whatever catch-ups remain change nothing observable
-        if (!fin) {
-            u = rec.x; v = rec.y;
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int tend = rr ? v : u;
-                if (s == 0) h.nupd += (unsigned)(max(tend - (rr ? vp : up) - 1, 0) * min(W, nb));
-                for (int t = max((rr ? vp : up) + 1, h.sh[5 + rr]); t < tend; ++t) {
-                    if (s < min(W, nb)) {  // the reference indexes b < beam_width
-                    const int node = h.e[F_ID][s], row = h.e[F_ROW][s], sy = h.e[F_SYM][s], par = h.e[F_PAR][s];
-                    const int bp = h.bps[s];
-                    const int prow = (bp >= 0) ? h.e[F_ROW][bp] : h.e[F_PROW][s];
-                    const int sym = sym_last(sy);
-                    const bool same = (sym_plast(sy) == sym), rootpar = (sy >> 9) & 1;
-                    Ent* myrow = pool + ((size_t)row * 2 + rr) * R;
-                    const double* yr = (rr ? yB : yA) + (int64_t)t * C;
-                    const double ya = yr[sym], yb = (MODEL == PO_MODEL_FLIPFLOP) ? yr[sym + A] : yr[A];
-                    double self[K], pp[K], out[K];
-                    const unsigned long long tg = make_tag(epoch, node, 0);
-                    st_read(myrow, t - 1, tg, self);
-                    if (par == 0) root_at(rr ? cumB : cumA, t - 1, pp);
-                    else st_read(pool + ((size_t)prow * 2 + rr) * R, t - 1, make_tag(epoch, par, 0), pp);
-                    po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
-                    Ent e;
-                    e.tag = tg + (unsigned)t;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) e.v[k] = out[k];
-                    myrow[t & Rm] = e;
-                    if (s == 0) h.nupd_x += (unsigned)min(W, nb);
-                    if (rr) atomicMax(&h.g_hi1[row / PO_A], t + 1);
-                    else atomicMax(&h.g_hi0[row / PO_A], t + 1);
-                    }
-                }
-            }
-        }
-        x2_sync();
-
-        TK(1);  // catch-up steps
-        // ------------------------------------------------------------ MAIN step at (u, v)  (:342-375)
-        // windows [u, ece) on read 0 and [v, ere) on read 1; every lane flows through, predicated
-        const bool dm = have && !fin;
-        const int ece = rec.z, ere = rec.w;
-        // ---- expansion state of the beam nodes, one lane per beam node
-        const bool bl = dm && s < nb;
-        bool isnew = false, need_group = false;
-        int id = 0, crow = -1;
-        if (bl) {
-            id = h.e[F_ID][s];
-            crow = h.e[F_CROW][s];
-            if (h.e[F_FC][s] < 0) { isnew = true; need_group = true; }
-            else if (crow < 0 || crow >= NG || h.g_owner[crow] != id) need_group = true;  // old rows recycled: all dead
-        }
-        // ---- INCREMENTAL step.  If every beam node was a beam node in the previous main step and keeps its children
-        // and their rows, every element of this step was an element of the previous one, with the same parent links:
-        // over the part of its windows that step covered, each would recompute exactly the bits that are stored (see
-        // "redundant stores" below).  Such a step only computes the times the windows have grown by, seeded from the
-        // store at the previous window ends; the score's maximum over the rest of the window is carried over (or
-        // re-read from the store when its position has left the window).  About 3 of 4 steps are of this kind.
-        bool fastH;
-        {
-            const unsigned long long nf_ = __ballot(bl && (isnew || need_group || !h.stay[s]));
-            fastH = dm && ((SG == 64) ? nf_ : (g ? (nf_ >> 32) : (nf_ & 0xffffffffull))) == 0;
-#ifdef PO_X2_NOFAST
-            fastH = false;
-#endif
-        }
-        const int su = fastH ? min(max(h.sh[5], u), ece) : u;   // first time to compute on read 0
-        const int sv = fastH ? min(max(h.sh[6], v), ere) : v;   // ... on read 1
-        // The y rows of the step's first buffer fill are requested now, into registers: the window is known from
-        // the schedule, and the loads fly while the (serial) expansion and the element table are built.
-        // (One-value model only: the 3-value kernels have no registers to spare — it would cost them a wave per SIMD.)
-        constexpr bool YEARLY = (K == 1);
-        constexpr int YPRE = YEARLY ? (X2Half<K, SG>::YD + SG - 1) / SG : 1;   // doubles per lane of one buffer fill
-        double ypre[YPRE];
-        if (YEARLY) {
-            const int l0 = dm ? ece - su : 0, l1 = dm ? ere - sv : 0;
-            const int yrows_ = X2Half<K, SG>::YD / C;
-            const int kend = min(l0 + l1, yrows_);
-            const int nA = min(kend, l0) * C, nT = kend * C;
-            const double* srcA = yA + (int64_t)su * C;
-            const double* srcB = yB + (int64_t)sv * C - nA;   // buffer index i >= nA reads srcB[i]
-#pragma unroll
-            for (int q = 0; q < YPRE; ++q) {
-                const int i = s + q * SG;
-                ypre[q] = (i < nT) ? ((i < nA) ? srcA[i] : srcB[i]) : 0.0;
-            }
-        }
-        // A STEADY step: the previous prune kept every beam node in its slot and nothing is created or moved now, so
-        // the element table of the previous step is this step's, entry for entry (about 2 of 3 steps).  When that
-        // holds for both pairs of the wave, expansion and table building reduce to marking the row groups in use.
-        const bool steady = steadyH && fastH;
-        const bool wsteady = __ballot(dm && !steady) == 0;
-        if (wsteady) {
-            if (bl) {
-                h.newfc[s] = 0;
-                const int go = h.e[F_ROW][s] / PO_A;
-                atomicMax(&h.g_hi0[go], ece); atomicMax(&h.g_hi1[go], ere);
-                atomicMax(&h.g_hi0[crow], ece); atomicMax(&h.g_hi1[crow], ere);
-            }
-        } else
-        // ---- expansion: children ids and row groups of the beam nodes.  New node ids are
-        // handed out in beam order (a prefix count over the lanes that need them: ids break score ties); row
-        // groups, which only name storage, are allocated one lane after the other, after every group in use has
-        // been marked with this step's window ends.
-        {
-            const unsigned long long bn = __ballot(isnew), bg = __ballot(need_group);
-            const unsigned long long hn = (SG == 64) ? bn : (g ? (bn >> 32) : (bn & 0xffffffffull));
-            unsigned long long hg = (SG == 64) ? bg : (g ? (bg >> 32) : (bg & 0xffffffffull));
-            const int base = h.sh[2];
-            if (isnew) {
-                const int fc = base + A * __popcll(hn & ((1ull << s) - 1ull));
-                h.e[F_FC][s] = fc;
-                afc[id] = fc;
-                for (int c = 0; c < A; ++c) { apl[fc + c] = po_pack_node(id, c); afc[fc + c] = -1; acrow[fc + c] = -1; }
-            }
-            if (bl) {
-                h.newfc[s] = (isnew ? 1 : 0) | (need_group ? 2 : 0);
-                const int go = h.e[F_ROW][s] / PO_A;
-                atomicMax(&h.g_hi0[go], ece); atomicMax(&h.g_hi1[go], ere);
-                if (!need_group) { atomicMax(&h.g_hi0[crow], ece); atomicMax(&h.g_hi1[crow], ere); }
-            }
-            x2_sync();
-            if (dm && s == 0) h.sh[2] = base + A * __popcll(hn);
-            // (the loop runs while either half still has a lane to serve)
-            while (__ballot(hg != 0) != 0) {
-                if (hg != 0) {
-                    const int j = __builtin_ctzll(hg);
-                    hg &= hg - 1;
-                    if (s == j) {
-                        const int gg = alloc_group(id, u - 1, v - 1);
-                        h.e[F_CROW][s] = gg;
-                        acrow[id] = gg;
-                        h.g_hi0[gg] = ece; h.g_hi1[gg] = ere;
-                    }
-                }
-                x2_sync();
-            }
-        }
-        x2_sync();
-        TK(2);  // expansion
-        if (dm && h.sh[4] != PO_OK) {  // out of row groups: hand the pair to beam2d_kernel
-            if (s == 0) { a.meta[pi] = make_int2(PO_OK, X2_DEFERRED); a.queue[16] = 1; }
-            have = false; fin = true;
-        }
-        const bool dmm = dm && !fin;
-        const int ne = dmm ? nb * (A + 1) : 0;
-        int my_fc = -1, my_cr = -1;  // a child's own expansion state (arena), loaded behind the scan
-        if (!wsteady) {
-        dupf = 0;
-        if (s < ne) {
-            if (s < nb) {
-                int ps = h.bps[s];
-                if (h.e[F_PAR][s] == 0) ps = PS_ROOT;
-                else if (ps < 0) {
-                    ps = PS_FROZEN;
-                    const int gp = h.e[F_GPAR][s];
-                    for (int i = 0; i < nb; ++i) if (h.e[F_ID][i] == gp) ps = nb + A * i + sym_plast(h.e[F_SYM][s]);
-                }
-                h.e[F_PSLOT][s] = ps;
-            } else {
-                const int j = ((s - nb) * divA) >> 16, c = (s - nb) - j * A;
-                const int id = h.e[F_FC][j] + c;
-                h.e[F_ID][s] = id; h.e[F_ROW][s] = h.e[F_CROW][j] * PO_A + c;
-                h.e[F_SYM][s] = sym_pack(c, sym_last(h.e[F_SYM][j]), false);
-                h.e[F_PSLOT][s] = j;
-                if (!(h.newfc[j] & 1)) { my_fc = afc[id]; my_cr = acrow[id]; }
-#pragma unroll
-                for (int i = 0; i < WB; ++i) dupf |= (i < nb && h.e[F_ID][i] == id);
-            }
-        }
-        x2_sync();
-        if (s < nb && s < ne && h.e[F_PSLOT][s] >= nb) h.e[F_PROW][s] = h.e[F_ROW][h.e[F_PSLOT][s]];  // parent's current row
-        }
-
-        TK(3);  // element table
-        // ---- the scan: read 0's window, then read 1's, one t per iteration
-        {
-            const int len0 = dmm ? ece - su : 0, len1 = dmm ? ere - sv : 0;
-            const int tot = len0 + len1;
-            const int Ltot = max(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 64 - SG));
-            const bool part = s < ne;
-            int pslot = PS_ROOT, sym = 0;
-            bool same = false, rootpar = false;
-            double self[K], self1[K], mx0 = PO_NEG_INF, mx = PO_NEG_INF;
-            int mt0 = -1, mt = -1;                      // where the maxima are (the latest such time)
-            double c1 = PO_NEG_INF;                     // read 1: maximum carried over from the previous step
-            int ct1 = -1;
-            Ent *myrow = pool, *row1 = pool;
-            Ent seed0, seed1;
-            const Ent *prow = pool, *prow1 = pool;
-            unsigned long long tag0 = 0, ptag0 = 0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) { self[k] = PO_NEG_INF; self1[k] = PO_NEG_INF; }
-            if (part) {
-                pslot = h.e[F_PSLOT][s];
-                const int sy = h.e[F_SYM][s];
-                sym = sym_last(sy); same = (sym_plast(sy) == sym); rootpar = (sy >> 9) & 1;
-                myrow = pool + (size_t)h.e[F_ROW][s] * 2 * R;
-                row1 = myrow + R;
-                tag0 = make_tag(epoch, h.e[F_ID][s], 0);
-                // the seeds are only requested here; they are looked at after the re-read of maxima below, so that
-                // the two memory round trips overlap
-                seed0 = myrow[(su - 1) & Rm];
-                seed1 = row1[(sv - 1) & Rm];
-                if (pslot == PS_FROZEN) {
-                    prow = pool + (size_t)h.e[F_PROW][s] * 2 * R;
-                    prow1 = prow + R;
-                    ptag0 = make_tag(epoch, h.e[F_PAR][s], 0);
-                }
-            }
-            // The part [u, su) / [v, sv) of an incremental step's windows is not recomputed: its maximum comes from
-            // the previous step's (kept per element slot in the y buffer, which is idle between scans) — unless that
-            // maximum sat at a time the window has left.  Then the stored values are read back: the half-wave shares
-            // the work, 4 lanes per (element, read) with 4 loads in flight each, so that a step pays one or two
-            // memory round trips for it, not one per value.
-            {
-                bool need0 = false, need1 = false;
-                int ps = 0;
-                if (part && fastH) {
-                    ps = h.sel[min(s, WB - 1)];
-                    if (s >= nb) { const int j = ((s - nb) * divA) >> 16; ps = nbq + A * h.sel[j] + ((s - nb) - j * A); }
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const int lo = rr ? v : u, hi = rr ? sv : su;
-                        if (hi > lo) {
-                            const double pm = h.stg_v()[rr * SG + ps];
-                            const int pt = h.stg_t()[rr * SG + ps];
-                            if (pm == PO_NEG_INF || (pt >= lo && pt < hi)) {
-                                if (rr) { c1 = pm; ct1 = pt; } else { mx = pm; mt = pt; }
-                            } else if (rr) need1 = true;
-                            else need0 = true;
-                        }
-                    }
-                }
-                const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
-                if ((b0 | b1) != 0) {   // (wave-uniform)
-                    const unsigned long long hm0 = (SG == 64) ? b0 : (g ? (b0 >> 32) : (b0 & 0xffffffffull));
-                    const unsigned long long hm1 = (SG == 64) ? b1 : (g ? (b1 >> 32) : (b1 & 0xffffffffull));
-                    const unsigned long long below = (1ull << s) - 1ull;
-                    const int n0 = __popcll(hm0), nit = n0 + __popcll(hm1);
-                    int* const list = (int*)&h.xch[0][0][0];   // free until the first iteration ends
-                    if (need0) list[__popcll(hm0 & below)] = s;
-                    if (need1) list[n0 + __popcll(hm1 & below)] = s;
-                    x2_sync();
-                    constexpr int G = 4, PER = SG / G;
-                    const int rounds_h = (nit + PER - 1) / PER;
-                    const int rounds = max(__builtin_amdgcn_readlane(rounds_h, 0), __builtin_amdgcn_readlane(rounds_h, 64 - SG));
-#ifdef PO_B2_TIMING
-                    if (g == 0 && s == 0) { tk[0] += 1000000; tk[1] += 1000000ll * nit; }
-#endif
-                    for (int r = 0; r < rounds; ++r) {
-                        const int item = r * PER + s / G, sub = s & (G - 1);
-                        const bool act = item < nit;
-                        double c = PO_NEG_INF;
-                        int ct = -1, wr = 0;
-                        if (act) {
-                            const int rr = (item >= n0) ? 1 : 0;
-                            const int sl = list[item];
-                            const int lo = rr ? v : u, hi = rr ? sv : su;
-                            const Ent* rp = pool + ((size_t)h.e[F_ROW][sl] * 2 + rr) * R;
-                            const unsigned long long tg = make_tag(epoch, h.e[F_ID][sl], 0);
-                            int psl = h.sel[min(sl, WB - 1)];
-                            if (sl >= nb) { const int j = ((sl - nb) * divA) >> 16; psl = nbq + A * h.sel[j] + ((sl - nb) - j * A); }
-                            wr = rr * SG + psl;
-                            for (int bt = lo + sub; bt < hi; bt += 4 * G) {
-                                Ent e4[4];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) e4[q] = rp[(bt + q * G) & Rm];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const int tq = bt + q * G;
-                                    const double val = (tq < hi && e4[q].tag == tg + (unsigned)tq) ? e4[q].v[0] : PO_NEG_INF;
-                                    if (tq < hi && val >= c) { c = val; ct = tq; }
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int off = 1; off < G; off <<= 1) {   // the latest time among equal maxima
-                            const double oc = __shfl_xor(c, off);
-                            const int ot = __shfl_xor(ct, off);
-                            if (oc > c || (oc == c && ot > ct)) { c = oc; ct = ot; }
-                        }
-                        if (act && sub == 0) { h.stg_v()[wr] = c; h.stg_t()[wr] = ct; }
-                    }
-                    x2_sync();
-                    if (need0) { mx = h.stg_v()[ps]; mt = h.stg_t()[ps]; }
-                    if (need1) { c1 = h.stg_v()[SG + ps]; ct1 = h.stg_t()[SG + ps]; }
-                }
-            }
-            if (part) {
-                const bool hit0 = (su >= 1) && (seed0.tag == tag0 + (unsigned)(su - 1));
-                const bool hit1 = (sv >= 1) && (seed1.tag == tag0 + (unsigned)(sv - 1));
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    self[k] = hit0 ? seed0.v[k] : PO_NEG_INF;
-                    self1[k] = hit1 ? seed1.v[k] : PO_NEG_INF;
-                    h.xch[1][s][k] = (len0 > 0) ? self[k] : self1[k];
-                }
-            }
-            x2_sync();   // the carried maxima are read before the y buffer is filled
-            // Redundant stores.  An element that was an element in the previous main step too recomputes, over
-            // the part of its window that step already covered, exactly the bits that are stored — IF every
-            // ancestor of it inside the element set is in the same situation (same seed, same parent values,
-            // same y).  Beam nodes always come out of the previous step's element set; children were elements
-            // iff their parent was a beam node then and kept its row group.  "bad" marks the others and is
-            // pushed down the parent links; everyone else only stores from the previous window end on.
-            bool bad = false;
-            if (part && s >= nb) { const int j = pslot; bad = !(h.stay[j] && h.newfc[j] == 0); }
-            {
-                unsigned long long bm = __ballot(bad);
-                for (int round = 0; round < WB + 1 && bm != 0; ++round) {   // until nothing changes (usually at once)
-                    const unsigned long long hm = (SG == 64) ? bm : (g ? (bm >> 32) : (bm & 0xffffffffull));
-                    if (part && pslot >= 0 && ((hm >> pslot) & 1ull)) bad = true;
-                    const unsigned long long nbm = __ballot(bad);
-                    if (nbm == bm) break;
-                    bm = nbm;
-                }
-            }
-#ifdef PO_B2_TIMING
-            {   // statistics: steps of this half without any element that needs its full window
-                const unsigned long long bmm = __ballot(bad && part);
-                const unsigned long long hmm = (SG == 64) ? bmm : (g ? (bmm >> 32) : (bmm & 0xffffffffull));
-                if (dmm && g == 0 && s == 0) { tk[10] += 1; if (fastH) tk[11] += 1; tk[9] += __popcll(hmm); }
-            }
-#endif
-            int sfrom = bad ? INT_MIN : h.sh[5];        // first time whose value must be written (current read)
-            const int ca = sym, cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
-            int t = su;                                 // time of the current iteration
-            const double* cump = cumA;                  // fetch context of a non-moving parent: root sums, next time
-            int tf = su;
-            if (len0 == 0) { cump = cumB; prow = prow1; tf = sv; }
-            double pr_n[K];
-            Ent pe_n;
-            pe_n.tag = 0;
-#pragma unroll
-            for (int q = 0; q < K; ++q) { pr_n[q] = PO_NEG_INF; pe_n.v[q] = PO_NEG_INF; }
-            auto fetch = [&]() {  // value at t-1 of a parent that does not move, one iteration ahead (rare)
-                const int tp = tf - 1;
-                if (pslot == PS_ROOT) root_at(cump, tp, pr_n);
-                else if (tp >= 0) pe_n = prow[tp & Rm];
-                tf++;
-            };
-            if (part && pslot < 0) fetch();
-            // The y rows of both windows go through LDS, one copy per step (two contiguous runs of rows;
-            // buffer row = iteration index).  With no vector-memory LOAD left in the iteration loop, the
-            // wave never waits there for the acknowledgement of its value-store writes (vmcnt counts loads
-            // and stores in order: waiting for any load also waits for every store issued before it).
-            const int yrows = X2Half<K, SG>::YD / C;  // iterations per buffer fill
-            for (int k0 = 0; k0 < Ltot; k0 += yrows) {
-            if (YEARLY && k0 == 0) {   // the first fill was requested at the top of the step
-#pragma unroll
-                for (int q = 0; q < YPRE; ++q) {
-                    const int i = s + q * SG;
-                    if (i < X2Half<K, SG>::YD) h.ybuf[i] = ypre[q];
-                }
-            } else {
-                const int kend = min(tot, k0 + yrows);
-                const int ka1 = min(kend, len0);                 // read-0 iterations [k0, ka1)
-                const int nA = max(0, ka1 - k0) * C;
-                const double* srcA = yA + (int64_t)(su + k0) * C;
-                for (int i = s; i < nA; i += SG) h.ybuf[i] = srcA[i];
-                const int kb0 = max(k0, len0);                   // read-1 iterations [kb0, kend)
-                const int nB = max(0, kend - kb0) * C;
-                const double* srcB = yB + (int64_t)(sv + kb0 - len0) * C;
-                for (int i = s; i < nB; i += SG) h.ybuf[nA + i] = srcB[i];
-            }
-            x2_sync();
-            TK(4);  // scan: seeds + y window copy
-            const int kchunk = min(Ltot, k0 + yrows);
-            for (int kv = k0; kv < kchunk; ++kv) {
-                const int k = __builtin_amdgcn_readfirstlane(kv);
-                if (part && k < tot) {
-                    if (k == len0) {  // read 0's window is done: continue on read 1 from its seed
-                        mx0 = mx; mt0 = mt; mx = c1; mt = ct1; t = sv; myrow = row1;
-                        sfrom = bad ? INT_MIN : h.sh[6];
-#pragma unroll
-                        for (int q = 0; q < K; ++q) self[q] = self1[q];
-                    }
-                    const double* yrow = h.ybuf + (k - k0) * C;
-                    const double ya = yrow[ca], yb = yrow[cb];
-                    double pp[K], out[K];
-#pragma unroll
-                    for (int q = 0; q < K; ++q) pp[q] = h.xch[(k + 1) & 1][pslot >= 0 ? pslot : s][q];
-                    if (pslot < 0) {  // rare: the parent does not move in this scan
-                        const bool hit = (t >= 1) && (pe_n.tag == ptag0 + (unsigned)(t - 1));
-#pragma unroll
-                        for (int q = 0; q < K; ++q) pp[q] = (pslot == PS_ROOT) ? pr_n[q] : (hit ? pe_n.v[q] : PO_NEG_INF);
-                    }
-                    if (pslot < 0 && k + 1 < tot) {
-                        if (k + 1 == len0) { cump = cumB; prow = prow1; tf = sv; }
-                        fetch();
-                    }
-                    po_update<MODEL>(self, pp, ya, yb, same, rootpar && t == 0, out, lae);
-#ifdef PO_ABL_NOSTORE   // timing ablation only (results are wrong)
-                    if (out[0] == 12345.678) pool[0].tag = 1;
-#else
-                    if (t >= sfrom) {
-                        Ent e;
-                        // (t < 2^24 sits in the low word of the tag: a 32-bit add, no carry)
-                        e.tag = (tag0 & 0xffffffff00000000ull) | (unsigned)((unsigned)tag0 + (unsigned)t);
-#pragma unroll
-                        for (int q = 0; q < K; ++q) e.v[q] = out[q];
-                        myrow[(unsigned)(t & Rm)] = e;
-                    }
-#endif
-                    const bool sw = (k + 1 == len0);  // the next iteration starts read 1: hand its seed over
-#pragma unroll
-                    for (int q = 0; q < K; ++q) { self[q] = out[q]; h.xch[k & 1][s][q] = sw ? self1[q] : out[q]; }
-                    if (out[0] >= mx) { mx = out[0]; mt = t; }
-                    t++;
-                }
-                x2_sync();
-            }
-            TK(5);  // scan: iterations
-            }
-            if (len1 == 0) { mx0 = mx; mt0 = mt; mx = c1; mt = ct1; }   // (no iteration switched to read 1)
-            if (part) {   // this step's maxima, for the next one
-                h.stg_v()[s] = mx0; h.stg_v()[SG + s] = mx;
-                h.stg_t()[s] = mt0; h.stg_t()[SG + s] = mt;
-            }
-            {   // node_greater_max_sym: max over read 0 + max over read 1
-                X2Cand c;
-                c.sc = mx0 + mx; c.id = part ? h.e[F_ID][s] : 0; c.dup = part ? dupf : 1;
-                h.cand[s] = c;
-            }
-            // (the counter counts the evaluations the reference's step makes: ne over both full windows)
-            if (part && s == 0) {
-                h.nupd += (unsigned)(ne * ((ece - u) + (ere - v))); h.nupd_x += (unsigned)(ne * tot);
-                h.sh[5] = ece; h.sh[6] = ere;
-            }
-            if (part && s >= nb && !wsteady) { h.e[F_FC][s] = my_fc; h.e[F_CROW][s] = my_cr; }
-        }
-        x2_sync();
-
-        TK(6);  // scores
-        // ---- prune (Beam.h:93-108) + next beam table: rank by (score, id) among the distinct candidates, then the
-        // W best gather their fields from the old table (and find their parent in the new beam through `sel`)
-        {
-            const bool live = (s < ne) && !dupf;
-            // Most steps keep the beam as it is.  That is the case iff the beam nodes are still in order and the
-            // last of them still beats every child — two comparisons per lane instead of a full ranking.
-            bool viol = false;
-            if (dmm && nb != W) viol = true;
-            else if (live) {   // (strictly: an exact tie is resolved by the full path, as the reference's partial_sort does)
-                const X2Cand me = h.cand[s];
-                if (s >= nb) { const X2Cand lb = h.cand[nb - 1]; viol = !(lb.sc > me.sc); }
-                else if (s + 1 < nb) { const X2Cand nx = h.cand[s + 1]; viol = !(me.sc > nx.sc); }
-            }
-            const unsigned long long cand = __ballot(live);
-            const int ncand = (SG == 64) ? __popcll(cand) : __popcll(g ? (cand >> 32) : (cand & 0xffffffffull));
-            bool teq = false;
-            if (__ballot(viol) == 0) {
-                if (dmm && s < nb) h.sel[s] = s;
-            } else if (live) {
-                int rank = 0, neq = 0;
-                const X2Cand me = h.cand[s];
-#pragma unroll 8
-                for (int o = 0; o < SG; ++o) {   // (branch-free: the candidates' LDS reads go out in batches)
-                    const X2Cand c = h.cand[o];
-                    const int lv = c.dup ? 0 : 1;
-                    rank += lv & (((c.sc > me.sc) | (!(me.sc > c.sc) & (c.id < me.id))) ? 1 : 0);
-                    neq += lv & ((c.sc == me.sc) ? 1 : 0);
-                }
-                if (rank < W) h.sel[rank] = s;
-                teq = (neq > 1) && (rank < W);   // an exact score tie that reaches into the beam
-            }
-            {   // exact ties: the beam libstdc++'s partial_sort / sort leave on the creation-ordered candidates (po_device.h)
-                const unsigned long long tb = __ballot(teq);
-                if (tb != 0ull) {
-                    const bool tieH = ((SG == 64) ? tb : (g ? (tb >> 32) : (tb & 0xffffffffull))) != 0ull;
-                    x2_sync();
-                    if (tieH && live) {
-                        const X2Cand me = h.cand[s];
-                        int pos = 0;
-                        for (int o = 0; o < SG; ++o) { const X2Cand c = h.cand[o]; pos += (!c.dup && c.id < me.id) ? 1 : 0; }
-                        h.ord[pos] = s;
-                    }
-                    x2_sync();
-                    if (tieH && s == 0) {
-                        const X2Cand* cp = h.cand;
-                        po_stl_prune<WB>(h.ord, ncand, W, [&](int slot) { return cp[slot].sc; });
-                        for (int j = 0; j < min(W, ncand); ++j) h.sel[j] = h.ord[j];
-                    }
-                }
-            }
-            x2_sync();
-            const int nbn = dmm ? min(W, ncand) : 0;
-            // the beam comes out as it went in (same nodes, same slots): nothing to move
-            const unsigned long long mvb = __ballot(dmm && ((s < nbn && h.sel[s] != s) || nbn != nb));
-            const bool ident = dmm && ((SG == 64) ? mvb : (g ? (mvb >> 32) : (mvb & 0xffffffffull))) == 0;
-            steadyH = ident;
-            if (mvb == 0) {
-                if (s < nbn) h.stay[s] = 1;
-#ifdef PO_B2_TIMING
-                if (dmm && g == 0 && s == 0) tk[8] += 1000000;
-#endif
-            } else {
-            int nf[F_COUNT], nbp = -1, nstay = 0;
-#pragma unroll
-            for (int f = 0; f < F_COUNT; ++f) nf[f] = 0;
-            if (s < nbn) {
-                const int e = h.sel[s];
-                nstay = (e < nb) ? 1 : 0;
-                if (e < nb) {
-#pragma unroll
-                    for (int f = 0; f < F_COUNT; ++f) nf[f] = h.e[f][e];
-                } else {  // a child enters the beam
-                    const int p = h.e[F_PSLOT][e];
-                    nf[F_ID] = h.e[F_ID][e]; nf[F_ROW] = h.e[F_ROW][e]; nf[F_PSLOT] = PS_FROZEN;
-                    nf[F_SYM] = sym_pack(sym_last(h.e[F_SYM][e]), sym_last(h.e[F_SYM][p]), false);
-                    nf[F_PAR] = h.e[F_ID][p]; nf[F_GPAR] = h.e[F_PAR][p];
-                    nf[F_PROW] = h.e[F_ROW][p]; nf[F_DEPTH] = h.e[F_DEPTH][p] + 1;
-                    nf[F_FC] = h.e[F_FC][e]; nf[F_CROW] = h.e[F_CROW][e];
-                }
-                // the parent's element slot in this step -> its slot in the new beam (if it made it), and the row
-                // its values are being written to
-                const int oldpar = h.e[F_PSLOT][e];
-                if (oldpar >= 0) {
-                    nf[F_PROW] = h.e[F_ROW][oldpar];
-#pragma unroll
-                    for (int i = 0; i < WB; ++i) if (i < nbn && h.sel[i] == oldpar) nbp = i;
-                }
-            }
-            x2_sync();  // every lane has read its source slot before any slot is overwritten
-            if (s < nbn) {
-#pragma unroll
-                for (int f = 0; f < F_COUNT; ++f) h.e[f][s] = nf[f];
-                h.stay[s] = nstay;
-                h.bps[s] = nbp;
-            }
-            }
-            if (dmm) {
-                nbq = nb;
-                nb = nbn;
-                up = u; vp = v;
-                mstep++;
-                rec = rec_n; rec_n = sched[max(0, min(mstep + 1, nmain - 1))];
-                if (mstep >= nmain) fin = true;
-            }
-            x2_sync();
-        }
-
-        TK(7);  // prune + next beam
-        // ------------------------------------------------------------ label of the top node
-        if (have && fin) {
-            if (s == 0) {
-                int nout = 0;
-                if (st == PO_OK) {
-                    int node = h.e[F_ID][0];
-                    nout = h.e[F_DEPTH][0];
-                    char* out = a.seq + a.seq_off[pi];
-                    const int cap = (int)(a.seq_off[pi + 1] - a.seq_off[pi]);
-                    if (nout > cap) { st = PO_E_CAP; nout = 0; }
-                    else
-                        for (int i = nout - 1; i >= 0; --i) {
-                            const int pk = apl[node];
-                            out[i] = (char)((a.alphabet >> (8 * (po_node_last(pk) & 3))) & 0xffu);
-                            node = po_node_parent(pk);
-                        }
-                }
-                a.seq_len[pi] = nout;
-                a.status[pi] = st;
-            }
-            have = false;
-        }
-        TK(8);  // label walk
-    }
-    if (a.upd_count && s == 0) { atomicAdd(a.upd_count, h.nupd); atomicAdd(a.upd_count + 1, h.nupd_x); }
-#ifdef PO_B2_TIMING
-    if (lane == 0 && a.dbg && blockIdx.x == 0)
-        for (int i = 0; i < 12; ++i) a.dbg[i] = tk[i];
-#endif
-}
 
 // =================================================================================================
 // method "grid" (beam_search_2d_grid, BeamSearch2.h:33-184; hidden upstream option): ONE BEAM PER CELL.
@@ -2457,133 +1657,38 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(const int64_t* y1_off,
     for (int i = tid; i < n; i += 1024) order[atomicAdd(&hist[bin_of(i)], 1)] = i;
 }
 
-// ---- two-pairs-per-wave path (row_col, envelope, W <= 6, one-value model)
-struct X2Geom {
-    int blocks, npw;
-    size_t pool_bytes, arena_cap;
-    size_t off_queue, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_fb, fb_bytes, off_order, total;
-};
 constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over deferred pairs (16 / 32 MB of store each)
 // Kernel routing is a process-wide setting of the library (po_set_pair_route), not something a launch looks up in the
-// environment: PO_ROUTE_AUTO (the engine's choice, below), PO_ROUTE_X2 (beam2d_x2_kernel whenever it can run),
-// PO_ROUTE_LEGACY (always beam2d_kernel) — the last two exist for the tests, which run the pair path on both kernels,
-// and for A/B timing.  The environment variables PO_X2_FORCE / PO_B2_LEGACY / PO_X2_DEFER_ODD only give the INITIAL
-// value, read once when the library is first used, so that a workspace size and the launch that follows always agree.
-struct B2Route { int route, defer_odd, x2_per_cu, debug_occ, ring_auto, ring_small, no_order, reg_auto; };
+// environment: PO_ROUTE_AUTO (the engine's choice: beam2d_reg_kernel wherever it applies — row_col with an envelope, W <= 12,
+// every tree model — and beam2d_kernel elsewhere), PO_ROUTE_REG (the same, named), PO_ROUTE_LEGACY (always beam2d_kernel) —
+// for the tests, which run the pair path on both kernels, and for A/B timing.  The environment variables PO_B2_LEGACY /
+// PO_REG_NEVER / PO_X2_DEFER_ODD only give the INITIAL value, read once when the library is first used, so that a workspace
+// size and the launch that follows always agree.  (Rounds 1 - 4 had two more kernels and routes — two pairs per wave, LDS
+// rings — which the register-state kernel replaced at every size: DESIGN.md, appendix.)
+struct B2Route { int route, defer_odd, debug_occ, no_order, reg_auto; };
 B2Route& b2_route() {
     static B2Route r = [] {
         B2Route x;
-        x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_X2_FORCE") ? PO_ROUTE_X2 : (getenv("PO_RING_FORCE") ? PO_ROUTE_RING : (getenv("PO_REG_FORCE") ? PO_ROUTE_REG : PO_ROUTE_AUTO)));
-        x.reg_auto = getenv("PO_REG_NEVER") ? 0 : 1;      // beam2d_reg_kernel for launches beyond the ring kernel's range (the default)
+        x.route = getenv("PO_B2_LEGACY") ? PO_ROUTE_LEGACY : (getenv("PO_REG_FORCE") ? PO_ROUTE_REG : PO_ROUTE_AUTO);
+        x.reg_auto = getenv("PO_REG_NEVER") ? 0 : 1;      // A/B: beam2d_kernel for everything
         x.defer_odd = getenv("PO_X2_DEFER_ODD") ? 1 : 0;
         x.no_order = getenv("PO_B2_NO_ORDER") ? 1 : 0;   // A/B: pairs taken in input order
         x.debug_occ = getenv("PO_DEBUG_OCC") ? 1 : 0;
-        x.ring_auto = getenv("PO_RING_AUTO") ? 1 : 0;     // beam2d_ring_kernel at every batch size (A/B)
-        x.ring_small = getenv("PO_RING_NEVER") ? 0 : 1;   // ... for launches within its resident workgroups (the default)
-        const char* e = getenv("PO_X2_PER_CU");
-        x.x2_per_cu = e ? atoi(e) : 0;
         return x;
     }();
     return r;
 }
-bool x2_eligible(int n, int W, int model, int method) {
-    if (b2_route().route == PO_ROUTE_LEGACY || method != PO_METHOD_ROW_COL || W > 12) return false;
-    if (b2_route().route == PO_ROUTE_X2) return true;
-    // 7 <= W <= 12: one pair per wave with the reads one after the other — since the incremental steps it beats
-    // beam2d_kernel's two waves per pair at every batch size (W = 10: 6.5k vs 3.5k pairs/s at 256 pairs, 22.9k vs
-    // 12.7k at 1024, 36.6k vs 19.6k at 3328, 55k at 13k; Bonito W = 10: 29.2k vs 24.5k at 10k).
-    if (W > 6) return true;
-    // W <= 6: beam2d_kernel (one wave per pair, 16 resident per CU) is both the lower-latency and — since it fits 4
-    // waves per SIMD — the higher-throughput form: ctc W = 5 84.8k vs 78.9k pairs/s at 10 000 pairs, 83.8k vs 65.1k at
-    // 4096, 89.7k vs 81.6k at 16 384; Bonito 54.7k vs 39.0k.  The two-pairs-per-wave kernel (168 VGPRs: 3 waves per
-    // SIMD) stays reachable through PO_X2_FORCE and serves 7 <= W <= 12.
-    return false;
-}
 void (*g_b2_mark_fwd)(int begin, hipStream_t stream) = nullptr;   // set through po_b2_set_mark
-template <int MODEL>
-void x2_launch(const X2Args& a, int n, int W, int blocks, size_t plds, hipStream_t stream) {
-    hipLaunchKernelGGL(beam2d_prepass_kernel<MODEL>, dim3(n), dim3(256), plds, stream, a);
-    hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
-    if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
-    if (W <= 6) hipLaunchKernelGGL((beam2d_x2_kernel<MODEL, 32>), dim3(blocks), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((beam2d_x2_kernel<MODEL, 64>), dim3(blocks), dim3(64), 0, stream, a);
-    if (g_b2_mark_fwd) g_b2_mark_fwd(0, stream);
-}
-template <int MODEL>
-const void* x2_fn(int W) {
-    return W <= 6 ? (const void*)beam2d_x2_kernel<MODEL, 32> : (const void*)beam2d_x2_kernel<MODEL, 64>;
-}
-int x2_blocks_per_cu(int model, int W) {
-    static PoPerDeviceCache<6> per_cu;
-    const int mi = model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2), wi = W <= 6 ? 0 : 1;
-    return per_cu.get(mi * 2 + wi, [=] {
-        int nblk = 0;
-        const void* fn = mi == 0 ? x2_fn<PO_MODEL_CTC>(W) : (mi == 1 ? x2_fn<PO_MODEL_MERGE>(W) : x2_fn<PO_MODEL_FLIPFLOP>(W));
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, 64, 0) != hipSuccess || nblk <= 0) nblk = 8;
-        if (b2_route().debug_occ) fprintf(stderr, "[po] beam2d_x2_kernel model %d W %d: %d resident workgroups per CU\n", model, W, nblk);
-        if (b2_route().x2_per_cu > 0 && b2_route().x2_per_cu < nblk) nblk = b2_route().x2_per_cu;  // experiment knob
-        return nblk;
-    });
-}
-X2Geom x2_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model) {
-    X2Geom g;
-    const int npw = W <= 6 ? 2 : 1;  // pairs per wave
-    g.npw = npw;
-    g.blocks = b2_num_cus() * x2_blocks_per_cu(model, W);
-    if (g.blocks > (n + npw - 1) / npw) g.blocks = n > 1 ? (n + npw - 1) / npw : 1;
-    g.pool_bytes = al256((size_t)(model == PO_MODEL_CTC ? 2 : 4) << (W <= 6 ? 20 : 21));  // 128 (256) row groups of R <= 128 entries
-    const int64_t WM = W > PO_A ? W : PO_A;
-    g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 1));
-    {   // as in b2_geometry: within the memory budget for long reads
-        const size_t per_block = (g.pool_bytes + sizeof(int) * 3 * g.arena_cap) * npw;
-        const size_t fit = std::max<size_t>(1, b2_mem_budget() / std::max<size_t>(per_block, 1));
-        if ((size_t)g.blocks > fit) g.blocks = (int)fit;
-    }
-    size_t o = 0;
-    g.off_queue = o; o += 256;
-    g.off_meta = o; o += al256(sizeof(int2) * (size_t)(n > 0 ? n : 1));
-    g.off_nmain = o; o += al256(sizeof(int) * (size_t)(n > 0 ? n : 1));
-    g.off_sched = o; o += al256(sizeof(int4) * (size_t)(tr2 > 0 ? tr2 : 1));
-    g.off_envt = o; o += al256(sizeof(int) * 2 * (size_t)tr2);
-    g.off_cum1 = o; o += al256(sizeof(double) * (size_t)tr1);
-    g.off_cum2 = o; o += al256(sizeof(double) * (size_t)tr2);
-    g.off_pool = o; o += g.pool_bytes * npw * g.blocks;
-    g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * npw * g.blocks);
-    g.off_fb = o;
-    g.fb_bytes = b2_geometry(n, mr1, mr2, W, model, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
-    o += al256(g.fb_bytes);
-    g.off_order = o; o += al256(sizeof(int) * (size_t)std::max(n, 1));   // the queue's order (pair_order_kernel)
-    g.total = o + 256;
-    return g;
-}
-
-// ---- LDS-ring path (beam2d_ring_kernel, po_beam2d_ring.hip): row_col with an envelope, one-value model, W * (A + 1)
-// elements within its ring rows.  One wave per pair; pre-pass and walk are the two-pairs-per-wave path's.
-extern "C" int po_ring_blocks_per_cu();
-extern "C" int po_ring_max_elements();
-extern "C" int po_ring_ngl();
-extern "C" void po_ring_launch(const void* x2args, int blocks, hipStream_t stream);
-// The engine's own choice (PO_ROUTE_AUTO): the LDS-ring kernel for launches that fit its resident workgroups (8 per
-// CU: 2 048 pairs) — there a pair's latency is what counts and it is 5 - 8 % faster (single pair 19.4 vs 20.7 ms, 1 250
-// pairs 45.3k vs 43.2k pairs/s) — and beam2d_kernel beyond, where throughput counts (104k vs 82k pairs/s at 10 000).
-bool ring_eligible(int n, int W, int A, int model, int method) {
-    const int rt = b2_route().route;
-    if (!(model == PO_MODEL_CTC && method == PO_METHOD_ROW_COL && W <= 6 && A >= 1 && W * (A + 1) <= po_ring_max_elements())) return false;
-    if (rt == PO_ROUTE_RING) return true;
-    if (rt != PO_ROUTE_AUTO) return false;
-    if (b2_route().ring_auto) return true;
-    return b2_route().ring_small && n <= b2_num_cus() * po_ring_blocks_per_cu();
-}
-struct RingGeom {
-    int blocks;
+// The register-state kernel (beam2d_reg_kernel, po_beam2d_reg.hip) with its batch-parallel pre-pass and walk kernels
+// (po_beam2d_pre.h): the engine's choice (PO_ROUTE_AUTO) for row_col with an envelope at every batch size, every tree
+// model, W <= 12.  PO_REG_NEVER / PO_ROUTE_LEGACY send everything to beam2d_kernel.
+struct RegGeom {
+    int blocks;        // pair slots (one-wave workgroups) of this launch
+    int pool_slots;    // slices the pool region is laid out for (>= blocks: see reg_geometry)
     size_t pool_bytes, arena_cap;
-    size_t off_queue, off_state, off_meta, off_nmain, off_sched, off_envt, off_cum1, off_cum2, off_pool, off_arena, off_order, off_fb, fb_bytes, total;
+    size_t off_queue, off_state, off_pool, off_meta, off_nmain, off_sched, off_envt, off_arena, off_order, off_fb, fb_bytes, total, min_total;
     unsigned long long magic;
 };
-// The register-state kernel (beam2d_reg_kernel, po_beam2d_reg.hip): the same pre-pass, walk and meta words; the engine's
-// choice (PO_ROUTE_AUTO) at every batch size since round 4 — 16 pairs per CU instead of the ring kernel's 8, and the
-// lower latency of the two for a single pair as well (16.6 vs 17.3 ms; 1 250 pairs 24.9 vs 25.3 ms; 10 000 pairs 74.4 vs
-// 106 ms, beam2d_kernel 89.1).  PO_REG_NEVER gives the round-3 routing back (ring up to 2 048 pairs, beam2d_kernel beyond).
 extern "C" int po_reg_slots_per_cu(int model, int wide);
 extern "C" int po_reg_max_elements(int wide);
 extern "C" int po_reg_ngl(int wide);
@@ -2600,13 +1705,23 @@ bool reg_eligible(int n, int W, int A, int model, int method) {
     if (rt != PO_ROUTE_AUTO) return false;
     return b2_route().reg_auto != 0;
 }
-RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model, bool reg = false) {
-    RingGeom g;
-    g.blocks = b2_num_cus() * (reg ? po_reg_slots_per_cu(model, reg_wide(W)) : po_ring_blocks_per_cu());
+// Workspace layout: [queue | state words of every slot the device can hold | value store slices | per-launch arrays | arenas |
+// the deferred-pairs pass].  The slices keep their tags across launches (epoch counters in the state words: no memset of
+// 8 GB per launch), so a slot's slice must stay where it is from launch to launch — also when the launches differ in size,
+// as the waves of one pipelined job do (1 250, 2 500, 3 334 ... pairs through the same buffer).  Hence: state words and
+// slices come FIRST, at offsets that do not depend on n, and the pool region is laid out for as many slices as the caller's
+// buffer has room for (ws_bytes; 0 = the smallest layout, what the size query reports): a small launch in a large buffer puts
+// its own arrays BEHIND the slices of the larger launches before it instead of on top of them.  reg_ws_claim() keeps count of
+// which slots' slices are intact.
+RegGeom reg_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model, size_t ws_bytes = 0) {
+    (void)tr1;
+    RegGeom g;
+    const int max_slots = b2_num_cus() * po_reg_slots_per_cu(model, reg_wide(W));
+    g.blocks = max_slots;
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
-    // ring kernel, tier 2: 128 row groups at R = 256 (windows up to 254 frames), 96 tracked; register-state kernel: the
-    // whole store, 2 MB = 128 groups at R = 128 (beam2d_kernel's W <= 6 geometry)
-    g.pool_bytes = reg ? po_reg_pool_bytes(model, reg_wide(W)) : ((size_t)4 << 20);
+    // the whole store of a pair slot: 2 MB = 128 row groups at R = 128 for the one-value model at W <= 6 (beam2d_kernel's
+    // geometry), twice that for three values per entry, twice again for the 64-slot layout
+    g.pool_bytes = po_reg_pool_bytes(model, reg_wide(W));
     const int64_t WM = W > PO_A ? W : PO_A;
     g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
     {
@@ -2614,24 +1729,30 @@ RingGeom ring_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2
         const size_t fit = std::max<size_t>(1, b2_mem_budget() / std::max<size_t>(per_block, 1));
         if ((size_t)g.blocks > fit) g.blocks = (int)fit;
     }
-    size_t o = 0;
-    g.off_queue = o; o += 256;
-    g.off_state = o; o += al256(sizeof(unsigned long long) * 2 * (size_t)g.blocks);
-    g.off_meta = o; o += al256(sizeof(int2) * (size_t)(n > 0 ? n : 1));
-    g.off_nmain = o; o += al256(sizeof(int) * (size_t)(n > 0 ? n : 1));
-    g.off_sched = o; o += al256(sizeof(int4) * (size_t)(tr2 > 0 ? tr2 : 1));
-    g.off_envt = o; o += al256(sizeof(int) * 2 * (size_t)tr2);
-    g.off_cum1 = o; o += al256(sizeof(double) * (size_t)tr1);
-    g.off_cum2 = o; o += al256(sizeof(double) * (size_t)tr2);
-    g.off_pool = o; o += g.pool_bytes * g.blocks;
-    g.off_arena = o; o += al256(sizeof(int) * 3 * g.arena_cap * g.blocks);
-    g.off_order = o; o += al256(sizeof(int) * (size_t)std::max(n, 1));   // the queue's order (pair_order_kernel)
-    g.off_fb = o;
+    g.off_queue = 0;
+    g.off_state = 256;
+    g.off_pool = g.off_state + al256(sizeof(unsigned long long) * 2 * (size_t)max_slots);
+    const size_t np = (size_t)(n > 0 ? n : 1);
+    const size_t b_meta = al256(sizeof(int2) * np), b_nmain = al256(sizeof(int) * np), b_sched = al256(sizeof(int4) * (size_t)(tr2 > 0 ? tr2 : 1));
+    const size_t b_envt = al256(sizeof(int) * 2 * (size_t)tr2), b_arena = al256(sizeof(int) * 3 * g.arena_cap * g.blocks), b_order = al256(sizeof(int) * np);
     g.fb_bytes = b2_geometry(n, mr1, mr2, W, model, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
-    o += al256(g.fb_bytes);
+    const size_t tail = b_meta + b_nmain + b_sched + b_envt + b_arena + b_order + al256(g.fb_bytes) + 256;
+    g.min_total = g.off_pool + g.pool_bytes * (size_t)g.blocks + tail;
+    g.pool_slots = g.blocks;
+    if (ws_bytes > g.min_total) g.pool_slots = (int)std::min<size_t>((size_t)max_slots, (ws_bytes - g.off_pool - tail) / g.pool_bytes);
+    size_t o = g.off_pool + g.pool_bytes * (size_t)g.pool_slots;
+    g.off_meta = o; o += b_meta;
+    g.off_nmain = o; o += b_nmain;
+    g.off_sched = o; o += b_sched;
+    g.off_envt = o; o += b_envt;
+    g.off_arena = o; o += b_arena;
+    g.off_order = o; o += b_order;   // the queue's order (pair_order_kernel)
+    g.off_fb = o; o += al256(g.fb_bytes);
     g.total = o + 256;
-    g.magic = (reg ? 0x51ed270b0a1f3c97ull : 0xa0761d6478bd642full) ^ ((unsigned long long)g.pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)g.blocks << 40) ^
-              ((unsigned long long)g.off_pool * 0x9e3779b97f4a7c15ull);
+    // (names the slices' geometry AND what is stored in them: entries of 16 or 32 bytes — two layouts of equal slice size
+    //  must not take each other's tags for their own)
+    g.magic = 0x51ed270b0a1f3c97ull ^ ((unsigned long long)g.pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)g.off_pool * 0x9e3779b97f4a7c15ull) ^
+              ((unsigned long long)(model * 2 + reg_wide(W) + 1) << 56);
     return g;
 }
 
@@ -2701,9 +1822,7 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
     (void)C;
     if (method == PO_METHOD_GRID) return grid_geometry(n, mr1, mr2, W, model, true).total;
     if (method == PO_METHOD_GRID_NOENV) return grid_geometry(n, mr1, mr2, W, model, false).total;
-    if (reg_eligible(n, W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return ring_geometry(n, tr1, tr2, mr1, mr2, W, model, true).total;
-    if (ring_eligible(n, W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return ring_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
-    if (x2_eligible(n, W, model, method)) return x2_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
+    if (reg_eligible(n, W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return reg_geometry(n, tr1, tr2, mr1, mr2, W, model).min_total;
     return b2_geometry(n, mr1, mr2, W, model, method).total + b2_geometry(n, mr1, mr2, W, model, method, X2_FB_BLOCKS).total;
 }
 
@@ -2714,7 +1833,7 @@ namespace {
 // inside the other's store while both keep writing tags into overlapping memory.  The host therefore remembers, per
 // workspace base pointer, the layout of the last pair-beam launch there; a launch with another layout zeroes the
 // (small) state region first, which makes every workgroup clear its slice.
-struct B2Layout { size_t off_state, total; unsigned long long magic; };
+struct B2Layout { size_t off_state, total; unsigned long long magic; int valid_slots; /* reg layouts: slots whose slices are intact; -1: beam2d_kernel's */ };
 std::mutex g_b2_layout_mu;
 std::unordered_map<const void*, B2Layout> g_b2_layouts;
 bool b2_ws_layout_changed(const void* ws, size_t off_state, size_t total, unsigned long long magic) {
@@ -2728,16 +1847,36 @@ bool b2_ws_layout_changed(const void* ws, size_t off_state, size_t total, unsign
             if (jt->first != ws && b < (const char*)ws + total && (const char*)ws < b + jt->second.total) jt = g_b2_layouts.erase(jt);
             else ++jt;
         }
-        g_b2_layouts[ws] = B2Layout{off_state, total, magic};
+        g_b2_layouts[ws] = B2Layout{off_state, total, magic, -1};
     }
     return !same;
+}
+// The register-state kernel's claim on a workspace: which slots' state words must be cleared before this launch (their slices
+// hold something else: first use, another layout, or the per-launch arrays of a launch that had fewer slices laid out).
+void reg_ws_claim(const void* ws, const RegGeom& g, int* first, int* count) {
+    std::lock_guard<std::mutex> lk(g_b2_layout_mu);
+    auto it = g_b2_layouts.find(ws);
+    const bool same = it != g_b2_layouts.end() && it->second.off_state == g.off_state && it->second.magic == g.magic && it->second.valid_slots >= 0;
+    int valid = same ? it->second.valid_slots : 0;
+    valid = std::min(valid, g.pool_slots);   // (what lay beyond this launch's pool region is overwritten by its arrays)
+    // whatever else is remembered inside the memory this launch writes (up to where its deferred-pairs pass — which makes its
+    // own claim — begins) is stale
+    for (auto jt = g_b2_layouts.begin(); jt != g_b2_layouts.end();) {
+        const char* b = (const char*)jt->first;
+        if (jt->first != ws && b < (const char*)ws + g.off_fb && (const char*)ws < b + jt->second.total) jt = g_b2_layouts.erase(jt);
+        else ++jt;
+    }
+    *first = std::min(valid, g.blocks);
+    *count = g.blocks - *first;
+    valid = std::max(valid, g.blocks);
+    g_b2_layouts[ws] = B2Layout{g.off_state, g.off_pool + g.pool_bytes * (size_t)valid, g.magic, valid};
 }
 unsigned long long* g_b2_upd_counter = nullptr;
 void (*g_b2_mark)(int begin, hipStream_t stream) = nullptr;   // profiling: brackets the main pair beam kernel
 }
 extern "C" void po_b2_set_mark(void (*f)(int, hipStream_t)) { g_b2_mark = f; g_b2_mark_fwd = f; }
 extern "C" int po_set_pair_route(int route, int defer_odd) {
-    if (route != PO_ROUTE_AUTO && route != PO_ROUTE_X2 && route != PO_ROUTE_LEGACY && route != PO_ROUTE_RING && route != PO_ROUTE_REG) return PO_E_ARG;
+    if (route != PO_ROUTE_AUTO && route != PO_ROUTE_LEGACY && route != PO_ROUTE_REG) return PO_E_ARG;   // (PO_ROUTE_X2 / PO_ROUTE_RING: kernels retired in round 5)
     b2_route().route = route;
     b2_route().defer_odd = defer_odd ? 1 : 0;
     return PO_OK;
@@ -2894,10 +2033,9 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         else grid_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
         return PO_OK;
     }
-    const bool use_reg = reg_eligible(n, W, A, model, method);
-    if (use_reg || ring_eligible(n, W, A, model, method)) {
-        const RingGeom g = ring_geometry(n, tr1, tr2, mr1, mr2, W, model, use_reg);
-        if (ws_bytes < g.total) return PO_E_CAP;
+    if (reg_eligible(n, W, A, model, method)) {
+        const RegGeom g = reg_geometry(n, tr1, tr2, mr1, mr2, W, model, ws_bytes);
+        if (ws_bytes < g.min_total || ws_bytes < g.total) return PO_E_CAP;
         char* w = (char*)ws;
         X2Args a;
         a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
@@ -2908,15 +2046,15 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.nmain = (int*)(w + g.off_nmain);
         a.sched = (int4*)(w + g.off_sched);
         a.envt = (int*)(w + g.off_envt);
-        a.cum1 = (double*)(w + g.off_cum1); a.cum2 = (double*)(w + g.off_cum2);
+        a.cum1 = nullptr; a.cum2 = nullptr;   // (the kernel adds the ctc root's alpha up as its scans pass the times)
         a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
         a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
         a.dbg = nullptr;
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
         a.need_mono = 1;
-        a.no_cum = use_reg ? 1 : 0;
-        a.order = nullptr;   // (the ring kernel by default gets at most as many pairs as resident workgroups: all start at once)
+        a.no_cum = 1;
+        a.order = nullptr;
         if (n > g.blocks && !b2_route().no_order) {   // more pairs than resident workgroups: longest first
             a.order = (int*)(w + g.off_order);
             hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
@@ -2925,78 +2063,24 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.magic = g.magic;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
         const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
-        a.ngl = use_reg ? po_reg_ngl(reg_wide(W)) : po_ring_ngl();
+        a.ngl = po_reg_ngl(reg_wide(W));
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-        // (the range this layout answers for ends where the nested workspace of the deferred-pairs pass begins)
-        if (b2_ws_layout_changed(ws, g.off_state, g.off_fb, g.magic) &&
-            hipMemsetAsync(w + g.off_state, 0, sizeof(unsigned long long) * 2 * (size_t)g.blocks, stream) != hipSuccess)
-            return PO_E_HIP;
+        {
+            int first_stale = 0, n_stale = 0;
+            reg_ws_claim(ws, g, &first_stale, &n_stale);
+            if (n_stale > 0 && hipMemsetAsync(w + g.off_state + sizeof(unsigned long long) * 2 * (size_t)first_stale, 0,
+                                              sizeof(unsigned long long) * 2 * (size_t)n_stale, stream) != hipSuccess)
+                return PO_E_HIP;
+        }
         if (model == PO_MODEL_CTC) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
         else if (model == PO_MODEL_MERGE) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(256), plds, stream, a);
         else hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(256), plds, stream, a);
         hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
         if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
-        if (use_reg) po_reg_launch(&a, g.blocks, model, reg_wide(W), stream);
-        else po_ring_launch(&a, g.blocks, stream);
+        po_reg_launch(&a, g.blocks, model, reg_wide(W), stream);
         if (g_b2_mark_fwd) g_b2_mark_fwd(0, stream);
         // pairs the pre-pass or the kernel deferred (tier-2 row groups exhausted, windows beyond the store's ring):
         // one small pass of beam2d_kernel, a no-op when there are none
-        return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off,
-                                seq_len, status, use_pre_status, w + g.off_fb, g.fb_bytes, stream, X2_FB_BLOCKS, a.meta, 0, a.queue + 16);
-    }
-    if (x2_eligible(n, W, model, method)) {
-        const X2Geom g = x2_geometry(n, tr1, tr2, mr1, mr2, W, model);
-        if (ws_bytes < g.total) return PO_E_CAP;
-        char* w = (char*)ws;
-        X2Args a;
-        a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
-        a.n = n; a.A = A; a.W = W; a.C = C; a.alphabet = alphabet;
-        a.seq = seq; a.seq_off = seq_off; a.seq_len = seq_len; a.status = status; a.use_pre_status = use_pre_status;
-        a.queue = (int*)(w + g.off_queue);
-        a.meta = (int2*)(w + g.off_meta);
-        a.nmain = (int*)(w + g.off_nmain);
-        a.sched = (int4*)(w + g.off_sched);
-        a.envt = (int*)(w + g.off_envt);
-        a.cum1 = (double*)(w + g.off_cum1); a.cum2 = (double*)(w + g.off_cum2);
-        a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
-        a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
-        a.dbg = nullptr;
-        a.upd_count = g_b2_upd_counter;
-        a.defer_odd = b2_route().defer_odd;
-        a.need_mono = 0;
-        a.no_cum = 0;
-        a.order = nullptr;
-        if (n > g.blocks * g.npw && !b2_route().no_order) {   // more pairs than resident half-waves: longest first
-            a.order = (int*)(w + g.off_order);
-            hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
-        }
-#ifdef PO_B2_TIMING
-        static long long* dbg_x2 = nullptr;
-        if (!dbg_x2) (void)hipMalloc((void**)&dbg_x2, 12 * sizeof(long long));
-        a.dbg = dbg_x2;
-#endif
-        if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-        if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.npw * g.blocks, stream) != hipSuccess) return PO_E_HIP;
-        a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);  // 2 ints per column: <= 48 KB of LDS
-        const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
-        a.ngl = (W <= 6) ? X2_NGL : 2 * X2_NGL;
-        if (model == PO_MODEL_CTC) x2_launch<PO_MODEL_CTC>(a, n, W, g.blocks, plds, stream);
-        else if (model == PO_MODEL_MERGE) x2_launch<PO_MODEL_MERGE>(a, n, W, g.blocks, plds, stream);
-        else x2_launch<PO_MODEL_FLIPFLOP>(a, n, W, g.blocks, plds, stream);
-#ifdef PO_B2_TIMING
-        {
-            long long hh[12];
-            (void)hipStreamSynchronize(stream);
-            (void)hipMemcpy(hh, a.dbg, sizeof(hh), hipMemcpyDeviceToHost);
-            const char* nm[9] = {"queue+setup", "catch-up steps", "expansion (serial)", "element table", "scan: seeds + y copy",
-                                 "scan: iterations", "scores", "prune + next beam", "label walk"};
-            fprintf(stderr, "[po_b2_timing x2] block 0, wall_clock64 ticks (100 MHz => 10 ns each):\n");
-            for (int i = 0; i < 9; ++i) fprintf(stderr, "   %-24s %12lld\n", nm[i], hh[i]);
-            fprintf(stderr, "   main steps %lld, of which without a new element %lld; new elements in all %lld\n", hh[10], hh[11], hh[9]);
-        }
-#endif
-        // pairs the pre-pass or the kernel deferred (window too wide for its store geometry, row groups
-        // exhausted): one small pass of beam2d_kernel, a no-op when there are none
         return b2_launch_legacy(y1, y1_off, y2, y2_off, env, n, C, A, alphabet, W, model, method, mr1, mr2, seq, seq_off,
                                 seq_len, status, use_pre_status, w + g.off_fb, g.fb_bytes, stream, X2_FB_BLOCKS, a.meta, 0, a.queue + 16);
     }

@@ -1,4 +1,4 @@
-// Shared by the pair-beam translation units (po_beam2d.hip, po_beam2d_ring.hip): the tagged value store entry, kernel
+// Shared by the pair-beam translation units (po_beam2d.hip, po_beam2d_reg.hip): the tagged value store entry, kernel
 // argument blocks, element-table field names and the wave-level hand-over helpers.  Everything sits in an anonymous
 // namespace: each translation unit gets its own copy.
 #pragma once
@@ -134,12 +134,12 @@ struct X2Args {
     int* arena; long long arena_cap;  // per half-wave: 3 int arrays
     long long* dbg;
     int defer_odd;                    // test hook (PO_X2_DEFER_ODD): hand every odd pair to beam2d_kernel
-    int need_mono;                    // the main kernel takes monotone envelopes only (beam2d_ring_kernel): others are deferred
+    int need_mono;                    // the main kernel takes monotone envelopes only (beam2d_reg_kernel): others are deferred
     const int* order;                 // optional: the pair the q-th queue ticket stands for (longest first, pair_order_kernel)
     int pre_vcols;                    // pre-pass: columns its LDS table holds
     int ngl;                          // row groups the main kernel tracks per pair
     unsigned long long* upd_count;    // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
-    unsigned long long* wgstate;      // beam2d_ring_kernel: per workgroup {magic, epoch counter} (see beam2d_kernel)
+    unsigned long long* wgstate;      // beam2d_reg_kernel: per pair slot {magic, epoch counter} (see beam2d_kernel)
     unsigned long long magic;
     int reg_slots;                    // beam2d_reg_kernel: pair slots (waves that decode pairs) of the launch, each with its own store slice
     int no_cum;                       // pre-pass: leave the blank prefix sums out (beam2d_reg_kernel adds the root's alpha up as it goes)

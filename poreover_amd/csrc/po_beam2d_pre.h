@@ -1,5 +1,5 @@
-// Per-pair pre-pass and diagonal walk of the row_col pair beam search, shared by the two-pairs-per-wave path
-// (po_beam2d.hip) and the LDS-ring path (po_beam2d_ring.hip launches through po_beam2d.hip's host code).  Kept in a
+// Per-pair pre-pass and diagonal walk of the row_col pair beam search for the register-state kernel (po_beam2d_reg.hip,
+// launched through po_beam2d.hip's host code).  Kept in a
 // header of their own so that tools/simt_emu can run them on the CPU next to the kernel under development.
 #pragma once
 #include "po_beam2d_common.h"

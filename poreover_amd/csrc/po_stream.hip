@@ -12,16 +12,27 @@
 //     (po_launch_pair_decode_geom: Viterbi x2, alignment + envelope, pair beam search)  ->  D2H of the results
 //
 // all asynchronous on the slot's stream, so while the GPU decodes wave k the host packs and uploads wave k + 1 on the
-// other stream, and the tail of one wave's persistent kernels overlaps the head of the next.  Buffers are allocated
-// once and grow only; the working set is bounded by the wave size whatever n is (the drivers never hold more
-// than two waves of device memory).
+// other stream, and the tail of one wave's persistent kernels overlaps the head of the next.  The working set is bounded
+// by the wave size whatever n is.
+//
+// Round 5 — what the FIRST call of a process pays (the reference's CLI is one process per job, pair_decode.py:230-303).
+// Rounds 3 - 4 staged a whole wave in pinned memory per slot: 1.3 GB of hipHostMalloc for the 10 000-pair job, ~ 0.14 ms
+// per MB — 0.33 s of a 0.55 s first call, paid again whenever a wave outgrew its slot (profiles/r05_cold_start.txt).  Now:
+//   * inputs go through a small fixed RING of pinned chunks (4 x 16 MB, allocated when the pipeline is created): host
+//     threads pack chunk k + 1 while chunk k is on the wire, so a wave's upload also starts with its first chunk, not
+//     after its last item has been packed;
+//   * the pinned result buffer holds what is copied back (texts and lengths; the envelopes only when asked for);
+//   * device buffers are sized ONCE per call, from the plan of its waves, before the first wave — nothing is freed and
+//     re-allocated mid-job (hipFree waits for the device).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -71,9 +82,81 @@ struct GrowBuf {   // grow-only buffer: device memory or pinned host memory
     }
 };
 
+// The pinned chunks every wave's input goes through (one ring per pipeline, allocated once).
+struct StageRing {
+    static constexpr int N = 4;
+    size_t chunk = 0;
+    char* buf[N] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[N] = {nullptr, nullptr, nullptr, nullptr};
+    bool used[N] = {false, false, false, false};
+    int next = 0;
+    bool create(size_t chunk_bytes) {
+        static const bool trace = getenv("PO_PIPE_TRACE") != nullptr;
+        const double t0 = trace ? now_ms() : 0.0;
+        chunk = chunk_bytes;
+        for (int i = 0; i < N; ++i) {
+            if (hipHostMalloc((void**)&buf[i], chunk, hipHostMallocDefault) != hipSuccess) { buf[i] = nullptr; return false; }
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { ev[i] = nullptr; return false; }
+        }
+        if (trace) fprintf(stderr, "[po_pipe] staging ring %d x %.0f MB pinned: %.2f ms\n", N, chunk / 1048576.0, now_ms() - t0);
+        return true;
+    }
+    void destroy() {
+        for (int i = 0; i < N; ++i) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (buf[i]) (void)hipHostFree(buf[i]);
+            ev[i] = nullptr; buf[i] = nullptr; used[i] = false;
+        }
+    }
+};
+
+// Host threads that pack chunks: started once per pipeline, woken per chunk (a std::thread per chunk and worker would cost
+// more than the copy of a small chunk).  run(f) calls f(0 .. n - 1), f(0) on the calling thread.
+class WorkerPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    unsigned gen = 0;
+    int pending = 0;
+    bool stop = false;
+    void loop(int i) {
+        unsigned seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            const std::function<void(int)>* f = job;
+            lk.unlock();
+            (*f)(i);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+  public:
+    const int n;
+    explicit WorkerPool(int n_) : n(std::max(1, n_)) {
+        for (int i = 1; i < n; ++i) th.emplace_back([this, i] { loop(i); });
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void run(const std::function<void(int)>& f) {
+        if (n == 1) { f(0); return; }
+        { std::lock_guard<std::mutex> lk(mu); job = &f; pending = n - 1; ++gen; }
+        cv_go.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
 struct Slot {
     hipStream_t st = nullptr;
-    GrowBuf h_in{true}, h_off{true}, h_out{true};
+    GrowBuf h_off{true}, h_out{true};
     GrowBuf d_in{false}, d_y{false}, d_off{false}, d_out{false}, d_ws{false};
     // the wave in flight
     int first = 0, n = 0;
@@ -148,6 +231,8 @@ struct po_pipeline {
     int device = 0, wave_pairs = 0 /* 0: auto_wave_pairs(n) */, threads = 8;
     int64_t wave_rows = (int64_t)64 << 20;
     Slot slot[PO_MAX_SLOTS];
+    StageRing ring;
+    WorkerPool* pool = nullptr;
     int nslots = 3;   // waves in flight: one decoding, the next ones packed / uploading behind it (PO_PIPELINE_SLOTS)
     double pack_ms = 0, wait_ms = 0, total_ms = 0;
     int waves = 0, pairs = 0;
@@ -166,31 +251,31 @@ int fail(po_pipeline* p, int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(p, PO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-// copy the items [lo, hi) of a wave into the pinned staging buffer, split over host threads by bytes
-void pack_items(const void* const* src, const int64_t* rows, int first, int n, size_t row_bytes, char* dst,
-                const std::vector<int64_t>& off, int threads) {
-    if (n <= 0) return;
-    const int nt = std::max(1, std::min(threads, n));
-    if (nt == 1) {
-        for (int i = 0; i < n; ++i) std::memcpy(dst + (size_t)off[i] * row_bytes, src[first + i], (size_t)rows[first + i] * row_bytes);
-        return;
-    }
-    const int64_t total = off[n];
-    std::vector<std::thread> th;
-    int lo = 0;
-    for (int t = 0; t < nt; ++t) {
-        const int64_t target = total * (t + 1) / nt;
-        int hi = lo;
-        while (hi < n && (off[hi + 1] <= target || t == nt - 1)) ++hi;
-        if (t == nt - 1) hi = n;
-        if (hi > lo)
-            th.emplace_back([=, &off]() {
-                for (int i = lo; i < hi; ++i)
-                    std::memcpy(dst + (size_t)off[i] * row_bytes, src[first + i], (size_t)rows[first + i] * row_bytes);
-            });
-        lo = hi;
-    }
-    for (auto& x : th) x.join();
+// Bytes [lo, hi) of a wave's input region (the items' rows back to back: item i at off[i] * row_bytes) -> dst[0, hi - lo),
+// split over the pool's threads by bytes; items are cut where the range cuts them.
+void pack_bytes(WorkerPool& pool, const void* const* src, int first, int n, size_t row_bytes, const std::vector<int64_t>& off,
+                size_t lo, size_t hi, char* dst) {
+    if (hi <= lo || n <= 0) return;
+    const int nt = (hi - lo < ((size_t)1 << 20)) ? 1 : pool.n;
+    const std::function<void(int)> work = [&](int t) {
+        if (t >= nt) return;
+        size_t a = lo + (hi - lo) * (size_t)t / (size_t)nt;
+        const size_t b = lo + (hi - lo) * (size_t)(t + 1) / (size_t)nt;
+        if (b <= a) return;
+        // the item that holds byte a: the last one starting at or before it
+        int i = (int)(std::upper_bound(off.begin(), off.begin() + n + 1, (int64_t)(a / row_bytes)) - off.begin()) - 1;
+        if (i < 0) i = 0;
+        while (a < b && i < n) {
+            const size_t i0 = (size_t)off[i] * row_bytes, i1 = (size_t)off[i + 1] * row_bytes;
+            if (a >= i1) { ++i; continue; }
+            const size_t e = std::min(b, i1);
+            std::memcpy(dst + (a - lo), (const char*)src[first + i] + (a - i0), e - a);
+            a = e;
+            if (a >= i1) ++i;
+        }
+    };
+    if (nt == 1) work(0);
+    else pool.run(work);
 }
 }  // namespace
 
@@ -210,6 +295,7 @@ struct DeviceScope {
 
 extern "C" {
 
+void po_pipeline_destroy(po_pipeline* p);
 po_pipeline* po_pipeline_create(int device, int wave_pairs, int64_t wave_rows, int threads) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { po_set_error("po_pipeline_create: no such device"); return nullptr; }
@@ -227,9 +313,17 @@ po_pipeline* po_pipeline_create(int device, int wave_pairs, int64_t wave_rows, i
     for (auto& s : p->slot)
         if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
             po_set_error("po_pipeline_create: hipStreamCreate failed");
-            delete p;
+            po_pipeline_destroy(p);
             return nullptr;
         }
+    size_t chunk_mb = 16;
+    if (const char* e = getenv("PO_STAGE_MB")) { const int v = atoi(e); if (v >= 1 && v <= 1024) chunk_mb = (size_t)v; }
+    if (!p->ring.create(chunk_mb << 20)) {
+        po_set_error("po_pipeline_create: hipHostMalloc of the staging ring failed");
+        po_pipeline_destroy(p);
+        return nullptr;
+    }
+    p->pool = new WorkerPool(p->threads);
     return p;
 }
 
@@ -239,6 +333,8 @@ void po_pipeline_destroy(po_pipeline* p) {
     for (auto& s : p->slot) {
         if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
     }
+    p->ring.destroy();
+    delete p->pool;
     delete p;
 }
 
@@ -272,6 +368,10 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
                 if (s.busy) (void)hipStreamSynchronize(s.st);
                 s.busy = false;
             }
+            for (int k = 0; k < StageRing::N; ++k) {   // (a failed call may leave chunks on the wire: their streams are drained above)
+                if (p->ring.used[k]) (void)hipEventSynchronize(p->ring.ev[k]);
+                p->ring.used[k] = false;
+            }
         }
         explicit Quiesce(po_pipeline* p_) : p(p_) { run(); }
         ~Quiesce() { run(); }
@@ -283,6 +383,50 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
     p->pack_ms = p->wait_ms = 0;
     p->waves = 0;
     p->pairs = 0;
+    static const bool trace = getenv("PO_PIPE_TRACE") != nullptr;
+    const bool direct = (in_mode == PO_INGEST_F64 && !c.perm1 && !c.perm2 && !c.reverse2);   // log-probabilities as they are
+
+    // ---- every buffer at its largest, before the first wave: the plan of the call's waves is known (the planner is
+    // deterministic), so nothing is freed and re-allocated while waves are in flight
+    auto out_layout = [&](int wn, int64_t r1, int64_t r2, Slot* s) -> size_t {
+        size_t o = 0, o_seq1d, o_seq, o_l1, o_l2, o_len, o_st, o_id, o_env;
+        o_seq1d = o; o += al256((size_t)(r1 + r2) + 16);
+        o_seq = o; o += al256((size_t)(r1 + r2) + 16);
+        o_l1 = o; o += al256(sizeof(int32_t) * wn);
+        o_l2 = o; o += al256(sizeof(int32_t) * wn);
+        o_len = o; o += al256(sizeof(int32_t) * wn);
+        o_st = o; o += al256(sizeof(int32_t) * wn);
+        o_id = o; o += al256(sizeof(double) * wn);
+        o_env = o; o += al256(sizeof(int32_t) * 2 * (size_t)r1);
+        if (s) { s->o_seq1d = o_seq1d; s->o_seq = o_seq; s->o_l1 = o_l1; s->o_l2 = o_l2; s->o_len = o_len; s->o_st = o_st; s->o_id = o_id; s->o_env = o_env; s->out_bytes = o; }
+        return o;
+    };
+    {
+        WavePlanner sim;
+        sim.rows1 = plan.rows1; sim.rows2 = plan.rows2; sim.n = plan.n; sim.wave_pairs = plan.wave_pairs; sim.wave_rows = plan.wave_rows;
+        sim.ramp = plan.ramp; sim.tail = plan.tail;
+        size_t mx_in = 0, mx_y = 0, mx_off = 0, mx_out = 0, mx_hout = 0, mx_ws = 0;
+        int f = 0, wn = 0, nw = 0;
+        int64_t r1 = 0, r2 = 0, m1 = 0, m2 = 0;
+        while (sim.take(&f, &wn, &r1, &r2, &m1, &m2)) {
+            ++nw;
+            mx_in = std::max(mx_in, al256(row_in * (size_t)r1) + al256(row_in * (size_t)r2));
+            mx_y = std::max(mx_y, al256(row_y * (size_t)r1) + al256(row_y * (size_t)r2));
+            mx_off = std::max(mx_off, sizeof(int64_t) * ((size_t)(wn + 1) * 3 + (size_t)(2 * wn + 1)));
+            const size_t ob = out_layout(wn, r1, r2, nullptr);
+            mx_out = std::max(mx_out, ob);
+            mx_hout = std::max(mx_hout, c.env_out_h ? ob : ob - al256(sizeof(int32_t) * 2 * (size_t)r1));
+            mx_ws = std::max(mx_ws, po_pair_ws_bytes_impl(wn, r1, r2, m1, m2, C, c.opt));
+        }
+        const double t0 = now_ms();
+        for (int k = 0; k < std::min(nw, p->nslots); ++k) {
+            Slot& s = p->slot[k];
+            if (!s.h_off.ensure(mx_off) || !s.d_off.ensure(mx_off) || !s.d_y.ensure(mx_y) || (!direct && !s.d_in.ensure(mx_in)) ||
+                !s.d_out.ensure(mx_out) || !s.h_out.ensure(mx_hout) || !s.d_ws.ensure(mx_ws))
+                return fail(p, PO_E_HIP, "po_pipeline_pair_decode: out of memory (wave buffers; lower wave_pairs / wave_rows)");
+        }
+        if (trace) fprintf(stderr, "[po_pipe] %d wave(s) planned, buffers sized in %.2f ms\n", nw, now_ms() - t0);
+    }
 
     // results of the wave a slot holds -> the caller's arrays (after the slot's stream has drained)
     auto drain = [&](Slot& s) -> int {
@@ -350,33 +494,17 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
         s.so.assign(so, so + wn + 1);
         std::vector<int64_t> off1(o1, o1 + wn + 1), off2(o2, o2 + wn + 1);
 
-        // ---- buffers
+        // ---- buffers (sized before the first wave; ensure() only acts if a wave outgrows the plan)
         const size_t in1 = al256(row_in * (size_t)r1), in2 = al256(row_in * (size_t)r2);
         const size_t yb1 = al256(row_y * (size_t)r1), yb2 = al256(row_y * (size_t)r2);
-        size_t o = 0;
-        s.o_seq1d = o; o += al256((size_t)(r1 + r2) + 16);
-        s.o_seq = o; o += al256((size_t)(r1 + r2) + 16);
-        s.o_l1 = o; o += al256(sizeof(int32_t) * wn);
-        s.o_l2 = o; o += al256(sizeof(int32_t) * wn);
-        s.o_len = o; o += al256(sizeof(int32_t) * wn);
-        s.o_st = o; o += al256(sizeof(int32_t) * wn);
-        s.o_id = o; o += al256(sizeof(double) * wn);
-        s.o_env = o; o += al256(sizeof(int32_t) * 2 * (size_t)r1);
-        s.out_bytes = o;
+        out_layout(wn, r1, r2, &s);
         const size_t wsb = po_pair_ws_bytes_impl(wn, r1, r2, m1, m2, C, c.opt);
-        const bool direct = (in_mode == PO_INGEST_F64 && !c.perm1 && !c.perm2 && !c.reverse2);   // log-probabilities as they are
-        if (!s.h_in.ensure(in1 + in2) || !s.d_y.ensure(yb1 + yb2) || (!direct && !s.d_in.ensure(in1 + in2)) ||
-            !s.d_out.ensure(s.out_bytes) || !s.h_out.ensure(s.out_bytes) || !s.d_ws.ensure(wsb))
+        if (!s.d_y.ensure(yb1 + yb2) || (!direct && !s.d_in.ensure(in1 + in2)) || !s.d_out.ensure(s.out_bytes) ||
+            !s.h_out.ensure(c.env_out_h ? s.out_bytes : s.o_env) || !s.d_ws.ensure(wsb))
             return fail(p, PO_E_HIP, "po_pipeline_pair_decode: out of memory (wave buffers; lower wave_pairs / wave_rows)");
 
-        // ---- pack: item arrays -> pinned staging (the GPU is busy with the previous wave meanwhile)
-        const double tp = now_ms();
-        char* hin = (char*)s.h_in.p;
-        pack_items(c.y1_h, c.rows1, first, wn, row_in, hin, off1, p->threads);
-        pack_items(c.y2_h, c.rows2, first, wn, row_in, hin + in1, off2, p->threads);
-        p->pack_ms += now_ms() - tp;
-
-        // ---- upload + ingest + decode + download, all on the slot's stream
+        // ---- upload through the ring of pinned chunks: chunk k + 1 is packed (host threads) while chunk k is on the wire;
+        // then ingest + decode + download, all on the slot's stream
         double* dy1 = (double*)s.d_y.p;
         double* dy2 = (double*)((char*)s.d_y.p + yb1);
         PCHK(hipMemcpyAsync(s.d_off.p, s.h_off.p, sizeof(int64_t) * n_off, hipMemcpyHostToDevice, s.st));
@@ -384,13 +512,34 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
         const int64_t* d_o2 = d_o1 + (wn + 1);
         const int64_t* d_s1o = d_o2 + (wn + 1);
         const int64_t* d_so = d_s1o + (2 * wn + 1);
-        if (direct) {
-            PCHK(hipMemcpyAsync(dy1, hin, row_in * (size_t)r1, hipMemcpyHostToDevice, s.st));
-            PCHK(hipMemcpyAsync(dy2, hin + in1, row_in * (size_t)r2, hipMemcpyHostToDevice, s.st));
-        } else {
-            char* din = (char*)s.d_in.p;
-            PCHK(hipMemcpyAsync(din, hin, row_in * (size_t)r1, hipMemcpyHostToDevice, s.st));
-            PCHK(hipMemcpyAsync(din + in1, hin + in1, row_in * (size_t)r2, hipMemcpyHostToDevice, s.st));
+        char* din = direct ? nullptr : (char*)s.d_in.p;
+        {
+            StageRing& rg = p->ring;
+            for (int region = 0; region < 2; ++region) {
+                const size_t bytes = row_in * (size_t)(region ? r2 : r1);
+                char* dst = direct ? (char*)(region ? dy2 : dy1) : din + (region ? in1 : 0);
+                const void* const* src = region ? c.y2_h : c.y1_h;
+                const std::vector<int64_t>& off = region ? off2 : off1;
+                for (size_t lo = 0; lo < bytes; lo += rg.chunk) {
+                    const size_t hi = std::min(bytes, lo + rg.chunk);
+                    const int k = rg.next;
+                    rg.next = (k + 1) % StageRing::N;
+                    if (rg.used[k]) {   // (the copy that last used this chunk: long done unless the link is the bottleneck)
+                        const double tw = now_ms();
+                        PCHK(hipEventSynchronize(rg.ev[k]));
+                        p->wait_ms += now_ms() - tw;
+                    }
+                    const double tp = now_ms();
+                    pack_bytes(*p->pool, src, first, wn, row_in, off, lo, hi, rg.buf[k]);
+                    p->pack_ms += now_ms() - tp;
+                    PCHK(hipMemcpyAsync(dst + lo, rg.buf[k], hi - lo, hipMemcpyHostToDevice, s.st));
+                    PCHK(hipEventRecord(rg.ev[k], s.st));
+                    rg.used[k] = true;
+                }
+            }
+        }
+        if (trace) fprintf(stderr, "[po_pipe] wave %d: %d pairs, uploaded (enqueued) at %.2f ms\n", wave, wn, now_ms() - t_begin);
+        if (!direct) {
             rc = po_launch_ingest(din, d_o1, wn, C, in_mode, c.perm1, 0, r1, dy1, s.st);
             if (rc == PO_OK) rc = po_launch_ingest(din + in1, d_o2, wn, C, in_mode, c.perm2, c.reverse2, r2, dy2, s.st);
             if (rc != PO_OK) return fail(p, rc, "po_pipeline_pair_decode: bad permutation / input mode");

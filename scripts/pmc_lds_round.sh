@@ -11,7 +11,7 @@ timeout 400 rocprofv3 --pmc $C --output-format csv -d $root/gpurun_out/lds_${tag
 python3 - <<PY
 import csv, glob, collections, json
 res = {}
-for part, keys in (("reg", ("beam2d_reg",)), ("ring", ("beam2d_ring",)), ("b1", ("beam1d",))):
+for part, keys in (("reg", ("beam2d_reg",)), ("b1", ("beam1d",))):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for f in glob.glob("$root/gpurun_out/lds_${tag}_%s/**/*counter_collection.csv" % part, recursive=True):
         for r in csv.DictReader(open(f)):

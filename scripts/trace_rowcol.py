@@ -1,8 +1,8 @@
-"""Step-by-step comparison of beam2d_ring_kernel with the oracle on ONE saved case (tests/golden/fuzz_cases/*.npz):
+"""Step-by-step comparison of beam2d_reg_kernel with the oracle on ONE saved case (tests/golden/fuzz_cases/*.npz):
 every candidate's score before every prune.
    on the GPU box:  POREOVER_HIP_LIB=scripts/variants/libporeover_hip_ringtrace.so python scripts/trace_rowcol.py gpu CASE > gpurun_out/trace_gpu.txt
    here (CPU):      python scripts/trace_rowcol.py cpu CASE gpurun_out/trace_gpu.txt
-(the library: scripts/build_file_variant.sh po_beam2d_ring ringtrace -DPO_RING_TRACE)"""
+(the library: scripts/build_file_variant.sh po_beam2d_reg ringtrace -DPO_RING_TRACE)"""
 import os
 import subprocess
 import sys

@@ -9,13 +9,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "x2", "ring", "reg", "legacy"])
+@pytest.fixture(autouse=True, params=["default", "reg", "legacy"])
 def kernel_route(request, monkeypatch):
     """every test runs four times: with the engine's own choice of pair beam kernel (by model, width and batch size), with
     the two-pairs-per-wave kernel forced wherever it can run, with the LDS-ring kernel wherever it can run, and with
     beam2d_kernel always (_lib.set_pair_route)"""
     from poreover_amd import _lib
-    _lib.set_pair_route({"x2": "x2", "ring": "ring", "reg": "reg", "legacy": "legacy"}.get(request.param, "auto"))
+    _lib.set_pair_route({"reg": "reg", "legacy": "legacy"}.get(request.param, "auto"))
     yield request.param
     _lib.set_pair_route("auto")
 

@@ -55,8 +55,8 @@ def test_fuzz_pair_beam_kernels(eng, oracle):
                 wants.append((oracle.cpp_beam_search_2d(y1s[i], y2s[i], envs[i], W, model_=MODELS[kind], method_=method), 0))
             except oracle.OracleError as e:
                 wants.append(("", e.code))
-        # the engine's choice, beam2d_kernel always, and the LDS-ring kernel where it can run (one-value model, row_col, W * (A + 1) <= 26)
-        for route in (("auto", "ring", "reg", "legacy") if (kind == "poreover" and method == "row_col" and W <= 5) else ("auto", "legacy")):
+        # the engine's choice, the register-state kernel named (row_col: every model, W <= 12) and beam2d_kernel always
+        for route in (("auto", "reg", "legacy") if method == "row_col" else ("auto", "legacy")):
             _lib.set_pair_route(route)
             try:
                 got, st = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=MODELS[kind], method=method, return_status=True)
@@ -287,7 +287,7 @@ def test_saved_fuzz_cases_on_every_route(eng, oracle):
     """Cases the open-ended fuzz runs found (tests/golden/fuzz_cases/*.npz: inputs + the oracle's answer, checked against the
     compiled reference when they were saved).  seed21_stairs_W5: a beam node whose frozen parent becomes an element again —
     everything below it recomputes its window; seed21_bursts_W4: an envelope whose row ends move backwards (values of an
-    earlier incarnation beyond a node's last time) — the ring kernel hands such envelopes to beam2d_kernel."""
+    earlier incarnation beyond a node's last time) — the register-state kernel hands such envelopes to beam2d_kernel."""
     import glob
     import os
     from poreover_amd import _lib, batch
@@ -300,7 +300,7 @@ def test_saved_fuzz_cases_on_every_route(eng, oracle):
             W, model, method = int(d["W"]), str(d["model"]), str(d["method"])
             want = oracle.cpp_beam_search_2d(y1, y2, env, W, model_=model, method_=method)
             assert want == str(d["want"])
-            for route in ("auto", "legacy", "x2", "ring", "reg"):
+            for route in ("auto", "legacy", "reg"):
                 _lib.set_pair_route(route)
                 got = batch.beam_search_2d_batch([y1], [y2], [env], W, model=model, method=method)
                 assert got[0] == want, (os.path.basename(f), route)

@@ -8,13 +8,13 @@ from poreover_amd.synth import synth_pair
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "x2", "ring", "reg", "legacy"])
+@pytest.fixture(autouse=True, params=["default", "reg", "legacy"])
 def kernel_route(request, monkeypatch):
     """every test runs four times: with the engine's own choice of pair beam kernel (by model, width and batch size), with
     the two-pairs-per-wave kernel forced wherever it can run, with the LDS-ring kernel wherever it can run, and with
     beam2d_kernel always (_lib.set_pair_route)"""
     from poreover_amd import _lib
-    _lib.set_pair_route({"x2": "x2", "ring": "ring", "reg": "reg", "legacy": "legacy"}.get(request.param, "auto"))
+    _lib.set_pair_route({"reg": "reg", "legacy": "legacy"}.get(request.param, "auto"))
     _ROUTE[0] = request.param
     yield request.param
     _lib.set_pair_route("auto")
@@ -86,7 +86,7 @@ def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
     decoded by beam2d_kernel in the same call.  set_pair_route(defer_odd=True) sends every odd pair down the second
     path: one batch, both kernels, every string equal to the oracle's."""
     from poreover_amd import _lib
-    route = {"x2": "x2", "ring": "ring", "reg": "reg", "legacy": "legacy"}.get(kernel_route_name(), "auto")
+    route = {"reg": "reg", "legacy": "legacy"}.get(kernel_route_name(), "auto")
     _lib.set_pair_route(route, defer_odd=True)
     y1s, y2s, envs, want = [], [], [], []
     for i in range(9):
@@ -122,7 +122,7 @@ def test_rowcol_wide_beam_one_pair_per_wave(eng, oracle, monkeypatch, model, ff)
         try:
             assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want, W
         finally:
-            _lib.set_pair_route({"x2": "x2", "ring": "ring", "reg": "reg", "legacy": "legacy"}.get(kernel_route_name(), "auto"))
+            _lib.set_pair_route({"reg": "reg", "legacy": "legacy"}.get(kernel_route_name(), "auto"))
 
 
 def test_rowcol_full_size(eng, oracle):

@@ -152,7 +152,7 @@ def test_alternating_wave_geometries_on_one_pipeline(eng, kind):
             a, b = synth_pair(base + i, T=T + 29 * (i % 7))
             y1s.append(a); y2s.append(b)
         batches.append((y1s, y2s))
-    for route in ("auto", "ring", "reg"):
+    for route in ("auto", "legacy"):
         _lib.set_pair_route(route)
         try:
             first = [None, None]

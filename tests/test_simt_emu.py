@@ -1,5 +1,5 @@
 """CPU: the pair-beam kernels' LOGIC without a GPU.  tools/simt_emu compiles the product's own kernel sources
-(po_beam2d_pre.h, po_beam2d_ring.hip, po_beam2d_reg.hip) with g++ against a lane-by-lane emulation of the HIP execution
+(po_beam2d_pre.h, po_beam2d_reg.hip) with g++ against a lane-by-lane emulation of the HIP execution
 model (one fibre per lane, cross-lane operations as rendezvous points) and runs them on small pairs; the strings must be the
 oracle's.  Both lane schedules (ascending / descending) must agree: a result that changes with the schedule means a kernel
 relies on lockstep execution across an LDS hand-over without a fence.  This is test infrastructure around the SAME sources
@@ -20,11 +20,13 @@ def emu_lib():
     return os.path.join(EMU, "_build", "libemu_pair_beam.so")
 
 
-@pytest.mark.parametrize("kernel", ["reg", "ring"])
+@pytest.mark.parametrize("model,W", [("ctc", "0"), ("merge", "0"), ("flipflop", "5"), ("ctc", "10"), ("merge", "12")])
 @pytest.mark.parametrize("sched", ["0", "1"])
-def test_emulated_kernel_matches_oracle(emu_lib, oracle, kernel, sched):
+def test_emulated_kernel_matches_oracle(emu_lib, oracle, model, W, sched):
+    """every tree model, both lane layouts (W <= 6: lane = (read, slot); 7 <= W <= 12: lane = slot, reads in sequence)"""
+    kernel = "reg"
     env = dict(os.environ, EMU_SCHED=sched)
-    out = subprocess.run([sys.executable, os.path.join(EMU, "check_ring.py"), "--n", "18", "--T", "320", "--W", "0", "--seed", "31",
+    out = subprocess.run([sys.executable, os.path.join(EMU, "check_emu.py"), "--n", "18", "--T", "320", "--W", W, "--model", model, "--seed", "31",
                           "--procs", "4", "--kernel", kernel, "--styles", "pipeline,stairs,wobble", "--lib", emu_lib],
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]

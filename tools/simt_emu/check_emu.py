@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE ONLY.  Runs the LDS-ring pair beam kernel on the CPU (SIMT emulator, `make -C tools/simt_emu`)
-and compares its strings with the oracle's: python tools/simt_emu/check_ring.py [--n 16] [--T 300] [--seed 1] [--procs 8]
+"""TEST INFRASTRUCTURE ONLY.  Runs the register-state pair beam kernel (beam2d_reg_kernel, every model and lane layout) on the CPU (SIMT emulator, `make -C tools/simt_emu`)
+and compares its strings with the oracle's: python tools/simt_emu/check_emu.py [--n 16] [--T 300] [--seed 1] [--procs 8]
 Envelopes: the pipeline's own (Viterbi + banded alignment) and the fuzz script's stairs / wobble / bursts."""
 import argparse
 import ctypes as C
@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--lib", default=os.path.join(HERE, "_build", "libemu_pair_beam.so"))
     ap.add_argument("--styles", default="pipeline,stairs,wobble,bursts")
     ap.add_argument("--batch", type=int, default=1, help="pairs per emulated launch (with as many pair slots)")
-    ap.add_argument("--kernel", default="ring", help="ring | reg")
+    ap.add_argument("--kernel", default="reg", help="reg (kept for old command lines)")
     ap.add_argument("--model", default=MODEL[0], help="ctc | merge | flipflop (the register-state kernel serves all three)")
     args = ap.parse_args()
     MODEL[0] = args.model
@@ -113,7 +113,7 @@ def main():
     with ProcessPoolExecutor(args.procs) as pool:
         cases = list(pool.map(make_case, jobs))
         keep = [(c, j) for c, j in zip(cases, jobs) if c is not None]
-        kid = {"ring": 0, "reg": 1}[args.kernel]
+        kid = 1
         if args.batch <= 1:
             res = list(pool.map(run_emu, [(c, j[2], args.lib, kid) for c, j in keep]))
         else:   # batches of equal beam width

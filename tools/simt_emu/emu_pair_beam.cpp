@@ -1,10 +1,9 @@
-// TEST INFRASTRUCTURE ONLY — the row_col pair beam search of the LDS-ring route (pre-pass, walk, beam2d_ring_kernel)
-// executed on the CPU by the SIMT emulator, behind one C entry point for ctypes (tools/simt_emu/check_ring.py compares
+// TEST INFRASTRUCTURE ONLY — the row_col pair beam search of the register-state route (pre-pass, walk, beam2d_reg_kernel)
+// executed on the CPU by the SIMT emulator, behind one C entry point for ctypes (tools/simt_emu/check_emu.py compares
 // it with the oracle).  The kernels are the product's own sources, compiled with -DPO_EMU.
 #include <hip/hip_runtime.h>
 
 #include "../../poreover_amd/csrc/po_beam2d_pre.h"
-#include "../../poreover_amd/csrc/po_beam2d_ring.hip"
 #include "../../poreover_amd/csrc/po_beam2d_reg.hip"
 
 extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
@@ -27,7 +26,8 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     std::vector<int4> sched((size_t)tr2 + 1);
     std::vector<double> cum1((size_t)tr1 + 1), cum2((size_t)tr2 + 1);
     const int wide = (W > 6) ? 1 : 0;
-    const size_t pool_bytes = kernel >= 1 ? po_reg_pool_bytes(model, wide) : ((size_t)4 << 20);
+    const size_t pool_bytes = po_reg_pool_bytes(model, wide);
+    (void)kernel;
     const int64_t WM = W > PO_A ? W : PO_A;
     const size_t arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
     std::vector<char> pool(pool_bytes * blocks, 0);
@@ -39,8 +39,8 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     a.dbg = nullptr; a.upd_count = upd_count; a.defer_odd = 0; a.need_mono = 1; a.order = nullptr;
     a.wgstate = wgstate.data(); a.magic = 0x1234567ull;
     a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
-    a.ngl = kernel >= 1 ? po_reg_ngl(wide) : po_ring_ngl();
-    a.no_cum = kernel >= 1 ? 1 : 0;
+    a.ngl = po_reg_ngl(wide);
+    a.no_cum = 1;
     for (int i = 0; i < n; ++i) status[i] = PO_OK;
     const bool vb = getenv("EMU_VERBOSE") != nullptr;
     if (vb) fprintf(stderr, "[emu] prepass\n");
@@ -50,8 +50,7 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     if (vb) fprintf(stderr, "[emu] walk\n");
     hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, nullptr, a);
     if (vb) fprintf(stderr, "[emu] main kernel\n");
-    if (kernel >= 1) po_reg_launch(&a, blocks, model, wide, nullptr);
-    else po_ring_launch(&a, blocks, nullptr);
+    po_reg_launch(&a, blocks, model, wide, nullptr);
     int deferred = 0;
     for (int i = 0; i < n; ++i)
         if (meta[i].y == X2_DEFERRED) { deferred++; status[i] = -100; }   // (the product hands these to beam2d_kernel)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE ONLY.  Replays the rounds scripts/fuzz_parity.py draws in pair mode (same seed, same --focus) on
-the CPU emulation of the register-state / ring kernel and compares with the oracle — for a round that faults on the GPU:
+the CPU emulation of the register-state kernel and compares with the oracle — for a round that faults on the GPU:
 python tools/simt_emu/replay_fuzz.py --seed 411 --focus --rounds 8 [--lib tools/simt_emu/_build_asan/libemu_pair_beam.so]
 (with the ASan build: LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0)"""
 import argparse
@@ -39,8 +39,8 @@ def main():
     ap.add_argument("--lib", default=os.path.join(HERE, "_build", "libemu_pair_beam.so"))
     args = ap.parse_args()
     from fuzz_parity import draw_round
-    from check_ring import run_emu_batch
-    kid = {"ring": 0, "reg": 1}[args.kernel]
+    from check_emu import run_emu_batch
+    kid = 1
     rng = np.random.default_rng(args.seed)
     bad = 0
     with ProcessPoolExecutor(args.procs) as pool:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE ONLY.  First step at which the emulated ring kernel's candidate scores differ from the oracle's,
-for one check_ring.py case:  python tools/simt_emu/trace_case.py SEED T W STYLE   (builds the -DPO_RING_TRACE emulation)"""
+for one check_emu.py case:  python tools/simt_emu/trace_case.py SEED T W STYLE   (builds the -DPO_RING_TRACE emulation)"""
 import os
 import subprocess
 import sys
@@ -12,14 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
 job = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
 if len(sys.argv) > 5 and sys.argv[5] == "emu":
-    import check_ring as cr
+    import check_emu as cr
     c = cr.make_case(job)
     r = cr.run_emu((c, job[2], os.path.join(HERE, "_build_trace", "libemu_pair_beam.so"), 1 if os.environ.get("EMU_KERNEL") == "reg" else 0))
     sys.stdout.flush()
     print("\nRESULT", r[0])
     sys.exit(0)
 if len(sys.argv) > 5 and sys.argv[5] == "oracle":
-    import check_ring as cr
+    import check_emu as cr
     c = cr.make_case(job)
     sys.stdout.flush()
     print("\nRESULT", c[3])
