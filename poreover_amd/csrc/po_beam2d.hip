@@ -1683,11 +1683,8 @@ void (*g_b2_mark_fwd)(int begin, hipStream_t stream) = nullptr;   // set through
 // (po_beam2d_pre.h): the engine's choice (PO_ROUTE_AUTO) for row_col with an envelope at every batch size, every tree
 // model, W <= 12.  PO_REG_NEVER / PO_ROUTE_LEGACY send everything to beam2d_kernel.
 struct RegGeom {
-    int blocks;        // pair slots (one-wave workgroups) of this launch
-    int pool_slots;    // slices the pool region is laid out for (>= blocks: see reg_geometry)
-    size_t pool_bytes, arena_cap;
-    size_t off_queue, off_state, off_pool, off_meta, off_nmain, off_sched, off_envt, off_arena, off_order, off_fb, fb_bytes, total, min_total;
-    unsigned long long magic;
+    int blocks;        // pair waves (one-wave workgroups) of this launch
+    size_t off_queue, off_meta, off_nmain, off_sched, off_envt, off_order, off_fb, fb_bytes, total;
 };
 extern "C" int po_reg_slots_per_cu(int model, int wide);
 extern "C" int po_reg_max_elements(int wide);
@@ -1705,54 +1702,88 @@ bool reg_eligible(int n, int W, int A, int model, int method) {
     if (rt != PO_ROUTE_AUTO) return false;
     return b2_route().reg_auto != 0;
 }
-// Workspace layout: [queue | state words of every slot the device can hold | value store slices | per-launch arrays | arenas |
-// the deferred-pairs pass].  The slices keep their tags across launches (epoch counters in the state words: no memset of
-// 8 GB per launch), so a slot's slice must stay where it is from launch to launch — also when the launches differ in size,
-// as the waves of one pipelined job do (1 250, 2 500, 3 334 ... pairs through the same buffer).  Hence: state words and
-// slices come FIRST, at offsets that do not depend on n, and the pool region is laid out for as many slices as the caller's
-// buffer has room for (ws_bytes; 0 = the smallest layout, what the size query reports): a small launch in a large buffer puts
-// its own arrays BEHIND the slices of the larger launches before it instead of on top of them.  reg_ws_claim() keeps count of
-// which slots' slices are intact.
-RegGeom reg_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model, size_t ws_bytes = 0) {
+
+// ---- The library's SLICE POOL of the register-state kernel (one per device, tree model and lane layout; made at the first
+// launch that needs it, kept for the life of the process).  A slice = the value store of one pair wave (2 - 8 MB: 128 row
+// groups at R = 128) + its tree arena.  Rounds 1 - 4 carved these out of every call's workspace: 12 GB for a 10 000-pair call,
+// 28 GB per slot of a pipeline — and a hipMalloc of that size stalls for 0.5 - 2.5 s on this driver every now and then
+// (scripts/micro/malloc_cost.hip: never below 4 GB, one in three at 16 GB), which is what a process's FIRST call paid.
+// There are never more pair waves on the device than its register file and LDS admit, whatever the number of launches in
+// flight: ONE pool of that many slices serves them all, in chunks of at most ~ 3.5 GB; a wave claims a slice when it starts
+// (po_beam2d_reg.hip).  A slice keeps its tags and epoch counter from launch to launch, so nothing is ever memset or cleared
+// but a slice's first use.
+struct RegPool {
+    int nslices = 0, spc_log2 = 0;
+    size_t pool_bytes = 0, slice_bytes = 0;
+    long long arena_cap = 0;
+    char* chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int* claim = nullptr;
+    unsigned long long* state = nullptr;
+    unsigned long long magic = 0;
+};
+std::mutex g_reg_pool_mu;
+RegPool* g_reg_pools[PO_MAX_DEVICES][6] = {};
+std::atomic<unsigned> g_reg_salt{0};
+RegPool* reg_pool(int model, int wide) {
+    const int dev = po_cur_device();
+    const int key = (model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2)) * 2 + (wide ? 1 : 0);
+    std::lock_guard<std::mutex> lk(g_reg_pool_mu);
+    if (g_reg_pools[dev][key]) return g_reg_pools[dev][key];
+    RegPool* p = new RegPool();
+    p->nslices = b2_num_cus() * po_reg_slots_per_cu(model, wide);
+    p->pool_bytes = po_reg_pool_bytes(model, wide);
+    // tree nodes a slice's arena holds: four per node that ever enters the beam.  1 024 beam entries per beam slot is ~ 4 x what
+    // a T = 4000 pair makes; a pair that needs more is handed to beam2d_kernel (whose arenas are worst-case sized)
+    const long long WM = wide ? 12 : 6;
+    p->arena_cap = 1 + PO_A + (long long)PO_A * WM * 1024;
+    p->slice_bytes = al256(p->pool_bytes + sizeof(int) * 3 * (size_t)p->arena_cap);
+    int spc = 1;
+    while ((size_t)(2 * spc) * p->slice_bytes <= ((size_t)7 << 29) && 2 * spc <= p->nslices) spc *= 2;   // chunks of <= 3.5 GB
+    while ((p->nslices + spc - 1) / spc > 8) spc *= 2;
+    p->spc_log2 = 0;
+    while ((1 << p->spc_log2) < spc) ++p->spc_log2;
+    const int nchunks = (p->nslices + spc - 1) / spc;
+    bool ok = true;
+    for (int c = 0; c < nchunks && ok; ++c) {
+        const int here = std::min(spc, p->nslices - c * spc);
+        ok = hipMalloc((void**)&p->chunk[c], (size_t)here * p->slice_bytes) == hipSuccess;
+    }
+    const size_t words = sizeof(int) * (size_t)p->nslices + sizeof(unsigned long long) * 2 * (size_t)p->nslices + 256;
+    char* w = nullptr;
+    ok = ok && hipMalloc((void**)&w, words) == hipSuccess && hipMemset(w, 0, words) == hipSuccess;
+    if (!ok) {
+        for (auto c : p->chunk) if (c) (void)hipFree(c);
+        if (w) (void)hipFree(w);
+        delete p;
+        return nullptr;
+    }
+    p->state = (unsigned long long*)w;
+    p->claim = (int*)(w + sizeof(unsigned long long) * 2 * (size_t)p->nslices);
+    p->magic = 0x51ed270b0a1f3c97ull ^ ((unsigned long long)p->pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)(key + 1) << 56);
+    if (b2_route().debug_occ)
+        fprintf(stderr, "[po] register-state kernel pool (model %d, %s layout): %d slices of %.2f MB in %d chunk(s)\n", model, wide ? "64-slot" : "32-slot",
+                p->nslices, p->slice_bytes / 1048576.0, nchunks);
+    g_reg_pools[dev][key] = p;
+    return p;
+}
+// Per-call workspace of the route: the batch-sized arrays of the pre-pass and the walk, and the deferred-pairs pass.
+RegGeom reg_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, int W, int model) {
     (void)tr1;
     RegGeom g;
-    const int max_slots = b2_num_cus() * po_reg_slots_per_cu(model, reg_wide(W));
-    g.blocks = max_slots;
+    g.blocks = b2_num_cus() * po_reg_slots_per_cu(model, reg_wide(W));
     if (g.blocks > n) g.blocks = n > 0 ? n : 1;
-    // the whole store of a pair slot: 2 MB = 128 row groups at R = 128 for the one-value model at W <= 6 (beam2d_kernel's
-    // geometry), twice that for three values per entry, twice again for the 64-slot layout
-    g.pool_bytes = po_reg_pool_bytes(model, reg_wide(W));
-    const int64_t WM = W > PO_A ? W : PO_A;
-    g.arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
-    {
-        const size_t per_block = g.pool_bytes + sizeof(int) * 3 * g.arena_cap;
-        const size_t fit = std::max<size_t>(1, b2_mem_budget() / std::max<size_t>(per_block, 1));
-        if ((size_t)g.blocks > fit) g.blocks = (int)fit;
-    }
-    g.off_queue = 0;
-    g.off_state = 256;
-    g.off_pool = g.off_state + al256(sizeof(unsigned long long) * 2 * (size_t)max_slots);
     const size_t np = (size_t)(n > 0 ? n : 1);
-    const size_t b_meta = al256(sizeof(int2) * np), b_nmain = al256(sizeof(int) * np), b_sched = al256(sizeof(int4) * (size_t)(tr2 > 0 ? tr2 : 1));
-    const size_t b_envt = al256(sizeof(int) * 2 * (size_t)tr2), b_arena = al256(sizeof(int) * 3 * g.arena_cap * g.blocks), b_order = al256(sizeof(int) * np);
+    size_t o = 0;
+    g.off_queue = o; o += 256;
+    g.off_meta = o; o += al256(sizeof(int2) * np);
+    g.off_nmain = o; o += al256(sizeof(int) * np);
+    g.off_sched = o; o += al256(sizeof(int4) * (size_t)(tr2 > 0 ? tr2 : 1));
+    g.off_envt = o; o += al256(sizeof(int) * 2 * (size_t)tr2);
+    g.off_order = o; o += al256(sizeof(int) * np);   // the queue's order (pair_order_kernel)
+    g.off_fb = o;
     g.fb_bytes = b2_geometry(n, mr1, mr2, W, model, PO_METHOD_ROW_COL, X2_FB_BLOCKS).total;
-    const size_t tail = b_meta + b_nmain + b_sched + b_envt + b_arena + b_order + al256(g.fb_bytes) + 256;
-    g.min_total = g.off_pool + g.pool_bytes * (size_t)g.blocks + tail;
-    g.pool_slots = g.blocks;
-    if (ws_bytes > g.min_total) g.pool_slots = (int)std::min<size_t>((size_t)max_slots, (ws_bytes - g.off_pool - tail) / g.pool_bytes);
-    size_t o = g.off_pool + g.pool_bytes * (size_t)g.pool_slots;
-    g.off_meta = o; o += b_meta;
-    g.off_nmain = o; o += b_nmain;
-    g.off_sched = o; o += b_sched;
-    g.off_envt = o; o += b_envt;
-    g.off_arena = o; o += b_arena;
-    g.off_order = o; o += b_order;   // the queue's order (pair_order_kernel)
-    g.off_fb = o; o += al256(g.fb_bytes);
+    o += al256(g.fb_bytes);
     g.total = o + 256;
-    // (names the slices' geometry AND what is stored in them: entries of 16 or 32 bytes — two layouts of equal slice size
-    //  must not take each other's tags for their own)
-    g.magic = 0x51ed270b0a1f3c97ull ^ ((unsigned long long)g.pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)g.off_pool * 0x9e3779b97f4a7c15ull) ^
-              ((unsigned long long)(model * 2 + reg_wide(W) + 1) << 56);
     return g;
 }
 
@@ -1822,7 +1853,7 @@ extern "C" size_t po_beam2d_ws_bytes_impl(int n, int64_t tr1, int64_t tr2, int64
     (void)C;
     if (method == PO_METHOD_GRID) return grid_geometry(n, mr1, mr2, W, model, true).total;
     if (method == PO_METHOD_GRID_NOENV) return grid_geometry(n, mr1, mr2, W, model, false).total;
-    if (reg_eligible(n, W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return reg_geometry(n, tr1, tr2, mr1, mr2, W, model).min_total;
+    if (reg_eligible(n, W, (model == PO_MODEL_FLIPFLOP) ? C / 2 : C - 1, model, method)) return reg_geometry(n, tr1, tr2, mr1, mr2, W, model).total;
     return b2_geometry(n, mr1, mr2, W, model, method).total + b2_geometry(n, mr1, mr2, W, model, method, X2_FB_BLOCKS).total;
 }
 
@@ -1833,7 +1864,7 @@ namespace {
 // inside the other's store while both keep writing tags into overlapping memory.  The host therefore remembers, per
 // workspace base pointer, the layout of the last pair-beam launch there; a launch with another layout zeroes the
 // (small) state region first, which makes every workgroup clear its slice.
-struct B2Layout { size_t off_state, total; unsigned long long magic; int valid_slots; /* reg layouts: slots whose slices are intact; -1: beam2d_kernel's */ };
+struct B2Layout { size_t off_state, total; unsigned long long magic; };
 std::mutex g_b2_layout_mu;
 std::unordered_map<const void*, B2Layout> g_b2_layouts;
 bool b2_ws_layout_changed(const void* ws, size_t off_state, size_t total, unsigned long long magic) {
@@ -1847,29 +1878,9 @@ bool b2_ws_layout_changed(const void* ws, size_t off_state, size_t total, unsign
             if (jt->first != ws && b < (const char*)ws + total && (const char*)ws < b + jt->second.total) jt = g_b2_layouts.erase(jt);
             else ++jt;
         }
-        g_b2_layouts[ws] = B2Layout{off_state, total, magic, -1};
+        g_b2_layouts[ws] = B2Layout{off_state, total, magic};
     }
     return !same;
-}
-// The register-state kernel's claim on a workspace: which slots' state words must be cleared before this launch (their slices
-// hold something else: first use, another layout, or the per-launch arrays of a launch that had fewer slices laid out).
-void reg_ws_claim(const void* ws, const RegGeom& g, int* first, int* count) {
-    std::lock_guard<std::mutex> lk(g_b2_layout_mu);
-    auto it = g_b2_layouts.find(ws);
-    const bool same = it != g_b2_layouts.end() && it->second.off_state == g.off_state && it->second.magic == g.magic && it->second.valid_slots >= 0;
-    int valid = same ? it->second.valid_slots : 0;
-    valid = std::min(valid, g.pool_slots);   // (what lay beyond this launch's pool region is overwritten by its arrays)
-    // whatever else is remembered inside the memory this launch writes (up to where its deferred-pairs pass — which makes its
-    // own claim — begins) is stale
-    for (auto jt = g_b2_layouts.begin(); jt != g_b2_layouts.end();) {
-        const char* b = (const char*)jt->first;
-        if (jt->first != ws && b < (const char*)ws + g.off_fb && (const char*)ws < b + jt->second.total) jt = g_b2_layouts.erase(jt);
-        else ++jt;
-    }
-    *first = std::min(valid, g.blocks);
-    *count = g.blocks - *first;
-    valid = std::max(valid, g.blocks);
-    g_b2_layouts[ws] = B2Layout{g.off_state, g.off_pool + g.pool_bytes * (size_t)valid, g.magic, valid};
 }
 unsigned long long* g_b2_upd_counter = nullptr;
 void (*g_b2_mark)(int begin, hipStream_t stream) = nullptr;   // profiling: brackets the main pair beam kernel
@@ -2034,8 +2045,10 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         return PO_OK;
     }
     if (reg_eligible(n, W, A, model, method)) {
-        const RegGeom g = reg_geometry(n, tr1, tr2, mr1, mr2, W, model, ws_bytes);
-        if (ws_bytes < g.min_total || ws_bytes < g.total) return PO_E_CAP;
+        const RegGeom g = reg_geometry(n, tr1, tr2, mr1, mr2, W, model);
+        if (ws_bytes < g.total) return PO_E_CAP;
+        RegPool* const rp = reg_pool(model, reg_wide(W));
+        if (!rp) return PO_E_NOMEM;
         char* w = (char*)ws;
         X2Args a;
         a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
@@ -2047,8 +2060,13 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.sched = (int4*)(w + g.off_sched);
         a.envt = (int*)(w + g.off_envt);
         a.cum1 = nullptr; a.cum2 = nullptr;   // (the kernel adds the ctc root's alpha up as its scans pass the times)
-        a.pool = w + g.off_pool; a.pool_bytes = g.pool_bytes;
-        a.arena = (int*)(w + g.off_arena); a.arena_cap = (long long)g.arena_cap;
+        a.pool = nullptr; a.pool_bytes = rp->pool_bytes;
+        a.arena = nullptr; a.arena_cap = rp->arena_cap;
+        for (int c = 0; c < 8; ++c) a.slice_chunk[c] = rp->chunk[c];
+        a.slice_spc_log2 = rp->spc_log2; a.nslices = rp->nslices; a.slice_bytes = rp->slice_bytes; a.slice_claim = rp->claim;
+        a.slice_salt = g_reg_salt.fetch_add(0x9e3779b1u);
+        a.wgstate = rp->state;
+        a.magic = rp->magic;
         a.dbg = nullptr;
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd;
@@ -2059,19 +2077,10 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
             a.order = (int*)(w + g.off_order);
             hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
         }
-        a.wgstate = (unsigned long long*)(w + g.off_state);
-        a.magic = g.magic;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
         const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
         a.ngl = po_reg_ngl(reg_wide(W));
         if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-        {
-            int first_stale = 0, n_stale = 0;
-            reg_ws_claim(ws, g, &first_stale, &n_stale);
-            if (n_stale > 0 && hipMemsetAsync(w + g.off_state + sizeof(unsigned long long) * 2 * (size_t)first_stale, 0,
-                                              sizeof(unsigned long long) * 2 * (size_t)n_stale, stream) != hipSuccess)
-                return PO_E_HIP;
-        }
         if (model == PO_MODEL_CTC) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
         else if (model == PO_MODEL_MERGE) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(256), plds, stream, a);
         else hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(256), plds, stream, a);

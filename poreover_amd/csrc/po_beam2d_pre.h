@@ -97,8 +97,9 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             while (R < wmax + 2) R <<= 1;
             const long long pool_entries = (long long)(a.pool_bytes / sizeof(Entry<K>));
             const long long ng = pool_entries / ((long long)PO_A * 2 * R);
+            // (node ids go into 24 tag bits; the slice's arena is smaller than this worst case and checked as nodes are made)
             const long long need = 1 + A + (long long)A * max(W, A) * ((long long)min(U, V) + 1);
-            if (need > a.arena_cap || need >= (1 << 24)) st = PO_E_NOMEM;
+            if (need >= (1 << 24)) st = PO_E_NOMEM;
             // too few row groups for this window width here, or (test hook) odd pairs: beam2d_kernel takes it
             // ... or an envelope whose row starts / ends move backwards, for a kernel that builds on windows that only
             // move forward (what build_envelope makes; anything else is a caller's own array)

@@ -32,6 +32,7 @@
 // cannot hold (row groups exhausted, windows beyond 254 frames, non-monotone envelopes) go to beam2d_kernel through the
 // meta word.  Results are bit-identical to beam2d_kernel's: the same arithmetic in the same order within every chain.
 #include <climits>
+#include <type_traits>
 
 #define PO_LAE_EARLY_TABLE 1   // (po_device.h: the exp table entry is requested before the polynomial — a lone wave's chain is latency)
 #define PO_LAE_TRIM 1          // (... two instructions fewer: -|x1 - x2| through source modifiers, the exponent add in two)
@@ -139,15 +140,62 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     const int lane = threadIdx.x & 63, s = (NR == 1) ? (lane & 31) : lane, hb = (NR == 1) ? (lane & 32) : 0;
     const bool lo_half = (NR == 1) ? (lane < 32) : true;
     auto RD = [&](int q) -> int { return (NR == 1) ? (lane >> 5) : q; };   // the read a lane's q-th state belongs to
+    // one bit per element slot: 32 bits do for NR = 1 (scalar 32-bit operations; the 64-bit forms cost the W = 5 kernel 1.6 %)
+    using SMask = typename std::conditional<NR == 1, unsigned, unsigned long long>::type;
+    auto smask_of = [&](bool p) -> SMask { return (SMask)__ballot(p && lo_half); };
+    auto sm_pop = [&](SMask m) -> int { return (NR == 1) ? __popc((unsigned)m) : __popcll((unsigned long long)m); };
+    auto sm_ctz = [&](SMask m) -> int { return (NR == 1) ? __builtin_ctz((unsigned)m) : (int)__builtin_ctzll((unsigned long long)m); };
     RegSmem<MODEL, NR>& sm = gsm.w;
-    const int slotid = blockIdx.x;      // this pair wave's slice of the workspace
     const int A = a.A, W = a.W, C = a.C;
     const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here
-    Ent* const pool = (Ent*)(a.pool + (size_t)slotid * a.pool_bytes);
+    // ---- this wave's SLICE of the library's pool: value store + tree arena.  The pool has one slice per pair wave the device
+    // can hold (po_beam2d.hip::reg_pool), shared by every launch of this kernel on the device — the waves of a pipelined job on
+    // their streams, the next call — so a workspace no longer carries 2 - 8 MB per resident pair and a slice's tags and epoch
+    // counter live on from launch to launch.  A wave CLAIMS a free slice when it starts (all 64 lanes look at 64 claim words
+    // at a time) and gives it back when the queue is empty.  The hand-over between waves is an agent-scope release / acquire
+    // pair (per-XCD L2s are not coherent, a CU's L1 is never refreshed by another CU's stores): once per wave's lifetime.
+    int slotid = -1;
+    {
+        const int n = a.nslices;
+        // first try: the slice this wave's number names (distinct within a launch, so a launch alone on the device claims its
+        // slices without ever meeting another wave); only when that one is taken — a wave of another launch holds it — the
+        // wave looks further, 64 claim words at a time from a hashed position
+        const unsigned home = (unsigned)(((unsigned long long)blockIdx.x + (unsigned long long)a.slice_salt) % (unsigned)n);
+        {
+            int got = 0;
+            if (lane == 0) got = (atomicCAS(&a.slice_claim[home], 0, 1) == 0) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(got)) slotid = (int)home;
+        }
+        const unsigned start = (unsigned)((((unsigned long long)blockIdx.x * 2654435761ull) + (unsigned long long)a.slice_salt * 40503ull) % (unsigned)n);
+        for (int round = 0; slotid < 0; ++round) {
+            for (int base = 0; base < n && slotid < 0; base += 64) {
+                const bool valid = base + lane < n;
+                const int idx = (int)((start + (unsigned)(base + lane)) % (unsigned)n);
+                const int v = valid ? atomicAdd(&a.slice_claim[idx], 0) : 1;   // (an L2 read: never a stale L1 line)
+                unsigned long long fm = __ballot(v == 0);
+                // (waves that look at the same words start with different candidates: rotate the order by the wave's number)
+                const int rot = (int)(blockIdx.x & 63u);
+                fm = (fm >> rot) | (rot ? (fm << (64 - rot)) : 0ull);
+                while (fm != 0ull && slotid < 0) {   // (wave-uniform)
+                    const int L = ((int)__builtin_ctzll(fm) + rot) & 63;
+                    fm &= fm - 1ull;
+                    int got = 0;
+                    if (lane == L) got = (atomicCAS(&a.slice_claim[idx], 0, 1) == 0) ? 1 : 0;
+                    got = __builtin_amdgcn_readlane(got, L);
+                    if (got) slotid = __builtin_amdgcn_readlane(idx, L);
+                }
+            }
+            if (slotid < 0) __builtin_amdgcn_s_sleep(32);   // (every slice taken: cannot last — residency is what the pool is sized for)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    char* const slice = a.slice_chunk[slotid >> a.slice_spc_log2] + (size_t)(slotid & ((1 << a.slice_spc_log2) - 1)) * a.slice_bytes;
+    Ent* const pool = (Ent*)slice;
     const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
-    int* const apl = a.arena + (size_t)slotid * 3 * a.arena_cap;
+    int* const apl = (int*)(slice + a.pool_bytes);
     int* const afc = apl + a.arena_cap;
     int* const acrow = afc + a.arena_cap;
+    const int arena_cap = (int)a.arena_cap;   // nodes a slice's arena holds: a pair that needs more goes to beam2d_kernel
     auto g_hi = [&](int r) -> int* { return r ? sm.g_hi1 : sm.g_hi0; };
 
     // ---- epoch tags across pairs and launches (as beam2d_kernel): no memset of the store
@@ -158,7 +206,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     };
     {
         unsigned long long* stp = a.wgstate + 2 * (size_t)slotid;
-        const unsigned long long w0 = stp[0], w1 = stp[1];
+        const unsigned long long w0 = atomicAdd(&stp[0], 0ull), w1 = atomicAdd(&stp[1], 0ull);   // (L2 reads)
         const bool ok = (w0 == (a.magic ^ (unsigned long long)slotid));
         epoch = ok ? (unsigned)w1 : 0u;
         if (!ok) clear_slice();
@@ -755,18 +803,19 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 need_group = isnew || n_crow2 < 0 || n_crow2 >= NG || sm.g_owner[n_crow2] != n_id;   // (old rows recycled: all dead)
             }
             {
-                const unsigned long long bn = __ballot(isnew && lo_half);
+                const SMask bn = smask_of(isnew);
                 if (isnew) {
-                    n_fc = next_id + A * __popcll(bn & ((1ull << s) - 1ull));
+                    n_fc = next_id + A * sm_pop(bn & (((SMask)1 << s) - (SMask)1));
                     if (lo_half) afc[n_id] = n_fc;
                 }
-                next_id += A * __popcll(bn);
+                next_id += A * sm_pop(bn);
+                if (__builtin_expect(next_id > arena_cap, 0)) st = PO_E_NOMEM;   // (the slice's arena is full: beam2d_kernel takes the pair)
                 if (rb && !need_group) { atomicMax(&sm.g_hi0[n_crow2], nce); atomicMax(&sm.g_hi1[n_crow2], nre); }
                 rk_sync();
-                unsigned long long hg = __ballot(need_group && lo_half);
-                while (hg != 0ull) {   // (uniform: every lane walks the group table, lane 0 writes)
-                    const int jj = (int)__builtin_ctzll(hg);
-                    hg &= hg - 1ull;
+                SMask hg = smask_of(need_group);
+                while (hg != 0) {   // (uniform: every lane walks the group table, lane 0 writes)
+                    const int jj = sm_ctz(hg);
+                    hg &= hg - (SMask)1;
                     const int owner = __builtin_amdgcn_readlane(n_id, jj);
                     int gg = -1;
                     for (int tries = 0; tries < NG; ++tries) {
@@ -791,7 +840,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 n_id = p_fc + c; n_row2 = p_crow2 * PO_A + c; n_sym = sym_pack(c, sym_last(p_sym), false);
                 n_par = p_id; n_gpar = p_par; n_prow2 = p_row2; n_depth = p_depth + 1; n_ps = j;
                 n_fc = p_isnew ? -1 : -2; n_crow2 = p_isnew ? -1 : -2;
-                if (p_isnew && lo_half) { apl[n_id] = po_pack_node(p_id, c); afc[n_id] = -1; acrow[n_id] = -1; }
+                if (p_isnew && lo_half && n_id < arena_cap) { apl[n_id] = po_pack_node(p_id, c); afc[n_id] = -1; acrow[n_id] = -1; }
             }
             // a child slot whose node is also a beam slot is the same node pushed twice (Beam::prune's std::unique)
             for (int i = 0; i < nbn; ++i) {
@@ -1128,30 +1177,30 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             }   // (!run_viol)
             const bool cand = live;
             // ---- full ranking among the distinct candidates
-            const unsigned long long cm = __ballot(cand && lo_half);
-            const int ncand = __popcll(cm);
+            const SMask cm = smask_of(cand);
+            const int ncand = sm_pop(cm);
             // Only the beam nodes and the children that reach the smallest beam score can be among the W best (every
             // other child has W candidates above it), and nothing outside that set outranks a member of it: the ranks
             // are taken within it (a handful of candidates instead of W * (A + 1)).
-            unsigned long long smask = cm;
+            SMask smask = cm;
             if (nb == W) {
                 const double thr = rk_row0_min(sc, nb, lane);
-                smask = __ballot(cand && lo_half && (s < nb || sc >= thr));
+                smask = smask_of(cand && (s < nb || sc >= thr));
             }
             int rank = 0, neq = 0;
-            for (unsigned long long mm = smask; mm != 0ull; mm &= mm - 1ull) {
-                const int o = (int)__builtin_ctzll(mm);
+            for (SMask mm = smask; mm != 0; mm &= mm - (SMask)1) {
+                const int o = sm_ctz(mm);
                 const double so = rk_readlane_d(sc, o);
                 const int io = __builtin_amdgcn_readlane(e_id, o);
                 rank += ((so > sc) | (!(sc > so) & (io < e_id))) ? 1 : 0;
                 neq += (so == sc) ? 1 : 0;
             }
-            if (!((smask >> s) & 1ull)) { rank = 64; neq = 0; }
+            if (!((smask >> s) & (SMask)1)) { rank = 64; neq = 0; }
             const int nbn = min(W, ncand);
 #pragma unroll
             for (int jx = 0; jx < WS; ++jx) {
-                const unsigned long long bj = __ballot(cand && lo_half && rank == jx);
-                sel[jx] = (bj != 0ull) ? (int)__builtin_ctzll(bj) : 0;
+                const SMask bj = smask_of(cand && rank == jx);
+                sel[jx] = (bj != 0) ? sm_ctz(bj) : 0;
             }
             if (__builtin_expect(__ballot(cand && neq > 1 && rank < W) != 0ull, 0)) {
                 // exact ties reaching into the beam: what libstdc++'s partial_sort / sort leave on the candidates in
@@ -1159,7 +1208,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 int pos = 0;   // (the replay runs over ALL candidates in creation order)
                 for (int o = 0; o < ne; ++o) {
                     const int io = __builtin_amdgcn_readlane(e_id, o);
-                    pos += (int)((cm >> o) & 1ull) & ((io < e_id) ? 1 : 0);
+                    pos += (int)((cm >> o) & (SMask)1) & ((io < e_id) ? 1 : 0);
                 }
                 if (cand && lo_half) { sm.ord[pos] = s; sm.csc[s] = sc; }
                 rk_sync();
@@ -1206,12 +1255,18 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     if (lane == 0 && a.dbg && slotid == 0)
         for (int i = 0; i < 40; ++i) a.dbg[i] = tk[i];
 #endif
-    if (lane == 0) {   // the next launch on this workspace continues from here
+    if (lane == 0) {   // the slice's next owner continues from here
         unsigned long long* stp = a.wgstate + 2 * (size_t)slotid;
-        stp[0] = a.magic ^ (unsigned long long)slotid;
-        stp[1] = (unsigned long long)epoch;
+        atomicExch(&stp[0], a.magic ^ (unsigned long long)slotid);
+        atomicExch(&stp[1], (unsigned long long)epoch);
         if (COUNT && a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
     }
+    // (everything this wave wrote into the slice leaves this XCD's L2 before another wave — any CU, any XCD — may claim it)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifndef PO_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    if (lane == 0) atomicExch(&a.slice_claim[slotid], 0);
 }
 
 // pair slots per CU (registers and LDS decide): 16 one-wave workgroups for the one-value model at W <= 6 (4 waves per SIMD),

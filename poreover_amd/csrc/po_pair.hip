@@ -842,20 +842,28 @@ PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     const int64_t lmax1 = std::max<int64_t>(64, mr1 / 4 + 8), lmax2 = std::max<int64_t>(64, mr2 / 4 + 8);
     g.row_cap = (size_t)(lmax1 + 1);
     const int64_t width = opt->full_alignment ? (lmax2 + 1) : std::min<int64_t>(lmax2 + 1, 2 * NW_BAND + 1);
-    g.dp_cap = (size_t)((lmax1 + 1) * width);
-    if (g.one_wave) g.dp_cap = std::max(g.dp_cap, pp_skew_cells(lmax1, lmax2, NW_BAND));
+    // (the skewed-wavefront kernel keeps trace-back flags, not the score table: 1.2 MB per workgroup at T = 4000 instead of the
+    //  4.4 MB the row-at-a-time kernel needs — 13 GB less per 4 096 resident workgroups.  The table's size is reserved only
+    //  when that kernel can run: po_set_align_route(1) / PO_PP_LEGACY, or a read 2 beyond SK_MAXB column blocks; a launch
+    //  re-derives the geometry, so a route switched after the size query fails with PO_E_CAP instead of overrunning.)
+    const bool skew_only = g.one_wave && !pp_legacy() && lmax2 <= (int64_t)SK_MAXB * SK_BW && mr2 + 8 <= (int64_t)SK_MAXB * SK_BW;
+    g.dp_cap = skew_only ? pp_skew_cells(lmax1, lmax2, NW_BAND) : (size_t)((lmax1 + 1) * width);
+    if (g.one_wave && !skew_only) g.dp_cap = std::max(g.dp_cap, pp_skew_cells(lmax1, lmax2, NW_BAND));
     g.aln_cap = (size_t)(lmax1 + lmax2 + 16);
-    {   // the first pass's slices within 1/16 of the board's memory (very long reads: fewer workgroups)
+    {   // the first pass's slices within 2.5 GB (T = 4000: ~ 2 000 workgroups of 1.2 MB, eight per CU — the kernel is 2 ms of a
+        // 10 000-pair step and loses nothing to that — so that a wave's workspace stays a few GB: large allocations are what
+        // a process's first call waits for) and within 1/16 of the board's memory (very long reads: fewer workgroups)
+        static const size_t budget = [] { const char* e = getenv("PO_PP_BUDGET_MB"); return (size_t)(e ? atoi(e) : 2560) << 20; }();
         const size_t per_block = sizeof(int) * g.dp_cap + sizeof(int) * 4 * g.row_cap + 2 * g.aln_cap;
-        const size_t fit = std::max<size_t>(1, (pp_total_mem() / 16) / std::max<size_t>(per_block, 1));
-        g.blocks = (int)std::min<size_t>((size_t)g.blocks, fit);
+        const size_t fit = std::max<size_t>(1, std::min(budget, pp_total_mem() / 16) / std::max<size_t>(per_block, 1));
+        g.blocks = (int)std::min<size_t>((size_t)g.blocks, std::max<size_t>(fit, (size_t)pp_num_cus()));
     }
     {
         const int64_t b1 = mr1 + 8, b2 = mr2 + 8;
         g.big_row_cap = (size_t)(b1 + 1);
         const int64_t bw = opt->full_alignment ? (b2 + 1) : std::min<int64_t>(b2 + 1, 2 * NW_BAND + 1);
-        g.big_dp_cap = (size_t)((b1 + 1) * bw);
-        if (g.one_wave) g.big_dp_cap = std::max(g.big_dp_cap, pp_skew_cells(b1, b2, NW_BAND));
+        g.big_dp_cap = skew_only ? pp_skew_cells(b1, b2, NW_BAND) : (size_t)((b1 + 1) * bw);
+        if (g.one_wave && !skew_only) g.big_dp_cap = std::max(g.big_dp_cap, pp_skew_cells(b1, b2, NW_BAND));
         g.big_aln_cap = (size_t)(b1 + b2 + 16);
         const size_t per_block = sizeof(int) * g.big_dp_cap + sizeof(int) * 4 * g.big_row_cap + 2 * g.big_aln_cap;
         const size_t fit = ((size_t)2 << 30) / std::max<size_t>(per_block, 1);     // 2 GB for the pass; at least one slice

@@ -207,7 +207,7 @@ struct WavePlanner {
     }
 };
 
-constexpr int PO_MAX_SLOTS = 4;
+constexpr int PO_MAX_SLOTS = 8;
 // Wave size when the caller names none.  Measured on the 10 000-pair job (scripts/e2e_ab.sh, one MI355X, host float32 in ->
 // strings out): three waves in flight and four even waves of 2 500 pairs 66.5k pairs/s; 2 x 4 096 + 1 808 on two slots 58.4k;
 // 3 x 3 334 63.4k; 5 x 2 048 (the LDS-ring kernel's range) 50.8k; a short first wave (ramp) 54 - 59k.  The first wave is what
@@ -434,6 +434,7 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
         const double t0 = now_ms();
         PCHK(hipStreamSynchronize(s.st));
         p->wait_ms += now_ms() - t0;
+        if (trace) fprintf(stderr, "[po_pipe] wave of %d pairs (first %d) done at %.2f ms (waited %.2f ms)\n", s.n, s.first, now_ms() - t_begin, now_ms() - t0);
         const char* ho = (const char*)s.h_out.p;
         const int32_t* l1 = (const int32_t*)(ho + s.o_l1);
         const int32_t* l2 = (const int32_t*)(ho + s.o_l2);

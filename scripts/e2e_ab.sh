@@ -1,7 +1,11 @@
-# A/B of the pipelined host layer on the 10 000-pair end-to-end job: waves in flight x wave size x first-wave ramp
-for cfg in "3 2500 0" "3 2500 1250" "3 2500 640" "3 2800 0" "3 3000 0" "3 3334 0" "3 3334 1700" "3 2200 0"; do
+#!/bin/bash
+# A/B of the pipelined host layer on the 10 000-pair end-to-end job, in ONE gpurun call: waves in flight x wave size x first-wave
+# ramp x last-wave size (scripts/cold_start.py: host float32 in -> strings out, three calls; the later two are printed).
+#   scripts/e2e_ab.sh "SLOTS WAVE RAMP TAIL" ...      (0 = the engine's own choice)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+for cfg in "$@"; do
   set -- $cfg
-  echo -n "slots=$1 wave=$2 ramp=$3: "
-  PO_PIPELINE_SLOTS=$1 PO_WAVE_PAIRS=$2 PO_WAVE_RAMP=$3 timeout 300 python bench.py --steps 1 --warmup 1 --no_secondary --cpu_sample 0 2>&1 | tail -1 | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); s=d['strong_scaling']; print(s['pairs_per_s'], s['seconds'], {k: round(v,1) for k,v in s['pipeline_rank0'].items()})"
+  echo -n "slots=$1 wave=$2 ramp=$3 tail=$4: "
+  env $( [ "$1" != 0 ] && echo PO_PIPELINE_SLOTS=$1 ) $( [ "$2" != 0 ] && echo PO_WAVE_PAIRS=$2 ) $( [ "$3" != x ] && echo PO_WAVE_RAMP=$3 ) $( [ "$4" != x ] && echo PO_WAVE_TAIL=$4 ) \
+    timeout 300 python scripts/cold_start.py --reps 4 2>&1 | tail -1
 done

@@ -28,14 +28,19 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     const int wide = (W > 6) ? 1 : 0;
     const size_t pool_bytes = po_reg_pool_bytes(model, wide);
     (void)kernel;
-    const int64_t WM = W > PO_A ? W : PO_A;
-    const size_t arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * (std::min(mr1, mr2) + 2));
-    std::vector<char> pool(pool_bytes * blocks, 0);
-    std::vector<int> arena(3 * arena_cap * blocks, 0);
+    // the library's slice pool, stood in for by host memory: one chunk, a slice per pair wave of the launch
+    const int64_t WM = wide ? 12 : 6;
+    const size_t arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * 1024);
+    const size_t slice_bytes = (pool_bytes + sizeof(int) * 3 * arena_cap + 255) & ~size_t(255);
+    std::vector<char> pool(slice_bytes * blocks, 0);
+    std::vector<int> claim((size_t)blocks, 0);
     std::vector<unsigned long long> wgstate(2 * (size_t)blocks, 0);
     a.queue = queue.data(); a.meta = meta.data(); a.nmain = nmain.data(); a.sched = sched.data(); a.envt = envt.data();
     a.cum1 = cum1.data(); a.cum2 = cum2.data();
-    a.pool = pool.data(); a.pool_bytes = pool_bytes; a.arena = arena.data(); a.arena_cap = (long long)arena_cap;
+    a.pool = nullptr; a.pool_bytes = pool_bytes; a.arena = nullptr; a.arena_cap = (long long)arena_cap;
+    for (int c = 0; c < 8; ++c) a.slice_chunk[c] = nullptr;
+    a.slice_chunk[0] = pool.data(); a.slice_spc_log2 = 30; a.nslices = blocks; a.slice_bytes = slice_bytes; a.slice_claim = claim.data();
+    a.slice_salt = 12345u;
     a.dbg = nullptr; a.upd_count = upd_count; a.defer_odd = 0; a.need_mono = 1; a.order = nullptr;
     a.wgstate = wgstate.data(); a.magic = 0x1234567ull;
     a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
