@@ -541,7 +541,8 @@ def main():
             check = {"checked": 0, "mismatches": 0, "statuses": _status_counts(h_st),
                      "status_names": {"0": "decoded", str(_lib.SKIP_LENGTH): "skipped: basecall lengths differ by more than 1000 (pair_decode.py:331)",
                                       str(_lib.SKIP_IDENTITY): "skipped: alignment identity below 0.5 (pair_decode.py:382)",
-                                      "-4": "refused: the reference's own frame-map assertion fails for this pair (pair_decode.py:379)"}}
+                                      "-2": "refused as the reference refuses it: its assertion that the frame map has one entry per base fails "
+                                            "(pair_decode.py:379; Bonito's get_sequence_mapping compares frame 0 with path[-1]) - the oracle returns the same code"}}
             if digest_key in sec_dig:
                 want = sec_dig[digest_key]
                 kk = min(n, len(want))

@@ -85,7 +85,13 @@ int po_device_info(int device, char* name, int name_cap, int* compute_units, int
 #define PO_ROUTE_AUTO 0
 #define PO_ROUTE_LEGACY 2
 #define PO_ROUTE_REG 4   /* beam2d_reg_kernel: element state in registers, values in the tagged HBM store */
+/* defer_odd bits 1 and 2 (values 2, 4) are further test hooks of that hand-over: the kernel runs with a dozen row groups /
+ * with a tree arena of a few nodes, so that pairs run out of them and are handed on (tests/test_gpu_parity_2d.py). */
 int po_set_pair_route(int route, int defer_odd);
+/* test hook: pairs the register-state kernel or its pre-pass handed to beam2d_kernel on the current device since the last
+ * reset (windows beyond its store geometry or its packed walk records, row groups or arena exhausted, non-monotone envelopes,
+ * the defer_odd hooks); reset != 0 clears the count.  Synchronises the device; -1 on a HIP error. */
+long long po_debug_deferred_pairs(int reset);
 /* test / tuning hook: legacy != 0 -> the banded aligner (align.pyx:100-178) runs the row-at-a-time kernel that stores the
  * score table instead of the skewed-wavefront kernel.  Process-wide; results are identical. */
 int po_set_align_route(int legacy);

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "po_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_size_t)]),
     "po_set_pair_route": (C.c_int, [C.c_int, C.c_int]),
+    "po_debug_deferred_pairs": (C.c_longlong, [C.c_int]),
     "po_set_align_route": (C.c_int, [C.c_int]),
     "po_ingest_batch": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _dp, _vp]),
     "po_ingest_batch_h": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _dp]),
@@ -185,9 +186,16 @@ def current_device():
 ROUTES = {"auto": 0, "legacy": 2, "reg": 4}
 
 
-def set_pair_route(route="auto", defer_odd=False):
-    """test / tuning hook (po_set_pair_route): which kernel serves the pair beam search"""
-    check(load(False).po_set_pair_route(ROUTES[route], 1 if defer_odd else 0), "po_set_pair_route")
+def set_pair_route(route="auto", defer_odd=False, starve=0):
+    """test / tuning hook (po_set_pair_route): which kernel serves the pair beam search; defer_odd: every odd pair is handed
+    to beam2d_kernel; starve: 1 = the register-state kernel runs with a dozen row groups, 2 = with a tiny tree arena (pairs run
+    out of them and are handed on)"""
+    check(load(False).po_set_pair_route(ROUTES[route], (1 if defer_odd else 0) | ((int(starve) & 3) << 1)), "po_set_pair_route")
+
+
+def deferred_pairs(reset=False):
+    """test hook (po_debug_deferred_pairs): pairs handed from the register-state kernel to beam2d_kernel since the last reset"""
+    return int(load(False).po_debug_deferred_pairs(1 if reset else 0))
 
 
 def set_align_route(legacy=False):

@@ -467,6 +467,8 @@ def pair_decode_stream(arrays1, arrays2, kind="poreover", beam_width=5, method="
     records(done, n)
     if stats is not None:
         stats.update(py_in_ms=(_t1 - _t0) * 1e3, call_ms=(_t2 - _t1) * 1e3, py_out_ms=(_time.perf_counter() - _t2) * 1e3)
+    del raw1, raw
+    release_scratch(_SCRATCH_KEEP)   # (a thread keeps its text buffers between calls up to this size; one huge job does not pin them)
     return out
 
 

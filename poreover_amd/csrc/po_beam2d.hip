@@ -1719,6 +1719,7 @@ struct RegPool {
     char* chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int* claim = nullptr;
     unsigned long long* state = nullptr;
+    unsigned long long* defer_count = nullptr;   // pairs handed to beam2d_kernel since the last reset (tests)
     unsigned long long magic = 0;
 };
 std::mutex g_reg_pool_mu;
@@ -1748,7 +1749,7 @@ RegPool* reg_pool(int model, int wide) {
         const int here = std::min(spc, p->nslices - c * spc);
         ok = hipMalloc((void**)&p->chunk[c], (size_t)here * p->slice_bytes) == hipSuccess;
     }
-    const size_t words = sizeof(int) * (size_t)p->nslices + sizeof(unsigned long long) * 2 * (size_t)p->nslices + 256;
+    const size_t words = sizeof(int) * (size_t)p->nslices + sizeof(unsigned long long) * 2 * (size_t)p->nslices + 256;   // (+ the deferral counter)
     char* w = nullptr;
     ok = ok && hipMalloc((void**)&w, words) == hipSuccess && hipMemset(w, 0, words) == hipSuccess;
     if (!ok) {
@@ -1759,6 +1760,7 @@ RegPool* reg_pool(int model, int wide) {
     }
     p->state = (unsigned long long*)w;
     p->claim = (int*)(w + sizeof(unsigned long long) * 2 * (size_t)p->nslices);
+    p->defer_count = (unsigned long long*)(w + words - 128);
     p->magic = 0x51ed270b0a1f3c97ull ^ ((unsigned long long)p->pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)(key + 1) << 56);
     if (b2_route().debug_occ)
         fprintf(stderr, "[po] register-state kernel pool (model %d, %s layout): %d slices of %.2f MB in %d chunk(s)\n", model, wide ? "64-slot" : "32-slot",
@@ -1889,11 +1891,27 @@ extern "C" void po_b2_set_mark(void (*f)(int, hipStream_t)) { g_b2_mark = f; g_b
 extern "C" int po_set_pair_route(int route, int defer_odd) {
     if (route != PO_ROUTE_AUTO && route != PO_ROUTE_LEGACY && route != PO_ROUTE_REG) return PO_E_ARG;   // (PO_ROUTE_X2 / PO_ROUTE_RING: kernels retired in round 5)
     b2_route().route = route;
-    b2_route().defer_odd = defer_odd ? 1 : 0;
+    b2_route().defer_odd = defer_odd & 7;   // bit 0: odd pairs are handed on; bits 1, 2: starve the row groups / the arena
     return PO_OK;
 }
 // profiling: a device counter that the pair beam kernels add their number of update_prob evaluations to
 extern "C" void po_b2_set_update_counter(unsigned long long* dev_counter) { g_b2_upd_counter = dev_counter; }
+// tests: pairs the register-state kernel (or its pre-pass) handed to beam2d_kernel on this device since the last reset, summed
+// over the pools in use (synchronises the device)
+extern "C" long long po_debug_deferred_pairs(int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const int dev = po_cur_device();
+    long long tot = 0;
+    std::lock_guard<std::mutex> lk(g_reg_pool_mu);
+    for (RegPool* p : g_reg_pools[dev]) {
+        if (!p) continue;
+        unsigned long long v = 0;
+        if (hipMemcpy(&v, p->defer_count, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        tot += (long long)v;
+        if (reset && hipMemset(p->defer_count, 0, sizeof(v)) != hipSuccess) return -1;
+    }
+    return tot;
+}
 
 // ---- logaddexp micro-benchmark: the peak rate of the specialised logaddexp on this device (4 independent
 // chains per lane, tables in LDS, every lane busy) — the compute ceiling the pair kernels are priced against
@@ -2065,11 +2083,13 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         for (int c = 0; c < 8; ++c) a.slice_chunk[c] = rp->chunk[c];
         a.slice_spc_log2 = rp->spc_log2; a.nslices = rp->nslices; a.slice_bytes = rp->slice_bytes; a.slice_claim = rp->claim;
         a.slice_salt = g_reg_salt.fetch_add(0x9e3779b1u);
+        a.defer_count = rp->defer_count;
+        a.starve = (b2_route().defer_odd >> 1) & 3;
         a.wgstate = rp->state;
         a.magic = rp->magic;
         a.dbg = nullptr;
         a.upd_count = g_b2_upd_counter;
-        a.defer_odd = b2_route().defer_odd;
+        a.defer_odd = b2_route().defer_odd & 1;
         a.need_mono = 1;
         a.no_cum = 1;
         a.order = nullptr;

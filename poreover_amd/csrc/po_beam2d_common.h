@@ -149,6 +149,9 @@ struct X2Args {
     size_t slice_bytes;
     int* slice_claim;
     unsigned slice_salt;              // spreads the first probes of concurrent launches
+    unsigned long long* defer_count;  // pairs handed to beam2d_kernel, counted for the tests (po_debug_deferred_pairs)
+    int starve;                       // test hook (po_set_pair_route's defer_odd bits 1, 2): bit 0 = a dozen row groups only,
+                                      // bit 1 = a tree arena of a few nodes only — every hand-over reason can be forced
     int no_cum;                       // pre-pass: leave the blank prefix sums out (beam2d_reg_kernel adds the root's alpha up as it goes)
 };
 

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             // too few row groups for this window width here, or (test hook) odd pairs: beam2d_kernel takes it
             // ... or an envelope whose row starts / ends move backwards, for a kernel that builds on windows that only
             // move forward (what build_envelope makes; anything else is a caller's own array)
-            else if (min((long long)a.ngl, ng) < 8 * max(W, PO_A) || (a.defer_odd && (pi & 1)) || (a.need_mono && !mono)) R = X2_DEFERRED;
+            else if (min((long long)a.ngl, ng) < 8 * max(W, PO_A) || ((a.defer_odd & 1) && (pi & 1)) || (a.need_mono && !mono)) R = X2_DEFERRED;
         }
     }
     // blank prefix sums = the CTC root's alpha (PrefixTree.h:509-515): serial in t so the rounding is the
@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
     if (tid == 0) {
         a.meta[pi] = make_int2(st, R);
         a.nmain[pi] = 0;
-        if (st == PO_OK && R == X2_DEFERRED) a.queue[16] = 1;   // the pass over the deferred pairs has something to do
+        if (st == PO_OK && R == X2_DEFERRED) {   // the pass over the deferred pairs has something to do
+            a.queue[16] = 1;
+            if (a.defer_count) atomicAdd(a.defer_count, 1ull);
+        }
     }
 }
 

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     int* const apl = (int*)(slice + a.pool_bytes);
     int* const afc = apl + a.arena_cap;
     int* const acrow = afc + a.arena_cap;
-    const int arena_cap = (int)a.arena_cap;   // nodes a slice's arena holds: a pair that needs more goes to beam2d_kernel
+    // nodes a slice's arena holds: a pair that needs more goes to beam2d_kernel (starve: the tests' way to get there)
+    const int arena_cap = (a.starve & 2) ? min((int)a.arena_cap, 1 + a.A + 24 * a.A) : (int)a.arena_cap;
     auto g_hi = [&](int r) -> int* { return r ? sm.g_hi1 : sm.g_hi0; };
 
     // ---- epoch tags across pairs and launches (as beam2d_kernel): no memset of the store
@@ -255,10 +256,10 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         const int nmain = a.nmain[pi];
         const int R2 = m.y, Rm2 = R2 - 1;
         if (__builtin_expect(R2 > 256, 0)) {   // windows of 255 frames and more: the packed walk records below keep a window's length in 8 bits
-            if (lane == 0) { a.meta[pi] = make_int2(PO_OK, X2_DEFERRED); a.queue[16] = 1; }
+            if (lane == 0) { a.meta[pi] = make_int2(PO_OK, X2_DEFERRED); a.queue[16] = 1; if (a.defer_count) atomicAdd(a.defer_count, 1ull); }
             continue;
         }
-        const int NG = (int)min((long long)RK_NGL, pool_entries / ((long long)PO_A * 2 * R2));
+        const int NG = (int)min((long long)((a.starve & 1) ? 12 : RK_NGL), pool_entries / ((long long)PO_A * 2 * R2));
         int st = PO_OK;
 
         // ---------------------------------------------------------------- the value store
@@ -1229,6 +1230,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         if (st == PO_E_NOMEM && lane == 0) {   // out of row groups (or a window end moved back): beam2d_kernel takes the pair
             a.meta[pi] = make_int2(PO_OK, X2_DEFERRED);
             a.queue[16] = 1;
+            if (a.defer_count) atomicAdd(a.defer_count, 1ull);
         } else if (lane == 0) {
             int nout = 0;
             if (st == PO_OK) {

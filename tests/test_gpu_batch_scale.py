@@ -96,3 +96,72 @@ def test_more_pairs_than_workgroups_mixed_lengths(oracle):
     for k, i in enumerate(idx):
         w = base[i][2]
         assert got[k]["status"] == w["status"] and (got[k]["consensus"] or "") == (w["consensus"] or "") and got[k]["seq1"] == w["seq1"], (k, int(i))
+
+
+# ---- the secondary legs of bench.py at test size, against the oracle's committed digests (tests/golden/secondary_digest.json,
+# made by make_secondary_digest.py): the occupancies the small parity tests never reach
+@pytest.fixture(scope="module")
+def secondary_digests():
+    with open(os.path.join(GOLDEN_DIR, "secondary_digest.json")) as f:
+        return json.load(f)["legs"]
+
+
+def _gen_ff_read(i):
+    from poreover_amd.synth import synth_read
+    return synth_read(500000 + i, 4000, 0, True)
+
+
+def _gen_ff_pair(i):
+    from poreover_amd.synth import synth_pair
+    return synth_pair(700000 + i, T=4000, flipflop=True)
+
+
+def _md5(*parts):
+    import hashlib
+    return hashlib.md5("|".join(p if p is not None else "" for p in parts).encode()).hexdigest()[:10]
+
+
+@pytest.mark.parametrize("leg", ["config2", "config5"])
+def test_beam1d_1000_reads_one_launch_vs_oracle_digest(workload, secondary_digests, leg):
+    """BASELINE configs 2 and 5 as ONE launch of 1 000 reads (one wave per SIMD: the occupancy bench.py times) — every string
+    against the oracle's digest"""
+    from poreover_amd import batch
+    want = secondary_digests[leg]
+    n = len(want)
+    if leg == "config2":
+        pairs, _ = workload
+        reads = [p[0] for p in pairs][:n]
+        model = "ctc"
+    else:
+        with get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
+            reads = pool.map(_gen_ff_read, range(n), chunksize=16)
+        model = "ctc_flipflop"
+    n = min(n, len(reads))
+    got = batch.beam_search_batch(reads[:n], beam_width=10, model=model)
+    bad = [i for i in range(n) if [0, len(got[i]), _md5(got[i])] != want[i]]
+    assert bad == [], (leg, bad[:5])
+
+
+@pytest.mark.parametrize("leg,kind,W,method", [("pair_bonito_W5", "bonito", 5, "row_col"), ("pair_row_W5", "poreover", 5, "row"),
+                                               ("pair_row_col_W10", "poreover", 10, "row_col"), ("pair_flipflop_W5", "flipflop", 5, "row_col")])
+def test_secondary_pair_legs_512_pairs_vs_oracle_digest(workload, secondary_digests, leg, kind, W, method):
+    """the other pair-decode configurations bench.py times (Bonito's tree model, method row, W = 10, flip-flop pairs), 512 pairs
+    in one call each, whole stage chain: statuses, lengths and strings against the oracle's digests"""
+    from poreover_amd import _lib, batch
+    n = 512
+    want = secondary_digests[leg][:n]
+    if kind == "flipflop":
+        with get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
+            pairs = pool.map(_gen_ff_pair, range(n), chunksize=16)
+    else:
+        pairs = workload[0][:n]
+    got = batch.pair_decode_stream([p[0] for p in pairs], [p[1] for p in pairs], kind, W, method, strict=False)
+    bad = []
+    for i, (g, r) in enumerate(zip(got, want)):
+        if g["status"] in (0, _lib.SKIP_LENGTH, _lib.SKIP_IDENTITY):
+            rec = [g["status"], g["length1"], g["length2"], len(g["consensus"] or ""), _md5(g["seq1"], g["seq2"], g["consensus"])]
+        else:   # (refused as the reference's own assertion refuses it: the oracle records the code with empty strings)
+            rec = [g["status"], 0, 0, 0, _md5("", "", "")]
+        if rec != r:
+            bad.append(i)
+    assert bad == [], (leg, bad[:5], [got[i]["status"] for i in bad[:5]])

@@ -82,9 +82,9 @@ def test_rowcol_matches_oracle_batch(eng, oracle, model, ff, W):
 
 
 def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
-    """row_col / W <= 6 / ctc runs two pairs per wave (beam2d_x2_kernel); pairs that kernel defers are
-    decoded by beam2d_kernel in the same call.  set_pair_route(defer_odd=True) sends every odd pair down the second
-    path: one batch, both kernels, every string equal to the oracle's."""
+    """row_col with an envelope runs beam2d_reg_kernel; pairs that kernel hands on are decoded by beam2d_kernel in the same
+    call.  set_pair_route(defer_odd=True) sends every odd pair down the second path: one batch, both kernels, every string
+    equal to the oracle's."""
     from poreover_amd import _lib
     route = {"reg": "reg", "legacy": "legacy"}.get(kernel_route_name(), "auto")
     _lib.set_pair_route(route, defer_odd=True)
@@ -106,8 +106,8 @@ def test_rowcol_two_kernel_paths_in_one_batch(eng, oracle, monkeypatch):
 
 @pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
 def test_rowcol_wide_beam_one_pair_per_wave(eng, oracle, monkeypatch, model, ff):
-    """7 <= W <= 12 runs beam2d_x2_kernel with one pair per wave (route "legacy" forces beam2d_kernel): same strings
-    as the oracle from both"""
+    """7 <= W <= 12 runs beam2d_reg_kernel's 64-slot layout (lane = element slot, the reads one after the other; route
+    "legacy" forces beam2d_kernel): same strings as the oracle from both"""
     kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
     y1s, y2s, envs = [], [], []
     for i in range(5):
@@ -430,3 +430,62 @@ def test_exact_ties_follow_the_reference(eng, oracle):
             got = eng.beam_search_2d_batch(a, b, envs, W, model=model, method=method)
             for i in range(len(a)):
                 assert got[i] == oracle.cpp_beam_search_2d(a[i], b[i], envs[i], W, model_=model, method_=method), (kind, method, W, i)
+
+
+
+# ---- every reason the register-state kernel hands a pair to beam2d_kernel, forced one by one: the
+# pair must come back with the oracle's string, and the hand-over must really have happened (po_debug_deferred_pairs)
+def _wide_env(U, V, half):
+    return np.array([(max(0, int(u * V / U) - half), min(V, int(u * V / U) + half + 1)) for u in range(U)], dtype=np.int64)
+
+
+@pytest.mark.parametrize("reason", ["window_beyond_walk_records", "window_beyond_store_geometry", "non_monotone_envelope",
+                                    "row_groups_exhausted", "arena_exhausted", "odd_pairs"])
+@pytest.mark.parametrize("model,ff", [("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)])
+def test_reg_kernel_hands_over_and_result_is_the_oracles(eng, oracle, reason, model, ff):
+    from poreover_amd import _lib
+    if kernel_route_name() == "legacy":
+        pytest.skip("beam2d_kernel alone: nothing is handed over")
+    kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
+    route = {"reg": "reg"}.get(kernel_route_name(), "auto")
+    W, starve, odd = 5, 0, False
+    y1s, y2s, envs = [], [], []
+    for i in range(4):
+        y1, y2 = synth_pair(4700 + i, T=420 + 50 * i, flipflop=ff)
+        env = np.asarray(oracle.pair_decode(y1, y2, kind, 5, "row_col")["envelope"], dtype=np.int64)
+        if reason == "window_beyond_walk_records":       # 255 <= window < 512 at W <= 4: the store holds it (32 row groups of
+            W = 3                                        # R = 512), the packed walk records (8-bit lengths) do not
+            env = _wide_env(len(y1), len(y2), 140)
+        elif reason == "window_beyond_store_geometry":   # ... at W = 5 the 32 row groups are too few: the pre-pass hands on
+            env = _wide_env(len(y1), len(y2), 140)
+        elif reason == "non_monotone_envelope":          # a row that starts before its predecessor (a caller's own array)
+            env = env.copy()
+            for u in range(40, len(env) - 1, 37):
+                env[u, 0] = max(0, env[u, 0] - 6)
+        y1s.append(y1); y2s.append(y2); envs.append(env)
+    if reason == "row_groups_exhausted":
+        starve = 1
+    elif reason == "arena_exhausted":
+        starve = 2
+    elif reason == "odd_pairs":
+        odd = True
+    want = []
+    for a, b, e in zip(y1s, y2s, envs):
+        try:
+            want.append(oracle.cpp_beam_search_2d(a, b, e, W, model_=model, method_="row_col"))
+        except oracle.OracleError:
+            want.append(None)
+    assert all(w is not None for w in want)
+    _lib.deferred_pairs(reset=True)
+    _lib.set_pair_route(route, defer_odd=odd, starve=starve)
+    try:
+        got = eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col")
+        handed = _lib.deferred_pairs(reset=True)
+    finally:
+        _lib.set_pair_route(route)
+    assert got == want, reason
+    assert handed >= (2 if reason == "odd_pairs" else 1), (reason, handed)
+    # ... and the same pairs without the hook / with ordinary envelopes are decoded by the kernel itself
+    if reason in ("row_groups_exhausted", "arena_exhausted", "odd_pairs"):
+        assert eng.beam_search_2d_batch(y1s, y2s, envs, W, model=model, method="row_col") == want
+        assert _lib.deferred_pairs(reset=True) == 0
