@@ -1720,11 +1720,11 @@ struct RegPool {
     int* claim = nullptr;
     unsigned long long* state = nullptr;
     unsigned long long* defer_count = nullptr;   // pairs handed to beam2d_kernel since the last reset (tests)
+    unsigned* tickets = nullptr;                 // {take, give} tickets of the ring of free slices (claim)
     unsigned long long magic = 0;
 };
 std::mutex g_reg_pool_mu;
 RegPool* g_reg_pools[PO_MAX_DEVICES][6] = {};
-std::atomic<unsigned> g_reg_salt{0};
 RegPool* reg_pool(int model, int wide) {
     const int dev = po_cur_device();
     const int key = (model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2)) * 2 + (wide ? 1 : 0);
@@ -1752,6 +1752,11 @@ RegPool* reg_pool(int model, int wide) {
     const size_t words = sizeof(int) * (size_t)p->nslices + sizeof(unsigned long long) * 2 * (size_t)p->nslices + 256;   // (+ the deferral counter)
     char* w = nullptr;
     ok = ok && hipMalloc((void**)&w, words) == hipSuccess && hipMemset(w, 0, words) == hipSuccess;
+    if (ok) {   // every slice is free: ring word i holds slice i
+        std::vector<int> ids((size_t)p->nslices);
+        for (int i = 0; i < p->nslices; ++i) ids[(size_t)i] = i;
+        ok = hipMemcpy(w + sizeof(unsigned long long) * 2 * (size_t)p->nslices, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) {
         for (auto c : p->chunk) if (c) (void)hipFree(c);
         if (w) (void)hipFree(w);
@@ -1761,6 +1766,7 @@ RegPool* reg_pool(int model, int wide) {
     p->state = (unsigned long long*)w;
     p->claim = (int*)(w + sizeof(unsigned long long) * 2 * (size_t)p->nslices);
     p->defer_count = (unsigned long long*)(w + words - 128);
+    p->tickets = (unsigned*)(w + words - 64);
     p->magic = 0x51ed270b0a1f3c97ull ^ ((unsigned long long)p->pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)(key + 1) << 56);
     if (b2_route().debug_occ)
         fprintf(stderr, "[po] register-state kernel pool (model %d, %s layout): %d slices of %.2f MB in %d chunk(s)\n", model, wide ? "64-slot" : "32-slot",
@@ -2082,8 +2088,12 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.arena = nullptr; a.arena_cap = rp->arena_cap;
         for (int c = 0; c < 8; ++c) a.slice_chunk[c] = rp->chunk[c];
         a.slice_spc_log2 = rp->spc_log2; a.nslices = rp->nslices; a.slice_bytes = rp->slice_bytes; a.slice_claim = rp->claim;
-        a.slice_salt = g_reg_salt.fetch_add(0x9e3779b1u);
+        a.slice_tickets = rp->tickets;
         a.defer_count = rp->defer_count;
+        {   // PO_REG_PERSIST=0 / 1 pins the launch form (A/B)
+            static const int env = [] { const char* e = getenv("PO_REG_PERSIST"); return e ? atoi(e) : -1; }();
+            a.persist = env >= 0 ? (env != 0) : 1;
+        }
         a.starve = (b2_route().defer_odd >> 1) & 3;
         a.wgstate = rp->state;
         a.magic = rp->magic;
@@ -2097,6 +2107,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
             a.order = (int*)(w + g.off_order);
             hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
         }
+        const int grid = a.persist ? g.blocks : n;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
         const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
         a.ngl = po_reg_ngl(reg_wide(W));
@@ -2106,7 +2117,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         else hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(256), plds, stream, a);
         hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
         if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
-        po_reg_launch(&a, g.blocks, model, reg_wide(W), stream);
+        po_reg_launch(&a, grid, model, reg_wide(W), stream);
         if (g_b2_mark_fwd) g_b2_mark_fwd(0, stream);
         // pairs the pre-pass or the kernel deferred (tier-2 row groups exhausted, windows beyond the store's ring):
         // one small pass of beam2d_kernel, a no-op when there are none

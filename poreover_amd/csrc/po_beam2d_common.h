@@ -147,8 +147,10 @@ struct X2Args {
     char* slice_chunk[8];             // slice i lives in chunk i >> slice_spc_log2 (chunks of <= 4 GB: see reg_pool)
     int slice_spc_log2, nslices;
     size_t slice_bytes;
-    int* slice_claim;
-    unsigned slice_salt;              // spreads the first probes of concurrent launches
+    int* slice_claim;                 // the ring of free slices (slice number, -1 = empty) ...
+    unsigned* slice_tickets;          // ... and its {take, give} tickets
+    int persist;                      // 1: a wave takes pairs from the launch's queue until it is empty (as many waves as the device
+                                      // holds); 0: one wave per pair, in queue order (the dispatcher interleaves concurrent launches)
     unsigned long long* defer_count;  // pairs handed to beam2d_kernel, counted for the tests (po_debug_deferred_pairs)
     int starve;                       // test hook (po_set_pair_route's defer_odd bits 1, 2): bit 0 = a dozen row groups only,
                                       // bit 1 = a tree arena of a few nodes only — every hand-over reason can be forced

@@ -154,39 +154,22 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     // counter live on from launch to launch.  A wave CLAIMS a free slice when it starts (all 64 lanes look at 64 claim words
     // at a time) and gives it back when the queue is empty.  The hand-over between waves is an agent-scope release / acquire
     // pair (per-XCD L2s are not coherent, a CU's L1 is never refreshed by another CU's stores): once per wave's lifetime.
+    // The free slices sit in a ring of nslices words (slice number, or -1: empty) with a take ticket and a give ticket: a wave
+    // that starts takes the word its ticket names (and waits for it to be filled, should every slice be out: residency is what
+    // the pool is sized for, so that cannot last), a wave that ends puts its slice into the word ITS ticket names.  Two atomics
+    // per hand-over, no search — with a wave per pair (persist = 0) that is per pair.
     int slotid = -1;
     {
-        const int n = a.nslices;
-        // first try: the slice this wave's number names (distinct within a launch, so a launch alone on the device claims its
-        // slices without ever meeting another wave); only when that one is taken — a wave of another launch holds it — the
-        // wave looks further, 64 claim words at a time from a hashed position
-        const unsigned home = (unsigned)(((unsigned long long)blockIdx.x + (unsigned long long)a.slice_salt) % (unsigned)n);
-        {
-            int got = 0;
-            if (lane == 0) got = (atomicCAS(&a.slice_claim[home], 0, 1) == 0) ? 1 : 0;
-            if (__builtin_amdgcn_readfirstlane(got)) slotid = (int)home;
-        }
-        const unsigned start = (unsigned)((((unsigned long long)blockIdx.x * 2654435761ull) + (unsigned long long)a.slice_salt * 40503ull) % (unsigned)n);
-        for (int round = 0; slotid < 0; ++round) {
-            for (int base = 0; base < n && slotid < 0; base += 64) {
-                const bool valid = base + lane < n;
-                const int idx = (int)((start + (unsigned)(base + lane)) % (unsigned)n);
-                const int v = valid ? atomicAdd(&a.slice_claim[idx], 0) : 1;   // (an L2 read: never a stale L1 line)
-                unsigned long long fm = __ballot(v == 0);
-                // (waves that look at the same words start with different candidates: rotate the order by the wave's number)
-                const int rot = (int)(blockIdx.x & 63u);
-                fm = (fm >> rot) | (rot ? (fm << (64 - rot)) : 0ull);
-                while (fm != 0ull && slotid < 0) {   // (wave-uniform)
-                    const int L = ((int)__builtin_ctzll(fm) + rot) & 63;
-                    fm &= fm - 1ull;
-                    int got = 0;
-                    if (lane == L) got = (atomicCAS(&a.slice_claim[idx], 0, 1) == 0) ? 1 : 0;
-                    got = __builtin_amdgcn_readlane(got, L);
-                    if (got) slotid = __builtin_amdgcn_readlane(idx, L);
-                }
+        int v = -1;
+        if (lane == 0) {
+            const unsigned t = atomicAdd(&a.slice_tickets[0], 1u) % (unsigned)a.nslices;
+            for (;;) {
+                v = atomicExch(&a.slice_claim[t], -1);
+                if (v >= 0) break;
+                __builtin_amdgcn_s_sleep(8);
             }
-            if (slotid < 0) __builtin_amdgcn_s_sleep(32);   // (every slice taken: cannot last — residency is what the pool is sized for)
         }
+        slotid = __builtin_amdgcn_readfirstlane(v);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     char* const slice = a.slice_chunk[slotid >> a.slice_spc_log2] + (size_t)(slotid & ((1 << a.slice_spc_log2) - 1)) * a.slice_bytes;
@@ -227,11 +210,13 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
 #define KC(i, n) do {} while (0)
 #endif
 
-    for (;;) {
+    for (int taken = 0;; ++taken) {
         // ---------------------------------------------------------------- next pair from the queue
+        // (persist = 0: this wave's one pair is the one its number names; the launch has a wave per pair)
+        if (!a.persist && taken > 0) break;
         int pi = 0;
         if (lane == 0) {
-            const int q = atomicAdd(a.queue, 1);
+            const int q = a.persist ? atomicAdd(a.queue, 1) : (int)blockIdx.x;
             pi = (a.order != nullptr && q < a.n) ? a.order[q] : q;   // longest pairs first (pair_order_kernel)
         }
         pi = __builtin_amdgcn_readfirstlane(pi);
@@ -1268,7 +1253,10 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
 #ifndef PO_EMU
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    if (lane == 0) atomicExch(&a.slice_claim[slotid], 0);
+    if (lane == 0) {
+        const unsigned t = atomicAdd(&a.slice_tickets[1], 1u) % (unsigned)a.nslices;
+        while (atomicCAS(&a.slice_claim[t], -1, slotid) != -1) __builtin_amdgcn_s_sleep(8);   // (its taker has a ticket: the word empties)
+    }
 }
 
 // pair slots per CU (registers and LDS decide): 16 one-wave workgroups for the one-value model at W <= 6 (4 waves per SIMD),

@@ -310,8 +310,11 @@ po_pipeline* po_pipeline_create(int device, int wave_pairs, int64_t wave_rows, i
     if (const char* e = getenv("PO_PIPELINE_SLOTS")) { const int v = atoi(e); if (v >= 2 && v <= PO_MAX_SLOTS) p->nslots = v; }
     const unsigned hc = std::thread::hardware_concurrency();
     p->threads = threads > 0 ? threads : (int)std::max(1u, std::min(16u, hc ? hc / 2 : 4u));
-    for (auto& s : p->slot)
-        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
+    // (only the slots in use get a stream: HIP maps streams onto a handful of hardware queues — four by default — and two streams
+    //  on one queue run one after the other; a process that has made other streams before, as bench.py's two-streams leg does,
+    //  leaves fewer free ones)
+    for (int k = 0; k < p->nslots; ++k)
+        if (Slot& s = p->slot[k]; hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
             po_set_error("po_pipeline_create: hipStreamCreate failed");
             po_pipeline_destroy(p);
             return nullptr;
