@@ -204,7 +204,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # (the timing barrier and the max / sum of a few floats: gloo does that without touching the fabric — north_star: RCCL
+        #  unused; rounds 1 - 4 initialised an nccl group for it)
+        dist.init_process_group("gloo")
 
     from poreover_amd import _lib
     lib = _lib.load()

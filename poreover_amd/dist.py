@@ -48,6 +48,8 @@ def job_aggregate(dist, elapsed_s, units, device=None):
     if dist is None or not dist.is_initialized():
         return elapsed_s, list(units)
     import torch
+    if dist.get_backend() == "gloo":
+        device = None   # (host tensors: a timing figure and a few counts)
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     u = torch.tensor(list(units), dtype=torch.float64, device=device)

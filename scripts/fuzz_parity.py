@@ -183,9 +183,9 @@ def draw_round(rng, focus):
     model, ff = [("ctc", False), ("ctc", False), ("ctc_merge_repeats", False), ("ctc_flipflop", True)][rng.integers(4)]
     method = ["row_col", "row_col", "row_col", "row", "grid"][rng.integers(5)]
     W = int([1, 2, 3, 4, 5, 5, 5, 6, 7, 9, 10, 12, 13, 16, 25][rng.integers(15)])
-    if focus:
-        model, ff, method = "ctc", False, "row_col"
-        W = int([1, 2, 3, 4, 5, 5, 5, 5, 6][rng.integers(9)])
+    if focus:   # what beam2d_reg_kernel serves: row_col, every tree model, W <= 12 (both lane layouts)
+        method = "row_col"
+        W = int([1, 2, 3, 4, 5, 5, 5, 5, 6, 7, 9, 10, 12][rng.integers(13)])
     # (grid with the other models in a narrow band: every score -inf — the reference's own order is heap-address
     #  order there; engine and oracle both replay libstdc++ on creation order and agree)
     tmax = 260 if method == "grid" else 1400
@@ -223,8 +223,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--procs", type=int, default=min(32, os.cpu_count() or 1))
-    ap.add_argument("--route", default="auto", help="pin the pair beam kernel: auto | legacy | x2 | ring | reg")
-    ap.add_argument("--focus", action="store_true", help="pair mode: only what the ring / register-state kernels serve "
+    ap.add_argument("--route", default="auto", help="pin the pair beam kernel: auto | legacy | reg")
+    ap.add_argument("--focus", action="store_true", help="pair mode: only what the register-state kernel serves "
                     "(ctc, row_col, W <= 6, monotone envelope styles)")
     ap.add_argument("--json", default="", help="append a summary record to this JSON file (profiles/rNN_fuzz_*.json)")
     ap.add_argument("--dump", default="", help="pair mode: save every round's inputs here before the GPU call (a GPU fault kills "
