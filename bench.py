@@ -519,11 +519,15 @@ def main():
             o = _lib.PairOptions(W, _lib.MODELS[model], _lib.METHODS[method], 5, 0, 0, 50)
             wsz = lib.po_pair_decode_workspace_bytes(n, int(h1[n]), int(h2[n]), int(q1.max()), int(q2.max()), Cn, C.byref(o))
             d_w = torch.empty(wsz, dtype=torch.uint8, device=dev)
+            def launch():
+                _lib.check(lib.po_pair_decode_batch(
+                    dy1.data_ptr(), do1.data_ptr(), dy2.data_ptr(), do2.data_ptr(), n, Cn, C.byref(o), t_seq1d.data_ptr(),
+                    t_s1o.data_ptr(), t_l1.data_ptr(), t_l2.data_ptr(), t_id.data_ptr(), t_env.data_ptr(), t_seq.data_ptr(),
+                    t_so.data_ptr(), t_len.data_ptr(), t_st.data_ptr(), d_w.data_ptr(), wsz, stream), "po_pair_decode_batch")
+            launch()   # (the first launch of a tree model / lane layout makes its slice pool: not part of the figures below)
+            torch.cuda.synchronize()
             lib.po_profile_enable(1); lib.po_profile_reset()
-            ms = timed(lambda: _lib.check(lib.po_pair_decode_batch(
-                dy1.data_ptr(), do1.data_ptr(), dy2.data_ptr(), do2.data_ptr(), n, Cn, C.byref(o), t_seq1d.data_ptr(),
-                t_s1o.data_ptr(), t_l1.data_ptr(), t_l2.data_ptr(), t_id.data_ptr(), t_env.data_ptr(), t_seq.data_ptr(),
-                t_so.data_ptr(), t_len.data_ptr(), t_st.data_ptr(), d_w.data_ptr(), wsz, stream), "po_pair_decode_batch"))
+            ms = timed(launch)
             torch.cuda.synchronize()
             kms, kn, mms, mn = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
             lib.po_profile_get(_lib.K_BEAM2D, C.byref(kms), C.byref(kn))

@@ -1732,6 +1732,9 @@ RegPool* reg_pool(int model, int wide) {
     if (g_reg_pools[dev][key]) return g_reg_pools[dev][key];
     RegPool* p = new RegPool();
     p->nslices = b2_num_cus() * po_reg_slots_per_cu(model, wide);
+    // (PO_REG_POOL_SLICES: a smaller pool — several processes sharing one board, each with its own 9 GB otherwise; launches
+    //  are cut to that many waves)
+    if (const char* e = getenv("PO_REG_POOL_SLICES")) { const int v = atoi(e); if (v >= 64 && v < p->nslices) p->nslices = v & ~1; }
     p->pool_bytes = po_reg_pool_bytes(model, wide);
     // tree nodes a slice's arena holds: four per node that ever enters the beam.  1 024 beam entries per beam slot is ~ 4 x what
     // a T = 4000 pair makes; a pair that needs more is handed to beam2d_kernel (whose arenas are worst-case sized)
@@ -2107,7 +2110,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
             a.order = (int*)(w + g.off_order);
             hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
         }
-        const int grid = a.persist ? g.blocks : n;
+        const int grid = a.persist ? std::min(g.blocks, rp->nslices) : n;
         a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
         const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
         a.ngl = po_reg_ngl(reg_wide(W));

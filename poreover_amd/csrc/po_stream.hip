@@ -227,6 +227,14 @@ static int auto_wave_pairs(int n) {
     const int waves = (n + PO_WAVE_TARGET - 1) / PO_WAVE_TARGET;
     return (n + waves - 1) / waves;
 }
+// a single pipeline's short first waves and short last wave (one place: po_pipeline_pair_decode runs this plan, po_wave_plan
+// reports it; PO_WAVE_RAMP / PO_WAVE_TAIL override either, 0 = off)
+static void ramp_and_tail(bool engine_plans, int n, int* ramp, int* tail) {
+    *ramp = (engine_plans && n > PO_WAVE_MAX) ? PO_WAVE_RAMP : 0;
+    *tail = (engine_plans && n > PO_WAVE_MAX) ? PO_WAVE_TAIL : 0;
+    if (const char* e = getenv("PO_WAVE_RAMP")) *ramp = std::max(0, atoi(e));
+    if (const char* e = getenv("PO_WAVE_TAIL")) *tail = std::max(0, atoi(e));
+}
 struct po_pipeline {
     int device = 0, wave_pairs = 0 /* 0: auto_wave_pairs(n) */, threads = 8;
     int64_t wave_rows = (int64_t)64 << 20;
@@ -363,7 +371,24 @@ struct PairCall {
 
 // One pipeline (one device, the calling thread) decodes the waves the planner hands it, two in flight.  Whatever way the
 // call ends, no slot is left marked busy: a failed call's results are discarded, never drained into a later call's arrays.
-static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
+// The pipelines of several devices start taking waves TOGETHER, after each has sized its buffers (the first call allocates: a
+// pipeline that is ready early would otherwise have dealt itself most of a short job before the others are through).
+struct StartGate {
+    std::atomic<int> arrived{0};
+    int n = 1;
+};
+static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c, StartGate* gate = nullptr) {
+    struct Arrive {   // (every exit before the gate counts as arrived: nobody waits for a pipeline that has failed)
+        StartGate* g;
+        bool done = false;
+        void now(bool wait) {
+            if (!g || done) return;
+            done = true;
+            g->arrived.fetch_add(1);
+            while (wait && g->arrived.load() < g->n) std::this_thread::yield();
+        }
+        ~Arrive() { now(false); }
+    } arrive{gate};
     struct Quiesce {   // entry and every exit: both streams drained, both slots free
         po_pipeline* p;
         void run() {
@@ -430,6 +455,7 @@ static int pipeline_run(po_pipeline* p, WavePlanner& plan, const PairCall& c) {
         }
         if (trace) fprintf(stderr, "[po_pipe] %d wave(s) planned, buffers sized in %.2f ms\n", nw, now_ms() - t0);
     }
+    arrive.now(true);
 
     // results of the wave a slot holds -> the caller's arrays (after the slot's stream has drained)
     auto drain = [&](Slot& s) -> int {
@@ -601,10 +627,7 @@ int po_pipeline_pair_decode(po_pipeline* p, const void* const* y1_h, const int64
     WavePlanner plan;
     plan.rows1 = rows1; plan.rows2 = rows2; plan.n = n; plan.wave_rows = p->wave_rows;
     plan.wave_pairs = p->wave_pairs > 0 ? p->wave_pairs : auto_wave_pairs(n);
-    plan.ramp = (p->wave_pairs <= 0 && n > PO_WAVE_MAX) ? PO_WAVE_RAMP : 0;   // a job of several waves starts with a short one, doubling
-    if (const char* e = getenv("PO_WAVE_RAMP")) plan.ramp = std::max(0, atoi(e));
-    plan.tail = (p->wave_pairs <= 0 && n > PO_WAVE_MAX) ? PO_WAVE_TAIL : 0;
-    if (const char* e = getenv("PO_WAVE_TAIL")) plan.tail = std::max(0, atoi(e));
+    ramp_and_tail(p->wave_pairs <= 0, n, &plan.ramp, &plan.tail);   // a job of several waves starts with a short one, doubling, and ends with one
     // (Tried: a job within the latency-bound regime of the pair beam kernel — <= 2 048 pairs, one GPU's share of a multi-GPU
     //  job — cut into two waves whose kernels run side by side while the second uploads: 36.8 vs 36.9 ms for 1 250 pairs,
     //  three waves on the two slots 60 ms.  The upload is not what such a job waits for.  PO_PIPELINE_SPLIT=1 still does it.)
@@ -636,7 +659,7 @@ int po_wave_plan(const int64_t* rows1, const int64_t* rows2, int n, int wave_pai
     const int wp = wave_pairs > 0 ? wave_pairs : auto_wave_pairs(n);
     plan.wave_pairs = (ndev > 1) ? std::max(1, std::min(wp, (n + 2 * ndev - 1) / (2 * ndev))) : wp;
     plan.wave_rows = wave_rows > 0 ? wave_rows : ((int64_t)64 << 20);
-    if (ndev == 1 && wave_pairs <= 0 && n > PO_WAVE_MAX) { plan.ramp = PO_WAVE_RAMP; plan.tail = PO_WAVE_TAIL; }   // (po_pipeline_pair_decode's own plan)
+    if (ndev == 1) ramp_and_tail(wave_pairs <= 0, n, &plan.ramp, &plan.tail);   // (po_pipeline_pair_decode's own plan)
     int k = 0, f = 0, c = 0;
     int64_t r1, r2, m1, m2;
     while (plan.take(&f, &c, &r1, &r2, &m1, &m2)) {
@@ -701,11 +724,13 @@ int po_multi_pair_decode(po_multi* m, const void* const* y1_h, const int64_t* ro
     std::vector<int> rcs((size_t)nd, PO_OK);
     std::vector<std::string> errs((size_t)nd);
     std::vector<std::thread> th;
+    StartGate gate;
+    gate.n = nd;
     for (int i = 0; i < nd; ++i)
         th.emplace_back([&, i]() {
             po_pipeline* p = m->pipes[(size_t)i];
-            if (hipSetDevice(p->device) != hipSuccess) { rcs[(size_t)i] = PO_E_HIP; errs[(size_t)i] = "hipSetDevice failed"; return; }
-            rcs[(size_t)i] = pipeline_run(p, plan, c);
+            if (hipSetDevice(p->device) != hipSuccess) { rcs[(size_t)i] = PO_E_HIP; errs[(size_t)i] = "hipSetDevice failed"; gate.arrived.fetch_add(1); return; }
+            rcs[(size_t)i] = pipeline_run(p, plan, c, &gate);
             if (rcs[(size_t)i] != PO_OK) {
                 errs[(size_t)i] = p->err;
                 std::lock_guard<std::mutex> lk(plan.mu);   // the other devices finish what they hold and stop taking waves
