@@ -1740,7 +1740,8 @@ RegPool* reg_pool(int model, int wide) {
     // a T = 4000 pair makes; a pair that needs more is handed to beam2d_kernel (whose arenas are worst-case sized)
     const long long WM = wide ? 12 : 6;
     p->arena_cap = 1 + PO_A + (long long)PO_A * WM * 1024;
-    p->slice_bytes = al256(p->pool_bytes + sizeof(int) * 3 * (size_t)p->arena_cap);
+    // (+ the row headers: one int per store row and read)
+    p->slice_bytes = al256(p->pool_bytes + sizeof(int) * 3 * (size_t)p->arena_cap + sizeof(int) * 2 * PO_A * (size_t)po_reg_ngl(wide));
     int spc = 1;
     while ((size_t)(2 * spc) * p->slice_bytes <= ((size_t)7 << 29) && 2 * spc <= p->nslices) spc *= 2;   // chunks of <= 3.5 GB
     while ((p->nslices + spc - 1) / spc > 8) spc *= 2;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             __syncthreads();
             wmax = shw;
             while (R < wmax + 2) R <<= 1;
-            const long long pool_entries = (long long)(a.pool_bytes / sizeof(Entry<K>));
+            const long long pool_entries = (long long)(a.pool_bytes / (8 * K));   // (beam2d_reg_kernel's entries: the values, no tag)
             const long long ng = pool_entries / ((long long)PO_A * 2 * R);
             // (node ids go into 24 tag bits; the slice's arena is smaller than this worst case and checked as nodes are made)
             const long long need = 1 + A + (long long)A * max(W, A) * ((long long)min(U, V) + 1);

@@ -7,9 +7,10 @@
 // form (method row, no envelope, W > 12) and decodes the pairs this kernel hands on.
 //
 // The design (DESIGN.md §3.3 has the measurements and the history):
-//   * VALUE STORE (HBM, L2-resident in practice): the reference's per-node maps (PrefixTree.h:76-145), entry =
-//     {tag(epoch, node, t), K values}, ring rows of R entries, rows in groups of four per parent.  Every read of a value
-//     "at rest" is a tagged lookup: absent reads as -inf, exactly probability_at().  Written once per computed
+//   * VALUE STORE (HBM, L2-resident in practice): the reference's per-node maps (PrefixTree.h:76-145), entry = the node's K
+//     values at one time (8 or 24 bytes, no tag), ring rows of R entries, rows in groups of four per parent.  Whether a
+//     (node, time) is present — probability_at() answers -inf otherwise — follows from where the node's values end: an
+//     element's lane knows, a row header remembers it for nodes that are no elements.  Written once per computed
 //     (node, read, time).
 //   * REGISTERS: a lane's element (ids, rows, parent slot), where its values end (v_done), its last values (v_self),
 //     the carried window maximum (value, time, last rise).  Within a scan a child takes its parent's previous values
@@ -59,7 +60,7 @@ struct RegCfg {
     static constexpr int KP = (K == 1) ? 1 : 2;                   // how many of its PARENT's values an update reads ...
     static constexpr int PC0 = (MODEL == PO_MODEL_FLIPFLOP) ? 1 : 0;   // ... and which: {alpha} | {alpha, gap} | {flip, flop}
     static constexpr int YC = (MODEL == PO_MODEL_FLIPFLOP) ? 8 : 5;    // doubles per y row (A + 1 <= 5, or 2 A <= 8)
-    static constexpr int ESH = (K == 1) ? 4 : 5;                  // log2 of a store entry's size
+    static constexpr int EB = 8 * K;                              // bytes of a store entry: the values, nothing else (round 5)
     static constexpr int NS = (NR == 1) ? 32 : 64;                // element slots: W * (A + 1) <= NS
     static constexpr int WS = (NR == 1) ? 6 : 12;                 // widest beam
     static constexpr int NGL = (NR == 1) ? PO_REG_NGL : 2 * PO_REG_NGL;   // row groups tracked per pair
@@ -128,11 +129,9 @@ __device__ __forceinline__ double rk_readlane_d(double x, int l) {
 template <int MODEL, int NR, bool COUNT = false>
 __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_kernel(X2Args a) {
     using Cfg = RegCfg<MODEL, NR>;
-    constexpr int K = Cfg::K, KP = Cfg::KP, PC0 = Cfg::PC0, RK_YC = Cfg::YC, ESH = Cfg::ESH, RK_PS = Cfg::PS;
+    constexpr int K = Cfg::K, KP = Cfg::KP, PC0 = Cfg::PC0, RK_YC = Cfg::YC, EB = Cfg::EB, RK_PS = Cfg::PS;
     constexpr int NS = Cfg::NS, WS = Cfg::WS, RK_NGL = Cfg::NGL, PF0N = Cfg::PF0N;
-    using Ent = Entry<K>;
-    using Ent1 = Entry<1>;        // the first 16 bytes of an entry: {tag, alpha} — all a score ever looks at
-    using Val = RegVal<K>;        // a node's values at one time
+    using Val = RegVal<K>;        // a node's values at one time = a store entry
     using PVal = RegVal<KP>;      // ... the ones its children's updates read
     __shared__ RegGroup<MODEL, NR> gsm;
     // lane = (read, slot) [NR = 1] or slot [NR = 2]; hb = first lane of this lane's read; lo_half = the lanes that do what is
@@ -150,10 +149,9 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here
     // ---- this wave's SLICE of the library's pool: value store + tree arena.  The pool has one slice per pair wave the device
     // can hold (po_beam2d.hip::reg_pool), shared by every launch of this kernel on the device — the waves of a pipelined job on
-    // their streams, the next call — so a workspace no longer carries 2 - 8 MB per resident pair and a slice's tags and epoch
-    // counter live on from launch to launch.  A wave CLAIMS a free slice when it starts (all 64 lanes look at 64 claim words
-    // at a time) and gives it back when the queue is empty.  The hand-over between waves is an agent-scope release / acquire
-    // pair (per-XCD L2s are not coherent, a CU's L1 is never refreshed by another CU's stores): once per wave's lifetime.
+    // their streams, the next call — so a workspace no longer carries megabytes per resident pair.  A wave CLAIMS a free slice
+    // when it starts and gives it back when the queue is empty.  The hand-over between waves is an agent-scope release /
+    // acquire pair (per-XCD L2s are not coherent, a CU's L1 is never refreshed by another CU's stores): once per wave's lifetime.
     // The free slices sit in a ring of nslices words (slice number, or -1: empty) with a take ticket and a give ticket: a wave
     // that starts takes the word its ticket names (and waits for it to be filled, should every slice be out: residency is what
     // the pool is sized for, so that cannot last), a wave that ends puts its slice into the word ITS ticket names.  Two atomics
@@ -173,28 +171,17 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     char* const slice = a.slice_chunk[slotid >> a.slice_spc_log2] + (size_t)(slotid & ((1 << a.slice_spc_log2) - 1)) * a.slice_bytes;
-    Ent* const pool = (Ent*)slice;
-    const long long pool_entries = (long long)(a.pool_bytes / sizeof(Ent));
+    const long long pool_entries = (long long)(a.pool_bytes / EB);
     int* const apl = (int*)(slice + a.pool_bytes);
     int* const afc = apl + a.arena_cap;
     int* const acrow = afc + a.arena_cap;
+    // row headers, one int per (store row, read): the time a node's stored values END at (exclusive), written when the node
+    // stops being an element; RK_FRESH = nothing stored.  See "the value store" below.
+    int* const rowhdr = acrow + a.arena_cap;
     // nodes a slice's arena holds: a pair that needs more goes to beam2d_kernel (starve: the tests' way to get there)
     const int arena_cap = (a.starve & 2) ? min((int)a.arena_cap, 1 + a.A + 24 * a.A) : (int)a.arena_cap;
     auto g_hi = [&](int r) -> int* { return r ? sm.g_hi1 : sm.g_hi0; };
 
-    // ---- epoch tags across pairs and launches (as beam2d_kernel): no memset of the store
-    unsigned epoch = 0;
-    auto clear_slice = [&]() {
-        for (long long i = lane; i < pool_entries; i += 64) pool[i].tag = 0ull;
-        rk_sync();
-    };
-    {
-        unsigned long long* stp = a.wgstate + 2 * (size_t)slotid;
-        const unsigned long long w0 = atomicAdd(&stp[0], 0ull), w1 = atomicAdd(&stp[1], 0ull);   // (L2 reads)
-        const bool ok = (w0 == (a.magic ^ (unsigned long long)slotid));
-        epoch = ok ? (unsigned)w1 : 0u;
-        if (!ok) clear_slice();
-    }
     po_lae_tables_load(&gsm.lae, (int)threadIdx.x, (int)blockDim.x);
     const PoLaeFast lae{&gsm.lae};
     if (lane == 0) { sm.nupd = 0; sm.nupd_x = 0; }
@@ -221,8 +208,6 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         }
         pi = __builtin_amdgcn_readfirstlane(pi);
         if (pi >= a.n) break;
-        epoch++;
-        if (__builtin_expect((epoch & 0xffffu) == 0, 0)) { clear_slice(); epoch++; }
         const int2 m = a.meta[pi];
         if (__builtin_expect(m.y == X2_DEFERRED, 0)) continue;                 // beam2d_kernel decodes it after this kernel
         if (__builtin_expect(m.x != PO_OK || m.y < 0, 0)) {                    // refused by the pre-pass, or skipped upstream
@@ -248,46 +233,35 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         int st = PO_OK;
 
         // ---------------------------------------------------------------- the value store
-        // (entry index and byte offset stay within 32 bits: a workgroup's slice is a few MB — one v_lshl_add per access
-        //  instead of 64-bit address arithmetic; the tag's words are put together from per-call constants the same way)
-        const char* const poolb = (const char*)pool;
-        const unsigned tag_ep = (epoch & 0xffffu) << 16;
-        auto t2_off = [&](int r, int row2, int tq) -> unsigned { return (unsigned)(((row2 * 2 + r) * R2 + (tq & Rm2)) << ESH); };
-        auto t2_entry = [&](int r, int row2, int tq) -> const Ent* { return (const Ent*)(poolb + (size_t)t2_off(r, row2, tq)); };
-        auto t2_entry1 = [&](int r, int row2, int tq) -> const Ent1* { return (const Ent1*)(poolb + (size_t)t2_off(r, row2, tq)); };
-        auto tag_of = [&](int node, int tq) -> unsigned long long {   // == make_tag(epoch, node, tq) for 0 <= tq < 2^24
-            const unsigned hi = tag_ep | (((unsigned)node >> 8) & 0xffffu), lo = ((unsigned)node << 24) | (unsigned)tq;   // (0 <= tq < 2^24: the pre-pass)
-            return ((unsigned long long)hi << 32) | lo;
-        };
+        // The reference's per-node maps (PrefixTree.h:76-145): every node owns a ring row of R2 entries per read, an entry is
+        // the node's K values at one time — 8 or 24 bytes, no tag (rounds 1 - 4 stored {tag(epoch, node, t), values}: twice the
+        // bytes for the one-value model, and two thirds of the kernel's HBM-side traffic is these writes).  Whether (node, t) is
+        // PRESENT — probability_at() answers -inf otherwise — is known without looking at the entry:
+        //   * an ELEMENT's stored values are [.., v_done) of its lane (every read in this kernel asks for t >= window start - 1,
+        //     and an element's first time is the window start of the step it was created in, or later);
+        //   * a node that is NO element (a frozen parent's older values; the seed of a node that becomes an element again) has
+        //     its end in the row's HEADER, written when it stopped being an element; a row group's headers are emptied when the
+        //     group is handed to a parent, so nothing of an earlier owner — or of an earlier pair in this slice — is ever valid;
+        //   * the ring cannot have wrapped over a time that is asked for: R2 >= widest window + 2.
+        // (entry index and byte offset stay within 32 bits: a slice is a few MB)
+        const char* const poolb = (const char*)slice;
+        auto t2_off = [&](int r, int row2, int tq) -> unsigned { return (unsigned)(((row2 * 2 + r) * R2 + (tq & Rm2)) * EB); };
         auto val_neg = [&]() -> Val { Val x; for (int q = 0; q < K; ++q) x.v[q] = PO_NEG_INF; return x; };
         auto pval_neg = [&]() -> PVal { PVal x; for (int q = 0; q < KP; ++q) x.v[q] = PO_NEG_INF; return x; };
         auto pval_of = [&](const Val& x) -> PVal { PVal y; for (int q = 0; q < KP; ++q) y.v[q] = x.v[PC0 + q]; return y; };
         auto pval_shfl = [&](const PVal& x, int src) -> PVal { PVal y; for (int q = 0; q < KP; ++q) y.v[q] = __shfl(x.v[q], src); return y; };
         auto val_shfl = [&](const Val& x, int src) -> Val { Val y; for (int q = 0; q < K; ++q) y.v[q] = __shfl(x.v[q], src); return y; };
-        auto ent_val = [&](const Ent& e, unsigned long long tag) -> Val {   // what a tagged lookup answers: absent reads as -inf
-            Val x;
-            const bool hit = e.tag == tag;
-            for (int q = 0; q < K; ++q) x.v[q] = hit ? e.v[q] : PO_NEG_INF;
-            return x;
-        };
-        auto t2_read = [&](int r, int row2, int node, int tq) -> Val {   // (every value of the entry)
+        auto t2_load = [&](int r, int row2, int tq) -> Val { return *(const Val*)(poolb + (size_t)t2_off(r, row2, tq)); };   // (all K values)
+        auto t2_load0 = [&](int r, int row2, int tq) -> double { return *(const double*)(poolb + (size_t)t2_off(r, row2, tq)); };   // (alpha alone)
+        auto hdr_of = [&](int r, int row2) -> int* { return rowhdr + (row2 * 2 + r); };
+        // values of (row, time) when `present` says they are there
+        auto t2_read = [&](int r, int row2, int tq, bool present) -> Val {
             Val v = val_neg();
-            if (tq >= 0 && row2 >= 0) v = ent_val(*t2_entry(r, row2, tq), tag_of(node, tq));
+            if (present && tq >= 0 && row2 >= 0) v = t2_load(r, row2, tq);
             return v;
         };
-        auto t2_read0 = [&](int r, int row2, int node, int tq) -> double {   // (alpha alone)
-            double v = PO_NEG_INF;
-            if (tq >= 0 && row2 >= 0) {
-                const Ent1 e = *t2_entry1(r, row2, tq);
-                if (e.tag == tag_of(node, tq)) v = e.v[0];
-            }
-            return v;
-        };
-        auto t2_write = [&](int r, int row2, int node, int tq, const Val& v) {
-            Ent e;
-            e.tag = tag_of(node, tq);
-            for (int q = 0; q < K; ++q) e.v[q] = v.v[q];
-            *(Ent*)(const_cast<char*>(poolb) + (size_t)t2_off(r, row2, tq)) = e;
+        auto t2_write = [&](int r, int row2, int tq, const Val& v) {
+            *(Val*)(const_cast<char*>(poolb) + (size_t)t2_off(r, row2, tq)) = v;
         };
         // update_prob of one element at one time: sp = its own values at t - 1, pk = its parent's (the ones read), ya / yb = the
         // two y entries of the row (own symbol; blank, or the symbol's flop column), same = parent->last == last
@@ -338,6 +312,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             apl[0] = po_pack_node(-1, A); afc[0] = 1; acrow[0] = 0;
             sm.g_owner[0] = 0; sm.g_hi0[0] = 1; sm.g_hi1[0] = 1;
         }
+        if (lane < 2 * PO_A) rowhdr[lane] = RK_FRESH;   // (row group 0: the root's children)
         if (s < A) {
             if (lo_half) { apl[1 + s] = po_pack_node(0, s); afc[1 + s] = -1; acrow[1 + s] = -1; }
             e_id = 1 + s; e_row2 = s; e_sym = sym_pack(s, A, true); e_ps = PS_ROOT;
@@ -352,7 +327,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     root_values<MODEL>(-1, 0.0, pp);
                     po_update<MODEL>(sp, pp, yr[s], (MODEL == PO_MODEL_FLIPFLOP) ? yr[s + A] : yr[A], false, true, out.v, lae);
                 }
-                t2_write(r, e_row2, e_id, 0, out);
+                t2_write(r, e_row2, 0, out);
                 v_done[q] = 1; v_fresh[q] = 0; v_self[q] = out;
                 v_mx[q] = out.v[0]; v_mt[q] = 0; v_td[q] = 0;   // (the window maximum over [0, 1))
                 if (MODEL == PO_MODEL_CTC && s == 0) { sm.rootcum[r] = 0.0 + yr[A]; sm.rootT[r] = 0; }   // (serial in t from 0.0, as the reference adds)
@@ -386,8 +361,9 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         auto done0 = [&]() -> int { return __builtin_amdgcn_readlane(v_done[0], 0); };
         auto done1 = [&]() -> int { return (NR == 1) ? __builtin_amdgcn_readlane(v_done[0], 32) : __builtin_amdgcn_readlane(v_done[NR - 1], 0); };
 
-        auto read_own = [&](int r, int tq) -> double { return t2_read0(r, e_row2, e_id, tq); };
-        auto read_own_all = [&](int r, int tq) -> Val { return t2_read(r, e_row2, e_id, tq); };
+        // a lane's own stored values: the caller knows tq to be inside [.., v_done) (an element), or says how it knows
+        auto read_own = [&](int r, int tq) -> double { return (tq >= 0) ? t2_load0(r, e_row2, tq) : PO_NEG_INF; };
+        auto read_own_all = [&](int r, int tq, bool present) -> Val { return t2_read(r, e_row2, tq, present); };
 
         // ---------------------------------------------------------------- y rows [t0, t0 + RK_NY) of a read -> LDS
         // (all of a lane's loads go out together: one memory round trip per reload)
@@ -436,7 +412,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 const int L = (int)__builtin_ctzll(m);
                 m &= m - 1ull;
                 const int wsL = __builtin_amdgcn_readlane(ws, L), teL = __builtin_amdgcn_readlane(min(td + 1, start), L);
-                const int rowL = __builtin_amdgcn_readlane(e_row2, L), idL = __builtin_amdgcn_readlane(e_id, L);
+                const int rowL = __builtin_amdgcn_readlane(e_row2, L);
                 const int rowbase = (rowL * 2 + ((NR == 1) ? (L >> 5) : q)) * R2;
                 double bmx = PO_NEG_INF, pvc = PO_NEG_INF;
                 int bmt = -1, btd = wsL;
@@ -444,10 +420,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     const int tq = base + lane;
                     const bool valid = tq < teL;
                     double val = PO_NEG_INF;
-                    if (valid) {
-                        const Ent1 e = *(const Ent1*)(poolb + (size_t)(unsigned)((rowbase + (tq & Rm2)) << ESH));
-                        if (e.tag == tag_of(idL, tq)) val = e.v[0];
-                    }
+                    if (valid) val = *(const double*)(poolb + (size_t)(unsigned)((rowbase + (tq & Rm2)) * EB));   // (the lane computed every one of them)
                     const double mxv = po_wave_max(val);
                     const unsigned long long eq = __ballot(valid && val == mxv);   // (later times win ties: the highest lane)
                     if (mxv >= bmx && eq != 0ull) { bmx = mxv; bmt = base + 63 - (int)__builtin_clzll(eq); }
@@ -484,7 +457,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             if (part) {
                 if (v_fresh[q] != 0) {
                     start = ws;
-                    if (v_fresh[q] == 1) self = read_own_all(r, start - 1);
+                    if (v_fresh[q] == 1) self = read_own_all(r, start - 1, start - 1 < *hdr_of(r, e_row2));   // (an element again: the header knows)
                 } else if (start > v_done[q]) {
                     // a gap (catch-ups went beyond the last window): the value at start - 1 was never computed
                 } else {
@@ -510,6 +483,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             // first iteration, then at the time it computed last)
             const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
             const int p_start = __shfl(part2 ? start : INT_MAX, plane), p_we = __shfl(part2 ? we : INT_MIN, plane);
+            const int p_done = __shfl(v_fresh[q] == 0 ? v_done[q] : RK_FRESH, plane);   // where the parent's STORED values end (an element's)
             int tm_ = part2 ? start : INT_MAX;
 #pragma unroll
             for (int off = NS / 2; off >= 1; off >>= 1) tm_ = min(tm_, __shfl_xor(tm_, off));
@@ -534,7 +508,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         PVal pp;
                         if (e_ps >= 0) {
                             if (tm >= p_start - 1 && tm < p_we && p_start != INT_MAX) pp = ps_self;
-                            else pp = pval_of(t2_read(r, sm.f_prow2[s], sm.f_par[s], tm));
+                            else pp = pval_of(t2_read(r, sm.f_prow2[s], tm, tm < p_done));
                         } else if (e_ps == PS_ROOT) {
                             // (t >= 1 here: the root's children got their t = 0 at the start of the pair; the other two models'
                             //  root holds nothing at times >= 0)
@@ -545,14 +519,15 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                             }
                         } else if (tm >= fz_t[q]) {
                             pp = (tm == fz_t[q]) ? fz_val[q] : pval_neg();                            // frozen parent: its last value, then nothing
-                        } else {
-                            pp = pval_of(t2_read(r, sm.f_prow2[s], sm.f_par[s], tm));
+                        } else {   // a frozen parent's older values: its row's header says where they end
+                            const int prow = sm.f_prow2[s];
+                            pp = pval_of(t2_read(r, prow, tm, prow >= 0 && tm < *hdr_of(r, max(prow, 0))));
                         }
                         const Val out = upd(self, pp, ya, yb, same);
 #ifdef PO_RING_TRACE_NODE
                         if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g G ps %d fzt %d main %d\n", e_id, r, t, out.v[0], pp.v[0], self.v[0], e_ps, fz_t[q], (int)is_main);
 #endif
-                        t2_write(r, e_row2, e_id, t, out);
+                        t2_write(r, e_row2, t, out);
                         if (out.v[0] > self.v[0]) tr = t;   // the last time a value rose
                         self = out;
                         mt = (out.v[0] >= mx) ? t : mt;
@@ -636,14 +611,15 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             const bool cont = live && v_fresh[q] == 0;
             const int n1 = dr - ws;   // (uniform over the read's lanes, >= 0): times the fresh lanes compute before everybody else starts
             // the fresh lanes' own seeds (an element again: its last value is in the store)
-            Ent se; se.tag = 0ull;
+            Val se;
             for (int c = 0; c < K; ++c) se.v[c] = 0.0;
+            int se_hdr = RK_FRESH;   // (a seed's row header: requested with the seed, looked at when both are there)
             const bool want_seed = fresh[q] && v_fresh[q] == 1 && ws - 1 >= 0;
             // (the same registers, other lanes: a continuing beam lane whose window maximum has left the window and whose
             //  values fall — the run that follows this step asks for its value at ws first thing)
             const bool want_pf = cont && s < nb && v_done[q] > ws && v_mx[q] != PO_NEG_INF && v_mt[q] < ws && v_td[q] <= ws;
-            if (want_seed) se = *t2_entry(r, e_row2, ws - 1);
-            else if (want_pf) se = *t2_entry(r, e_row2, ws);
+            if (want_seed) { se = t2_load(r, e_row2, ws - 1); se_hdr = *hdr_of(r, e_row2); }
+            else if (want_pf) se = t2_load(r, e_row2, ws);
             double mx = PO_NEG_INF;
             Val self = val_neg();
             int mt = -1, tr = INT_MIN;
@@ -663,17 +639,18 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 // (a block has RK_NY = 32 times: with 64 lanes per read the upper ones have nothing to stage)
                 const int i = k0 + s, tq = ws - 1 + i;
                 const bool stg = i < n1 && (NS == RK_NY || s < RK_NY);
-                Ent e01[2];
-                int pid01[2] = {0, 0};
+                // (a staged parent is a continuing beam lane: its stored values end at its v_done on this read)
+                Val e01[2];
+                bool ok01[2] = {false, false};
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    e01[k].tag = 0ull;
                     for (int c = 0; c < K; ++c) e01[k].v[c] = 0.0;
                     if (k < nps) {   // (wave-uniform)
                         const int jk = pj[k];
                         const int prow = __builtin_amdgcn_readlane(e_row2, jk);
-                        pid01[k] = __builtin_amdgcn_readlane(e_id, jk);
-                        if (stg && tq >= 0) e01[k] = *t2_entry(r, prow, tq);
+                        const int pdone = __shfl(v_done[q], hb | jk);
+                        ok01[k] = stg && tq >= 0 && tq < pdone;
+                        if (ok01[k]) e01[k] = t2_load(r, prow, tq);
                     }
                 }
                 {
@@ -683,20 +660,20 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
                     if (k < nps && stg) {
-                        const bool hit = tq >= 0 && e01[k].tag == tag_of(pid01[k], tq);
-                        for (int c = 0; c < KP; ++c) sm.pst[r][k * RK_NY + s][c] = hit ? e01[k].v[PC0 + c] : PO_NEG_INF;
+                        for (int c = 0; c < KP; ++c) sm.pst[r][k * RK_NY + s][c] = ok01[k] ? e01[k].v[PC0 + c] : PO_NEG_INF;
                     }
                 for (int k = 2; __builtin_expect(k < nps, 0); ++k) {   // (wave-uniform; three and more parents: rare)
                     int jk = pj[0];
 #pragma unroll
                     for (int c = 1; c < RK_PS; ++c) jk = (k == c) ? pj[c] : jk;
-                    const int prow = __builtin_amdgcn_readlane(e_row2, jk), pid = __builtin_amdgcn_readlane(e_id, jk);
+                    const int prow = __builtin_amdgcn_readlane(e_row2, jk);
+                    const int pdone = __shfl(v_done[q], hb | jk);
                     if (stg) {
-                        const PVal val = pval_of(t2_read(r, prow, pid, tq));
+                        const PVal val = pval_of(t2_read(r, prow, tq, tq < pdone));
                         for (int c = 0; c < KP; ++c) sm.pst[r][k * RK_NY + s][c] = val.v[c];
                     }
                 }
-                if (k0 == 0 && want_seed) self = ent_val(se, tag_of(e_id, ws - 1));
+                if (k0 == 0 && want_seed && ws - 1 < se_hdr) self = se;
                 rk_sync();
                 const int k1 = min(n1max, k0 + RK_NY);
                 // (the operands of an iteration are asked for one iteration ahead: a lone wave then waits for the LDS only
@@ -724,7 +701,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
 #ifdef PO_RING_TRACE_NODE
                         if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P1\n", e_id, r, t, out.v[0], pp.v[0], self.v[0]);
 #endif
-                        t2_write(r, e_row2, e_id, t, out);
+                        t2_write(r, e_row2, t, out);
                         if (out.v[0] > self.v[0]) tr = t;
                         self = out;
                         mt = (out.v[0] >= mx) ? t : mt;
@@ -732,10 +709,10 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     }
                 }
             }
-            if (n1max == 0 && want_seed) self = ent_val(se, tag_of(e_id, ws - 1));
+            if (n1max == 0 && want_seed && ws - 1 < se_hdr) self = se;
             if (s < PF0N) {
                 sm.pf0_t[r][s] = want_pf ? ws : -1;
-                if (want_pf) sm.pf0[r][s] = (se.tag == tag_of(e_id, ws)) ? se.v[0] : PO_NEG_INF;
+                if (want_pf) sm.pf0[r][s] = se.v[0];
             }
             // the fresh lanes are ordinary continuing lanes now, ending at dr like everybody else: the run loop does the step
             if (fresh[q]) {
@@ -812,6 +789,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     if (gg < 0) { st = PO_E_NOMEM; gg = 0; }
                     rk_sync();   // (every lane has walked the table before lane 0 changes it)
                     if (lane == 0) { sm.g_owner[gg] = owner; sm.g_hi0[gg] = nce; sm.g_hi1[gg] = nre; acrow[owner] = gg; }
+                    if (lane < 2 * PO_A) rowhdr[gg * 2 * PO_A + lane] = RK_FRESH;   // (the group's rows hold nothing of their new owners yet)
                     if (s == jj) n_crow2 = gg;
                     rk_sync();
                 }
@@ -821,6 +799,8 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             const int p_sym = __shfl(n_sym, hb | j), p_par = __shfl(n_par, hb | j), p_row2 = __shfl(n_row2, hb | j);
             const int p_depth = __shfl(n_depth, hb | j);
             const bool p_isnew = __shfl((int)isnew, hb | j) != 0;
+            // (children of a parent that got a NEW row group have nothing stored, whether the nodes are new or not)
+            const bool p_newrows = __shfl((int)(isnew || need_group), hb | j) != 0;
             int n_alias = -1, n_ps = PS_FROZEN;
             if (rc) {
                 n_id = p_fc + c; n_row2 = p_crow2 * PO_A + c; n_sym = sym_pack(c, sym_last(p_sym), false);
@@ -851,6 +831,21 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 if (!rb && src >= nbo && oa >= 0) src = oa;
             }
             const bool nlive = (rb || (rc && n_alias < 0));
+            // ---- E. an old element that continues in no slot of the new table LEAVES: where its stored values end goes into its
+            // row's header — whoever asks for them while it is no element (a frozen parent's older values, its own seed should it
+            // become an element again) finds the answer there.  (A handful of lanes per table build: writing every element's
+            // header every time cost 12 GB of 4-byte stores per 10 000-pair launch.)
+            {
+                if (lo_half) sm.ord[s] = 0;
+                rk_sync();
+                if (lo_half && nlive && src >= 0) sm.ord[src] = 1;
+                rk_sync();
+                const bool leaving = live && sm.ord[s] == 0;
+#pragma unroll
+                for (int q = 0; q < NR; ++q)
+                    if (leaving && v_fresh[q] == 0) *hdr_of(RD(q), e_row2) = v_done[q];
+                rk_sync();   // (ord is the tie replay's scratch as well)
+            }
             // ---- F. the lanes take their new identity
             const int gsrc = hb | max(src, 0);
             const int g_fc = sm.f_fc[max(src, 0)], g_crow2 = sm.f_crow2[max(src, 0)];
@@ -873,7 +868,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 if (nlive && src >= 0) {
                     v_done[q] = g_done; v_fresh[q] = g_fresh; v_mt[q] = g_mt; v_td[q] = g_td; v_self[q] = g_self; v_mx[q] = g_mx;
                 } else {
-                    v_done[q] = RK_FRESH; v_fresh[q] = (rc && p_isnew) ? 2 : 1;
+                    v_done[q] = RK_FRESH; v_fresh[q] = (rc && p_newrows) ? 2 : 1;
                     v_self[q] = val_neg(); v_mx[q] = PO_NEG_INF; v_mt[q] = -1; v_td[q] = 0;
                 }
             }
@@ -919,7 +914,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         const int r = RD(q);
                         const int wsn = r ? nv : nu;
                         if (rew && live && v_fresh[q] == 0 && v_done[q] > wsn) {
-                            v_self[q] = read_own_all(r, wsn - 1);
+                            v_self[q] = read_own_all(r, wsn - 1, true);   // (wsn - 1 < v_done: its own)
                             v_done[q] = wsn;
                         }
                     }
@@ -957,15 +952,15 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
                 const bool child = s >= nb;
                 const bool fzl = e_ps < 0;
-                Ent1 pf_e[NR];   // the entry requested at the end of the previous step of this run
+                double pf_e[NR];   // the value requested at the end of the previous step of this run
                 int pf_t[NR];
 #pragma unroll
                 for (int q = 0; q < NR; ++q) {
-                    pf_e[q].tag = 0ull; pf_e[q].v[0] = 0.0; pf_t[q] = -1;
+                    pf_e[q] = 0.0; pf_t[q] = -1;
                     if (pf0_step == mstep && s < PF0N) {   // ... or with the staging of the new elements' step just before this run
                         const int r = RD(q);
                         pf_t[q] = sm.pf0_t[r][s];
-                        if (pf_t[q] >= 0) { pf_e[q].tag = tag_of(e_id, pf_t[q]); pf_e[q].v[0] = sm.pf0[r][s]; }
+                        if (pf_t[q] >= 0) pf_e[q] = sm.pf0[r][s];
                     }
                 }
                 for (;;) {
@@ -999,7 +994,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         has_c[q] = live && dr > ws;
                         bnd[q] = has_c[q] && child && !(v_mx[q] == PO_NEG_INF || v_mt[q] >= ws);
                         mx[q] = PO_NEG_INF; cmx[q] = PO_NEG_INF; mt[q] = -1; cmt[q] = -1; td[q] = has_c[q] ? v_td[q] : ws; tr[q] = INT_MIN;
-                        pf_val[q] = (pf_t[q] >= 0 && pf_e[q].tag == tag_of(e_id, pf_t[q])) ? pf_e[q].v[0] : PO_NEG_INF;
+                        pf_val[q] = (pf_t[q] >= 0) ? pf_e[q] : PO_NEG_INF;
                         bool rsc = false;
                         if (has_c[q]) {
                             if (v_mx[q] == PO_NEG_INF || v_mt[q] >= ws || child) { cmx[q] = v_mx[q]; cmt[q] = v_mt[q]; }
@@ -1040,7 +1035,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
 #ifdef PO_RING_TRACE_NODE
                                     if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g RUN ps %d fzt %d\n", e_id, r, t, out.v[0], pp.v[0], self.v[0], e_ps, fz_t[q]);
 #endif
-                                    t2_write(r, e_row2, e_id, t, out);
+                                    t2_write(r, e_row2, t, out);
                                     if (out.v[0] > self.v[0]) tr[q] = t;
                                     self = out;
                                     mt[q] = (out.v[0] >= mx[q]) ? t : mt[q];
@@ -1109,7 +1104,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         const int r = RD(q);
                         const int wsn = r ? rec.y : rec.x;
                         pf_t[q] = -1;
-                        if (live && (!child || hot[q]) && v_done[q] > wsn && v_mx[q] != PO_NEG_INF && v_mt[q] < wsn) { pf_t[q] = wsn; pf_e[q] = *t2_entry1(r, e_row2, wsn); }
+                        if (live && (!child || hot[q]) && v_done[q] > wsn && v_mx[q] != PO_NEG_INF && v_mt[q] < wsn) { pf_t[q] = wsn; pf_e[q] = t2_load0(r, e_row2, wsn); }
                     }
                     KC(12, 1);
                     if (__ballot(viol) != 0ull) { run_viol = true; break; }
@@ -1242,12 +1237,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     if (lane == 0 && a.dbg && slotid == 0)
         for (int i = 0; i < 40; ++i) a.dbg[i] = tk[i];
 #endif
-    if (lane == 0) {   // the slice's next owner continues from here
-        unsigned long long* stp = a.wgstate + 2 * (size_t)slotid;
-        atomicExch(&stp[0], a.magic ^ (unsigned long long)slotid);
-        atomicExch(&stp[1], (unsigned long long)epoch);
-        if (COUNT && a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
-    }
+    if (COUNT && lane == 0 && a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
     // (everything this wave wrote into the slice leaves this XCD's L2 before another wave — any CU, any XCD — may claim it)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #ifndef PO_EMU
@@ -1292,8 +1282,9 @@ extern "C" int po_reg_slots_per_cu(int model, int wide) {
 }
 extern "C" int po_reg_max_elements(int wide) { return wide ? 64 : 32; }
 extern "C" int po_reg_ngl(int wide) { return wide ? 2 * PO_REG_NGL : PO_REG_NGL; }
-// bytes of value store per pair slot: 128 row groups at R = 128 for W <= 6 (beam2d_kernel's geometry), twice that for the wide form
-extern "C" size_t po_reg_pool_bytes(int model, int wide) { return (size_t)(model == PO_MODEL_CTC ? 2 : 4) << (wide ? 21 : 20); }
+// bytes of value store per pair slot: 128 row groups at R = 128 of 8-byte (24-byte: three values) entries for W <= 6, twice that
+// for the wide form
+extern "C" size_t po_reg_pool_bytes(int model, int wide) { return (size_t)(model == PO_MODEL_CTC ? 1 : 3) << (wide ? 21 : 20); }
 // `slots` pair slots (one-wave workgroups), each with its own store slice and arena
 extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide, hipStream_t stream) {
     X2Args a = *(const X2Args*)x2args;

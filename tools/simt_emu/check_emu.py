@@ -30,7 +30,10 @@ def make_case(job):
     rng = np.random.default_rng(seed)
     y1, y2 = synth_pair(int(rng.integers(1 << 30)), T=T, flipflop=(kind == "flipflop"))
     if style == "pipeline":
-        r = O.pair_decode(y1, y2, kind, W, "row_col")
+        try:
+            r = O.pair_decode(y1, y2, kind, W, "row_col")
+        except O.OracleError:   # (the reference's own assertions refuse some pairs: e.g. Bonito's frame map, pair_decode.py:379)
+            return None
         if r["status"] != 0 or r.get("envelope") is None:
             return None
         env = np.asarray(r["envelope"], dtype=np.int32)

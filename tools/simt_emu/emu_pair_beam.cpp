@@ -31,7 +31,7 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     // the library's slice pool, stood in for by host memory: one chunk, a slice per pair wave of the launch
     const int64_t WM = wide ? 12 : 6;
     const size_t arena_cap = (size_t)(1 + PO_A + (int64_t)PO_A * WM * 1024);
-    const size_t slice_bytes = (pool_bytes + sizeof(int) * 3 * arena_cap + 255) & ~size_t(255);
+    const size_t slice_bytes = (pool_bytes + sizeof(int) * 3 * arena_cap + sizeof(int) * 2 * PO_A * (size_t)po_reg_ngl(wide) + 255) & ~size_t(255);
     std::vector<char> pool(slice_bytes * blocks, 0);
     std::vector<int> claim((size_t)blocks, 0);
     for (int i = 0; i < blocks; ++i) claim[(size_t)i] = i;
