@@ -374,6 +374,18 @@ def main():
                   "mode": "one process per GPU (this launch), each rank its 1/N share of the same %d host arrays" % P,
                   "input": "list of host float32 logit matrices (T x 5), 80 KB per read over PCIe", "output": "Python strings",
                   "pipeline_rank0": dict(stt)}
+        if world == 1 and ns >= 2500:
+            # one GPU's share of the 8-GPU strong-scaling job (bench seeds 1250 .. 2499), end to end on this GPU: what the
+            # 8-GPU figure can be predicted from (a 1 250-pair launch is latency-bound: a pair is one serial chain on one wave)
+            sh = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pobatch.pair_decode_stream(l1s[1250:2500], l2s[1250:2500], "poreover", args.beam_width, "row_col")
+                sh.append(time.perf_counter() - t0)
+            sh.sort()
+            strong["shard_1250_e2e"] = {"pairs": 1250, "seconds": round(sh[1], 4), "pairs_per_s": round(1250 / sh[1], 1),
+                                        "seconds_min": round(sh[0], 4), "seconds_max": round(sh[2], 4),
+                                        "x8_prediction_pairs_per_s": round(10000 / sh[1], 1)}
         if world == 1 and args.inprocess_devices:
             devs = [int(x) for x in args.inprocess_devices.split(",") if x.strip() != ""]
             pobatch.pair_decode_stream(l1s, l2s, "poreover", args.beam_width, "row_col", wave_pairs=wp, devices=devs)

@@ -13,13 +13,15 @@
  * Conventions
  *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in _h
  *   - the device-pointer calls enqueue their kernels on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream) and return without waiting for them; none allocates or frees device memory: scratch comes from `ws`.
+ *     stream) and return without waiting for them; scratch comes from `ws`, and none allocates or frees device memory —
+ *     except that the first pair beam search (method row_col with an envelope, W <= 12) of a process on a device creates,
+ *     per tree model, a pool of value-store slices that the library keeps (5.3 GB for the default model).
  *     The calls whose geometry depends on batch maxima they are not given (po_pair_decode_batch, po_beam2d_batch,
  *     po_beam1d_batch, the lattice / alignment calls) first read the offset tables back (one small D2H copy and a
  *     stream synchronise) — enqueue the inputs before calling; po_viterbi_batch (CTC kinds) and po_ingest_batch do
  *     not.  The *_h forms and po_pipeline_pair_decode are synchronous.
- *   - a workspace may be reused from call to call and its contents need not be preserved; the pair beam search
- *     keeps per-workgroup epoch counters in it and clears what it finds untagged (first use)
+ *   - a workspace may be reused from call to call and its contents need not be preserved (beam2d_kernel keeps
+ *     per-workgroup epoch counters in it and clears what it finds untagged: first use)
  *   - po_last_error() is per host thread and refers to the last failing call of that thread; the profiling aid at
  *     the end of this header (po_profile_*) is process-wide and meant for one measuring thread
  *   - y:       concatenated C-contiguous (T_i, C) float64 natural-log probabilities

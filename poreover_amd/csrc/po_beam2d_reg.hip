@@ -68,7 +68,13 @@ struct RegCfg {
     static constexpr int PS = (K == 1) ? PO_REG_PS : 3;
     static constexpr int PF0N = (NR == 1) ? 8 : 16;               // beam slots whose window-start value a new-element step fetches ahead
     // waves per SIMD the register budget is set for (128 / 168 / 256 VGPRs)
-    static constexpr int WAVES = (K == 1 && NR == 1) ? 4 : ((K == 1 || NR == 1) ? 3 : 2);
+#ifndef PO_REG_WAVES_K1W
+#define PO_REG_WAVES_K1W 3   // <ctc, 64 slots>
+#endif
+#ifndef PO_REG_WAVES_K3N
+#define PO_REG_WAVES_K3N 3   // <three values, 32 slots>
+#endif
+    static constexpr int WAVES = (K == 1 && NR == 1) ? 4 : (K == 1 ? PO_REG_WAVES_K1W : (NR == 1 ? PO_REG_WAVES_K3N : 2));
 };
 template <int K> struct RegVal { double v[K]; };
 
