@@ -257,17 +257,27 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         auto pval_of = [&](const Val& x) -> PVal { PVal y; for (int q = 0; q < KP; ++q) y.v[q] = x.v[PC0 + q]; return y; };
         auto pval_shfl = [&](const PVal& x, int src) -> PVal { PVal y; for (int q = 0; q < KP; ++q) y.v[q] = __shfl(x.v[q], src); return y; };
         auto val_shfl = [&](const Val& x, int src) -> Val { Val y; for (int q = 0; q < K; ++q) y.v[q] = __shfl(x.v[q], src); return y; };
-        auto t2_load = [&](int r, int row2, int tq) -> Val { return *(const Val*)(poolb + (size_t)t2_off(r, row2, tq)); };   // (all K values)
+        // (value by value: an aggregate copy of the 24-byte entry keeps v_self and friends in scratch memory instead of registers)
+        auto t2_load = [&](int r, int row2, int tq) -> Val {   // (all K values)
+            const double* const p = (const double*)(poolb + (size_t)t2_off(r, row2, tq));
+            Val v;
+            for (int q = 0; q < K; ++q) v.v[q] = p[q];
+            return v;
+        };
         auto t2_load0 = [&](int r, int row2, int tq) -> double { return *(const double*)(poolb + (size_t)t2_off(r, row2, tq)); };   // (alpha alone)
         auto hdr_of = [&](int r, int row2) -> int* { return rowhdr + (row2 * 2 + r); };
         // values of (row, time) when `present` says they are there
         auto t2_read = [&](int r, int row2, int tq, bool present) -> Val {
             Val v = val_neg();
-            if (present && tq >= 0 && row2 >= 0) v = t2_load(r, row2, tq);
+            if (present && tq >= 0 && row2 >= 0) {
+                const double* const p = (const double*)(poolb + (size_t)t2_off(r, row2, tq));
+                for (int q = 0; q < K; ++q) v.v[q] = p[q];
+            }
             return v;
         };
         auto t2_write = [&](int r, int row2, int tq, const Val& v) {
-            *(Val*)(const_cast<char*>(poolb) + (size_t)t2_off(r, row2, tq)) = v;
+            double* const p = (double*)(const_cast<char*>(poolb) + (size_t)t2_off(r, row2, tq));
+            for (int q = 0; q < K; ++q) p[q] = v.v[q];
         };
         // update_prob of one element at one time: sp = its own values at t - 1, pk = its parent's (the ones read), ya / yb = the
         // two y entries of the row (own symbol; blank, or the symbol's flop column), same = parent->last == last
@@ -459,6 +469,11 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             // (st stays wave-uniform: the walk loop's condition reads it)
             if (is_main && __ballot(part && v_fresh[q] == 0 && v_done[q] > we) != 0ull) st = PO_E_NOMEM;
             int start = max(v_done[q], ws);
+            // (the lane's own state is read HERE, not inside the branches below: a branch that loads a double from the store next
+            //  to one that loads it from v_self / fz_val has the two loads merged into one through a pointer — and the lane's
+            //  state lives in scratch memory from then on, in every phase of the kernel; measured: Bonito pairs 6 % slower)
+            const Val own = v_self[q];
+            const PVal fzv = fz_val[q];
             Val self = val_neg();
             if (part) {
                 if (v_fresh[q] != 0) {
@@ -467,7 +482,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 } else if (start > v_done[q]) {
                     // a gap (catch-ups went beyond the last window): the value at start - 1 was never computed
                 } else {
-                    self = v_self[q];
+                    self = own;
                 }
             }
             const bool part2 = part && start < we;
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                                 if (tm >= 0) { pp.v[0] = sm.rootcum[r]; bad_root = bad_root || (tm != sm.rootT[r]); }
                             }
                         } else if (tm >= fz_t[q]) {
-                            pp = (tm == fz_t[q]) ? fz_val[q] : pval_neg();                            // frozen parent: its last value, then nothing
+                            pp = (tm == fz_t[q]) ? fzv : pval_neg();                            // frozen parent: its last value, then nothing
                         } else {   // a frozen parent's older values: its row's header says where they end
                             const int prow = sm.f_prow2[s];
                             pp = pval_of(t2_read(r, prow, tm, prow >= 0 && tm < *hdr_of(r, max(prow, 0))));
@@ -679,7 +694,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         for (int c = 0; c < KP; ++c) sm.pst[r][k * RK_NY + s][c] = val.v[c];
                     }
                 }
-                if (k0 == 0 && want_seed && ws - 1 < se_hdr) self = se;
+                if (k0 == 0 && want_seed && ws - 1 < se_hdr) for (int c = 0; c < K; ++c) self.v[c] = se.v[c];
                 rk_sync();
                 const int k1 = min(n1max, k0 + RK_NY);
                 // (the operands of an iteration are asked for one iteration ahead: a lone wave then waits for the LDS only
@@ -715,7 +730,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     }
                 }
             }
-            if (n1max == 0 && want_seed && ws - 1 < se_hdr) self = se;
+            if (n1max == 0 && want_seed && ws - 1 < se_hdr) for (int c = 0; c < K; ++c) self.v[c] = se.v[c];
             if (s < PF0N) {
                 sm.pf0_t[r][s] = want_pf ? ws : -1;
                 if (want_pf) sm.pf0[r][s] = se.v[0];
@@ -868,7 +883,8 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 const PVal o_last = pval_shfl(pval_of(v_self[q]), opl);
                 const PVal q_val = pval_shfl(fz_val[q], gsrc);
                 const int q_t = __shfl(fz_t[q], gsrc);
-                const PVal c_val = (op >= 0) ? o_last : q_val;
+                PVal c_val;   // (value by value: a conditional between two aggregates becomes a select of scratch addresses)
+                for (int c2 = 0; c2 < KP; ++c2) c_val.v[c2] = (op >= 0) ? o_last.v[c2] : q_val.v[c2];
                 const int c_t = (op >= 0) ? ((o_fresh == 0) ? o_done - 1 : INT_MAX) : q_t;
                 fz_val[q] = c_val; fz_t[q] = (nlive && src >= 0) ? c_t : INT_MAX;
                 if (nlive && src >= 0) {

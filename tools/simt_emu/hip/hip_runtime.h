@@ -30,6 +30,8 @@
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 struct uint3_ { unsigned x, y, z; };
+struct double2 { double x, y; };
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
