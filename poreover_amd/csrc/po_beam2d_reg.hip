@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         // the step is not of this kind: scan() takes it.
         auto scan_new = [&](int u, int ce, int v, int re) -> bool {
             const int d0 = done0(), d1 = done1();
-            if (__builtin_expect(!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re), 0)) return false;
+            if (__builtin_expect(!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re), 0)) { KC(22, 1); return false; }
             bool fresh[NR], fresh_any = false;
             {
                 bool bad = false;
@@ -601,6 +601,10 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     // everybody who continues ends at dr; fresh lanes hang under a continuing lane; no root, no older frozen values
                     const bool pfresh = __shfl((int)fresh[q], hb | max(e_ps, 0)) != 0;
                     bad = bad || (cont && v_done[q] != dr) || (live && e_ps == PS_ROOT) || (fresh[q] && e_ps < 0) || (fresh[q] && pfresh);
+#ifdef PO_REG_TIMING
+                    KC(23, __ballot(cont && v_done[q] != dr) != 0ull); KC(24, __ballot(live && e_ps == PS_ROOT) != 0ull);
+                    KC(25, __ballot(fresh[q] && e_ps < 0) != 0ull); KC(26, __ballot(fresh[q] && pfresh) != 0ull);
+#endif
                     fresh_any = fresh_any || fresh[q];
                 }
                 if (__builtin_expect(__ballot(bad) != 0ull, 0)) return false;
@@ -618,7 +622,15 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     nps++;
                 } else many = true;
             }
-            if (__builtin_expect(many, 0)) return false;
+#ifdef PO_EMU_DEBUG_MANY
+            if (many && pi == 0) {
+                int cnt = 0;
+                for (int jj = 0; jj < nb; ++jj) if (__ballot(fresh_any && e_ps == jj) != 0ull) cnt++;
+                if (lane == 0) printf("MANY step %d nb %d parents %d\n", mstep, nb, cnt);
+                if (fresh_any) printf("   lane %d s %d id %d ps %d fresh %d row2 %d\n", lane, s, e_id, e_ps, v_fresh[0], e_row2);
+            }
+#endif
+            if (__builtin_expect(many, 0)) { KC(27, 1); return false; }
             int myk = 0;
 #pragma unroll
             for (int k = 1; k < RK_PS; ++k) myk = (e_ps == pj[k] && pj[k] >= 0) ? k : myk;
@@ -988,7 +1000,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 for (;;) {
                     u = rec.x; v = rec.y; ce = rec.z; re = rec.w;
                     const int d0 = done0(), d1 = done1();
-                    if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || mstep + 1 >= nmain) break;
+                    if (!(u <= d0 && d0 <= ce && v <= d1 && d1 <= re) || mstep + 1 >= nmain) { KC(28, 1); break; }
                     // (a frozen parent's older values would have to come from the store: only asked when there are new times)
                     if (ce > d0 || re > d1) {
                         bool old = false;
@@ -998,7 +1010,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                             const int dr = r ? d1 : d0, we = r ? re : ce;
                             old = old || (live && dr < we && e_ps == PS_FROZEN && dr - 1 < fz_t[q]);
                         }
-                        if (__builtin_expect(__ballot(old) != 0ull, 0)) break;
+                        if (__builtin_expect(__ballot(old) != 0ull, 0)) { KC(29, 1); break; }
                     }
                     // ---- the carried part [ws, dr) of the window: its maximum is what the previous step left while that time
                     // is inside the window; else the stored values are looked at (the one most steps need — a decaying
@@ -1150,6 +1162,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 tbl_fresh = false;
                 continue;
             }
+            KC(30, tbl_fresh ? 0 : 1); KC(32, tbl_uneven ? 1 : 0); KC(33, nb != W ? 1 : 0);
             scan(true, u, ce, v, re, NS);
             tbl_fresh = false; tbl_uneven = false;
             if constexpr (COUNT) cnt_ref += (unsigned)(ne * ((ce - u) + (re - v)));
@@ -1336,6 +1349,8 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide
         fprintf(stderr, "   steps with new elements: %lld steps; staging + carried maxima %lld, phase 1 %lld (%lld iterations)\n", h[13], h[1], h[2], h[14]);
         fprintf(stderr, "   general scans: main %lld ticks (%lld), catch-up %lld ticks (%lld); iterations %lld\n", h[4], h[16], h[5], h[17], h[18]);
         fprintf(stderr, "   step top + score + prune test %lld, ranking %lld, rebuild %lld, pair setup + label %lld\n", h[6], h[7], h[8], h[9]);
+        fprintf(stderr, "   new-element steps handed to the general scan: window order %lld, uneven ends %lld, root's children %lld, fresh without a parent lane %lld, fresh under fresh %lld, more than PS parents %lld\n", h[22], h[23], h[24], h[25], h[26], h[27]);
+        fprintf(stderr, "   run loop left for the general scan: window order / last step %lld, a frozen parent's older values %lld; general main scans on a table that is not fresh %lld, uneven %lld, beam not full %lld\n", h[28], h[29], h[30], h[32], h[33]);
         fprintf(stderr, "   table builds that ask the arena for a node's children: %lld; window rescans: %lld lanes in %lld calls; bounds made exact in %lld steps\n", h[20], h[21], h[10], h[31]);
     }
 #endif

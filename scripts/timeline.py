@@ -11,7 +11,7 @@ for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K", r["Kernel_Name"].split("(")[0].replace("void ", "")[:40], r.get("Stream_Id", r.get("Queue_Id", ""))))
 for f in glob.glob(root + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "M", r["Direction"].replace("MEMORY_COPY_", "")[:30], ""))
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "M", r["Direction"].replace("MEMORY_COPY_", "")[:30], r.get("Bytes", r.get("Size", "0"))))
 ev.sort()
 segs, cur, end = [], [], None
 for e in ev:
@@ -37,3 +37,15 @@ for e in ev:
     d = (e[1] - e[0]) / 1e6
     if d > mind and e[2] == "K":
         print("%8.2f ms + %7.2f ms  %s %s" % ((e[0] - t0) / 1e6, d, e[3], e[4]))
+
+# the uploads in 5 ms buckets: bytes on the wire and busy time
+print("H2D per 5 ms bucket: start ms, MB, busy ms")
+bk = {}
+for e in ev:
+    if e[2] == "M" and "HOST_TO_DEVICE" in e[3]:
+        b = int((e[0] - t0) / 5e6)
+        x = bk.setdefault(b, [0.0, 0.0])
+        try: x[0] += float(e[4]) / 1e6
+        except ValueError: pass
+        x[1] += (e[1] - e[0]) / 1e6
+for b in sorted(bk): print("%6d  %8.1f MB  %6.2f ms" % (b * 5, bk[b][0], bk[b][1]))
