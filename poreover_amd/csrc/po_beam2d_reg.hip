@@ -65,7 +65,10 @@ struct RegCfg {
     static constexpr int WS = (NR == 1) ? 6 : 12;                 // widest beam
     static constexpr int NGL = (NR == 1) ? PO_REG_NGL : 2 * PO_REG_NGL;   // row groups tracked per pair
     // parents whose stored window one step can stage for its new elements (a step with more goes the general way)
-    static constexpr int PS = (K == 1) ? PO_REG_PS : 3;
+    // (64 slots: ten — the reads go one after the other there, both use ONE staging buffer, and a block's 32 times leave half
+    //  the read's 64 lanes free to ask for a second parent: at W = 10 a third of the steps with new elements have five to
+    //  ten parents, and all of them went the general way)
+    static constexpr int PS = (NR == 2) ? 10 : ((K == 1) ? PO_REG_PS : 3);
     static constexpr int PF0N = (NR == 1) ? 8 : 16;               // beam slots whose window-start value a new-element step fetches ahead
     // waves per SIMD the register budget is set for (128 / 168 / 256 VGPRs)
 #ifndef PO_REG_WAVES_K1W
@@ -82,7 +85,7 @@ template <int MODEL, int NR>
 struct RegSmem {              // per pair wave
     using Cfg = RegCfg<MODEL, NR>;
     double ybuf[2][RK_NY][Cfg::YC];
-    double pst[2][Cfg::PS * RK_NY][Cfg::KP];   // staged values per read: a block of RK_NY times of every staged parent
+    double pst[(NR == 1) ? 2 : 1][Cfg::PS * RK_NY][Cfg::KP];   // staged values (per read for NR = 1): a block of RK_NY times of every staged parent
     int g_owner[Cfg::NGL], g_hi0[Cfg::NGL], g_hi1[Cfg::NGL];
     // the table fields only the table build (and the rare general scan) looks at, per element slot — the same for both reads:
     // in LDS they cost no register between two table builds
@@ -610,30 +613,21 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 if (__builtin_expect(__ballot(bad) != 0ull, 0)) return false;
             }
             // ---- the parents to stage (beam slots with fresh children): at most RK_PS
-            int pj[RK_PS], nps = 0;
-#pragma unroll
-            for (int k = 0; k < RK_PS; ++k) pj[k] = -1;
+            // (their slots — below 16 — in four bits each of one wave-uniform word: an int array indexed by k ends up in scratch)
+            unsigned long long pjb = 0ull;
+            int nps = 0;
+            auto pj = [&](int k) -> int { return (int)((pjb >> (4 * k)) & 15ull); };
             bool many = false;
             for (int jj = 0; jj < nb; ++jj) {   // (wave-uniform)
                 if (__ballot(fresh_any && e_ps == jj) == 0ull) continue;
                 if (nps < RK_PS) {
-#pragma unroll
-                    for (int k = 0; k < RK_PS; ++k) if (k == nps) pj[k] = jj;
+                    pjb |= (unsigned long long)jj << (4 * nps);
                     nps++;
                 } else many = true;
             }
-#ifdef PO_EMU_DEBUG_MANY
-            if (many && pi == 0) {
-                int cnt = 0;
-                for (int jj = 0; jj < nb; ++jj) if (__ballot(fresh_any && e_ps == jj) != 0ull) cnt++;
-                if (lane == 0) printf("MANY step %d nb %d parents %d\n", mstep, nb, cnt);
-                if (fresh_any) printf("   lane %d s %d id %d ps %d fresh %d row2 %d\n", lane, s, e_id, e_ps, v_fresh[0], e_row2);
-            }
-#endif
             if (__builtin_expect(many, 0)) { KC(27, 1); return false; }
             int myk = 0;
-#pragma unroll
-            for (int k = 1; k < RK_PS; ++k) myk = (e_ps == pj[k] && pj[k] >= 0) ? k : myk;
+            for (int k = 1; k < nps; ++k) myk = (e_ps == pj(k)) ? k : myk;   // (wave-uniform loop)
             const int sym = sym_last(e_sym), cb = (MODEL == PO_MODEL_FLIPFLOP) ? sym + A : A;
             const bool same = sym_plast(e_sym) == sym;
             KT(1); KC(13, 1);
@@ -664,14 +658,14 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             // of the iteration before.
             const int n1max = (NR == 1) ? max(d0 - u, d1 - v) : n1;
             KC(14, n1max);
-            const double* const ps_ = &sm.pst[r][myk * RK_NY][0];
+            const double* const ps_ = &sm.pst[(NR == 1) ? r : 0][myk * RK_NY][0];
             for (int k0 = 0; k0 < n1max; k0 += RK_NY) {
                 rk_sync();   // (every lane is done with the rows and staged values of the block before)
                 // (the first two parents' entries are asked for BEFORE the y rows: one memory round trip for the rows and the
                 //  staged values of the usual step — one or two nodes entered the beam — instead of one after the other)
-                // (a block has RK_NY = 32 times: with 64 lanes per read the upper ones have nothing to stage)
+                if constexpr (NR == 1) {
                 const int i = k0 + s, tq = ws - 1 + i;
-                const bool stg = i < n1 && (NS == RK_NY || s < RK_NY);
+                const bool stg = i < n1;
                 // (a staged parent is a continuing beam lane: its stored values end at its v_done on this read)
                 Val e01[2];
                 bool ok01[2] = {false, false};
@@ -679,7 +673,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 for (int k = 0; k < 2; ++k) {
                     for (int c = 0; c < K; ++c) e01[k].v[c] = 0.0;
                     if (k < nps) {   // (wave-uniform)
-                        const int jk = pj[k];
+                        const int jk = pj(k);
                         const int prow = __builtin_amdgcn_readlane(e_row2, jk);
                         const int pdone = __shfl(v_done[q], hb | jk);
                         ok01[k] = stg && tq >= 0 && tq < pdone;
@@ -696,15 +690,47 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         for (int c = 0; c < KP; ++c) sm.pst[r][k * RK_NY + s][c] = ok01[k] ? e01[k].v[PC0 + c] : PO_NEG_INF;
                     }
                 for (int k = 2; __builtin_expect(k < nps, 0); ++k) {   // (wave-uniform; three and more parents: rare)
-                    int jk = pj[0];
-#pragma unroll
-                    for (int c = 1; c < RK_PS; ++c) jk = (k == c) ? pj[c] : jk;
+                    const int jk = pj(k);
                     const int prow = __builtin_amdgcn_readlane(e_row2, jk);
                     const int pdone = __shfl(v_done[q], hb | jk);
                     if (stg) {
                         const PVal val = pval_of(t2_read(r, prow, tq, tq < pdone));
                         for (int c = 0; c < KP; ++c) sm.pst[r][k * RK_NY + s][c] = val.v[c];
                     }
+                }
+                } else {
+                // 64 lanes per read, 32 times per block: the lower half asks for parent k, the upper half for parent k + 1
+                const int sl = s & (RK_NY - 1), half = s >> 5;
+                const int i = k0 + sl, tq = ws - 1 + i;
+                const bool stg = i < n1;
+                auto parent_of = [&](int kk, int& prow, int& pdone) {   // (per lane: the two halves name different parents)
+                    const int jk = pj(min(kk, RK_PS - 1));   // (kk >= nps: slot 0, never used)
+                    prow = __shfl(e_row2, jk); pdone = __shfl(v_done[q], jk);
+                };
+                Val e0;
+                for (int c = 0; c < K; ++c) e0.v[c] = 0.0;
+                bool ok0 = false;
+                {
+                    int prow, pdone;
+                    parent_of(half, prow, pdone);
+                    ok0 = stg && half < nps && tq >= 0 && tq < pdone;
+                    if (ok0) e0 = t2_load(r, prow, tq);
+                }
+                {
+                    const int lo = ws + k0, hi = min(lo + RK_NY, dr);
+                    if (hi > lo && !(lo >= yhi[q] - RK_NY && hi <= yhi[q])) { y_reload(r, lo); yhi[q] = lo + RK_NY; }
+                }
+                if (stg && half < nps)
+                    for (int c = 0; c < KP; ++c) sm.pst[0][half * RK_NY + sl][c] = ok0 ? e0.v[PC0 + c] : PO_NEG_INF;
+                for (int k = 2; __builtin_expect(k < nps, 0); k += 2) {   // (wave-uniform)
+                    const int kk = k + half;
+                    int prow, pdone;
+                    parent_of(kk, prow, pdone);
+                    if (stg && kk < nps) {
+                        const PVal val = pval_of(t2_read(r, prow, tq, tq < pdone));
+                        for (int c = 0; c < KP; ++c) sm.pst[0][kk * RK_NY + sl][c] = val.v[c];
+                    }
+                }
                 }
                 if (k0 == 0 && want_seed && ws - 1 < se_hdr) for (int c = 0; c < K; ++c) self.v[c] = se.v[c];
                 rk_sync();
