@@ -49,6 +49,7 @@
 #include <mutex>
 #include <unordered_map>
 
+#define PO_WANT_ZERO_KERNEL 1
 #include "po_device.h"
 #include "po_host.h"
 #include "po_beam2d_common.h"
@@ -1997,9 +1998,9 @@ int b2_launch_legacy(const double* y1, const int64_t* y1_off, const double* y2, 
     // the queue counter starts from zero on every launch; the value store is NOT cleared: its tags are told apart by
     // the epoch counters the workgroups keep in the workspace (see beam2d_kernel) — unless this memory was last used
     // with another layout (b2_ws_layout_changed)
-    if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    if (po_zero_async(w + g.off_queue, 256, stream) != hipSuccess) return PO_E_HIP;
     if (b2_ws_layout_changed(ws, g.off_state, g.total, g.magic) &&
-        hipMemsetAsync(w + g.off_state, 0, sizeof(unsigned long long) * 2 * (size_t)g.blocks, stream) != hipSuccess)
+        po_zero_async(w + g.off_state, sizeof(unsigned long long) * 2 * (size_t)g.blocks, stream) != hipSuccess)
         return PO_E_HIP;
     a.order = nullptr;
     if (n > g.blocks && !only_meta && !retry && !b2_route().no_order) {   // more pairs than resident workgroups: the order of the queue matters
@@ -2065,8 +2066,8 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.dbg = nullptr; a.only_meta = nullptr;
         a.upd_count = g_b2_upd_counter;
         a.wgstate = nullptr; a.magic = 0;   // (the grid kernel clears its store per launch)
-        if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-        if (hipMemsetAsync(w + g.off_pool, 0, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
+        if (po_zero_async(w + g.off_queue, 256, stream) != hipSuccess) return PO_E_HIP;
+        if (po_zero_async(w + g.off_pool, g.pool_bytes * g.blocks, stream) != hipSuccess) return PO_E_HIP;
         if (model == PO_MODEL_CTC) grid_launch_w<PO_MODEL_CTC>(g, a, stream);
         else if (model == PO_MODEL_MERGE) grid_launch_w<PO_MODEL_MERGE>(g, a, stream);
         else grid_launch_w<PO_MODEL_FLIPFLOP>(g, a, stream);
@@ -2112,13 +2113,12 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
             hipLaunchKernelGGL(pair_order_kernel, dim3(1), dim3(1024), 0, stream, y1_off, y2_off, n, (int*)(w + g.off_order));
         }
         const int grid = a.persist ? std::min(g.blocks, rp->nslices) : n;
-        a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
-        const size_t plds = sizeof(int) * 2 * (size_t)a.pre_vcols;
+        a.pre_vcols = 0;
         a.ngl = po_reg_ngl(reg_wide(W));
-        if (hipMemsetAsync(w + g.off_queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
-        if (model == PO_MODEL_CTC) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(256), plds, stream, a);
-        else if (model == PO_MODEL_MERGE) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(256), plds, stream, a);
-        else hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(256), plds, stream, a);
+        if (po_zero_async(w + g.off_queue, 256, stream) != hipSuccess) return PO_E_HIP;
+        if (model == PO_MODEL_CTC) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(64), 0, stream, a);
+        else if (model == PO_MODEL_MERGE) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_FLIPFLOP>, dim3(n), dim3(64), 0, stream, a);
         hipLaunchKernelGGL(beam2d_walk_kernel, dim3(n), dim3(64), 0, stream, a);
         if (g_b2_mark_fwd) g_b2_mark_fwd(1, stream);
         po_reg_launch(&a, grid, model, reg_wide(W), stream);

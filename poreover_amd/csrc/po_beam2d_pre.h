@@ -4,29 +4,28 @@
 #pragma once
 #include "po_beam2d_common.h"
 
-// ---- per-pair pre-pass: envelope bounds, transposed envelope, widest window -> R, node budget, blank
-// prefix sums (BeamSearch.h:270-284; PrefixTree.h:509-515)
+// ---- per-pair pre-pass: envelope bounds, transposed envelope, widest window -> R, node budget (BeamSearch.h:270-284)
+// ONE wave per pair, no LDS, few registers: in the pipelined job this kernel of wave k + 1 runs next to a device full of
+// beam2d_reg_kernel waves of wave k, and a workgroup only starts where those have left room — one wave slot of 128
+// registers here and there, never four on one CU (round 5: the 256-thread form with a 35 KB column table waited for the
+// pair beam kernel before it to drain, and the whole wave behind it).  The transposed envelope is written straight into its
+// place in HBM: on a monotone envelope every column is written by exactly one row per bound.  (The ctc root's blank prefix
+// sums were added up here through round 4; beam2d_reg_kernel adds them up as its scans pass the times.)
 template <int MODEL>
-__global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
+__global__ __launch_bounds__(64) void beam2d_prepass_kernel(X2Args a) {
     constexpr int K = (MODEL == PO_MODEL_CTC) ? 1 : 3;
-    constexpr int nthr = 256;
-#ifdef PO_EMU
-    static int colbuf[2 * 6144];
-#else
-    extern __shared__ __attribute__((aligned(16))) int colbuf[];  // first[vcols] then cnt[vcols] (a.pre_vcols columns)
-#endif
-    __shared__ int shw;
-    const int pi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nthr = 64;
+    const int pi = blockIdx.x, tid = threadIdx.x;
     if (a.use_pre_status && a.status[pi] != PO_OK) {
         if (tid == 0) { a.meta[pi] = make_int2(a.status[pi], -1); a.nmain[pi] = 0; }
         return;
     }
     const int64_t o1 = a.y1_off[pi], o2 = a.y2_off[pi];
-    const int64_t b1 = a.y1_off[0], b2 = a.y2_off[0];
+    const int64_t b2 = a.y2_off[0];
     const int U = (int)(a.y1_off[pi + 1] - o1), V = (int)(a.y2_off[pi + 1] - o2);
     const int32_t* env = a.env + 2 * o1;
     int* envt = a.envt + 2 * (o2 - b2);
-    const int C = a.C, A = a.A, W = a.W;
+    const int A = a.A, W = a.W;
     int st = PO_OK, R = 32;
     if (U < 1 || V < 1 || U >= (1 << 24) || V >= (1 << 24)) st = PO_E_ARG;
     if (st == PO_OK) {
@@ -39,61 +38,47 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
         }
         if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
         const bool mono = !__syncthreads_or(nonmono);   // row starts and ends never move backwards (what build_envelope makes)
-        if (st == PO_OK) {
+        if (st == PO_OK && (mono || !a.need_mono)) {
             // transposed envelope (BeamSearch.h:270-284): the first row that covers column x starts its range
             // and every further covering row extends it by one, i.e. [first row, first row + number of rows)
-            if (V <= a.pre_vcols) {  // columns in LDS, rows in parallel
-                int* first = colbuf;
-                int* cnt = colbuf + a.pre_vcols;
-                for (int x = tid; x < V; x += nthr) { first[x] = 0x7fffffff; cnt[x] = mono ? -1 : 0; }
-                __syncthreads();
-                if (mono) {
-                    // The rows covering column x are then the contiguous range [a(x), b(x)], a = the first row whose end
-                    // lies beyond x, b = the last row that starts at or before x: row u is a(x) for the columns between
-                    // the previous row's end and its own, and b(x) for the columns between its start and the next
-                    // row's — every column is written once, no atomics.  (cnt holds b here.)
-                    for (int u = tid; u < U; u += nthr) {
-                        const int lo = env[2 * u], hi = env[2 * u + 1];
-                        const int hp = (u > 0) ? env[2 * u - 1] : 0, ln = (u + 1 < U) ? env[2 * u + 2] : V;
-                        for (int x = hp; x < hi; ++x) first[x] = u;
-                        for (int x = lo; x < ln; ++x) cnt[x] = u;
-                    }
-                    __syncthreads();
-                    for (int x = tid; x < V; x += nthr) {
-                        const int a_ = first[x], b_ = cnt[x];
-                        cnt[x] = (a_ != 0x7fffffff && b_ >= a_) ? b_ - a_ + 1 : 0;
-                    }
-                } else
+            for (int x = tid; x < V; x += nthr) { envt[2 * x] = 0x7fffffff; envt[2 * x + 1] = mono ? -1 : 0; }
+            __syncthreads();   // (one wave: the stores above are in memory before the ones below go out)
+            if (mono) {
+                // The rows covering column x are then the contiguous range [a(x), b(x)], a = the first row whose end
+                // lies beyond x, b = the last row that starts at or before x: row u is a(x) for the columns between
+                // the previous row's end and its own, and b(x) for the columns between its start and the next
+                // row's — every column is written once, no atomics.  (the second word holds b here)
                 for (int u = tid; u < U; u += nthr) {
                     const int lo = env[2 * u], hi = env[2 * u + 1];
-                    for (int x = lo; x < hi; ++x) { atomicMin(&first[x], u); atomicAdd(&cnt[x], 1); }
+                    const int hp = (u > 0) ? env[2 * u - 1] : 0, ln = (u + 1 < U) ? env[2 * u + 2] : V;
+                    for (int x = hp; x < hi; ++x) envt[2 * x] = u;
+                    for (int x = lo; x < ln; ++x) envt[2 * x + 1] = u;
                 }
                 __syncthreads();
                 for (int x = tid; x < V; x += nthr) {
-                    const int c = cnt[x], f = first[x];
+                    const int a_ = envt[2 * x], b_ = envt[2 * x + 1];
+                    const int c = (a_ != 0x7fffffff && b_ >= a_) ? b_ - a_ + 1 : 0;
+                    envt[2 * x] = c ? a_ : -1;
+                    envt[2 * x + 1] = c ? a_ + c : -1;
+                    wmax = max(wmax, c);
+                }
+            } else {   // (a caller's own envelope, and a launch that takes it: integer atomics, order-free)
+                for (int u = tid; u < U; u += nthr) {
+                    const int lo = env[2 * u], hi = env[2 * u + 1];
+                    for (int x = lo; x < hi; ++x) { atomicMin(&envt[2 * x], u); atomicAdd(&envt[2 * x + 1], 1); }
+                }
+                __syncthreads();
+                for (int x = tid; x < V; x += nthr) {
+                    const int c = envt[2 * x + 1], f = envt[2 * x];
                     envt[2 * x] = c ? f : -1;
                     envt[2 * x + 1] = c ? f + c : -1;
                     wmax = max(wmax, c);
                 }
-            } else {  // very long reads: column x is always visited by thread x % nthr, rows in order
-                for (int x = tid; x < V; x += nthr) { envt[2 * x] = -1; envt[2 * x + 1] = -1; }
-                __syncthreads();
-                for (int u = 0; u < U; ++u) {
-                    const int lo = env[2 * u], hi = env[2 * u + 1];
-                    int x = lo + ((tid - lo) % nthr + nthr) % nthr;
-                    for (; x < hi; x += nthr) {
-                        if (envt[2 * x] < 0) { envt[2 * x] = u; envt[2 * x + 1] = u + 1; }
-                        else envt[2 * x + 1]++;
-                    }
-                }
-                __syncthreads();
-                for (int x = tid; x < V; x += nthr) wmax = max(wmax, envt[2 * x + 1] - envt[2 * x]);
             }
-            if (tid == 0) shw = 0;
-            __syncthreads();
-            atomicMax(&shw, wmax);
-            __syncthreads();
-            wmax = shw;
+        }
+        if (st == PO_OK) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
             while (R < wmax + 2) R <<= 1;
             const long long pool_entries = (long long)(a.pool_bytes / (8 * K));   // (beam2d_reg_kernel's entries: the values, no tag)
             const long long ng = pool_entries / ((long long)PO_A * 2 * R);
@@ -104,30 +89,6 @@ __global__ __launch_bounds__(256) void beam2d_prepass_kernel(X2Args a) {
             // ... or an envelope whose row starts / ends move backwards, for a kernel that builds on windows that only
             // move forward (what build_envelope makes; anything else is a caller's own array)
             else if (min((long long)a.ngl, ng) < 8 * max(W, PO_A) || ((a.defer_odd & 1) && (pi & 1)) || (a.need_mono && !mono)) R = X2_DEFERRED;
-        }
-    }
-    // blank prefix sums = the CTC root's alpha (PrefixTree.h:509-515): serial in t so the rounding is the
-    // reference's; one wave per read loads 64 frames at a time (coalesced) and adds them in lane order
-    if (st == PO_OK && MODEL == PO_MODEL_CTC && wave < 2 && !a.no_cum) {
-        const int rr = wave;
-        const double* yr = rr ? a.y2 + o2 * C : a.y1 + o1 * C;
-        double* cw = rr ? a.cum2 + (o2 - b2) : a.cum1 + (o1 - b1);
-        const int Tn = rr ? V : U;
-        double acc = 0.0;
-        double xn = (lane < Tn) ? yr[(int64_t)lane * C + A] : 0.0;   // (the next 64 frames are requested a round ahead)
-        for (int t0 = 0; t0 < Tn; t0 += 64) {
-            const int t = t0 + lane;
-            const double x = xn;
-            xn = (t + 64 < Tn) ? yr[(int64_t)(t + 64) * C + A] : 0.0;
-            double mine = 0.0;
-#pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), j),
-                                                   __builtin_amdgcn_readlane(__double2loint(x), j));
-                if (t0 + j < Tn) acc += xj;   // uniform condition
-                if (lane == j) mine = acc;
-            }
-            if (t < Tn) cw[t] = mine;
         }
     }
     if (tid == 0) {

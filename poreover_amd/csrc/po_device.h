@@ -506,3 +506,23 @@ __device__ __forceinline__ void po_update(const double* sp, const double* pp, do
         out[2] = flop;
     }
 }
+
+// hipMemsetAsync's replacement on the decode path: the runtime's fill kernel comes in 256-thread workgroups, which find no
+// room next to a device full of one-wave pair beam workgroups (the pipelined job: a 256-byte queue reset waited 12 ms for
+// the launch before it to drain).  One-wave workgroups fit wherever one of those has left a slot.  bytes: a multiple of 4.
+// (only in the sources that define PO_WANT_ZERO_KERNEL before including this header)
+#if !defined(PO_EMU) && defined(PO_WANT_ZERO_KERNEL)
+static __global__ __launch_bounds__(64) void po_zero_kernel(unsigned* p, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 64) p[i] = 0u;
+}
+static inline hipError_t po_zero_async(void* p, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) != 0 || ((size_t)p & 3) != 0 || bytes > ((size_t)4 << 20)) return hipMemsetAsync(p, 0, bytes, stream);   // (large: the runtime's)
+    const size_t nwords = bytes >> 2;
+    const size_t nb_ = (nwords + 63) / 64;
+    const unsigned blocks = (unsigned)(nb_ < 4096 ? nb_ : 4096);
+    hipLaunchKernelGGL(po_zero_kernel, dim3(blocks), dim3(64), 0, stream, (unsigned*)p, nwords);
+    return hipGetLastError();
+}
+#endif
+

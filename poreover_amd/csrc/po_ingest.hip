@@ -24,7 +24,8 @@ struct IGArgs {
 }
 
 // mode 0: float32 logits -> log-softmax; 1: uint8 trace -> log prob; 2: float64 values, copy
-__global__ __launch_bounds__(256) void ingest_kernel(IGArgs a) {
+// (one-wave workgroups: they fit wherever a wave of the pair beam kernel of the wave before has left a slot)
+__global__ __launch_bounds__(64) void ingest_kernel(IGArgs a) {
     const int C = a.C;
     for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.total_rows;
          row += (int64_t)gridDim.x * blockDim.x) {
@@ -73,7 +74,7 @@ extern "C" int po_launch_ingest(const void* src, const int64_t* row_off, int n, 
     for (int c = 0; c < 8; ++c) a.perm[c] = (perm && c < C) ? perm[c] : c;
     for (int c = 0; c < C; ++c) if (a.perm[c] < 0 || a.perm[c] >= C) return PO_E_ARG;
     a.out = out; a.total_rows = total_rows;
-    const int64_t blocks = std::min<int64_t>((total_rows + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    const int64_t blocks = std::min<int64_t>((total_rows + 63) / 64, 256 * 32);
+    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, a);
     return PO_OK;
 }

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#define PO_WANT_ZERO_KERNEL 1
 #include "po_device.h"
 #include "po_host.h"
 
@@ -929,8 +930,8 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     if (ext_map1 && ext_map2) {
         map1 = const_cast<int32_t*>(ext_map1);
         map2 = const_cast<int32_t*>(ext_map2);
-        if (hipMemsetAsync(st1, 0, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
-        if (hipMemsetAsync(st2, 0, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
+        if (po_zero_async(st1, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
+        if (po_zero_async(st2, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
     } else if (!opt->diagonal_envelope) {
         po_prof_stage(PO_K_VITERBI, stream, 1, &tok);
         rc = po_launch_viterbi_strided(y1, y1_off, n, C, A, alphabet, kind, nullptr, seq1d, seq1d_off, 0, 2, len1, map1,
@@ -941,8 +942,8 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
         if (rc != PO_OK) return rc;
         po_prof_stage(PO_K_VITERBI, stream, 0, &tok);
     } else {
-        if (hipMemsetAsync(len1, 0, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
-        if (hipMemsetAsync(len2, 0, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
+        if (po_zero_async(len1, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
+        if (po_zero_async(len2, sizeof(int32_t) * n, stream) != hipSuccess) return PO_E_HIP;
     }
     // (2) alignment, skips, envelope
     PPArgs a;
@@ -962,7 +963,7 @@ extern "C" int po_launch_pair_decode_geom(const double* y1, const int64_t* y1_of
     a.dp = (int*)(w + g.off_dp); a.dp_cap = (long long)g.dp_cap;
     a.rowinfo = (int*)(w + g.off_rows); a.row_cap = (long long)g.row_cap;
     a.aln = w + g.off_aln; a.aln_cap = (long long)g.aln_cap;
-    if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    if (po_zero_async(a.queue, 256, stream) != hipSuccess) return PO_E_HIP;
     po_prof_stage(PO_K_ALIGN, stream, 1, &tok);
     pp_launch(a, g.blocks, g.one_wave, stream, mr2 + 8);
     if (g.big_blocks > 0 && !opt->diagonal_envelope) {   // pairs whose basecalls did not fit the first pass's slices (none, usually)
@@ -1055,7 +1056,7 @@ extern "C" int po_launch_align_scores(const char* seqs, const int64_t* seq_off, 
     a.dp = (int*)(w + o); o += al256(sizeof(int) * (size_t)a.dp_cap * blocks);
     a.row_cap = (long long)(max_len1 + 2); a.rowinfo = (int*)(w + o); o += al256(sizeof(int) * 4 * (size_t)a.row_cap * blocks);
     a.aln_cap = (long long)(max_len1 + max_len2 + 16); a.aln = w + o;
-    if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    if (po_zero_async(a.queue, 256, stream) != hipSuccess) return PO_E_HIP;
     pp_launch(a, blocks, one_wave, stream, max_len2);
     return PO_OK;
 }
@@ -1086,7 +1087,7 @@ extern "C" int po_launch_envelope(const char* aln1, const char* aln2, const int6
     a.cap_flag = a.queue + 32;
     a.aln_cap = (long long)(max_ncol + 16); a.aln = w + 256;
     a.dp = nullptr; a.dp_cap = 0; a.rowinfo = (int*)w; a.row_cap = 0;
-    if (hipMemsetAsync(a.queue, 0, 256, stream) != hipSuccess) return PO_E_HIP;
+    if (po_zero_async(a.queue, 256, stream) != hipSuccess) return PO_E_HIP;
     pp_launch(a, blocks, one_wave, stream);
     return PO_OK;
 }

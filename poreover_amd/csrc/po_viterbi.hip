@@ -10,6 +10,8 @@
 // bytes per instruction; all loads of a 512-frame tile are issued before the first use), the
 // per-frame argmax is taken from LDS, and the emitted bases are compacted with a wave scan plus a
 // 4-entry LDS scan across waves.
+#include <cstdlib>
+
 #include "po_device.h"
 
 #define VT_THREADS 256
@@ -41,16 +43,19 @@ __device__ __forceinline__ int block_exclusive_count(bool flag, int* wsum, int* 
 // issues its VT_LD = 10 coalesced 8-byte loads of the tile back to back BEFORE the first use, so a
 // workgroup keeps 20 KB in flight and a CU (6 resident workgroups) ~120 KB — enough to cover HBM
 // latency.  Every thread then decodes VT_FPT = 2 consecutive frames from LDS.
+// THREADS = 256 (four waves, the 512-frame tile above) or 64: ONE wave, a 128-frame tile and 5 KB of LDS — the form that finds
+// room next to a device full of one-wave pair beam workgroups (the pipelined job: wave k + 1's Viterbi pass runs while wave k's
+// pair beam kernel holds the device; a four-wave workgroup with 21 KB of LDS waits for a CU to drain).
 #define VT_FPT 2
-#define VT_TILE (VT_THREADS * VT_FPT)
 #define VT_CMAX (PO_A + 1)
-#define VT_LD ((VT_TILE * VT_CMAX) / VT_THREADS)
-__global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void viterbi_ctc_kernel(
     const double* __restrict__ y, const int64_t* __restrict__ y_off, int C, uint32_t alphabet, int kind,
     int8_t* __restrict__ path, char* __restrict__ seq, const int64_t* __restrict__ seq_off, int so_base,
     int so_stride, int32_t* __restrict__ seq_len, int32_t* __restrict__ map, int32_t* __restrict__ status) {
+    constexpr int VT_WAVES_ = THREADS / PO_WAVE, VT_TILE = THREADS * VT_FPT, VT_LD = (VT_TILE * VT_CMAX) / THREADS;
     __shared__ double tile[VT_TILE * VT_CMAX];
-    __shared__ int wsum[VT_WAVES];
+    __shared__ int wsum[VT_WAVES_];
     __shared__ int8_t pth[VT_TILE + 1];  // pth[0] = last state of the previous tile
     const int r = blockIdx.x, tid = threadIdx.x;
     const int64_t r0 = y_off[r];
@@ -89,13 +94,13 @@ __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
         const int nval2 = nval >> 1;
 #pragma unroll
         for (int q = 0; q < VT_LD / 2; ++q) {
-            const int i = tid + q * VT_THREADS;
+            const int i = tid + q * THREADS;
             reg[q] = (i < nval2) ? src2[i] : make_double2(0.0, 0.0);
         }
         const double tail = (nval & 1) ? src[nval - 1] : 0.0;   // odd number of values in a short last tile
 #pragma unroll
         for (int q = 0; q < VT_LD / 2; ++q) {
-            const int i = tid + q * VT_THREADS;
+            const int i = tid + q * THREADS;
             if (i < nval2) { tile[2 * i] = reg[q].x; tile[2 * i + 1] = reg[q].y; }
         }
         if ((nval & 1) && tid == 0) tile[nval - 1] = tail;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(VT_THREADS) void viterbi_ctc_kernel(
             __syncthreads();
             int base = 0, tot = 0;
 #pragma unroll
-            for (int w = 0; w < VT_WAVES; ++w) {
+            for (int w = 0; w < VT_WAVES_; ++w) {
                 const int c = wsum[w];
                 if (w < wave) base += c;
                 tot += c;
@@ -331,7 +336,13 @@ extern "C" int po_launch_viterbi_strided(const double* y, const int64_t* y_off, 
     }
     if (kind != PO_KIND_POREOVER && kind != PO_KIND_BONITO) return PO_E_ARG;
     if (C != A + 1) return PO_E_ARG;
-    hipLaunchKernelGGL(viterbi_ctc_kernel, dim3(n), dim3(VT_THREADS), 0, stream, y, y_off, C, alphabet, kind, path, seq,
-                       seq_off, so_base, so_stride, seq_len, map, status);
+    // (PO_VT_THREADS=256: the four-wave form, for A/B)
+    static const int vt_threads = [] { const char* e = getenv("PO_VT_THREADS"); return (e && atoi(e) == 256) ? 256 : 64; }();
+    if (vt_threads == 256)
+        hipLaunchKernelGGL(viterbi_ctc_kernel<256>, dim3(n), dim3(256), 0, stream, y, y_off, C, alphabet, kind, path, seq,
+                           seq_off, so_base, so_stride, seq_len, map, status);
+    else
+        hipLaunchKernelGGL(viterbi_ctc_kernel<64>, dim3(n), dim3(64), 0, stream, y, y_off, C, alphabet, kind, path, seq,
+                           seq_off, so_base, so_stride, seq_len, map, status);
     return PO_OK;
 }
