@@ -701,7 +701,11 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
     int k_pslot = -2, k_sym = 0;
     bool k_samef = false, k_dup = false;
 #ifdef PO_B1_COUNT
-    int cnt_fast = 0, cnt_same = 0;
+    int cnt_fast = 0, cnt_same = 0, cnt_gen = 0;
+    long long tk_run = 0, tk_gen = 0, tk_last = wall_clock64();
+#define B1_KT(x) do { const long long n_ = wall_clock64(); (x) += n_ - tk_last; tk_last = n_; } while (0)
+#else
+#define B1_KT(x) do {} while (0)
 #endif
     for (int t = 1; t < T; ++t) {
         const bool first = (t == 1);
@@ -748,11 +752,13 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
                 if (t >= T) break;
                 if ((t & 31) == 0) { y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync(); }
             }
+            B1_KT(tk_run);
             if (t >= T) break;
             yrow = &yblk[(t >> 5) & 1][t & 31][0];
         }
 #ifdef PO_B1_COUNT   // debugging builds: how many frames of read 0 take which path
         if (fastf) ++cnt_fast;
+        ++cnt_gen;
 #endif
         int q_id, q_depth, q_fc, par, gpar, plast, last, pslot, slot = -2, s_self, s_parent, sym;
         bool samef, expanded = false;
@@ -948,9 +954,10 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         if (MODEL == PO_MODEL_CTC) blank_cum += yrow[A];
         Pnb = Wc;
         Wc = Wn;
+        B1_KT(tk_gen);
     }
 #ifdef PO_B1_COUNT
-    if (r == 0 && lane == 0) printf("[b1 count] read 0: %d frames, %d on the steady table, %d kept the beam\n", T, cnt_fast, cnt_same);
+    if (r == 0 && lane == 0) printf("[b1 count] read 0: %d frames, %d on the steady table, %d kept the beam; run loop %lld ticks (10 ns), general frames %lld ticks in %d frames\n", T, cnt_fast, cnt_same, tk_run, tk_gen, cnt_gen);
 #endif
     // ---- label of the top node (PrefixTree::get_label, PrefixTree.h:449-457)
     const int top = __builtin_amdgcn_readlane(selv, 0);

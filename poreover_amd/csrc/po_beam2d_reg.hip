@@ -300,6 +300,23 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             sm.f_fc[s] = -1; sm.f_crow2[s] = -1; sm.f_par[s] = 0; sm.f_gpar[s] = -1; sm.f_prow2[s] = -1;
             sm.f_depth[s] = (s < A) ? 1 : 0; sm.f_alias[s] = -1;
         }
+        // (emulator builds with -DPO_EMU_SHADOW: what rounds 1 - 4's TAGS would have answered, kept beside the store — every read's
+        //  `present` is checked against it, and the first disagreement is reported)
+#ifdef PO_EMU_SHADOW
+        int sh_step = -1, sh_u = -1, sh_v = -1;
+        auto sh_key = [&](int r, int row2, int tq) -> unsigned long long { return ((unsigned long long)(unsigned)slotid << 40) | (unsigned long long)t2_off(r, row2, tq); };
+        auto sh_write = [&](int r, int row2, int tq, int node) { po_emu_shadow_put(sh_key(r, row2, tq), ((unsigned long long)(unsigned)pi << 48) | ((unsigned long long)(unsigned)node << 24) | (unsigned)tq); };
+        auto sh_chk = [&](int r, int row2, int tq, bool present, int node, int site) {
+            if (tq < 0 || row2 < 0) return;
+            const bool hit = po_emu_shadow_get(sh_key(r, row2, tq)) == (((unsigned long long)(unsigned)pi << 48) | ((unsigned long long)(unsigned)node << 24) | (unsigned)tq);
+            if (hit != present) printf("SHADOW site %d pair %d lane %d read %d row2 %d t %d node %d: present %d, a tag would %s (step %d, u %d v %d)\n", site, pi, (int)lane, r, row2, tq, node, (int)present, hit ? "HIT" : "MISS", sh_step, sh_u, sh_v);
+        };
+#define SH_WRITE(r, row2, tq, node) sh_write(r, row2, tq, node)
+#define SH_CHK(r, row2, tq, present, node, site) sh_chk(r, row2, tq, present, node, site)
+#else
+#define SH_WRITE(r, row2, tq, node) do {} while (0)
+#define SH_CHK(r, row2, tq, present, node, site) do {} while (0)
+#endif
         bool live = false;
         // values of a read: computed and stored up to v_done (exclusive); v_fresh: 1 = an element again, its last
         // value is in the store; 2 = a node that never computed
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     root_values<MODEL>(-1, 0.0, pp);
                     po_update<MODEL>(sp, pp, yr[s], (MODEL == PO_MODEL_FLIPFLOP) ? yr[s + A] : yr[A], false, true, out.v, lae);
                 }
-                t2_write(r, e_row2, 0, out);
+                t2_write(r, e_row2, 0, out); SH_WRITE(r, e_row2, 0, e_id);
                 v_done[q] = 1; v_fresh[q] = 0; v_self[q] = out;
                 v_mx[q] = out.v[0]; v_mt[q] = 0; v_td[q] = 0;   // (the window maximum over [0, 1))
                 if (MODEL == PO_MODEL_CTC && s == 0) { sm.rootcum[r] = 0.0 + yr[A]; sm.rootT[r] = 0; }   // (serial in t from 0.0, as the reference adds)
@@ -420,6 +437,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         // ballots.
         auto carried_one = [&](int r, int ws, double& cmx, int& cmt, int td, int pf_t = -1, double pf_val = 0.0) -> bool {
             if (td > ws) return true;
+            if (ws != pf_t) SH_CHK(r, e_row2, ws, true, e_id, 1);
             cmx = (ws == pf_t) ? pf_val : read_own(r, ws);
             cmt = ws;
             return false;
@@ -439,6 +457,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     const int tq = base + lane;
                     const bool valid = tq < teL;
                     double val = PO_NEG_INF;
+                    { const int idL_ = __builtin_amdgcn_readlane(e_id, L); (void)idL_; if (valid) SH_CHK((NR == 1) ? (L >> 5) : q, rowL, tq, true, idL_, 2); }
                     if (valid) val = *(const double*)(poolb + (size_t)(unsigned)((rowbase + (tq & Rm2)) * EB));   // (the lane computed every one of them)
                     const double mxv = po_wave_max(val);
                     const unsigned long long eq = __ballot(valid && val == mxv);   // (later times win ties: the highest lane)
@@ -481,6 +500,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             if (part) {
                 if (v_fresh[q] != 0) {
                     start = ws;
+                    if (v_fresh[q] == 1) SH_CHK(r, e_row2, start - 1, start - 1 < *hdr_of(r, e_row2), e_id, 3);
                     if (v_fresh[q] == 1) self = read_own_all(r, start - 1, start - 1 < *hdr_of(r, e_row2));   // (an element again: the header knows)
                 } else if (start > v_done[q]) {
                     // a gap (catch-ups went beyond the last window): the value at start - 1 was never computed
@@ -507,7 +527,13 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             // first iteration, then at the time it computed last)
             const int plane = (e_ps >= 0) ? (hb | e_ps) : lane;
             const int p_start = __shfl(part2 ? start : INT_MAX, plane), p_we = __shfl(part2 ? we : INT_MIN, plane);
-            const int p_done = __shfl(v_fresh[q] == 0 ? v_done[q] : RK_FRESH, plane);   // where the parent's STORED values end (an element's)
+            // where the parent's STORED values end: an element's v_done; an element AGAIN that has not computed since (a child slot
+            // during catch-up steps, which only the beam nodes take part in) still has what it stored before it left — its row's
+            // header says up to where (the round-5 fuzz: a beam node's catch-up read of such a parent was answered "absent")
+            int own_end = RK_FRESH;
+            if (live && v_fresh[q] == 0) own_end = v_done[q];
+            else if (live && v_fresh[q] == 1 && e_row2 >= 0) own_end = *hdr_of(r, e_row2);
+            const int p_done = __shfl(own_end, plane);
             int tm_ = part2 ? start : INT_MAX;
 #pragma unroll
             for (int off = NS / 2; off >= 1; off >>= 1) tm_ = min(tm_, __shfl_xor(tm_, off));
@@ -532,7 +558,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         PVal pp;
                         if (e_ps >= 0) {
                             if (tm >= p_start - 1 && tm < p_we && p_start != INT_MAX) pp = ps_self;
-                            else pp = pval_of(t2_read(r, sm.f_prow2[s], tm, tm < p_done));
+                            else { SH_CHK(r, sm.f_prow2[s], tm, tm < p_done, sm.f_par[s], 4); pp = pval_of(t2_read(r, sm.f_prow2[s], tm, tm < p_done)); }
                         } else if (e_ps == PS_ROOT) {
                             // (t >= 1 here: the root's children got their t = 0 at the start of the pair; the other two models'
                             //  root holds nothing at times >= 0)
@@ -545,13 +571,14 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                             pp = (tm == fz_t[q]) ? fzv : pval_neg();                            // frozen parent: its last value, then nothing
                         } else {   // a frozen parent's older values: its row's header says where they end
                             const int prow = sm.f_prow2[s];
+                            SH_CHK(r, prow, tm, prow >= 0 && tm < *hdr_of(r, max(prow, 0)), sm.f_par[s], 5);
                             pp = pval_of(t2_read(r, prow, tm, prow >= 0 && tm < *hdr_of(r, max(prow, 0))));
                         }
                         const Val out = upd(self, pp, ya, yb, same);
 #ifdef PO_RING_TRACE_NODE
                         if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g G ps %d fzt %d main %d\n", e_id, r, t, out.v[0], pp.v[0], self.v[0], e_ps, fz_t[q], (int)is_main);
 #endif
-                        t2_write(r, e_row2, t, out);
+                        t2_write(r, e_row2, t, out); SH_WRITE(r, e_row2, t, e_id);
                         if (out.v[0] > self.v[0]) tr = t;   // the last time a value rose
                         self = out;
                         mt = (out.v[0] >= mx) ? t : mt;
@@ -645,8 +672,8 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             // (the same registers, other lanes: a continuing beam lane whose window maximum has left the window and whose
             //  values fall — the run that follows this step asks for its value at ws first thing)
             const bool want_pf = cont && s < nb && v_done[q] > ws && v_mx[q] != PO_NEG_INF && v_mt[q] < ws && v_td[q] <= ws;
-            if (want_seed) { se = t2_load(r, e_row2, ws - 1); se_hdr = *hdr_of(r, e_row2); }
-            else if (want_pf) se = t2_load(r, e_row2, ws);
+            if (want_seed) { se = t2_load(r, e_row2, ws - 1); se_hdr = *hdr_of(r, e_row2); SH_CHK(r, e_row2, ws - 1, ws - 1 < se_hdr, e_id, 6); }
+            else if (want_pf) { se = t2_load(r, e_row2, ws); SH_CHK(r, e_row2, ws, true, e_id, 7); }
             double mx = PO_NEG_INF;
             Val self = val_neg();
             int mt = -1, tr = INT_MIN;
@@ -677,6 +704,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         const int prow = __builtin_amdgcn_readlane(e_row2, jk);
                         const int pdone = __shfl(v_done[q], hb | jk);
                         ok01[k] = stg && tq >= 0 && tq < pdone;
+                        { const int pid_ = __builtin_amdgcn_readlane(e_id, jk); (void)pid_; if (stg && tq >= 0) SH_CHK(r, prow, tq, tq < pdone, pid_, 8); }
                         if (ok01[k]) e01[k] = t2_load(r, prow, tq);
                     }
                 }
@@ -693,7 +721,9 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                     const int jk = pj(k);
                     const int prow = __builtin_amdgcn_readlane(e_row2, jk);
                     const int pdone = __shfl(v_done[q], hb | jk);
+                    const int pid9_ = __builtin_amdgcn_readlane(e_id, jk); (void)pid9_;
                     if (stg) {
+                        SH_CHK(r, prow, tq, tq < pdone, pid9_, 9);
                         const PVal val = pval_of(t2_read(r, prow, tq, tq < pdone));
                         for (int c = 0; c < KP; ++c) sm.pst[r][k * RK_NY + s][c] = val.v[c];
                     }
@@ -760,7 +790,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
 #ifdef PO_RING_TRACE_NODE
                         if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g P1\n", e_id, r, t, out.v[0], pp.v[0], self.v[0]);
 #endif
-                        t2_write(r, e_row2, t, out);
+                        t2_write(r, e_row2, t, out); SH_WRITE(r, e_row2, t, e_id);
                         if (out.v[0] > self.v[0]) tr = t;
                         self = out;
                         mt = (out.v[0] >= mx) ? t : mt;
@@ -974,6 +1004,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         const int r = RD(q);
                         const int wsn = r ? nv : nu;
                         if (rew && live && v_fresh[q] == 0 && v_done[q] > wsn) {
+                            SH_CHK(r, e_row2, wsn - 1, true, e_id, 10);
                             v_self[q] = read_own_all(r, wsn - 1, true);   // (wsn - 1 < v_done: its own)
                             v_done[q] = wsn;
                         }
@@ -998,6 +1029,9 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         KT(9);
         while (st == PO_OK && mstep < nmain) {
             int u = rec.x, v = rec.y, ce = rec.z, re = rec.w;
+#ifdef PO_EMU_SHADOW
+            sh_step = mstep; sh_u = u; sh_v = v;
+#endif
             double sc = PO_NEG_INF;
             bool viol = false, run_viol = false;
             KT(6);
@@ -1095,7 +1129,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
 #ifdef PO_RING_TRACE_NODE
                                     if (pi == 0 && e_id == PO_RING_TRACE_NODE) printf("V %d %d %d %.17g %.17g %.17g RUN ps %d fzt %d\n", e_id, r, t, out.v[0], pp.v[0], self.v[0], e_ps, fz_t[q]);
 #endif
-                                    t2_write(r, e_row2, t, out);
+                                    t2_write(r, e_row2, t, out); SH_WRITE(r, e_row2, t, e_id);
                                     if (out.v[0] > self.v[0]) tr[q] = t;
                                     self = out;
                                     mt[q] = (out.v[0] >= mx[q]) ? t : mt[q];
@@ -1164,7 +1198,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         const int r = RD(q);
                         const int wsn = r ? rec.y : rec.x;
                         pf_t[q] = -1;
-                        if (live && (!child || hot[q]) && v_done[q] > wsn && v_mx[q] != PO_NEG_INF && v_mt[q] < wsn) { pf_t[q] = wsn; pf_e[q] = t2_load0(r, e_row2, wsn); }
+                        if (live && (!child || hot[q]) && v_done[q] > wsn && v_mx[q] != PO_NEG_INF && v_mt[q] < wsn) { pf_t[q] = wsn; pf_e[q] = t2_load0(r, e_row2, wsn); SH_CHK(r, e_row2, wsn, true, e_id, 11); }
                     }
                     KC(12, 1);
                     if (__ballot(viol) != 0ull) { run_viol = true; break; }

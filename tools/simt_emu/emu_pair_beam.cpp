@@ -50,6 +50,9 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     a.no_cum = 1;
     for (int i = 0; i < n; ++i) status[i] = PO_OK;
     const bool vb = getenv("EMU_VERBOSE") != nullptr;
+#ifdef PO_EMU_SHADOW
+    po_emu_shadow_reset();
+#endif
     if (vb) fprintf(stderr, "[emu] prepass\n");
     if (model == PO_MODEL_CTC) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_CTC>, dim3(n), dim3(64), 0, nullptr, a);
     else if (model == PO_MODEL_MERGE) hipLaunchKernelGGL(beam2d_prepass_kernel<PO_MODEL_MERGE>, dim3(n), dim3(64), 0, nullptr, a);

@@ -167,3 +167,21 @@ template <class T> static inline T atomicExch(T* p, T v) { const T o = *p; *p = 
 template <class T> static inline T atomicCAS(T* p, T c, T v) { const T o = *p; if (o == c) *p = v; return o; }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+
+// -DPO_EMU_SHADOW: a tag per store address beside the emulated store (what rounds 1 - 4 kept IN the store), for checking the
+// presence bookkeeping of the tag-free entries against it
+#ifdef PO_EMU_SHADOW
+#include <unordered_map>
+static inline std::unordered_map<unsigned long long, unsigned long long>& po_emu_shadow_map() {
+    static std::unordered_map<unsigned long long, unsigned long long> m;
+    return m;
+}
+static inline void po_emu_shadow_reset() { po_emu_shadow_map().clear(); }   // (per emulated launch: tags of an earlier launch's pairs must not hit)
+static inline void po_emu_shadow_put(unsigned long long key, unsigned long long tag) { po_emu_shadow_map()[key] = tag; }
+static inline unsigned long long po_emu_shadow_get(unsigned long long key) {
+    auto& m = po_emu_shadow_map();
+    auto it = m.find(key);
+    return it == m.end() ? ~0ull : it->second;
+}
+#endif
+
