@@ -702,7 +702,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
     bool k_samef = false, k_dup = false;
 #ifdef PO_B1_COUNT
     int cnt_fast = 0, cnt_same = 0, cnt_gen = 0;
-    long long tk_run = 0, tk_gen = 0, tk_last = wall_clock64();
+    long long tk_run = 0, tk_gen = 0, tk_last = wall_clock64(), tk_a = 0, tk_b = 0, tk_c = 0, tk_d = 0, tk_f = 0; int cnt_ff = 0, cnt_refetch = 0, cnt_tie = 0, cnt_S = 0, cnt_rankf = 0;
 #define B1_KT(x) do { const long long n_ = wall_clock64(); (x) += n_ - tk_last; tk_last = n_; } while (0)
 #else
 #define B1_KT(x) do {} while (0)
@@ -789,17 +789,25 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             if (!first) {   // the parent's slot in the previous table: a beam slot, or a child of its grand-parent's
                 // (the same pass over the previous beam's ids finds, for a child lane, its node's previous beam slot: its
                 //  id is known before the expansion whenever its parent is not new)
+                // (this kernel's beam has at most 12 slots: the passes over the beam's ids are unrolled over constant lanes — a
+                //  lone wave paid ~ 60 cycles per trip of the v_readlane loops these were, and there are five of them per
+                //  beam change: 40 % of the kernel at W = 10)
                 int ps1 = -2, ps2 = -2;
-                for (int i = 0; i < Pnb; ++i) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
                     const int bid = __builtin_amdgcn_readlane(p_id, i);
-                    if (bid == par) ps1 = i;
-                    if (bid == gpar) ps2 = Pnb + A * i + plast;
-                    if (bid == xpre) sl0 = i;
+                    const bool in = i < Pnb;
+                    if (in && bid == par) ps1 = i;
+                    if (in && bid == gpar) ps2 = Pnb + A * i + plast;
+                    if (in && bid == xpre) sl0 = i;
                 }
                 if (src < Pnb && par != 0) pslot = (ps1 >= 0) ? ps1 : ps2;
             }
         }
         const bool refetch = rb && q_fc == -2;
+#ifdef PO_B1_COUNT
+        if (__ballot(refetch) != 0ull) ++cnt_refetch;
+#endif
         if (refetch) q_fc = afc[q_id];   // re-entered the beam: the arena remembers
         // ---- expansion: A fresh ids per beam node that has never had children, in beam order
         const bool need = rb && (q_fc == -1);
@@ -846,6 +854,9 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         sym = rb ? last : c;
         samef = rb ? (plast == last) : (pj_last == c);
         }
+#ifdef PO_B1_COUNT
+        { const long long n_ = wall_clock64(); if (fastf) { tk_f += n_ - tk_last; ++cnt_ff; } else tk_a += n_ - tk_last; tk_gen += n_ - tk_last; tk_last = n_; }
+#endif
         // ---- one update for every slot of the new table
         double sp[3], pp[3], out[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
 #pragma unroll
@@ -863,49 +874,74 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         const double ya = yrow[(rb || rc) ? sym : 0], yb = yrow[(MODEL == PO_MODEL_FLIPFLOP) ? ((rb || rc) ? sym + A : 0) : A];
         if (rb || rc)
             po_update<MODEL>(sp, pp, ya, yb, samef, false, out, lae);
+#ifdef PO_B1_COUNT
+        { const long long n_ = wall_clock64(); tk_b += n_ - tk_last; tk_gen += n_ - tk_last; tk_last = n_; }
+#endif
         // ---- prune (Beam.h:93-108): a child slot whose node is also a beam slot is the same node pushed twice
         bool dupf = fastf ? k_dup : false;
         const double sc = out[0];
-        double thr = PO_NEG_INF;
-        if (!fastf) {
-            thr = rg1_readlane_d(sc, 0);
-            for (int i = 0; i < Wc; ++i) {   // (one pass over the beam lanes: duplicate test and the smallest beam score)
+        if (!fastf) {   // (the duplicate test: one pass over the beam lanes' ids)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
                 const int bid = __builtin_amdgcn_readlane(q_id, i);
-                if (rc && bid == q_id) dupf = true;
-                thr = fmin(thr, rg1_readlane_d(sc, i));
+                if (i < Wc && rc && bid == q_id) dupf = true;
             }
         }
         const bool valid = (rb || rc) && !dupf;
+        // the smallest beam score: the beam lanes sit in row 0 of the wave (W <= 12) — four DPP steps
+        const double scmin = b1_row0_min(rb ? sc : HUGE_VAL);
+        double thr = scmin;
         // the beam as it was?  (strictly: exact ties go through the ranking, as partial_sort decides them)
         bool same_beam = false;
-        if (Wc == W && t != T - 1) {
-            const double scmin = b1_row0_min(rb ? sc : HUGE_VAL);
-            same_beam = (__ballot(rc && valid && !(scmin > sc)) == 0ull);
-        }
+        if (Wc == W && t != T - 1) same_beam = (__ballot(rc && valid && !(scmin > sc)) == 0ull);
         int Wn = Wc, nsel = lane;   // lane jx < Wn: the slot of the candidate of rank jx
 #ifdef PO_B1_COUNT
         if (same_beam) ++cnt_same;
 #endif
         if (!same_beam) {
-        if (fastf) {   // (the smallest beam score was not needed for the test above)
-            thr = rg1_readlane_d(sc, 0);
-            for (int i = 1; i < Wc; ++i) thr = fmin(thr, rg1_readlane_d(sc, i));
-        }
-        if (Wc != W) thr = PO_NEG_INF;
-        const bool inS = valid && (rb || sc >= thr);
+        // Only candidates at or above a score that W DISTINCT candidates reach can be among the W best, and their ranks among
+        // themselves are their ranks.  The W beam continuations give such a score (the smallest of them) — but in the frames
+        // that change the beam most children are above the weakest beam node: 35 of 50 candidates went through the ranking
+        // loop on average.  The best member of every FAMILY (a beam node and its A children) gives a higher one: W distinct
+        // candidates again, and the loop sees the 11 - 14 that matter.
+        if (Wc == W) {
+            const double vs = valid ? sc : PO_NEG_INF;
+            double fam = rb ? sc : PO_NEG_INF;
+            for (int cc = 0; cc < A; ++cc) {   // (wave-uniform; every lane takes part in the permute)
+                const int cl = min(Wc + A * min(lane, Wc - 1) + cc, PO_WAVE - 1);
+                const double v = __shfl(vs, cl);
+                if (rb) fam = fmax(fam, v);
+            }
+            thr = b1_row0_min(rb ? fam : HUGE_VAL);
+        } else thr = PO_NEG_INF;
+        const bool inS = valid && sc >= thr;
         const unsigned long long smk = __ballot(inS);
         const int kept = __popcll(__ballot(valid));
+#ifdef PO_B1_COUNT
+        cnt_S += __popcll(smk); ++cnt_rankf;
+#endif
         int rank = 0, neq = 0;
-        for (unsigned long long mm = smk; mm != 0ull; mm &= mm - 1ull) {
-            const int o = __builtin_ctzll(mm);
+        auto versus = [&](int o, bool on) {   // candidate o against this lane's
             const double so = rg1_readlane_d(sc, o);
             const int io = __builtin_amdgcn_readlane(q_id, o);
-            rank += ((so > sc) | (!(sc > so) & (io < q_id))) ? 1 : 0;
-            neq += (so == sc) ? 1 : 0;
+            rank += (on && ((so > sc) | (!(sc > so) & (io < q_id)))) ? 1 : 0;
+            neq += (on && so == sc) ? 1 : 0;
+        };
+        for (unsigned long long mm = smk; mm != 0ull;) {   // (two candidates per trip: half the branches, the lane reads overlap)
+            const int o1 = __builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            const bool two = mm != 0ull;
+            const int o2 = two ? __builtin_ctzll(mm) : o1;
+            mm &= mm - 1ull;   // (0 stays 0)
+            versus(o1, true);
+            versus(o2, two);
         }
         Wn = min(W, kept);
         nsel = 0;
         if (__ballot(inS && neq > 1 && rank < W) != 0ull) {
+#ifdef PO_B1_COUNT
+            ++cnt_tie;
+#endif
             // exact ties reaching into the beam: libstdc++'s partial_sort / sort on the candidates in node-id order
             int pos = 0;
             for (int o = 0; o < NCc; ++o) {
@@ -923,14 +959,18 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             po_wave_sync();
             nsel = ord[min(lane, 63)];
             po_wave_sync();
-        } else {
-            for (int jx = 0; jx < Wn; ++jx) {
-                const unsigned long long bj = __ballot(inS && rank == jx);
-                const int sj = (bj != 0ull) ? (int)__builtin_ctzll(bj) : 0;
-                if (lane == jx) nsel = sj;
-            }
+        } else {   // (no tie reaches into the beam: the ranks below W are taken once each — rank r's slot goes to lane r through LDS)
+            ord[lane] = 0;
+            po_wave_sync();
+            if (inS && rank < Wn) ord[rank] = lane;
+            po_wave_sync();
+            if (lane < Wn) nsel = ord[lane];
+            po_wave_sync();
         }
         }
+#ifdef PO_B1_COUNT
+        { const long long n_ = wall_clock64(); tk_c += n_ - tk_last; tk_gen += n_ - tk_last; tk_last = n_; }
+#endif
         // ---- the new table becomes the previous one
         p_id = q_id; p_fc = q_fc; p_depth = q_depth;
 #pragma unroll
@@ -942,10 +982,12 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             // path above knows it in the previous one) — the beam nodes' by one more pass over the beam's ids, a child's is
             // its beam node's lane.  Nothing will be expanded then: every beam node of this table has its children now.
             int ps1 = -2, ps2 = -2;
-            for (int i = 0; i < Wc; ++i) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
                 const int bid = __builtin_amdgcn_readlane(q_id, i);
-                if (bid == par) ps1 = i;
-                if (bid == gpar) ps2 = Wc + A * i + plast;
+                const bool in = i < Wc;
+                if (in && bid == par) ps1 = i;
+                if (in && bid == gpar) ps2 = Wc + A * i + plast;
             }
             k_pslot = (par == 0) ? -1 : ((ps1 >= 0) ? ps1 : ps2);
             k_sym = sym; k_samef = samef; k_dup = dupf;
@@ -957,7 +999,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         B1_KT(tk_gen);
     }
 #ifdef PO_B1_COUNT
-    if (r == 0 && lane == 0) printf("[b1 count] read 0: %d frames, %d on the steady table, %d kept the beam; run loop %lld ticks (10 ns), general frames %lld ticks in %d frames\n", T, cnt_fast, cnt_same, tk_run, tk_gen, cnt_gen);
+    if (r == 0 && lane == 0) printf("[b1 count] read 0: %d frames, %d on the steady table, %d kept the beam; run loop %lld ticks (10 ns), general frames %lld ticks in %d frames (%d on a steady table: %lld ticks to the update; rebuild %lld, update %lld, prune + rank %lld, rest %lld; arena lookups in %d frames, tie replays in %d; %d ranking frames, %d candidates ranked in all)\n", T, cnt_fast, cnt_same, tk_run, tk_gen, cnt_gen, cnt_ff, tk_f, tk_a, tk_b, tk_c, tk_gen - tk_f - tk_a - tk_b - tk_c, cnt_refetch, cnt_tie, cnt_rankf, cnt_S);
 #endif
     // ---- label of the top node (PrefixTree::get_label, PrefixTree.h:449-457)
     const int top = __builtin_amdgcn_readlane(selv, 0);
