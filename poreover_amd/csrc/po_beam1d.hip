@@ -452,6 +452,21 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             cand[s] = c;
         }
         po_wave_sync();   // (one wave per read)
+        // the smallest FAMILY maximum (a beam node and its non-duplicate children: W distinct candidates reach it — see
+        // beam1d_wave_kernel): the threshold of the two-stage selects below
+        auto family_threshold = [&]() -> double {
+            double fam = HUGE_VAL;
+            if (lane < Wc) {
+                fam = cand[lane].sc;
+                for (int cc = 0; cc < A; ++cc) {
+                    const int cs = Wc + A * lane + cc;
+                    if (cs < NCc && !dup[cs]) fam = fmax(fam, cand[cs].sc);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) fam = fmin(fam, __shfl_xor(fam, off));
+            return fam;
+        };
         int kept = 0;
         bool tie = false;
         // Two-stage select (tables of at most 64 candidates: W <= 12).  When the beam is full, its W own continuations
@@ -464,11 +479,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             const bool valid = (s < NCc) && !dup[s];
             const B1Cand me = cand[min(s, NCc - 1)];
             double thr = PO_NEG_INF;
-            if (Wc == W) {
-                thr = cand[0].sc;
-                for (int j = 1; j < Wc; ++j) thr = fmin(thr, cand[j].sc);
-            }
-            const bool inS = valid && (s < Wc || me.sc >= thr);
+            if (Wc == W) thr = family_threshold();
+            const bool inS = valid && me.sc >= thr;
             const unsigned long long sm_ = __ballot(inS);
             kept = __popcll(__ballot(valid));
             int rank = 0, neq = 0;
@@ -482,8 +494,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
         } else if (NCc <= 2 * PO_WAVE && Wc == W && Wc <= PO_WAVE) {
             // the same two-stage select for tables of up to 128 candidates (W <= 25): a lane holds two slots, the set
             // {beam slots} + {children >= the smallest beam score} is two ballot masks, the ranks are taken within it
-            double thr = cand[0].sc;
-            for (int j = 1; j < Wc; ++j) thr = fmin(thr, cand[j].sc);
+            const double thr = family_threshold();   // (Wc <= 64 here: one beam slot per lane)
             B1Cand me[2];
             bool val2[2], in2[2];
             unsigned long long smk[2];
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
                 const int s = lane + h * PO_WAVE;
                 val2[h] = (s < NCc) && !dup[min(s, NCc - 1)];
                 me[h] = cand[min(s, NCc - 1)];
-                in2[h] = val2[h] && (s < Wc || me[h].sc >= thr);
+                in2[h] = val2[h] && me[h].sc >= thr;
                 smk[h] = __ballot(in2[h]);
                 kept += __popcll(__ballot(val2[h]));
             }
