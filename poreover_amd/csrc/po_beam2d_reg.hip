@@ -1258,6 +1258,9 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
             // Only the beam nodes and the children that reach the smallest beam score can be among the W best (every
             // other child has W candidates above it), and nothing outside that set outranks a member of it: the ranks
             // are taken within it (a handful of candidates instead of W * (A + 1)).
+            // (the 1-D kernels' higher threshold — the smallest FAMILY maximum, a beam node and its children — was tried here in
+            //  round 5: a ranking sees 10.9 candidates at W = 5 and would see ~ 6, but the permutes that find the family maxima
+            //  cost more than the trips they save: 51.9 against 51.1 ms)
             SMask smask = cm;
             if (nb == W) {
                 const double thr = rk_row0_min(sc, nb, lane);
