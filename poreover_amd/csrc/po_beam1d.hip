@@ -727,6 +727,8 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
         const int j = rc ? (((lane - Wc) * divA) >> 16) : 0, c = rc ? (lane - Wc) - j * A : 0;   // (x / A for x < 64)
         const bool ident_in = !first && Wc == Pnb && (__ballot(rb && selv != lane) == 0ull);
         const bool fastf = stable && ident_in;
+        double o_keep[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
+        bool have_o = false;   // (wave-uniform)
         if (fastf && Wc == W) {
             // A RUN of frames on the steady table.  A lone wave pays for every instruction of a frame, and the general frame
             // below spends ~300 on a steady one; here everything a lane needs is hoisted out of the run — a frame is the
@@ -752,7 +754,12 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
                 if (act) po_update<MODEL>(p_val, pp, ya, yb, k_samef, false, o, lae);
                 const double sc = o[0];
                 const double scmin = b1_row0_min(rb ? sc : HUGE_VAL);   // (W <= 12: the beam lanes sit in row 0)
-                if (__ballot(validc && !(scmin > sc)) != 0ull) break;
+                if (__ballot(validc && !(scmin > sc)) != 0ull) {   // (the frame is ranked below: its update is this one)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) o_keep[k] = o[k];
+                    have_o = true;
+                    break;
+                }
 #pragma unroll
                 for (int k = 0; k < K; ++k) p_val[k] = o[k];
                 if (MODEL == PO_MODEL_CTC) blank_cum += yb;   // (iyb == A for this model: the blank column)
@@ -883,7 +890,10 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             for (int k = 0; k < K; ++k) sp[k] = PO_NEG_INF;
         }
         const double ya = yrow[(rb || rc) ? sym : 0], yb = yrow[(MODEL == PO_MODEL_FLIPFLOP) ? ((rb || rc) ? sym + A : 0) : A];
-        if (rb || rc)
+        if (have_o) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[k] = o_keep[k];
+        } else if (rb || rc)
             po_update<MODEL>(sp, pp, ya, yb, samef, false, out, lae);
 #ifdef PO_B1_COUNT
         { const long long n_ = wall_clock64(); tk_b += n_ - tk_last; tk_gen += n_ - tk_last; tk_last = n_; }
