@@ -29,51 +29,54 @@ __global__ __launch_bounds__(64) void beam2d_prepass_kernel(X2Args a) {
     int st = PO_OK, R = 32;
     if (U < 1 || V < 1 || U >= (1 << 24) || V >= (1 << 24)) st = PO_E_ARG;
     if (st == PO_OK) {
+        // ONE pass over the rows checks the envelope and writes the transposed one as if it were monotone (what build_envelope
+        // makes; should it turn out not to be, nothing reads what was written: the pair goes to beam2d_kernel).
+        // Transposed envelope (BeamSearch.h:270-284): the first row that covers column x starts its range and every further
+        // covering row extends it by one, i.e. [first row, first row + number of rows).  On a monotone envelope the rows covering
+        // column x are the contiguous range [a(x), b(x)], a = the first row whose end lies beyond x, b = the last row that
+        // starts at or before x: row u is a(x) for the columns between the previous row's end and its own, and b(x) for the
+        // columns between its start and the next row's — every column has one writer per bound, no atomics, no initialising
+        // pass (the columns nobody writes are known: a(x) for x at or beyond the last row's end, b(x) for x before the first
+        // row's start).
         int bad = 0, wmax = 0, nonmono = 0;
+        const int2* env2 = (const int2*)env;
         for (int u = tid; u < U; u += nthr) {
-            const int lo = env[2 * u], hi = env[2 * u + 1];
+            const int2 e = env2[u];
+            const int lo = e.x, hi = e.y;
+            const int2 ep = (u > 0) ? env2[u - 1] : make_int2(0, 0);
+            const int ln = (u + 1 < U) ? env2[u + 1].x : V;
             if (lo < hi && (lo < 0 || hi > V)) bad = 1;
-            if (lo < 0 || hi > V || (u > 0 && (lo < env[2 * u - 2] || hi < env[2 * u - 1]))) nonmono = 1;
+            if (lo < 0 || hi > V || (u > 0 && (lo < ep.x || hi < ep.y))) nonmono = 1;
             wmax = max(wmax, hi - lo);
+            const int hp = (u > 0) ? ep.y : 0;
+            for (int x = max(hp, 0); x < min(hi, V); ++x) envt[2 * x] = u;
+            for (int x = max(lo, 0); x < min(ln, V); ++x) envt[2 * x + 1] = u;
         }
+        __threadfence_block();                             // (one wave: the stores above are in memory before the loads below go out)
         if (__syncthreads_or(bad)) st = PO_E_ENVELOPE;
-        const bool mono = !__syncthreads_or(nonmono);   // row starts and ends never move backwards (what build_envelope makes)
-        if (st == PO_OK && (mono || !a.need_mono)) {
-            // transposed envelope (BeamSearch.h:270-284): the first row that covers column x starts its range
-            // and every further covering row extends it by one, i.e. [first row, first row + number of rows)
-            for (int x = tid; x < V; x += nthr) { envt[2 * x] = 0x7fffffff; envt[2 * x + 1] = mono ? -1 : 0; }
-            __syncthreads();   // (one wave: the stores above are in memory before the ones below go out)
-            if (mono) {
-                // The rows covering column x are then the contiguous range [a(x), b(x)], a = the first row whose end
-                // lies beyond x, b = the last row that starts at or before x: row u is a(x) for the columns between
-                // the previous row's end and its own, and b(x) for the columns between its start and the next
-                // row's — every column is written once, no atomics.  (the second word holds b here)
-                for (int u = tid; u < U; u += nthr) {
-                    const int lo = env[2 * u], hi = env[2 * u + 1];
-                    const int hp = (u > 0) ? env[2 * u - 1] : 0, ln = (u + 1 < U) ? env[2 * u + 2] : V;
-                    for (int x = hp; x < hi; ++x) envt[2 * x] = u;
-                    for (int x = lo; x < ln; ++x) envt[2 * x + 1] = u;
-                }
-                __syncthreads();
-                for (int x = tid; x < V; x += nthr) {
-                    const int a_ = envt[2 * x], b_ = envt[2 * x + 1];
-                    const int c = (a_ != 0x7fffffff && b_ >= a_) ? b_ - a_ + 1 : 0;
-                    envt[2 * x] = c ? a_ : -1;
-                    envt[2 * x + 1] = c ? a_ + c : -1;
-                    wmax = max(wmax, c);
-                }
-            } else {   // (a caller's own envelope, and a launch that takes it: integer atomics, order-free)
-                for (int u = tid; u < U; u += nthr) {
-                    const int lo = env[2 * u], hi = env[2 * u + 1];
-                    for (int x = lo; x < hi; ++x) { atomicMin(&envt[2 * x], u); atomicAdd(&envt[2 * x + 1], 1); }
-                }
-                __syncthreads();
-                for (int x = tid; x < V; x += nthr) {
-                    const int c = envt[2 * x + 1], f = envt[2 * x];
-                    envt[2 * x] = c ? f : -1;
-                    envt[2 * x + 1] = c ? f + c : -1;
-                    wmax = max(wmax, c);
-                }
+        const bool mono = !__syncthreads_or(nonmono);     // row starts and ends never move backwards
+        if (st == PO_OK && mono) {
+            const int lo0 = env[0], hil = env[2 * (U - 1) + 1];
+            for (int x = tid; x < V; x += nthr) {
+                const int a_ = (x < hil) ? envt[2 * x] : 0x7fffffff, b_ = (x >= lo0) ? envt[2 * x + 1] : -1;
+                const int c = (a_ != 0x7fffffff && b_ >= a_) ? b_ - a_ + 1 : 0;
+                envt[2 * x] = c ? a_ : -1;
+                envt[2 * x + 1] = c ? a_ + c : -1;
+                wmax = max(wmax, c);
+            }
+        } else if (st == PO_OK && !a.need_mono) {   // (a caller's own envelope, and a launch that takes it: integer atomics, order-free)
+            for (int x = tid; x < V; x += nthr) { envt[2 * x] = 0x7fffffff; envt[2 * x + 1] = 0; }
+            __syncthreads();
+            for (int u = tid; u < U; u += nthr) {
+                const int lo = env[2 * u], hi = env[2 * u + 1];
+                for (int x = lo; x < hi; ++x) { atomicMin(&envt[2 * x], u); atomicAdd(&envt[2 * x + 1], 1); }
+            }
+            __syncthreads();
+            for (int x = tid; x < V; x += nthr) {
+                const int c = envt[2 * x + 1], f = envt[2 * x];
+                envt[2 * x] = c ? f : -1;
+                envt[2 * x + 1] = c ? f + c : -1;
+                wmax = max(wmax, c);
             }
         }
         if (st == PO_OK) {
