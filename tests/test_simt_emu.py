@@ -100,3 +100,9 @@ def test_tag_free_store_answers_what_tags_would(oracle):
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
         assert "0 mismatches" in out.stdout
         assert "SHADOW" not in out.stdout and "SHADOW" not in out.stderr, (out.stdout + out.stderr)[-2000:]
+    # ... and eight pairs one after the other through ONE slice of the store: nothing an earlier pair left may be read as present
+    out = subprocess.run([sys.executable, os.path.join(EMU, "check_emu.py"), "--n", "16", "--T", "400", "--W", "5", "--model", "flipflop", "--seed", "78",
+                          "--procs", "2", "--kernel", "reg", "--batch", "8", "--slots", "1", "--lib", lib], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "0 mismatches" in out.stdout
+    assert "SHADOW" not in out.stdout and "SHADOW" not in out.stderr, (out.stdout + out.stderr)[-2000:]

@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--lib", default=os.path.join(HERE, "_build", "libemu_pair_beam.so"))
     ap.add_argument("--styles", default="pipeline,stairs,wobble,bursts")
     ap.add_argument("--batch", type=int, default=1, help="pairs per emulated launch (with as many pair slots)")
+    ap.add_argument("--slots", type=int, default=0, help="with --batch: pair slots of the emulated launch (0 = one per pair; 1 = every pair of a "
+                    "batch goes through ONE slice of the value store, one after the other)")
     ap.add_argument("--kernel", default="reg", help="reg (kept for old command lines)")
     ap.add_argument("--model", default=MODEL[0], help="ctc | merge | flipflop (the register-state kernel serves all three)")
     args = ap.parse_args()
@@ -128,7 +130,7 @@ def main():
             for W_, idx in groups.items():
                 for b in range(0, len(idx), args.batch):
                     part = idx[b:b + args.batch]
-                    jobs2.append(([keep[i][0] for i in part], W_, args.lib, kid, len(part))); where.append(part)
+                    jobs2.append(([keep[i][0] for i in part], W_, args.lib, kid, args.slots if args.slots > 0 else len(part))); where.append(part)
             for part, out in zip(where, pool.map(run_emu_batch, jobs2)):
                 for i, o in zip(part, out):
                     res[i] = o
