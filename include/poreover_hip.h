@@ -86,7 +86,7 @@ int po_device_info(int device, char* name, int name_cap, int* compute_units, int
  * (Values 1 and 3 named the two-pairs-per-wave and LDS-ring kernels of rounds 1 - 4, retired in round 5: PO_E_ARG.) */
 #define PO_ROUTE_AUTO 0
 #define PO_ROUTE_LEGACY 2
-#define PO_ROUTE_REG 4   /* beam2d_reg_kernel: element state in registers, values in the tagged HBM store */
+#define PO_ROUTE_REG 4   /* beam2d_reg_kernel: element state in registers, values in the (tag-free) HBM store */
 /* defer_odd bits 1 and 2 (values 2, 4) are further test hooks of that hand-over: the kernel runs with a dozen row groups /
  * with a tree arena of a few nodes, so that pairs run out of them and are handed on (tests/test_gpu_parity_2d.py). */
 int po_set_pair_route(int route, int defer_odd);
@@ -387,7 +387,7 @@ void po_event_destroy(void* ev);
 #define PO_K_BEAM2D 2
 #define PO_K_ALIGN 3
 #define PO_K_ENVELOPE 4
-#define PO_K_BEAM2D_MAIN 5 /* the pair beam search kernel alone (PO_K_BEAM2D = the stage: + pre-pass, walk, store memset) */
+#define PO_K_BEAM2D_MAIN 5 /* the pair beam search kernel alone (PO_K_BEAM2D = the stage: + pre-pass, walk, queue reset) */
 #define PO_K_COUNT 6
 void po_profile_enable(int on);
 void po_profile_reset(void);
