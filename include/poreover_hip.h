@@ -90,6 +90,24 @@ int po_device_info(int device, char* name, int name_cap, int* compute_units, int
 /* defer_odd bits 1 and 2 (values 2, 4) are further test hooks of that hand-over: the kernel runs with a dozen row groups /
  * with a tree arena of a few nodes, so that pairs run out of them and are handed on (tests/test_gpu_parity_2d.py). */
 int po_set_pair_route(int route, int defer_odd);
+/* How the register-state pair kernel computes the window of a NEW element (the children of a node that entered the beam:
+ * BeamSearch.h:342-375 -> update_prob over the whole window, PrefixTree.h:518-531).
+ *   PO_CHAIN_SERIAL (default): the reference's serial logaddexp chain, operation for operation.
+ *   PO_CHAIN_CLOSED_FORM: x_t = B_t + log(sum_{s<=t} exp(p_{s-1} + y_s - B_s)), B = running sum of the stay (blank) column —
+ *        one exp per (element, time), a prefix sum in the probability domain, one log; time-parallel (8 lanes per chain).
+ *        The VALUES differ from the serial chain's by ~ 1e-12 (they are closer to the exact value than the chain's:
+ *        scripts/check_chain_scan.cpp); decoded strings are held to north_star's tolerance (<= 0.1 % edit distance; measured:
+ *        0 differing pairs of the bench's 10 000 and of the parity suite).  A chain whose finite terms span more than 600 nats
+ *        sends its step to the kernel's general scan (the serial chain).  Round 6 built it as the one remaining lever on the
+ *        headline — and measured it SLOWER than the serial chain (65 vs 52 ms per 10 000 pairs: profiles/r06_ab_chain_scan.txt,
+ *        DESIGN.md 3.3 says why), so it is opt-in (also: environment variable PO_CHAIN_CLOSED as the initial value).
+ *   PO_CHAIN_CLOSED_GUARD3: test hook — the closed form with its 600-nat guard at 3 nats, so that most steps take the hand-over.
+ * Applies to the one-value tree model (ctc) on the register-state route.  Process-wide. */
+#define PO_CHAIN_SERIAL 0
+#define PO_CHAIN_CLOSED_FORM 1
+#define PO_CHAIN_CLOSED_GUARD3 2
+int po_set_chain_mode(int mode);
+int po_get_chain_mode(void);
 /* test hook: pairs the register-state kernel or its pre-pass handed to beam2d_kernel on the current device since the last
  * reset (windows beyond its store geometry or its packed walk records, row groups or arena exhausted, non-monotone envelopes,
  * the defer_odd hooks); reset != 0 clears the count.  Synchronises the device; -1 on a HIP error. */

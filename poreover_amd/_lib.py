@@ -51,6 +51,8 @@ PROTOTYPES = {
     "po_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_size_t)]),
     "po_set_pair_route": (C.c_int, [C.c_int, C.c_int]),
+    "po_set_chain_mode": (C.c_int, [C.c_int]),
+    "po_get_chain_mode": (C.c_int, []),
     "po_debug_deferred_pairs": (C.c_longlong, [C.c_int]),
     "po_set_align_route": (C.c_int, [C.c_int]),
     "po_ingest_batch": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _dp, _vp]),
@@ -191,6 +193,20 @@ def set_pair_route(route="auto", defer_odd=False, starve=0):
     to beam2d_kernel; starve: 1 = the register-state kernel runs with a dozen row groups, 2 = with a tiny tree arena (pairs run
     out of them and are handed on)"""
     check(load(False).po_set_pair_route(ROUTES[route], (1 if defer_odd else 0) | ((int(starve) & 3) << 1)), "po_set_pair_route")
+
+
+CHAIN_MODES = {"serial": 0, "closed_form": 1, "closed_guard3": 2}
+
+
+def set_chain_mode(mode="serial"):
+    """po_set_chain_mode: how the register-state pair kernel computes a new element's window — "serial" (default): the
+    reference's logaddexp chain; "closed_form": one exp, a prefix sum, one log per time (values within ~1e-12 of the
+    reference's, strings inside its edit tolerance; measured slower, opt-in); "closed_guard3": the tests' way to its hand-over"""
+    check(load(False).po_set_chain_mode(CHAIN_MODES[mode]), "po_set_chain_mode")
+
+
+def get_chain_mode():
+    return {v: k for k, v in CHAIN_MODES.items()}[int(load(False).po_get_chain_mode())]
 
 
 def deferred_pairs(reset=False):

@@ -1666,7 +1666,7 @@ constexpr int X2_FB_BLOCKS = 64;   // workgroups of the beam2d_kernel pass over 
 // PO_REG_NEVER / PO_X2_DEFER_ODD only give the INITIAL value, read once when the library is first used, so that a workspace
 // size and the launch that follows always agree.  (Rounds 1 - 4 had two more kernels and routes — two pairs per wave, LDS
 // rings — which the register-state kernel replaced at every size: DESIGN.md, appendix.)
-struct B2Route { int route, defer_odd, debug_occ, no_order, reg_auto; };
+struct B2Route { int route, defer_odd, debug_occ, no_order, reg_auto, chain_scan; };
 B2Route& b2_route() {
     static B2Route r = [] {
         B2Route x;
@@ -1675,6 +1675,7 @@ B2Route& b2_route() {
         x.defer_odd = getenv("PO_X2_DEFER_ODD") ? 1 : 0;
         x.no_order = getenv("PO_B2_NO_ORDER") ? 1 : 0;   // A/B: pairs taken in input order
         x.debug_occ = getenv("PO_DEBUG_OCC") ? 1 : 0;
+        x.chain_scan = getenv("PO_CHAIN_CLOSED") ? PO_CHAIN_CLOSED_FORM : PO_CHAIN_SERIAL;   // (po_set_chain_mode)
         return x;
     }();
     return r;
@@ -1905,6 +1906,13 @@ extern "C" int po_set_pair_route(int route, int defer_odd) {
     b2_route().defer_odd = defer_odd & 7;   // bit 0: odd pairs are handed on; bits 1, 2: starve the row groups / the arena
     return PO_OK;
 }
+// How beam2d_reg_kernel computes a NEW element's window (po_beam2d_reg.hip, "closed form"): see include/poreover_hip.h.
+extern "C" int po_set_chain_mode(int mode) {
+    if (mode != PO_CHAIN_SERIAL && mode != PO_CHAIN_CLOSED_FORM && mode != PO_CHAIN_CLOSED_GUARD3) return PO_E_ARG;
+    b2_route().chain_scan = mode;
+    return PO_OK;
+}
+extern "C" int po_get_chain_mode(void) { return b2_route().chain_scan; }
 // profiling: a device counter that the pair beam kernels add their number of update_prob evaluations to
 extern "C" void po_b2_set_update_counter(unsigned long long* dev_counter) { g_b2_upd_counter = dev_counter; }
 // tests: pairs the register-state kernel (or its pre-pass) handed to beam2d_kernel on this device since the last reset, summed
@@ -2107,6 +2115,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
         a.defer_odd = b2_route().defer_odd & 1;
         a.need_mono = 1;
         a.no_cum = 1;
+        a.chain_scan = b2_route().chain_scan;
         a.order = nullptr;
         if (n > g.blocks && !b2_route().no_order) {   // more pairs than resident workgroups: longest first
             a.order = (int*)(w + g.off_order);

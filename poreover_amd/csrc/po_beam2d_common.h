@@ -155,6 +155,9 @@ struct X2Args {
     int starve;                       // test hook (po_set_pair_route's defer_odd bits 1, 2): bit 0 = a dozen row groups only,
                                       // bit 1 = a tree arena of a few nodes only — every hand-over reason can be forced
     int no_cum;                       // pre-pass: leave the blank prefix sums out (beam2d_reg_kernel adds the root's alpha up as it goes)
+    int chain_scan;                   // beam2d_reg_kernel: PO_CHAIN_CLOSED_FORM (1; 2 = its guard at 3 nats) = a new element's window in closed
+                                      // form (one exp, a prefix sum, one log per time: not the reference's rounding, inside its tolerance),
+                                      // 0 = the serial chain (po_set_chain_mode)
 };
 
 }  // namespace

@@ -77,11 +77,29 @@ struct RegCfg {
 #ifndef PO_REG_WAVES_K3N
 #define PO_REG_WAVES_K3N 3   // <three values, 32 slots>
 #endif
-    static constexpr int WAVES = (K == 1 && NR == 1) ? 4 : (K == 1 ? PO_REG_WAVES_K1W : (NR == 1 ? PO_REG_WAVES_K3N : 2));
+#ifndef PO_REG_WAVES_K1N
+#define PO_REG_WAVES_K1N 4   // <ctc, 32 slots>: 128 VGPRs (5 = 96 VGPRs needs PO_REG_WPG_K1N=4 for the LDS: measured slower, below)
+#endif
+#ifndef PO_REG_WPG_K1N
+#define PO_REG_WPG_K1N 1     // pair waves per workgroup (4: they share ONE copy of the logaddexp tables)
+#endif
+    // pair waves per workgroup.  The waves of a workgroup have nothing to do with each other but the logaddexp tables at the
+    // front of the LDS block (2.5 KB).  Round 6 measured the kernel's time to be per-wave latency (12 / 14 / 16 waves per CU:
+    // 73 / 59 / 52 ms per 10 000 pairs), so a fifth wave per SIMD was built: four waves on ONE copy of the tables are 7.9 KB each
+    // (20 per CU fit) at 96 VGPRs — and the 96-register kernel is 23 % slower per wave (70 spilled registers against 33; at 16
+    // waves per CU 63.8 ms, at 20 57.2 ms against 52.0 ms for 16 waves of 128 registers: profiles/r06_ab_occupancy.txt).  The
+    // form stays selectable (-DPO_REG_WPG_K1N=4 -DPO_REG_WAVES_K1N=5); the default is one wave per workgroup.
+    static constexpr int WPG = (K == 1 && NR == 1) ? PO_REG_WPG_K1N : 1;
+    static constexpr int WAVES = (K == 1 && NR == 1) ? PO_REG_WAVES_K1N : (K == 1 ? PO_REG_WAVES_K1W : (NR == 1 ? PO_REG_WAVES_K3N : 2));
 };
 template <int K> struct RegVal { double v[K]; };
 
-template <int MODEL, int NR>
+// closed-form chains (SCAN): what a chain's 8 lanes hand to the child's lane (and the child's seed the other way), per
+// (half of the wave, symbol); nothing in the serial-chain kernel
+struct RegCResEntry { double mx, last; int mt, tr; };
+template <bool SCAN> struct RegCRes { RegCResEntry e[2][PO_A]; };
+template <> struct RegCRes<false> { RegCResEntry e[1][1]; };
+template <int MODEL, int NR, bool SCAN = false>
 struct RegSmem {              // per pair wave
     using Cfg = RegCfg<MODEL, NR>;
     double ybuf[2][RK_NY][Cfg::YC];
@@ -96,13 +114,14 @@ struct RegSmem {              // per pair wave
     int rootT[2];             // scans pass the times, while children of the root are in the table (the start of a pair)
     double pf0[2][Cfg::PF0N]; // a run's first step: the beam lanes' values at the window start, fetched with the staging of the
     int pf0_t[2][Cfg::PF0N];  // step before (their times; -1: none)
+    RegCRes<SCAN> cres;
     unsigned long long nupd, nupd_x;
 };
 
-template <int MODEL, int NR>
+template <int MODEL, int NR, bool SCAN = false>
 struct RegGroup {
     PoLaeTables lae;   // (first: at LDS address 0 the tables' offsets fit the immediate fields of ds_read2_b64 — one address per entry)
-    RegSmem<MODEL, NR> w;
+    RegSmem<MODEL, NR, SCAN> w[RegCfg<MODEL, NR>::WPG];   // (one per pair wave)
 };
 
 __device__ __forceinline__ void rk_sync() { b2_sync_lds<64>(); }
@@ -129,20 +148,63 @@ __device__ __forceinline__ double rk_readlane_d(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 
+// ---- exchanges inside groups of 8 lanes, all in the VALU (DPP): the closed-form chains below give a chain 8 lanes
+template <int CTRL>
+__device__ __forceinline__ double rk_dpp_d(double x) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), CTRL, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int rk_dpp_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+// lane ^ 1, lane ^ 2 (quad_perm) and 7 - lane (row_half_mirror: a lane of the OTHER quad — after the first two levels the four
+// lanes of a quad hold the same value, so any of them does)
+constexpr int RK_X1 = 0xB1, RK_X2 = 0x4E, RK_X4 = 0x141;
+__device__ __forceinline__ double rk_g8_max(double x) {
+    x = po_vmax(x, rk_dpp_d<RK_X1>(x));
+    x = po_vmax(x, rk_dpp_d<RK_X2>(x));
+    return po_vmax(x, rk_dpp_d<RK_X4>(x));
+}
+__device__ __forceinline__ int rk_g8_max_i(int x) {
+    x = max(x, rk_dpp_i<RK_X1>(x));
+    x = max(x, rk_dpp_i<RK_X2>(x));
+    return max(x, rk_dpp_i<RK_X4>(x));
+}
+// exclusive prefix sum of `tot` over the 8 lanes of a group (and the group's total, the same bits in every lane: a + b == b + a):
+// b0 / b1 / b2 = 1.0 where bit 0 / 1 / 2 of the lane number is set, else 0.0 — a multiply-add instead of two selects per level
+// (the summands are finite)
+__device__ __forceinline__ double rk_g8_excl(double tot, double b0, double b1, double b2, double& total) {
+    const double t1 = rk_dpp_d<RK_X1>(tot);
+    double e = b0 * t1;
+    const double p2 = tot + t1;
+    const double t2 = rk_dpp_d<RK_X2>(p2);
+    e = __builtin_fma(b1, t2, e);
+    const double p4 = p2 + t2;
+    const double t4 = rk_dpp_d<RK_X4>(p4);
+    e = __builtin_fma(b2, t4, e);
+    total = p4 + t4;
+    return e;
+}
+
 }  // namespace
 
 // COUNT: the instantiation po_profile_update_counter asks for (update_prob evaluations of the reference's schedule and executed
 // ones, added up per step: ballots, a wave reduction per scan); the product path carries none of it.
 // (The job-board form of round 4 — seven pair waves posting their new elements' chains to a chain wave — was measured
 //  slower at every batch size and is gone: DESIGN.md, appendix.)
-template <int MODEL, int NR, bool COUNT = false>
-__global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_kernel(X2Args a) {
+// SCAN: the new elements' chains in closed form (po_set_chain_mode(PO_CHAIN_CLOSED_FORM); the one-value model) — its own instantiation:
+// with both forms of the chain in one kernel the register allocation of EVERY phase suffered (the serial-only kernel ran at
+// 69 instead of 51 ms per 10 000 pairs with the closed form merely compiled in).
+template <int MODEL, int NR, bool COUNT = false, bool SCAN = false>
+__global__
+__launch_bounds__((64 * RegCfg<MODEL, NR>::WPG), (RegCfg<MODEL, NR>::WAVES))
+void beam2d_reg_kernel(X2Args a) {
+    static_assert(!SCAN || RegCfg<MODEL, NR>::K == 1, "closed-form chains: the one-value model");
     using Cfg = RegCfg<MODEL, NR>;
     constexpr int K = Cfg::K, KP = Cfg::KP, PC0 = Cfg::PC0, RK_YC = Cfg::YC, EB = Cfg::EB, RK_PS = Cfg::PS;
     constexpr int NS = Cfg::NS, WS = Cfg::WS, RK_NGL = Cfg::NGL, PF0N = Cfg::PF0N;
     using Val = RegVal<K>;        // a node's values at one time = a store entry
     using PVal = RegVal<KP>;      // ... the ones its children's updates read
-    __shared__ RegGroup<MODEL, NR> gsm;
+    __shared__ RegGroup<MODEL, NR, SCAN> gsm;
     // lane = (read, slot) [NR = 1] or slot [NR = 2]; hb = first lane of this lane's read; lo_half = the lanes that do what is
     // done once per element slot (arena and table writes, candidate masks)
     const int lane = threadIdx.x & 63, s = (NR == 1) ? (lane & 31) : lane, hb = (NR == 1) ? (lane & 32) : 0;
@@ -153,7 +215,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     auto smask_of = [&](bool p) -> SMask { return (SMask)__ballot(p && lo_half); };
     auto sm_pop = [&](SMask m) -> int { return (NR == 1) ? __popc((unsigned)m) : __popcll((unsigned long long)m); };
     auto sm_ctz = [&](SMask m) -> int { return (NR == 1) ? __builtin_ctz((unsigned)m) : (int)__builtin_ctzll((unsigned long long)m); };
-    RegSmem<MODEL, NR>& sm = gsm.w;
+    RegSmem<MODEL, NR, SCAN>& sm = gsm.w[(Cfg::WPG == 1) ? 0 : (int)(threadIdx.x >> 6)];
     const int A = a.A, W = a.W, C = a.C;
     const int divA = (65536 + A - 1) / A;   // x / A == (x * divA) >> 16 for the slot numbers divided here
     // ---- this wave's SLICE of the library's pool: value store + tree arena.  The pool has one slice per pair wave the device
@@ -165,6 +227,12 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     // that starts takes the word its ticket names (and waits for it to be filled, should every slice be out: residency is what
     // the pool is sized for, so that cannot last), a wave that ends puts its slice into the word ITS ticket names.  Two atomics
     // per hand-over, no search — with a wave per pair (persist = 0) that is per pair.
+    po_lae_tables_load(&gsm.lae, (int)threadIdx.x, (int)blockDim.x);
+    const PoLaeFast lae{&gsm.lae};
+    if (lane == 0) { sm.nupd = 0; sm.nupd_x = 0; }
+    __syncthreads();   // (the only time the waves of a workgroup meet)
+    const int gwave = (int)blockIdx.x * Cfg::WPG + (int)(threadIdx.x >> 6);   // this pair wave's number in the launch
+    if (gwave >= a.reg_slots) return;
     int slotid = -1;
     {
         int v = -1;
@@ -191,10 +259,6 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
     const int arena_cap = (a.starve & 2) ? min((int)a.arena_cap, 1 + a.A + 24 * a.A) : (int)a.arena_cap;
     auto g_hi = [&](int r) -> int* { return r ? sm.g_hi1 : sm.g_hi0; };
 
-    po_lae_tables_load(&gsm.lae, (int)threadIdx.x, (int)blockDim.x);
-    const PoLaeFast lae{&gsm.lae};
-    if (lane == 0) { sm.nupd = 0; sm.nupd_x = 0; }
-    __syncthreads();
 #ifdef PO_REG_TIMING
     // phase timers of workgroup 0 (wall_clock64: 100 MHz) and counts: see po_reg_launch for the names
     long long tk[40], tlast = wall_clock64();
@@ -212,7 +276,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
         if (!a.persist && taken > 0) break;
         int pi = 0;
         if (lane == 0) {
-            const int q = a.persist ? atomicAdd(a.queue, 1) : (int)blockIdx.x;
+            const int q = a.persist ? atomicAdd(a.queue, 1) : gwave;
             pi = (a.order != nullptr && q < a.n) ? a.order[q] : q;   // longest pairs first (pair_order_kernel)
         }
         pi = __builtin_amdgcn_readfirstlane(pi);
@@ -765,6 +829,134 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 if (k0 == 0 && want_seed && ws - 1 < se_hdr) for (int c = 0; c < K; ++c) self.v[c] = se.v[c];
                 rk_sync();
                 const int k1 = min(n1max, k0 + RK_NY);
+                // ---- the block's chains in CLOSED FORM (a.chain_scan; the one-value model).  A new element starts absent
+                // (PrefixTree.h:518-531) and x_t = logaddexp(p_{t-1} + ya_t, x_{t-1} + yb_t) unrolls to
+                //     x_t = B_t + log( exp(x_{ws-1}) + sum_{s <= t} exp(p_{s-1} + ya_s - B_s) ),   B_t = yb_ws + .. + yb_t :
+                // ONE exp per (element, time), a prefix sum in the probability domain, ONE log — instead of ~ 20 dependent
+                // logaddexp on 4 of a read's 32 lanes.  A chain gets 8 lanes (lane mI of the group holds the J <= 4 consecutive
+                // times J mI .. J mI + J - 1 of the block), the four children of a staged parent the four groups of a read's half
+                // of the wave [NR = 2: the halves take two parents], so a pass serves one parent on both reads.  The sums are
+                // scaled by the chain's largest term m; a chain whose finite terms span more than 600 nats (exp(c - m) would
+                // lose them) or whose blank column holds -inf sends the whole step to the general scan (this function returns
+                // false: nothing of the lanes' state has been changed by then, and what the passes before it stored is
+                // written again) — a serial chain in THIS kernel would cost every phase registers.  NOT the reference's
+                // rounding: the values differ from the serial chain's by ~ 1e-12 (less than the serial chain differs from the
+                // exact value: scripts/check_chain_scan.cpp), inside north_star's edit tolerance.  The
+                // SCAN = false instantiation below is the reference's chain, operation for operation.
+                if constexpr (SCAN) {
+                {
+                    const int half = lane >> 5, cg = (lane >> 3) & 3, mI = lane & 7;
+                    const double guard = (a.chain_scan == 2) ? -3.0 : -600.0;   // (2: the tests' way to the hand-over below — most chains span 3 nats)
+                    const int nvr = min(n1 - k0, RK_NY);          // times of this lane's read in the block (<= 0: none)
+                    const int J = (k1 - k0 + 7) >> 3;               // items per lane, 1 .. 4 (wave-uniform)
+                    const double b0 = (mI & 1) ? 1.0 : 0.0, b1 = (mI & 2) ? 1.0 : 0.0, b2 = (mI & 4) ? 1.0 : 0.0;
+                    const int cbcol = (MODEL == PO_MODEL_FLIPFLOP) ? cg + A : A;
+                    const int i0 = J * mI, tb = ws + k0 + i0;       // this lane's first item: index in the block, time
+                    // B_t over the block (every group computes its own: the column is the group's for the flip-flop model)
+                    double Bj[4];
+                    bool badB;
+                    {
+                        double run = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            Bj[j] = 0.0;
+                            if (j < J) {
+                                const double yv = yb_[((tb + j) & (RK_NY - 1)) * RK_YC + cbcol];
+                                run += (i0 + j < nvr) ? yv : 0.0;
+                                Bj[j] = run;
+                            }
+                        }
+                        double tot;
+                        const double e = rk_g8_excl(run, b0, b1, b2, tot);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Bj[j] += e;
+                        badB = !(tot > -1e300);   // (-inf or NaN in the column: the closed form has no B)
+                    }
+                    const unsigned long long fmask = __ballot(fresh[q]);
+                    for (int k = 0; k < nps; k += (NR == 1) ? 1 : 2) {   // (wave-uniform)
+                        const int kk = (NR == 1) ? k : k + half;
+                        const int jk = pj(min(kk, RK_PS - 1));                      // the parent's beam slot
+                        const int clane = ((NR == 1) ? (half << 5) : 0) | ((nb + A * jk + cg) & (NS - 1));   // the lane of this group's child
+                        const bool gv = kk < nps && cg < A && ((fmask >> clane) & 1ull) != 0ull;
+                        // this lane as a CHILD of the pass: its seed (an element again, or the block before) goes to its chain's lanes
+                        const bool mine = fresh[q] && ((NR == 1) ? (myk == k) : ((myk & ~1) == k));
+                        auto& cmine = sm.cres.e[(NR == 1) ? half : (myk & 1)][sym & (PO_A - 1)];
+                        auto& cgrp = sm.cres.e[half][cg];
+                        if (mine) cmine.last = self.v[0];
+                        rk_sync();
+                        const double sd = gv ? cgrp.last : PO_NEG_INF;
+                        const int crow = sm.f_crow2[jk] * PO_A + cg;
+                        const double* const pk_ = &sm.pst[(NR == 1) ? r : 0][min(kk, RK_PS - 1) * RK_NY][0];
+                        double xj[4];
+                        double m = PO_NEG_INF;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            xj[j] = PO_NEG_INF;
+                            if (j < J) {
+                                const double pkv = pk_[(i0 + j) * KP], ya = yb_[((tb + j) & (RK_NY - 1)) * RK_YC + cg];
+                                const double cj = (pkv + ya) - Bj[j];
+                                xj[j] = (gv && i0 + j < nvr) ? cj : PO_NEG_INF;
+                                m = po_vmax(m, xj[j]);
+                            }
+                        }
+                        m = po_vmax(rk_g8_max(m), sd);
+                        bool bad = (gv && badB) || (sd > PO_NEG_INF && sd - m < guard);
+                        double run = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < J) {
+                                const double d = xj[j] - m;
+                                bad = bad || (xj[j] > PO_NEG_INF && d < guard);
+                                run += lae.ex(d);
+                                xj[j] = run;
+                            }
+                        double tot;
+                        double e = rk_g8_excl(run, b0, b1, b2, tot);
+                        if (__ballot(sd > PO_NEG_INF) != 0ull) e += lae.ex(sd - m);   // (wave-uniform: most passes have no seed)
+                        KC(34, 1);
+                        if (__builtin_expect(__ballot(bad) != 0ull, 0)) { KC(35, 1); return false; }   // (wave-uniform; NR = 2: read 0 may be done — a consistent state)
+                        {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < J) xj[j] = (gv && i0 + j < nvr) ? (Bj[j] + m) + lae.lg(xj[j] + e) : PO_NEG_INF;
+                            double xl = xj[0];   // the lane's last item: what the next lane's first one is compared with
+                            if (J > 1) xl = xj[1];
+                            if (J > 2) xl = xj[2];
+                            if (J > 3) xl = xj[3];
+                            double prev = rk_dpp_d<0x111>(xl);   // (row_shr:1)
+                            prev = (mI == 0) ? sd : prev;
+                            double lm = PO_NEG_INF;
+                            int lt = -1, ltr = INT_MIN;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < J) {
+                                    const int t = tb + j;
+                                    if (gv && i0 + j < nvr) {
+                                        Val o;
+                                        o.v[0] = xj[j];
+                                        t2_write(r, crow, t, o); SH_WRITE(r, crow, t, sm.f_fc[jk] + cg);
+                                        if (xj[j] > prev) ltr = t;
+                                        if (xj[j] >= lm) { lm = xj[j]; lt = t; }
+                                        if (i0 + j == nvr - 1) cgrp.last = xj[j];
+                                    }
+                                    prev = xj[j];
+                                }
+                            const double gm = rk_g8_max(lm);
+                            const int gt = rk_g8_max_i((lm == gm) ? lt : -1);   // (the latest time of the maximum, as the serial chain leaves it)
+                            const int gtr = rk_g8_max_i(ltr);
+                            if (gv && mI == 0) { cgrp.mx = gm; cgrp.mt = gt; cgrp.tr = gtr; }
+                        }
+                        rk_sync();
+                        if (mine && nvr > 0) {
+                            const double bmx = cmine.mx;
+                            self.v[0] = cmine.last;
+                            if (bmx >= mx) { mx = bmx; mt = cmine.mt; }
+                            tr = max(tr, cmine.tr);
+                        }
+                        rk_sync();
+                    }
+                }
+                } else {
                 // (the operands of an iteration are asked for one iteration ahead: a lone wave then waits for the LDS only
                 //  inside logaddexp's own table lookups)
                 double nya = 0.0, nyb = 0.0;
@@ -797,6 +989,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                         mx = po_vmax(mx, out.v[0]);
                     }
                 }
+                }   // (!SCAN)
             }
             if (n1max == 0 && want_seed && ws - 1 < se_hdr) for (int c = 0; c < K; ++c) self.v[c] = se.v[c];
             if (s < PF0N) {
@@ -854,6 +1047,7 @@ __global__ __launch_bounds__(64, (RegCfg<MODEL, NR>::WAVES)) void beam2d_reg_ker
                 isnew = n_fc < 0;
                 need_group = isnew || n_crow2 < 0 || n_crow2 >= NG || sm.g_owner[n_crow2] != n_id;   // (old rows recycled: all dead)
             }
+            KC(36, sm_pop(smask_of(rb && mysel >= nbo))); KC(37, sm_pop(smask_of(rb && mysel >= nbo && !isnew))); KC(38, sm_pop(smask_of(rb && mysel >= nbo && !isnew && !need_group)));
             {
                 const SMask bn = smask_of(isnew);
                 if (isnew) {
@@ -1353,16 +1547,26 @@ namespace {
 template <int MODEL, int NR>
 int reg_occupancy() {
     int nblk = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel<MODEL, NR, false>, 64, 0) != hipSuccess || nblk <= 0)
+    constexpr int WPG = RegCfg<MODEL, NR>::WPG;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)beam2d_reg_kernel<MODEL, NR, false>, 64 * WPG, 0) != hipSuccess || nblk <= 0)
         nblk = 4 * RegCfg<MODEL, NR>::WAVES;
+    else nblk *= WPG;
     if (const char* e = getenv("PO_REG_PER_CU")) { const int v = atoi(e); if (v > 0 && v < nblk) nblk = v; }
-    if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_reg_kernel<model %d, %d read(s) per lane>: %d resident workgroups per CU, %zu B of LDS\n", MODEL, NR, nblk, sizeof(RegGroup<MODEL, NR>));
+    if (getenv("PO_DEBUG_OCC")) fprintf(stderr, "[po] beam2d_reg_kernel<model %d, %d read(s) per lane>: %d resident pair waves per CU (workgroups of %d), %zu B of LDS per workgroup\n", MODEL, NR, nblk, WPG, sizeof(RegGroup<MODEL, NR>));
     return nblk;
 }
 template <int MODEL, int NR>
 void reg_launch_model(const X2Args& a, int slots, hipStream_t stream) {
-    if (a.upd_count != nullptr) hipLaunchKernelGGL((beam2d_reg_kernel<MODEL, NR, true>), dim3(slots), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((beam2d_reg_kernel<MODEL, NR, false>), dim3(slots), dim3(64), 0, stream, a);
+    constexpr int WPG = RegCfg<MODEL, NR>::WPG;
+    const dim3 grid((slots + WPG - 1) / WPG), block(64 * WPG);   // (a.reg_slots = slots: the waves beyond it leave at once)
+    if constexpr (RegCfg<MODEL, NR>::K == 1) {
+        if (a.chain_scan && a.upd_count == nullptr) {   // (po_set_chain_mode(PO_CHAIN_CLOSED_FORM); the counting build is the serial chain's)
+            hipLaunchKernelGGL((beam2d_reg_kernel<MODEL, NR, false, true>), grid, block, 0, stream, a);
+            return;
+        }
+    }
+    if (a.upd_count != nullptr) hipLaunchKernelGGL((beam2d_reg_kernel<MODEL, NR, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((beam2d_reg_kernel<MODEL, NR, false, false>), grid, block, 0, stream, a);
 }
 }  // namespace
 // wide != 0: the 64-slot layout (7 <= W <= 12)
@@ -1414,6 +1618,8 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide
         fprintf(stderr, "   step top + score + prune test %lld, ranking %lld, rebuild %lld, pair setup + label %lld\n", h[6], h[7], h[8], h[9]);
         fprintf(stderr, "   new-element steps handed to the general scan: window order %lld, uneven ends %lld, root's children %lld, fresh without a parent lane %lld, fresh under fresh %lld, more than PS parents %lld\n", h[22], h[23], h[24], h[25], h[26], h[27]);
         fprintf(stderr, "   run loop left for the general scan: window order / last step %lld, a frozen parent's older values %lld; general main scans on a table that is not fresh %lld, uneven %lld, beam not full %lld\n", h[28], h[29], h[30], h[32], h[33]);
+        fprintf(stderr, "   closed-form chains: %lld passes (a staged parent's children on both reads), %lld of them left to the serial chain\n", h[34], h[35]);
+        fprintf(stderr, "   nodes entering the beam: %lld, of them expanded before %lld, with their children's row group still theirs %lld\n", h[36], h[37], h[38]);
         fprintf(stderr, "   table builds that ask the arena for a node's children: %lld; window rescans: %lld lanes in %lld calls; bounds made exact in %lld steps\n", h[20], h[21], h[10], h[31]);
     }
 #endif

@@ -197,6 +197,51 @@ struct PoLaeFast {
         return hi + f(lo - hi);
 #endif
     }
+    // The two halves of f() on their own, for the closed-form chains (po_beam2d_reg.hip: a new element's window as ONE
+    // exp per (element, time), a prefix sum in the probability domain and ONE log — not the reference's rounding, inside
+    // its documented tolerance: DESIGN.md §3.3, §5).  Same tables, same polynomials.
+    // ex(d) = exp(d) for d <= 0: exactly 0 below -700 (2^m is added into the exponent field: no subnormals) and for NaN
+    // (-inf - -inf: a chain without a single finite term).
+    __device__ __forceinline__ double ex(double d0) const {
+        const double d = po_vmax(d0, -700.0);   // (maxNum: NaN -> -700; zeroed below)
+        const double tm = __builtin_fma(d, PO_64_LN2, 0x1.8p52);
+        const double kf = tm - 0x1.8p52;
+        const int k = __double2loint(tm);
+        const int j = k & 63;
+        const double th = t->exp_t[j][0], tl = t->exp_t[j][1];
+        double r = __builtin_fma(-kf, PO_LN2_64_HI, d);   // (|k| < 2^17: k * hi is exact, scripts/gen_lae_tables.py)
+        r = __builtin_fma(-kf, PO_LN2_64_LO, r);
+        double p = po_fma_c(r, 1.0 / 720, 1.0 / 120);
+        p = po_fma_c(r, p, 1.0 / 24);
+        p = po_fma_c(r, p, 1.0 / 6);
+        p = po_fma_c(r, p, 0.5);
+        p = __builtin_fma(r * r, p, r);
+        const double x = th + __builtin_fma(th, p, tl);
+        const double e = __hiloint2double(__double2hiint(x) + (int)((unsigned)(k & ~63) << 14), __double2loint(x));
+        return (d0 >= -700.0) ? e : 0.0;
+    }
+    // lg(S) = log(S) for a finite S >= 0 that is 0 or normal (a sum of ex() values): -inf at 0.  S = 2^k z, z in [1, 2):
+    // k ln2 (hi + lo, k * hi exact) + the table-driven log of z.
+    __device__ __forceinline__ double lg(double S) const {
+        const int hw = __double2hiint(S);
+        const unsigned mant = (unsigned)hw & 0xFFFFFu;
+        const unsigned i = (mant + 0x2000u) >> 14;
+        const double z = __hiloint2double((int)(mant | 0x3FF00000u), __double2loint(S));
+        const double* lt = (const double*)((const char*)&t->log_t[0][0] + __umul24(i, 24u));
+        const double rc = lt[0], lh = lt[1], ll = lt[2];
+        const double kd = (double)((hw >> 20) - 1023);
+        const double w = __builtin_fma(z, rc, -1.0);
+        double q = po_fma_c(w, 1.0 / 7, -1.0 / 6);
+        q = po_fma_c(w, q, 1.0 / 5);
+        q = po_fma_c(w, q, -1.0 / 4);
+        q = po_fma_c(w, q, 1.0 / 3);
+        const double s = w * w;
+        double u = __builtin_fma(s * w, q, ll);
+        u = __builtin_fma(-0.5, s, u);
+        const double hi = __builtin_fma(kd, 64.0 * PO_LN2_64_HI, lh);
+        const double lo = __builtin_fma(kd, 64.0 * PO_LN2_64_LO, w + u);
+        return (S > 0.0) ? hi + lo : PO_NEG_INF;
+    }
 };
 
 // PoLaePoly: table-free variant of the same formula (no LDS lookups): exp by k*ln2 range reduction and a

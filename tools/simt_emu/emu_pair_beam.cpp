@@ -48,6 +48,7 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
     a.ngl = po_reg_ngl(wide);
     a.no_cum = 1;
+    a.chain_scan = getenv("EMU_CHAIN_SCAN") ? atoi(getenv("EMU_CHAIN_SCAN")) : 0;
     for (int i = 0; i < n; ++i) status[i] = PO_OK;
     const bool vb = getenv("EMU_VERBOSE") != nullptr;
 #ifdef PO_EMU_SHADOW

@@ -111,6 +111,42 @@ static inline unsigned long long ballot(bool p, int line) {
     return m;
 }
 }  // namespace emu
+// DPP (v_mov_b32_dpp through __builtin_amdgcn_update_dpp): the data-parallel-primitive lane patterns of GFX9 — quad_perm,
+// row_shl / row_shr / row_ror, wave_shr:1 & co, row_mirror, row_half_mirror, row_bcast15 / 31 — with row_mask, bank_mask and
+// bound_ctrl.  A source lane outside the row (or not executing) is invalid: the result is 0 with bound_ctrl, `old` without.
+namespace emu {
+static inline int dpp_src(int lane, int ctrl) {   // source lane, or -1: invalid
+    const int row = lane & ~15, l = lane & 15;
+    if (ctrl >= 0 && ctrl <= 0xFF) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl & 15; return (l + n < 16) ? lane + n : -1; }
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl & 15; return (l - n >= 0) ? lane - n : -1; }
+    if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl & 15; return row | ((l - n) & 15); }
+    if (ctrl == 0x130) return (lane + 1 < 64) ? lane + 1 : -1;
+    if (ctrl == 0x134) return (lane + 1) & 63;
+    if (ctrl == 0x138) return (lane - 1 >= 0) ? lane - 1 : -1;
+    if (ctrl == 0x13C) return (lane - 1) & 63;
+    if (ctrl == 0x140) return row | (15 - l);
+    if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));
+    if (ctrl == 0x142) return (lane >= 16) ? (row - 1) : -1;
+    if (ctrl == 0x143) return (lane >= 32) ? 31 : -1;
+    fprintf(stderr, "[simt_emu] unknown dpp_ctrl 0x%x\n", ctrl);
+    abort();
+}
+static inline int dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, int line) {
+    const int me = (int)g_cur->tid.x, base = me & ~63, lane = me & 63;
+    memcpy(&g_xch[me][0], &src, sizeof(int));
+    rendezvous_wave(line);
+    int r = old;
+    if (((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane & 15) >> 2)) & 1)) {
+        const int sl = dpp_src(lane, ctrl);
+        const bool ok = sl >= 0 && ((wave_group() >> sl) & 1ull);
+        r = ok ? xch_get<int>(base + sl) : (bound_ctrl ? 0 : old);
+    }
+    rendezvous_wave(line);
+    return r;
+}
+}  // namespace emu
+#define __builtin_amdgcn_update_dpp(old_, src_, ctrl_, rm_, bm_, bc_) emu::dpp((int)(old_), (int)(src_), (ctrl_), (rm_), (bm_), (bc_), __LINE__)
 #define __shfl(v_, l_) emu::shfl((v_), (l_), __LINE__)
 static inline int emu_lane_() { return (int)(emu::g_cur->tid.x & 63); }
 #define __shfl_xor(v_, m_) emu::shfl((v_), (int)(emu_lane_() ^ (m_)), __LINE__)
