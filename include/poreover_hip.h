@@ -108,6 +108,14 @@ int po_set_pair_route(int route, int defer_odd);
 #define PO_CHAIN_CLOSED_GUARD3 2
 int po_set_chain_mode(int mode);
 int po_get_chain_mode(void);
+/* The register-state pair kernel keeps its value stores and tree arenas in a slice POOL the library owns: one per device, tree
+ * model and lane layout (beam_width <= 6 / 7..12), as many slices as the device holds pair waves (<ctc, W <= 6>: 4 096 x 1.28 MB
+ * = 5.3 GB), made by the first workspace-size query that selects the route and kept for the life of the process.
+ * po_reg_pool_prewarm makes the pool of (model, beam_width) on the current device ahead of time (PO_E_NOMEM if it cannot be
+ * allocated: beam2d_kernel then serves the route, with results identical); po_reg_pool_release waits for the device and frees
+ * every pool of the current device — a long-lived process that has used several models and widths holds tens of GB otherwise. */
+int po_reg_pool_prewarm(int model, int beam_width);
+int po_reg_pool_release(void);
 /* test hook: pairs the register-state kernel or its pre-pass handed to beam2d_kernel on the current device since the last
  * reset (windows beyond its store geometry or its packed walk records, row groups or arena exhausted, non-monotone envelopes,
  * the defer_odd hooks); reset != 0 clears the count.  Synchronises the device; -1 on a HIP error. */
@@ -205,6 +213,11 @@ size_t po_align_workspace_bytes(int n, int64_t max_len1, int64_t max_len2, int b
 int po_align_batch(const char* seqs, const int64_t* seq_off, int n, int band_width, char* aln1, char* aln2,
                    const int64_t* aln_off, int32_t* ncol, int32_t* status, void* ws, size_t ws_bytes, void* stream);
 
+/* the third item align.global_pair returns (align.pyx:34-52,98): its dense DP matrix, (len1 + 1) x (len2 + 1) int32 row-major
+ * at dp + dp_off[i] (dp_off[n] = total cells), with the reference's score arguments.  Enqueue-only, no workspace. */
+int po_nw_matrix_batch(const char* seqs, const int64_t* seq_off, int n, int match, int mismatch, int gap_cost, int32_t* dp,
+                       const int64_t* dp_off, int32_t* status, void* stream);
+
 /* ---- envelope.get_alignment_columns + build_envelope -----------------------------------------
  * replaces decoding/envelope.py:26-87: alignment rows + the frame index of every base of both reads
  * (map*, get_sequence_mapping) + signal lengths U, V -> per-row column range [lo, hi) of read 2,
@@ -293,6 +306,8 @@ int po_prefix_search_batch_h(const double* y_h, const int64_t* y_off_h, int n, i
                              int32_t* status_h);
 int po_align_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, char* aln1_h, char* aln2_h,
                      const int64_t* aln_off_h, int32_t* ncol_h, int32_t* status_h);
+int po_nw_matrix_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int match, int mismatch, int gap_cost,
+                         int32_t* dp_h, const int64_t* dp_off_h, int32_t* status_h);
 /* the same with the reference's score arguments (align.pyx:29,100: match, mismatch, gap_cost) */
 int po_align_scores_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int band_width, int match, int mismatch,
                             int gap_cost, char* aln1_h, char* aln2_h, const int64_t* aln_off_h, int32_t* ncol_h,

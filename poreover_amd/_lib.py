@@ -53,6 +53,8 @@ PROTOTYPES = {
     "po_set_pair_route": (C.c_int, [C.c_int, C.c_int]),
     "po_set_chain_mode": (C.c_int, [C.c_int]),
     "po_get_chain_mode": (C.c_int, []),
+    "po_reg_pool_prewarm": (C.c_int, [C.c_int, C.c_int]),
+    "po_reg_pool_release": (C.c_int, []),
     "po_debug_deferred_pairs": (C.c_longlong, [C.c_int]),
     "po_set_align_route": (C.c_int, [C.c_int]),
     "po_ingest_batch": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _dp, _vp]),
@@ -84,6 +86,8 @@ PROTOTYPES = {
     "po_align_batch": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, _cp, _cp, _i64p, _i32p, _i32p, _vp, C.c_size_t, _vp]),
     "po_align_batch_h": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, _cp, _cp, _i64p, _i32p, _i32p]),
     "po_align_scores_batch_h": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _cp, _cp, _i64p, _i32p, _i32p]),
+    "po_nw_matrix_batch": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i64p, _i32p, _vp]),
+    "po_nw_matrix_batch_h": (C.c_int, [_cp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i64p, _i32p]),
     "po_envelope_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "po_envelope_batch": (C.c_int, [_cp, _cp, _i64p, _i32p, C.c_int, _i32p, _i64p, _i32p, _i64p, _i32p, _i32p, C.c_int,
                                     _i32p, _i64p, _i32p, _vp, C.c_size_t, _vp]),
@@ -207,6 +211,16 @@ def set_chain_mode(mode="serial"):
 
 def get_chain_mode():
     return {v: k for k, v in CHAIN_MODES.items()}[int(load(False).po_get_chain_mode())]
+
+
+def reg_pool_prewarm(model="ctc", beam_width=5):
+    """po_reg_pool_prewarm: make the register-state pair kernel's slice pool for (model, beam_width) on the current device now"""
+    check(load().po_reg_pool_prewarm(MODELS[model], int(beam_width)), "po_reg_pool_prewarm")
+
+
+def reg_pool_release():
+    """po_reg_pool_release: wait for the device and free every slice pool of the current device"""
+    check(load().po_reg_pool_release(), "po_reg_pool_release")
 
 
 def deferred_pairs(reset=False):

@@ -5,10 +5,10 @@ MATCH_DEFAULT, MISMATCH_DEFAULT, GAP_DEFAULT, BAND_DEFAULT = 2, -1, -1, 500
 
 
 def global_pair(seq1, seq2, match=MATCH_DEFAULT, mismatch=MISMATCH_DEFAULT, gap_cost=GAP_DEFAULT):
-    """Needleman-Wunsch (align.pyx:29-98).  Returns (align1, align2, None): two lists of characters; the
-    reference's third item, the dense DP matrix, stays on the device and is not returned."""
+    """Needleman-Wunsch (align.pyx:29-98).  Returns (align1, align2, dpMatrix) as the reference does: two lists of
+    characters and the dense (len1 + 1, len2 + 1) int32 DP matrix."""
     a1, a2 = _batch.align_batch([(seq1, seq2)], 0, match, mismatch, gap_cost)[0]
-    return list(a1), list(a2), None
+    return list(a1), list(a2), _batch.nw_matrix_batch([(seq1, seq2)], match, mismatch, gap_cost)[0]
 
 
 def global_pair_banded(seq1, seq2, band_width=BAND_DEFAULT, match=MATCH_DEFAULT, mismatch=MISMATCH_DEFAULT,

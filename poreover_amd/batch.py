@@ -626,6 +626,26 @@ def align_batch(pairs, band_width=500, match=2, mismatch=-1, gap_cost=-1):
     return list(zip(_strings(a1, ao, nc), _strings(a2, ao, nc)))
 
 
+def nw_matrix_batch(pairs, match=2, mismatch=-1, gap_cost=-1):
+    """the dense DP matrix align.global_pair returns as its third item (align.pyx:34-52,98), for a batch of (seq1, seq2)
+    string pairs: a list of (len1 + 1, len2 + 1) int32 arrays"""
+    lib = L.load()
+    n = len(pairs)
+    enc = []
+    for a, b in pairs:
+        enc += [a.encode("ascii"), b.encode("ascii")]
+    so = np.zeros(2 * n + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in enc], out=so[1:])
+    buf = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy()
+    do = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([(len(a) + 1) * (len(b) + 1) for a, b in pairs], out=do[1:])
+    dp = np.zeros(max(int(do[-1]), 1), dtype=np.int32)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    L.check(lib.po_nw_matrix_batch_h(_ptr(buf), _ptr(so), n, int(match), int(mismatch), int(gap_cost), _ptr(dp), _ptr(do), _ptr(st)),
+            "po_nw_matrix_batch_h")
+    return [dp[do[i]:do[i + 1]].reshape(len(a) + 1, len(b) + 1) for i, (a, b) in enumerate(pairs)]
+
+
 def envelope_batch(alignments, maps1, maps2, Us, Vs, padding=150):
     """envelope.build_envelope for a batch: alignments = [(row1, row2) strings], maps = frame index of every
     base (get_sequence_mapping), Us / Vs = signal lengths.  Returns a list of (U_i, 2) int arrays."""

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             // A RUN of frames on the steady table.  A lone wave pays for every instruction of a frame, and the general frame
             // below spends ~300 on a steady one; here everything a lane needs is hoisted out of the run — a frame is the
             // parent's value (one permute), the update and two comparisons.  The first frame that does not keep the beam
-            // strictly as it is leaves the run and goes through the regular path below (which computes it again).
+            // strictly as it is leaves the run and goes through the regular path below, which takes the update the run computed (o_keep).
             const bool act = rb || rc;
             const int par_lane = rb ? max(k_pslot, 0) : j;
             const bool rootp = rb && k_pslot == -1, nop = rb && k_pslot < -1;

@@ -1695,14 +1695,23 @@ extern "C" size_t po_reg_pool_bytes(int model, int wide);
 extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide, hipStream_t stream);
 // the 64-slot layout of the kernel (lane = element slot, the two reads one after the other): 7 <= W <= 12
 inline int reg_wide(int W) { return W > 6 ? 1 : 0; }
+struct RegPool;
+RegPool* reg_pool(int model, int wide);
 bool reg_eligible(int n, int W, int A, int model, int method) {
     const int rt = b2_route().route;
     // (every tree model since round 5: the kernel is templated on the model's values per entry)
     if (!(method == PO_METHOD_ROW_COL && W <= 12 && A >= 1 && W * (A + 1) <= po_reg_max_elements(reg_wide(W)))) return false;
     if (model != PO_MODEL_CTC && model != PO_MODEL_MERGE && model != PO_MODEL_FLIPFLOP) return false;
-    if (rt == PO_ROUTE_REG) return true;
-    if (rt != PO_ROUTE_AUTO) return false;
-    return b2_route().reg_auto != 0;
+    if (!(rt == PO_ROUTE_REG || (rt == PO_ROUTE_AUTO && b2_route().reg_auto != 0))) return false;
+    // The route needs the library's slice pool (below).  It is made HERE — by the workspace-size query that precedes every
+    // launch, a host-side call — and not inside the enqueue-only launch (multi-GB hipMalloc calls, a memset and a
+    // copy on the null stream do not belong in a stream capture).  A pool that cannot be allocated is remembered as such: the size
+    // query then answers for beam2d_kernel and the launch takes that kernel — the two always agree.
+    {   // (a host without a device can only PLAN — the CPU tests' size queries: answer for the engine's route)
+        static const bool no_device = [] { int nd = 0; const bool none = hipGetDeviceCount(&nd) != hipSuccess || nd <= 0; (void)hipGetLastError(); return none; }();
+        if (no_device) return true;
+    }
+    return reg_pool(model, reg_wide(W)) != nullptr;
 }
 
 // ---- The library's SLICE POOL of the register-state kernel (one per device, tree model and lane layout; made at the first
@@ -1711,27 +1720,29 @@ bool reg_eligible(int n, int W, int A, int model, int method) {
 // 28 GB per slot of a pipeline — and a hipMalloc of that size stalls for 0.5 - 2.5 s on this driver every now and then
 // (scripts/micro/malloc_cost.hip: never below 4 GB, one in three at 16 GB), which is what a process's FIRST call paid.
 // There are never more pair waves on the device than its register file and LDS admit, whatever the number of launches in
-// flight: ONE pool of that many slices serves them all, in chunks of at most ~ 3.5 GB; a wave claims a slice when it starts
-// (po_beam2d_reg.hip).  A slice keeps its tags and epoch counter from launch to launch, so nothing is ever memset or cleared
-// but a slice's first use.
+// flight: ONE pool of that many slices serves them all, in chunks of at most 3.5 GB; a wave claims a slice when it starts
+// (po_beam2d_reg.hip).  The slices hold VALUES only (no tags, no epochs: presence is bookkeeping in the kernel), so nothing is ever
+// memset or cleared.  po_reg_pool_prewarm makes a pool ahead of the first launch, po_reg_pool_release frees the current device's.
 struct RegPool {
     int nslices = 0, spc_log2 = 0;
     size_t pool_bytes = 0, slice_bytes = 0;
     long long arena_cap = 0;
     char* chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int* claim = nullptr;
-    unsigned long long* state = nullptr;
+    char* words = nullptr;                       // the allocation claim / defer_count / tickets live in
     unsigned long long* defer_count = nullptr;   // pairs handed to beam2d_kernel since the last reset (tests)
     unsigned* tickets = nullptr;                 // {take, give} tickets of the ring of free slices (claim)
-    unsigned long long magic = 0;
 };
 std::mutex g_reg_pool_mu;
 RegPool* g_reg_pools[PO_MAX_DEVICES][6] = {};
+bool g_reg_pool_failed[PO_MAX_DEVICES][6] = {};   // (sticky until po_reg_pool_release: the size query and the launch must agree)
+inline int reg_pool_key(int model, int wide) { return (model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2)) * 2 + (wide ? 1 : 0); }
 RegPool* reg_pool(int model, int wide) {
     const int dev = po_cur_device();
-    const int key = (model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2)) * 2 + (wide ? 1 : 0);
+    const int key = reg_pool_key(model, wide);
     std::lock_guard<std::mutex> lk(g_reg_pool_mu);
     if (g_reg_pools[dev][key]) return g_reg_pools[dev][key];
+    if (g_reg_pool_failed[dev][key]) return nullptr;
     RegPool* p = new RegPool();
     p->nslices = b2_num_cus() * po_reg_slots_per_cu(model, wide);
     // (PO_REG_POOL_SLICES: a smaller pool — several processes sharing one board, each with its own 9 GB otherwise; launches
@@ -1755,25 +1766,28 @@ RegPool* reg_pool(int model, int wide) {
         const int here = std::min(spc, p->nslices - c * spc);
         ok = hipMalloc((void**)&p->chunk[c], (size_t)here * p->slice_bytes) == hipSuccess;
     }
-    const size_t words = sizeof(int) * (size_t)p->nslices + sizeof(unsigned long long) * 2 * (size_t)p->nslices + 256;   // (+ the deferral counter)
+    // the ring of free slices (one int per slice), then — 256-byte aligned — the deferral counter and the two tickets
+    const size_t ring = al256(sizeof(int) * (size_t)p->nslices), words = ring + 256;
     char* w = nullptr;
     ok = ok && hipMalloc((void**)&w, words) == hipSuccess && hipMemset(w, 0, words) == hipSuccess;
     if (ok) {   // every slice is free: ring word i holds slice i
         std::vector<int> ids((size_t)p->nslices);
         for (int i = 0; i < p->nslices; ++i) ids[(size_t)i] = i;
-        ok = hipMemcpy(w + sizeof(unsigned long long) * 2 * (size_t)p->nslices, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice) == hipSuccess;
+        ok = hipMemcpy(w, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) {
+        (void)hipGetLastError();
         for (auto c : p->chunk) if (c) (void)hipFree(c);
         if (w) (void)hipFree(w);
         delete p;
+        g_reg_pool_failed[dev][key] = true;
+        if (b2_route().debug_occ) fprintf(stderr, "[po] register-state kernel pool (model %d, %s layout) could not be allocated: beam2d_kernel serves the route\n", model, wide ? "64-slot" : "32-slot");
         return nullptr;
     }
-    p->state = (unsigned long long*)w;
-    p->claim = (int*)(w + sizeof(unsigned long long) * 2 * (size_t)p->nslices);
-    p->defer_count = (unsigned long long*)(w + words - 128);
-    p->tickets = (unsigned*)(w + words - 64);
-    p->magic = 0x51ed270b0a1f3c97ull ^ ((unsigned long long)p->pool_bytes * 0x100000001b3ull) ^ ((unsigned long long)(key + 1) << 56);
+    p->words = w;
+    p->claim = (int*)w;
+    p->defer_count = (unsigned long long*)(w + ring);
+    p->tickets = (unsigned*)(w + ring + 128);
     if (b2_route().debug_occ)
         fprintf(stderr, "[po] register-state kernel pool (model %d, %s layout): %d slices of %.2f MB in %d chunk(s)\n", model, wide ? "64-slot" : "32-slot",
                 p->nslices, p->slice_bytes / 1048576.0, nchunks);
@@ -1904,6 +1918,27 @@ extern "C" int po_set_pair_route(int route, int defer_odd) {
     if (route != PO_ROUTE_AUTO && route != PO_ROUTE_LEGACY && route != PO_ROUTE_REG) return PO_E_ARG;   // (PO_ROUTE_X2 / PO_ROUTE_RING: kernels retired in round 5)
     b2_route().route = route;
     b2_route().defer_odd = defer_odd & 7;   // bit 0: odd pairs are handed on; bits 1, 2: starve the row groups / the arena
+    return PO_OK;
+}
+// The slice pool ahead of time / given back (include/poreover_hip.h).
+extern "C" int po_reg_pool_prewarm(int model, int beam_width) {
+    if (model != PO_MODEL_CTC && model != PO_MODEL_MERGE && model != PO_MODEL_FLIPFLOP) return PO_E_ARG;
+    if (beam_width < 1 || beam_width > 12) return PO_E_ARG;
+    return reg_pool(model, reg_wide(beam_width)) ? PO_OK : PO_E_NOMEM;
+}
+extern "C" int po_reg_pool_release(void) {
+    if (hipDeviceSynchronize() != hipSuccess) return PO_E_HIP;   // (no pair wave may still hold a slice)
+    const int dev = po_cur_device();
+    std::lock_guard<std::mutex> lk(g_reg_pool_mu);
+    for (int k = 0; k < 6; ++k) {
+        g_reg_pool_failed[dev][k] = false;
+        RegPool* p = g_reg_pools[dev][k];
+        if (!p) continue;
+        for (auto c : p->chunk) if (c) (void)hipFree(c);
+        if (p->words) (void)hipFree(p->words);
+        delete p;
+        g_reg_pools[dev][k] = nullptr;
+    }
     return PO_OK;
 }
 // How beam2d_reg_kernel computes a NEW element's window (po_beam2d_reg.hip, "closed form"): see include/poreover_hip.h.
@@ -2084,8 +2119,8 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
     if (reg_eligible(n, W, A, model, method)) {
         const RegGeom g = reg_geometry(n, tr1, tr2, mr1, mr2, W, model);
         if (ws_bytes < g.total) return PO_E_CAP;
-        RegPool* const rp = reg_pool(model, reg_wide(W));
-        if (!rp) return PO_E_NOMEM;
+        RegPool* const rp = reg_pool(model, reg_wide(W));   // (made by the size query before this launch: reg_eligible)
+        if (!rp) return PO_E_NOMEM;                          // (cannot happen: eligibility said it exists)
         char* w = (char*)ws;
         X2Args a;
         a.y1 = y1; a.y1_off = y1_off; a.y2 = y2; a.y2_off = y2_off; a.env = env;
@@ -2108,8 +2143,7 @@ extern "C" int po_launch_beam2d_geom(const double* y1, const int64_t* y1_off, co
             a.persist = env >= 0 ? (env != 0) : 1;
         }
         a.starve = (b2_route().defer_odd >> 1) & 3;
-        a.wgstate = rp->state;
-        a.magic = rp->magic;
+        a.wgstate = nullptr; a.magic = 0;   // (beam2d_kernel's epoch-tagged slices; this kernel's store is tag-free)
         a.dbg = nullptr;
         a.upd_count = g_b2_upd_counter;
         a.defer_odd = b2_route().defer_odd & 1;

@@ -139,12 +139,12 @@ struct X2Args {
     int pre_vcols;                    // pre-pass: columns its LDS table holds
     int ngl;                          // row groups the main kernel tracks per pair
     unsigned long long* upd_count;    // optional (po_profile_update_counter): update_prob evaluations {of the reference's schedule, executed}
-    unsigned long long* wgstate;      // beam2d_reg_kernel: per pair slot {magic, epoch counter} (see beam2d_kernel)
+    unsigned long long* wgstate;      // (unused since round 5: beam2d_reg_kernel's store carries no tags; kept for the argument block's layout)
     unsigned long long magic;
     int reg_slots;                    // beam2d_reg_kernel: pair waves of the launch
     // beam2d_reg_kernel: the library's pool of slices {value store of pool_bytes | tree arena: 3 x arena_cap ints}, one per
-    // pair wave the device can hold; a wave claims one (slice_claim) when it starts.  wgstate: {magic, epoch} per slice.
-    char* slice_chunk[8];             // slice i lives in chunk i >> slice_spc_log2 (chunks of <= 4 GB: see reg_pool)
+    // pair wave the device can hold; a wave claims one (slice_claim) when it starts.
+    char* slice_chunk[8];             // slice i lives in chunk i >> slice_spc_log2 (chunks of <= 3.5 GB: see reg_pool)
     int slice_spc_log2, nslices;
     size_t slice_bytes;
     int* slice_claim;                 // the ring of free slices (slice number, -1 = empty) ...

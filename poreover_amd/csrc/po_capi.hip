@@ -41,6 +41,7 @@ int po_launch_ingest(const void*, const int64_t*, int, int, int, const int*, int
 size_t po_align_ws_bytes(int, int64_t, int64_t, int);
 int po_launch_align(const char*, const int64_t*, int, int, int64_t, int64_t, char*, char*, const int64_t*, int32_t*, int32_t*,
                     void*, size_t, hipStream_t);
+int po_launch_nw_matrix(const char*, const int64_t*, int, int, int, int, int32_t*, const int64_t*, int32_t*, hipStream_t);
 int po_launch_align_scores(const char*, const int64_t*, int, int, int, int, int, int64_t, int64_t, char*, char*, const int64_t*,
                            int32_t*, int32_t*, void*, size_t, hipStream_t);
 size_t po_envelope_ws_bytes(int, int64_t);
@@ -765,6 +766,31 @@ int po_align_scores_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n,
     DOWN(aln1_h, a1, (size_t)aln_off_h[n]);
     DOWN(aln2_h, a2, (size_t)aln_off_h[n]);
     DOWN(ncol_h, nc, sizeof(int32_t) * n);
+    DOWN(status_h, st, sizeof(int32_t) * n);
+    return PO_OK;
+}
+
+int po_nw_matrix_batch(const char* seqs, const int64_t* seq_off, int n, int match, int mismatch, int gap_cost, int32_t* dp,
+                       const int64_t* dp_off, int32_t* status, void* stream) {
+    g_err.clear();
+    if (n < 0 || !seqs || !seq_off || !dp || !dp_off) { g_err = "po_nw_matrix_batch: null argument"; return PO_E_ARG; }
+    return po_launch_nw_matrix(seqs, seq_off, n, match, mismatch, gap_cost, dp, dp_off, status, (hipStream_t)stream);
+}
+int po_nw_matrix_batch_h(const char* seqs_h, const int64_t* seq_off_h, int n, int match, int mismatch, int gap_cost, int32_t* dp_h,
+                         const int64_t* dp_off_h, int32_t* status_h) {
+    g_err.clear();
+    if (n <= 0) return PO_OK;
+    DevBuf sq, so, dp, dpo, st;
+    UP(sq, seqs_h, (size_t)seq_off_h[2 * n]);
+    UP(so, seq_off_h, sizeof(int64_t) * (2 * n + 1));
+    UP(dp, nullptr, sizeof(int32_t) * (size_t)dp_off_h[n]);
+    UP(dpo, dp_off_h, sizeof(int64_t) * (n + 1));
+    UP(st, nullptr, sizeof(int32_t) * n);
+    const int rc = po_launch_nw_matrix((const char*)sq.p, (const int64_t*)so.p, n, match, mismatch, gap_cost, (int32_t*)dp.p,
+                                       (const int64_t*)dpo.p, (int32_t*)st.p, nullptr);
+    if (rc != PO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    DOWN(dp_h, dp, sizeof(int32_t) * (size_t)dp_off_h[n]);
     DOWN(status_h, st, sizeof(int32_t) * n);
     return PO_OK;
 }

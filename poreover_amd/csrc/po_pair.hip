@@ -856,8 +856,12 @@ PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
         // a process's first call waits for) and within 1/16 of the board's memory (very long reads: fewer workgroups)
         static const size_t budget = [] { const char* e = getenv("PO_PP_BUDGET_MB"); return (size_t)(e ? atoi(e) : 2560) << 20; }();
         const size_t per_block = sizeof(int) * g.dp_cap + sizeof(int) * 4 * g.row_cap + 2 * g.aln_cap;
-        const size_t fit = std::max<size_t>(1, std::min(budget, pp_total_mem() / 16) / std::max<size_t>(per_block, 1));
-        g.blocks = (int)std::min<size_t>((size_t)g.blocks, std::max<size_t>(fit, (size_t)pp_num_cus()));
+        // (the one-workgroup-per-CU floor applies against the 2.5 GB budget only — a comfort figure; the board's 1/16 is a HARD
+        //  cap: reads of 4e5 frames make a slice 105 MB, and a floor of 256 of them is 27 GB of workspace: ADVICE round 5)
+        const size_t pb = std::max<size_t>(per_block, 1);
+        const size_t fit_budget = std::max<size_t>(budget / pb, (size_t)pp_num_cus());
+        const size_t fit_mem = std::max<size_t>(1, (pp_total_mem() / 16) / pb);
+        g.blocks = (int)std::min<size_t>((size_t)g.blocks, std::max<size_t>(1, std::min(fit_budget, fit_mem)));
     }
     {
         const int64_t b1 = mr1 + 8, b2 = mr2 + 8;
@@ -1059,6 +1063,55 @@ extern "C" int po_launch_align_scores(const char* seqs, const int64_t* seq_off, 
     if (po_zero_async(a.queue, 256, stream) != hipSuccess) return PO_E_HIP;
     pp_launch(a, blocks, one_wave, stream, max_len2);
     return PO_OK;
+}
+
+// ---- the dense DP matrix of align.global_pair (align.pyx:34-52), the third item the reference returns: (len1 + 1) x
+// (len2 + 1) int32, row-major, boundary cells gap * i / gap * j, cell = max(diagonal + score, up + gap, left + gap).  An API
+// completeness kernel, not a hot path: one wave per pair, a row in chunks of 64 columns — the left-neighbour dependency
+// cell(j) = max(c(j), cell(j - 1) + gap) is a prefix maximum of c(k) - gap * k (integers: exact, order-free) —, the row
+// above read back from the matrix itself (a wave's own stores, program order).
+__global__ __launch_bounds__(64) void nw_matrix_kernel(const char* seqs, const int64_t* seq_off, int n, int match, int mismatch, int gap,
+                                                       int32_t* dp, const int64_t* dp_off, int32_t* status) {
+    const int p = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (p >= n) return;
+    const char* const s1 = seqs + seq_off[2 * p];
+    const char* const s2 = seqs + seq_off[2 * p + 1];
+    const int l1 = (int)(seq_off[2 * p + 1] - seq_off[2 * p]), l2 = (int)(seq_off[2 * p + 2] - seq_off[2 * p + 1]);
+    int32_t* const M = dp + dp_off[p];
+    const int64_t Wd = (int64_t)l2 + 1;
+    for (int j = lane; j <= l2; j += 64) M[j] = gap * j;
+    for (int i = 1; i <= l1; ++i) {
+        po_wave_sync();
+        const int32_t* const up_ = M + (int64_t)(i - 1) * Wd;
+        int32_t* const row = M + (int64_t)i * Wd;
+        const char ci = s1[i - 1];
+        int carry = gap * i;   // cell(i, 0), as g(0) = cell - gap * 0
+        if (lane == 0) row[0] = carry;
+        for (int base = 1; base <= l2; base += 64) {
+            const int j = base + lane;
+            const bool ok = j <= l2;
+            int v = INT_MIN / 2;
+            if (ok) {
+                const int sc = (ci == s2[j - 1]) ? match : mismatch;
+                v = max(up_[j - 1] + sc, up_[j] + gap) - gap * j;
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(v, d);
+                if (lane >= d) v = max(v, o);
+            }
+            v = max(v, carry);
+            if (ok) row[j] = v + gap * j;
+            carry = __shfl(v, 63);
+        }
+    }
+    if (lane == 0 && status) status[p] = PO_OK;
+}
+extern "C" int po_launch_nw_matrix(const char* seqs, const int64_t* seq_off, int n, int match, int mismatch, int gap, int32_t* dp,
+                                   const int64_t* dp_off, int32_t* status, hipStream_t stream) {
+    if (n <= 0) return PO_OK;
+    hipLaunchKernelGGL(nw_matrix_kernel, dim3(n), dim3(64), 0, stream, seqs, seq_off, n, match, mismatch, gap, dp, dp_off, status);
+    return hipGetLastError() == hipSuccess ? PO_OK : PO_E_HIP;
 }
 
 extern "C" size_t po_envelope_ws_bytes(int n, int64_t max_ncol) {

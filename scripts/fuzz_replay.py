@@ -17,7 +17,7 @@ for f in sys.argv[1:]:
     kind = {"ctc": "poreover", "ctc_merge_repeats": "bonito", "ctc_flipflop": "flipflop"}[model]
     want = O.cpp_beam_search_2d(y1, y2, env, W, model_=model, method_=method)
     print(f, dict(W=W, model=model, method=method, U=len(y1), V=len(y2)), "saved want == oracle now:", str(d["want"]) == want)
-    for route in ("auto", "legacy", "x2", "ring"):
+    for route in ("auto", "reg", "legacy"):
         try:
             _lib.set_pair_route(route)
             got, st = batch.beam_search_2d_batch([y1], [y2], [env], W, model=model, method=method, return_status=True)

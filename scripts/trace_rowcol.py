@@ -16,7 +16,7 @@ y1, y2, env = d["y1"], d["y2"], d["env"]
 W, model, method = int(d["W"]), str(d["model"]), str(d["method"])
 if mode == "gpu":
     from poreover_amd import _lib, batch
-    _lib.set_pair_route("ring")
+    _lib.set_pair_route("reg")
     got = batch.beam_search_2d_batch([y1], [y2], [env], W, model=model, method=method)
     sys.stdout.flush()
     print("RESULT", got[0])

@@ -9,6 +9,8 @@ bench used to check by status only:
     pair_row_W5        ... kind poreover, method row, W = 5
     pair_row_col_W10   ... kind poreover, method row_col, W = 10
     pair_flipflop_W5   flip-flop pairs synth_pair(700000 + i, flipflop), kind flipflop, row_col W = 5
+    pair_row_W25       the bench pairs, kind poreover, method row, W = 25 (the defaults of cpp_beam_search_2d, decoding_cpp.pyx:107)
+    pair_row_col_W25   ... method row_col, W = 25
 
 Records: 1-D legs [status, length, md5(seq)[:10]]; pair legs [status, len1, len2, len consensus, md5("seq1|seq2|consensus")[:10]]
 (the format of batch_digest.json).  bench.py and tests/test_gpu_batch_scale.py compare with this file, so these legs need no
@@ -75,6 +77,9 @@ LEGS = {
     "pair_row_W5": lambda n, m: (pair, [(i, "poreover", 5, "row", False) for i in range(n)]),
     "pair_row_col_W10": lambda n, m: (pair, [(i, "poreover", 10, "row_col", False) for i in range(n)]),
     "pair_flipflop_W5": lambda n, m: (pair, [(700000 + i, "flipflop", 5, "row_col", True) for i in range(n)]),
+    # the literal defaults of the Python API (decoding_cpp.pyx:107: beam_width_ = 25, method_ = "row"), and row_col at that width
+    "pair_row_W25": lambda n, m: (pair, [(i, "poreover", 25, "row", False) for i in range(n)]),
+    "pair_row_col_W25": lambda n, m: (pair, [(i, "poreover", 25, "row_col", False) for i in range(n)]),
 }
 
 

@@ -143,10 +143,12 @@ def test_beam1d_1000_reads_one_launch_vs_oracle_digest(workload, secondary_diges
 
 
 @pytest.mark.parametrize("leg,kind,W,method", [("pair_bonito_W5", "bonito", 5, "row_col"), ("pair_row_W5", "poreover", 5, "row"),
-                                               ("pair_row_col_W10", "poreover", 10, "row_col"), ("pair_flipflop_W5", "flipflop", 5, "row_col")])
+                                               ("pair_row_col_W10", "poreover", 10, "row_col"), ("pair_flipflop_W5", "flipflop", 5, "row_col"),
+                                               ("pair_row_W25", "poreover", 25, "row"), ("pair_row_col_W25", "poreover", 25, "row_col")])
 def test_secondary_pair_legs_512_pairs_vs_oracle_digest(workload, secondary_digests, leg, kind, W, method):
-    """the other pair-decode configurations bench.py times (Bonito's tree model, method row, W = 10, flip-flop pairs), 512 pairs
-    in one call each, whole stage chain: statuses, lengths and strings against the oracle's digests"""
+    """the other pair-decode configurations bench.py times (Bonito's tree model, method row, W = 10, flip-flop pairs, and — round 6 —
+    the Python API's literal defaults W = 25 / row with row_col beside it), 512 pairs in one call each, whole stage chain: statuses,
+    lengths and strings against the oracle's digests"""
     from poreover_amd import _lib, batch
     n = 512
     want = secondary_digests[leg][:n]

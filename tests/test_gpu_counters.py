@@ -56,3 +56,22 @@ def test_counting_instantiation_decodes_the_same(oracle):
     # both kernels count the schedule of the reference (to a few no-op catch-ups); the register-state kernel executes less of it
     assert abs(counts["reg"][0] - counts["legacy"][0]) <= 0.02 * counts["legacy"][0], counts
     assert counts["reg"][1] <= counts["legacy"][1], counts
+
+
+def test_reg_pool_prewarm_and_release(oracle):
+    """po_reg_pool_prewarm / po_reg_pool_release: the register-state kernel's slice pool made ahead of the first
+    launch, given back, and made again by the next call's size query — results identical before and after"""
+    from poreover_amd import _lib, batch
+    from poreover_amd.synth import synth_pair
+    _lib.load()
+    pairs = [synth_pair(880 + i, T=700) for i in range(6)]
+    want = [oracle.pair_decode(a, b, "poreover", 5, "row_col")["consensus"] for a, b in pairs]
+    _lib.reg_pool_prewarm("ctc", 5)
+    _lib.reg_pool_prewarm("ctc", 10)
+    got = batch.pair_decode_batch([p[0] for p in pairs], [p[1] for p in pairs], "poreover", 5, "row_col")
+    assert [g["consensus"] for g in got] == want
+    _lib.reg_pool_release()
+    got = batch.pair_decode_batch([p[0] for p in pairs], [p[1] for p in pairs], "poreover", 5, "row_col")   # (the pool is made again)
+    assert [g["consensus"] for g in got] == want
+    with pytest.raises(_lib.EngineError):
+        _lib.check(_lib.load().po_reg_pool_prewarm(0, 13), "po_reg_pool_prewarm")   # (W > 12 is beam2d_kernel's)

@@ -158,8 +158,28 @@ def test_bench_inprocess_devices_leg():
                           "--no_secondary", "--inprocess_devices", devs], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
-    assert rec["value"] > 0 and "strong_scaling" in rec
+    assert rec["value"] > 0 and "strong_scaling" in rec and rec["scaling"] == "strong" and rec["n_gpus"] == 1 and "weak_scaling" not in rec
     assert "inprocess" in rec["strong_scaling"] and rec["strong_scaling"]["inprocess"]["pairs_per_s"] > 0, rec["strong_scaling"].keys()
+
+
+def test_bench_two_ranks_one_job():
+    """bench.py at N = 2 (round 6: the headline is ONE job split over the ranks, `"scaling": "strong"`, the weak figure beside
+    it), both ranks on device 0 (--share_device: this box has one GPU; the figures mean nothing, the code path is the
+    driver's 2 / 4 / 8-GPU run)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share_device", "--pairs", "192", "--steps", "1",
+                          "--warmup", "1", "--cpu_sample", "0", "--no_secondary"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["pairs_per_job"] == 192 and rec["config"]["pairs_per_gpu"] == 96
+    assert rec["weak_scaling"]["scaling"] == "weak" and rec["weak_scaling"]["pairs_per_gpu"] == 192 and rec["weak_scaling"]["value"] > 0
+    assert rec["strong_scaling"]["n_gpus"] == 2 and rec["strong_scaling"]["pairs"] == 192
+    assert rec["parity_check"]["digest_mismatches"] == 0 and rec["parity_check"]["pairs_checked"] == 96
+    assert "roofline" in rec and rec["roofline"]["avg_launch_ms"] > 0
 
 
 def test_failed_call_leaves_the_pipeline_usable():

@@ -79,6 +79,14 @@ def test_workspace_bounded_for_long_reads():
         fixed = 4 * n * (62000 + 75600) + 8 * n * 62000      # frame maps + envelope: proportional to the input itself
         assert ws - fixed < 150 * 2**30, (W, method, ws / 2**30)
     opt = _lib.PairOptions(5, _lib.MODELS["ctc"], _lib.METHODS["row_col"], 5, 0, 0, 50)
+    # ultra-long reads through the direct API (the pipeline bounds its waves itself) — the aligner's slices stay
+    # within 1/16 of the board whatever the CU count says (a floor of one slice per CU was 27 GB at 4e5 frames, more beyond)
+    var = {}
+    for n_, mr in ((256, 1000000), (512, 1000000), (512, 400000)):
+        ws = lib.po_pair_decode_workspace_bytes(n_, n_ * mr, n_ * mr, mr, mr, 5, C.byref(opt))
+        var[(n_, mr)] = ws - (4 * n_ * 2 * mr + 8 * n_ * mr)
+        assert var[(n_, mr)] < 72 * 2**30, (n_, mr, var[(n_, mr)] / 2**30)
+    assert var[(512, 1000000)] < var[(256, 1000000)] + 24 * 2**30      # (twice the pairs: the per-pair arrays, not twice the slices)
     small = lib.po_pair_decode_workspace_bytes(10000, 40000000, 40000000, 4000, 4400, 5, C.byref(opt))
     assert small < 48 * 2**30      # (the bench configuration keeps its full occupancy: ~16 GB of DP slices + ~15 GB for the pair beam)
 

@@ -33,6 +33,19 @@ def test_emulated_kernel_matches_oracle(emu_lib, oracle, model, W, sched):
     assert "0 mismatches" in out.stdout
 
 
+@pytest.mark.parametrize("mode,W", [("1", "0"), ("1", "10"), ("2", "5")])
+def test_emulated_closed_form_chains(emu_lib, oracle, mode, W):
+    """po_set_chain_mode(PO_CHAIN_CLOSED_FORM): the new elements' windows in closed form (one exp, a prefix sum, one log per time;
+    both lane layouts), and with its guard at 3 nats (mode 2: most steps hand over to the general scan).  The values differ from
+    the serial chain's in the last bits; the strings of these small cases are the oracle's."""
+    env = dict(os.environ, EMU_CHAIN_SCAN=mode)
+    out = subprocess.run([sys.executable, os.path.join(EMU, "check_emu.py"), "--n", "16", "--T", "320", "--W", W, "--model", "ctc", "--seed", "77",
+                          "--procs", "4", "--styles", "pipeline,stairs,wobble", "--lib", emu_lib],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "0 mismatches" in out.stdout
+
+
 def test_emulated_kernel_hands_a_wide_window_on(emu_lib, oracle):
     """the fuzz case that faulted the GPU in round 4 (a 311-frame window at W = 1: the packed walk records keep a window
     length in 8 bits): the register-state kernel must DEFER the pair (beam2d_kernel decodes it), not decode it wrong"""

@@ -36,7 +36,6 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     std::vector<int> claim((size_t)blocks, 0);
     for (int i = 0; i < blocks; ++i) claim[(size_t)i] = i;
     unsigned tickets[2] = {0u, 0u};
-    std::vector<unsigned long long> wgstate(2 * (size_t)blocks, 0);
     a.queue = queue.data(); a.meta = meta.data(); a.nmain = nmain.data(); a.sched = sched.data(); a.envt = envt.data();
     a.cum1 = cum1.data(); a.cum2 = cum2.data();
     a.pool = nullptr; a.pool_bytes = pool_bytes; a.arena = nullptr; a.arena_cap = (long long)arena_cap;
@@ -44,7 +43,7 @@ extern "C" int emu_ring_pair_beam(const double* y1, const int64_t* y1_off, const
     a.slice_chunk[0] = pool.data(); a.slice_spc_log2 = 30; a.nslices = blocks; a.slice_bytes = slice_bytes; a.slice_claim = claim.data();
     a.slice_tickets = tickets; a.persist = 1; a.defer_count = nullptr; a.starve = 0;
     a.dbg = nullptr; a.upd_count = upd_count; a.defer_odd = 0; a.need_mono = 1; a.order = nullptr;
-    a.wgstate = wgstate.data(); a.magic = 0x1234567ull;
+    a.wgstate = nullptr; a.magic = 0;
     a.pre_vcols = (int)std::min<int64_t>(mr2, 6144);
     a.ngl = po_reg_ngl(wide);
     a.no_cum = 1;

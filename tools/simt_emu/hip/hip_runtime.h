@@ -155,6 +155,7 @@ static inline int emu_lane_() { return (int)(emu::g_cur->tid.x & 63); }
 #define __builtin_amdgcn_readfirstlane(v_) emu::shfl((int)(v_), 0, __LINE__)
 #define __builtin_amdgcn_ds_bpermute(a_, v_) emu::shfl((int)(v_), ((a_) >> 2), __LINE__)
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_sched_barrier(m_) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu::rendezvous_wave(__LINE__)
 #define __builtin_amdgcn_s_sleep(n) emu::yield()
 #define __builtin_amdgcn_s_barrier() emu::rendezvous_block(__LINE__)
