@@ -739,6 +739,62 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
             const bool rootp = rb && k_pslot == -1, nop = rb && k_pslot < -1;
             const int iya = act ? k_sym : 0, iyb = (MODEL == PO_MODEL_FLIPFLOP) ? (act ? k_sym + A : 0) : A;
             const bool validc = rc && !k_dup;
+            if constexpr (K == 1) {
+            // (round 6; the one-value model — with three logaddexp per update the thrown-away frames cost more than the overlap
+            //  gains: config 5 5.41 -> 5.78 ms, config 2 3.68 -> 3.59 ms) A lone wave's frame is latency: the update's ~ 40 dependent f64 operations and two table reads, THEN the
+            // prune test's four dependent DPP steps, a lane read, a ballot and a branch.  The two do not depend on each other
+            // once the frame's update is there — so the loop computes frame t + 1's update (as if frame t keeps the beam) in
+            // the same basic block as frame t's prune test, without a branch between them (every lane computes; root / no-parent
+            // values are selects), and the scheduler fills the update's latency slots with the test.  If frame t changes the
+            // beam, frame t + 1's update is thrown away.  Same arithmetic, same results.
+            auto upd_frame = [&](int tf, const double* pv, double bc, double* o_out, double& yb_out) {
+                const double* yq = &yblk[(tf >> 5) & 1][tf & 31][0];
+                const double ya = yq[iya], yb = yq[iyb];   // (requested before the permute: one LDS round trip for both)
+                double pp[3], rv[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, ov[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF};
+#pragma unroll
+                for (int k = 0; k < K; ++k) pp[k] = __shfl(pv[k], par_lane);
+                root_values<MODEL>(tf - 1, bc, rv);
+#pragma unroll
+                for (int k = 0; k < K; ++k) pp[k] = rootp ? rv[k] : (nop ? PO_NEG_INF : pp[k]);
+                po_update<MODEL>(pv, pp, ya, yb, k_samef, false, ov, lae);
+#pragma unroll
+                for (int k = 0; k < K; ++k) o_out[k] = act ? ov[k] : PO_NEG_INF;
+                yb_out = yb;
+            };
+            if (t < T - 1) {   // (the last frame is ranked: the label is the best node's)
+                double o_cur[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, yb_cur = 0.0;
+                upd_frame(t, p_val, blank_cum, o_cur, yb_cur);
+                for (;;) {
+                    double o_nx[3] = {PO_NEG_INF, PO_NEG_INF, PO_NEG_INF}, yb_nx = 0.0;
+                    const double bc_nx = blank_cum + yb_cur;   // (iyb == A for the ctc model: the blank column)
+                    upd_frame(t + 1, o_cur, bc_nx, o_nx, yb_nx);   // (t + 1 <= T - 1; a frame that opens a y block reads stale rows: redone below)
+                    const double sc = o_cur[0];
+                    const double scmin = b1_row0_min(rb ? sc : HUGE_VAL);   // (W <= 12: the beam lanes sit in row 0)
+                    if (__ballot(validc && !(scmin > sc)) != 0ull) {   // (the frame is ranked below: its update is this one)
+#pragma unroll
+                        for (int k = 0; k < K; ++k) o_keep[k] = o_cur[k];
+                        have_o = true;
+                        break;
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) p_val[k] = o_cur[k];
+                    if (MODEL == PO_MODEL_CTC) blank_cum = bc_nx;
+#ifdef PO_B1_COUNT
+                    ++cnt_fast; ++cnt_same;
+#endif
+                    ++t;
+                    if (t == T - 1) break;
+                    if ((t & 31) == 0) {
+                        y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync();
+                        upd_frame(t, p_val, blank_cum, o_cur, yb_cur);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) o_cur[k] = o_nx[k];
+                        yb_cur = yb_nx;
+                    }
+                }
+            }
+            } else {
             for (;;) {
                 if (t == T - 1) break;   // (the last frame is ranked: the label is the best node's)
                 const double* yq = &yblk[(t >> 5) & 1][t & 31][0];
@@ -769,6 +825,7 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
                 ++t;
                 if (t >= T) break;
                 if ((t & 31) == 0) { y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync(); }
+            }
             }
             B1_KT(tk_run);
             if (t >= T) break;
