@@ -128,13 +128,6 @@ __device__ __forceinline__ void rk_sync() { b2_sync_lds<64>(); }
 // the smallest of x over lanes 0 .. n - 1 (n <= 16: the beam slots sit in row 0 of the wave), wave-uniform: four row_shr steps
 // in the VALU and one pair of v_readlane instead of 2 n v_readlane and n - 1 minima
 __device__ __forceinline__ double rk_row0_min(double x, int n, int lane) {
-#ifdef PO_EMU
-    double m_ = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 0), __builtin_amdgcn_readlane(__double2loint(x), 0));
-    for (int i = 1; i < n; ++i)
-        m_ = fmin(m_, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), i), __builtin_amdgcn_readlane(__double2loint(x), i)));
-    (void)lane;
-    return m_;
-#else
     x = (lane < n) ? x : __builtin_inf();
 #define RK_STEP(ctrl)                                                                                                     \
     x = po_vmin(x, __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), ctrl, 0xf, 0xf, false), \
@@ -142,7 +135,6 @@ __device__ __forceinline__ double rk_row0_min(double x, int n, int lane) {
     RK_STEP(0x111); RK_STEP(0x112); RK_STEP(0x114); RK_STEP(0x118);
 #undef RK_STEP
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 15), __builtin_amdgcn_readlane(__double2loint(x), 15));
-#endif
 }
 __device__ __forceinline__ double rk_readlane_d(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));

@@ -142,7 +142,7 @@ struct PoLaeFast {
             const double kf = tm - 0x1.8p52;
             const int k = __double2loint(tm);
             const int j = k & 63;
-#if defined(PO_LAE_EARLY_TABLE) && !defined(PO_EMU)
+#if defined(PO_LAE_EARLY_TABLE)
             // The table entry is asked for as soon as its index exists and nothing is scheduled across that point: left
             // alone, the scheduler sinks the LDS read below the polynomial and a lone wave waits a full LDS round trip
             // per logaddexp in its dependent chain (same instructions, same result bits).
@@ -156,7 +156,7 @@ struct PoLaeFast {
             p = po_fma_c(r, p, 1.0 / 6);
             p = po_fma_c(r, p, 0.5);
             p = __builtin_fma(r * r, p, r);
-#if !(defined(PO_LAE_EARLY_TABLE) && !defined(PO_EMU))
+#if !defined(PO_LAE_EARLY_TABLE)
             const double th = t->exp_t[j][0], tl = t->exp_t[j][1];
 #endif
             const double x = th + __builtin_fma(th, p, tl);
@@ -305,24 +305,15 @@ __device__ __forceinline__ int po_lane() { return threadIdx.x & (PO_WAVE - 1); }
 // register with the lower half of another inside the VALU — two of them and two selects per double, instead of two
 // ds_bpermute_b32 round trips through the LDS crossbar.
 __device__ __forceinline__ int po_xor32_i(int x, bool upper) {
-#ifdef PO_EMU
-    (void)upper;
-    return __shfl_xor(x, 32);
-#else
     const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
     return (int)(upper ? r[0] : r[1]);
-#endif
 }
 // x + (x of lane ^ 32): after swapping the upper half of one copy with the lower half of another, every lane holds its own
 // value in one of the two and the other half's in the other — their sum needs no select (a + b == b + a bit for bit)
 __device__ __forceinline__ double po_sum32(double x) {
-#ifdef PO_EMU
-    return x + __shfl_xor(x, 32);
-#else
     const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
     return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-#endif
 }
 __device__ __forceinline__ double po_xor32(double x, bool upper) {   // upper: this lane is one of 32..63
     return __hiloint2double(po_xor32_i(__double2hiint(x), upper), po_xor32_i(__double2loint(x), upper));
@@ -332,10 +323,6 @@ __device__ __forceinline__ double po_xor32(double x, bool upper) {   // upper: t
 // (quad xor 1, quad xor 2, half-row mirror, row mirror — a maximum does not care which partner it sees), then the four
 // rows through v_readlane.  No LDS round trips: ~ 25 instructions.
 __device__ __forceinline__ double po_wave_max(double x) {
-#ifdef PO_EMU
-    for (int off = 32; off >= 1; off >>= 1) x = po_vmax(x, __shfl_xor(x, off));
-    return x;
-#else
 #define PO_DPP_D(ctrl) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), (ctrl), 0xf, 0xf, false), \
                                         __builtin_amdgcn_update_dpp(0, __double2loint(x), (ctrl), 0xf, 0xf, false))
     x = po_vmax(x, PO_DPP_D(0xB1));    // quad_perm [1,0,3,2]
@@ -345,7 +332,6 @@ __device__ __forceinline__ double po_wave_max(double x) {
 #undef PO_DPP_D
     auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l)); };
     return po_vmax(po_vmax(rl(0), rl(16)), po_vmax(rl(32), rl(48)));
-#endif
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every

@@ -151,6 +151,18 @@ static inline int dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
 static inline int emu_lane_() { return (int)(emu::g_cur->tid.x & 63); }
 #define __shfl_xor(v_, m_) emu::shfl((v_), (int)(emu_lane_() ^ (m_)), __LINE__)
 #define __ballot(p_) emu::ballot((p_), __LINE__)
+// v_permlane32_swap_b32 (gfx950): the upper half of the first operand and the lower half of the second change places; the builtin
+// returns both registers
+struct emu_u2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+static inline emu_u2 emu_permlane32_swap(unsigned a, unsigned b, int line) {
+    const int lane = emu_lane_();
+    const unsigned a_other = emu::shfl(a, lane ^ 32, line), b_other = emu::shfl(b, lane ^ 32, line);
+    emu_u2 r;
+    r.v[0] = (lane < 32) ? a : b_other;
+    r.v[1] = (lane < 32) ? a_other : b;
+    return r;
+}
+#define __builtin_amdgcn_permlane32_swap(a_, b_, fi_, bc_) emu_permlane32_swap((unsigned)(a_), (unsigned)(b_), __LINE__)
 #define __builtin_amdgcn_readlane(v_, l_) emu::shfl((int)(v_), (l_), __LINE__)
 #define __builtin_amdgcn_readfirstlane(v_) emu::shfl((int)(v_), 0, __LINE__)
 #define __builtin_amdgcn_ds_bpermute(a_, v_) emu::shfl((int)(v_), ((a_) >> 2), __LINE__)
