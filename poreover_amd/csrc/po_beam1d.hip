@@ -783,9 +783,12 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
                     ++cnt_fast; ++cnt_same;
 #endif
                     ++t;
+                    // (the y block of frame t is committed BEFORE the run can be left: the last frame, ranked by the general path,
+                    //  may be the one that opens a block — T - 1 a multiple of 32: the round's 1-D fuzz session, 61 of 51 806 reads)
+                    const bool opens = (t & 31) == 0;
+                    if (opens) { y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync(); }
                     if (t == T - 1) break;
-                    if ((t & 31) == 0) {
-                        y_commit(t >> 5); y_request((t >> 5) + 1); po_wave_sync();
+                    if (opens) {
                         upd_frame(t, p_val, blank_cum, o_cur, yb_cur);
                     } else {
 #pragma unroll

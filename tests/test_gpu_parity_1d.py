@@ -116,3 +116,18 @@ def test_beam1d_ragged_and_errors(eng):
         eng.beam_search_batch([np.zeros((10, 7))], 5)      # C does not match the model
     with pytest.raises(_lib.EngineError):
         eng.beam_search_batch(reads[:1], 5, alphabet="ACGTN")
+
+
+@pytest.mark.parametrize("model,kind", [("ctc", "poreover"), ("ctc_merge_repeats", "bonito"), ("ctc_flipflop", "flipflop")])
+@pytest.mark.parametrize("W", [3, 5, 10, 12, 25])
+def test_beam1d_last_frame_opens_a_y_block(oracle, model, kind, W):
+    """reads whose LAST frame is the first of a 32-frame y block (T - 1 a multiple of 32) and their neighbours: the steady run of
+    beam1d_wave_kernel must have the block in LDS before the general path ranks that frame (round 6: the open-ended 1-D fuzz found
+    61 of 51 806 reads wrong on a loop that left the run before committing the block; the seeded tests had no such length)"""
+    from poreover_amd import batch
+    from poreover_amd.synth import synth_pair
+    Ts = [32, 33, 34, 64, 65, 66, 97, 129, 1025, 1536, 1537, 1538, 2049]
+    reads = [synth_pair(91000 + i, T=max(T, 40), flipflop=(kind == "flipflop"))[0][:T] for i, T in enumerate(Ts)]
+    got = batch.beam_search_batch(reads, W, model=model)
+    for T, y, g in zip(Ts, reads, got):
+        assert g == oracle.cpp_beam_search(y, W, model_=model), (model, W, T)
