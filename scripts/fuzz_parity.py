@@ -44,7 +44,11 @@ def write_summary(args, mode, **counts):
         sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
     except OSError:
         sha = None
-    rec = dict(mode=mode, seed=args.seed, seconds=args.seconds, route=args.route, focus=bool(args.focus), git_head=args.head,
+    try:
+        chain = _lib.get_chain_mode()   # (serial unless PO_CHAIN_CLOSED / po_set_chain_mode says otherwise: round 6)
+    except Exception:
+        chain = None
+    rec = dict(mode=mode, seed=args.seed, seconds=args.seconds, route=args.route, focus=bool(args.focus), git_head=args.head, chain_mode=chain,
                lib=os.path.relpath(lib_path), lib_sha256=sha, when=time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), **counts)
     os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
     prev = []
