@@ -1694,7 +1694,10 @@ extern "C" int po_reg_ngl(int wide);
 extern "C" size_t po_reg_pool_bytes(int model, int wide);
 extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide, hipStream_t stream);
 // the 64-slot layout of the kernel (lane = element slot, the two reads one after the other): 7 <= W <= 12
-inline int reg_wide(int W) { return W > 6 ? 1 : 0; }
+inline int reg_wide(int W) {
+    static const int force = getenv("PO_REG_FORCE_WIDE") ? 1 : 0;   // (experiments: the 64-slot layout for every width)
+    return (W > 6 || force) ? 1 : 0;
+}
 struct RegPool;
 RegPool* reg_pool(int model, int wide);
 bool reg_eligible(int n, int W, int A, int model, int method) {
