@@ -169,7 +169,9 @@ int po_beam1d_batch(const double* y, const int64_t* y_off, int n, int C, const c
  * size the workspace with PO_METHOD_GRID_NOENV in that case.  grid needs row starts that do not move
  * backwards (PO_E_UNSUPPORTED otherwise) and keeps 2 x V x beam_width nodes of cell beams per pair in
  * flight; without an envelope every read-1 time of a node stays readable, so it only fits short reads
- * (PO_E_NOMEM otherwise).  */
+ * (PO_E_NOMEM otherwise).
+ * The size query is where the register-state route's slice pool is made (first query per device, tree model and lane layout
+ * that selects the route: po_reg_pool_prewarm above) — so that the launch that follows allocates nothing.  */
 size_t po_beam2d_workspace_bytes(int n, int64_t total_rows1, int64_t total_rows2, int64_t max_rows1,
                                  int64_t max_rows2, int C, int beam_width, int model, int method);
 int po_beam2d_batch(const double* y1, const int64_t* y1_off, const double* y2, const int64_t* y2_off,
