@@ -253,8 +253,8 @@ void beam2d_reg_kernel(X2Args a) {
 
 #ifdef PO_REG_TIMING
     // phase timers of workgroup 0 (wall_clock64: 100 MHz) and counts: see po_reg_launch for the names
-    long long tk[40], tlast = wall_clock64();
-    for (int i = 0; i < 40; ++i) tk[i] = 0;
+    long long tk[56], tlast = wall_clock64();
+    for (int i = 0; i < 56; ++i) tk[i] = 0;
 #define KT(i) do { const long long n_ = wall_clock64(); tk[(i)] += n_ - tlast; tlast = n_; } while (0)
 #define KC(i, n) do { tk[(i)] += (n); } while (0)
 #else
@@ -392,7 +392,6 @@ void beam2d_reg_kernel(X2Args a) {
         }
         int nb = A, ne = A;
         int next_id = 1 + A;
-        int gcur = 1;               // row group allocation cursor
         int sel[WS];
 #pragma unroll
         for (int i = 0; i < WS; ++i) sel[i] = i;
@@ -984,9 +983,12 @@ void beam2d_reg_kernel(X2Args a) {
                 }   // (!SCAN)
             }
             if (n1max == 0 && want_seed && ws - 1 < se_hdr) for (int c = 0; c < K; ++c) self.v[c] = se.v[c];
-            if (s < PF0N) {
-                sm.pf0_t[r][s] = want_pf ? ws : -1;
-                if (want_pf) sm.pf0[r][s] = se.v[0];
+            {   // (the slot's address from the lane number HERE: po_lane_here)
+                const int ln = po_lane_here(), sh = (NR == 1) ? (ln & 31) : ln, rh = (NR == 1) ? (ln >> 5) : r;
+                if (sh < PF0N) {
+                    sm.pf0_t[rh][sh] = want_pf ? ws : -1;
+                    if (want_pf) sm.pf0[rh][sh] = se.v[0];
+                }
             }
             // the fresh lanes are ordinary continuing lanes now, ending at dr like everybody else: the run loop does the step
             if (fresh[q]) {
@@ -1026,13 +1028,17 @@ void beam2d_reg_kernel(X2Args a) {
             int n_id = __shfl(e_id, hb | srcb), n_row2 = __shfl(e_row2, hb | srcb), n_sym = __shfl(e_sym, hb | srcb);
             int n_fc = sm.f_fc[srcb], n_crow2 = sm.f_crow2[srcb], n_par = sm.f_par[srcb];
             int n_gpar = sm.f_gpar[srcb], n_prow2 = sm.f_prow2[srcb], n_depth = sm.f_depth[srcb];
+            KT(40);
             // ---- every old element marks its row group with the times it has written there
 #pragma unroll
             for (int q = 0; q < NR; ++q)
                 if (live && v_fresh[q] == 0) atomicMax(&g_hi(RD(q))[e_row2 >> 2], v_done[q]);
             // ---- B. expansion of the new beam nodes
             KC(20, __ballot(rb && n_fc == -2) != 0ull ? 1 : 0);
-            if (__builtin_expect(rb && n_fc == -2, 0)) { n_fc = afc[n_id]; n_crow2 = acrow[n_id]; }   // a node whose parent re-entered: the arena knows
+            if (__builtin_expect(__ballot(rb && n_fc == -2) != 0ull, 0)) {   // (wave-uniform branch: see po_settle)
+                if (rb && n_fc == -2) { n_fc = afc[n_id]; n_crow2 = acrow[n_id]; }   // a node whose parent re-entered: the arena knows
+                po_settle(n_fc, n_crow2);
+            }
             rk_sync();
             bool isnew = false, need_group = false;
             if (rb) {
@@ -1050,25 +1056,47 @@ void beam2d_reg_kernel(X2Args a) {
                 if (__builtin_expect(next_id > arena_cap, 0)) st = PO_E_NOMEM;   // (the slice's arena is full: beam2d_kernel takes the pair)
                 if (rb && !need_group) { atomicMax(&sm.g_hi0[n_crow2], nce); atomicMax(&sm.g_hi1[n_crow2], nre); }
                 rk_sync();
-                SMask hg = smask_of(need_group);
-                while (hg != 0) {   // (uniform: every lane walks the group table, lane 0 writes)
-                    const int jj = sm_ctz(hg);
-                    hg &= hg - (SMask)1;
-                    const int owner = __builtin_amdgcn_readlane(n_id, jj);
-                    int gg = -1;
-                    for (int tries = 0; tries < NG; ++tries) {
-                        const int cc = gcur;
-                        gcur = (gcur + 1 == NG) ? 0 : gcur + 1;
-                        if (sm.g_owner[cc] < 0 || (sm.g_hi0[cc] <= nu - 1 && sm.g_hi1[cc] <= nv - 1)) { gg = cc; break; }
+                const SMask hg = smask_of(need_group);
+                if (hg != 0) {   // (wave-uniform)
+                    // Round 6: every row group the step needs in ONE pass.  (Rounds 4 - 5 handed them out one after the other — walk
+                    // the table from a cursor with three dependent LDS reads per entry, a fence, lane 0 writes the entry, a fence:
+                    // 61 % of the table build's time, 12 % of the kernel's, profiles/r06_ab_row_groups.txt.)  Lane l looks at groups
+                    // l, l + 64, ..: one LDS round trip for the whole table, a ballot per 64 groups; the k-th beam slot that needs a
+                    // group takes the k-th free one (scalar bit work) and writes its entry itself.  WHICH free group a parent gets
+                    // only names rows of the store: results do not depend on it.
+                    constexpr int GPL = (RK_NGL + 63) / 64;
+                    unsigned long long fm[GPL];
+#pragma unroll
+                    for (int g = 0; g < GPL; ++g) {
+                        const int cc = lane + 64 * g;
+                        bool fr = false;
+                        if (cc < NG) {
+                            const int ow = sm.g_owner[cc], h0 = sm.g_hi0[cc], h1 = sm.g_hi1[cc];   // (asked for together)
+                            fr = ow < 0 || (h0 <= nu - 1 && h1 <= nv - 1);
+                        }
+                        fm[g] = __ballot(fr);
                     }
-                    if (gg < 0) { st = PO_E_NOMEM; gg = 0; }
-                    rk_sync();   // (every lane has walked the table before lane 0 changes it)
-                    if (lane == 0) { sm.g_owner[gg] = owner; sm.g_hi0[gg] = nce; sm.g_hi1[gg] = nre; acrow[owner] = gg; }
-                    if (lane < 2 * PO_A) rowhdr[gg * 2 * PO_A + lane] = RK_FRESH;   // (the group's rows hold nothing of their new owners yet)
-                    if (s == jj) n_crow2 = gg;
+                    int mygg = 0;
+                    for (SMask h2 = hg; h2 != 0; h2 &= h2 - (SMask)1) {   // (wave-uniform; one trip per group handed out)
+                        const int jj = sm_ctz(h2);
+                        int gg = -1;
+#pragma unroll
+                        for (int g = 0; g < GPL; ++g)
+                            if (gg < 0 && fm[g] != 0ull) { gg = 64 * g + (int)__builtin_ctzll(fm[g]); fm[g] &= fm[g] - 1ull; }
+                        KC(47, 1);
+                        if (gg < 0) { st = PO_E_NOMEM; gg = 0; }   // (none free: beam2d_kernel takes the pair)
+                        if (s == jj) mygg = gg;
+                        if (lane < 2 * PO_A) rowhdr[gg * 2 * PO_A + lane] = RK_FRESH;   // (the group's rows hold nothing of their new owners yet)
+                    }
+                    rk_sync();   // (every lane has looked at the table before its entries change)
+                    if (need_group) {
+                        if (lo_half) { sm.g_owner[mygg] = n_id; sm.g_hi0[mygg] = nce; sm.g_hi1[mygg] = nre; acrow[n_id] = mygg; }
+                        n_crow2 = mygg;
+                    }
                     rk_sync();
                 }
             }
+            KT(41);
             // ---- C. children slots take their parent's (new) fields
             const int p_id = __shfl(n_id, hb | j), p_fc = __shfl(n_fc, hb | j), p_crow2 = __shfl(n_crow2, hb | j);
             const int p_sym = __shfl(n_sym, hb | j), p_par = __shfl(n_par, hb | j), p_row2 = __shfl(n_row2, hb | j);
@@ -1088,6 +1116,7 @@ void beam2d_reg_kernel(X2Args a) {
                 const int bid = __builtin_amdgcn_readlane(n_id, i);
                 if (rc && bid == n_id) n_alias = i;
             }
+            KT(42);
             // ---- D. which old slot continues here
             int src = -1;
             if (rb) src = mysel;
@@ -1106,6 +1135,7 @@ void beam2d_reg_kernel(X2Args a) {
                 if (!rb && src >= nbo && oa >= 0) src = oa;
             }
             const bool nlive = (rb || (rc && n_alias < 0));
+            KT(43);
             // ---- E. an old element that continues in no slot of the new table LEAVES: where its stored values end goes into its
             // row's header — whoever asks for them while it is no element (a frozen parent's older values, its own seed should it
             // become an element again) finds the answer there.  (A handful of lanes per table build: writing every element's
@@ -1121,6 +1151,7 @@ void beam2d_reg_kernel(X2Args a) {
                     if (leaving && v_fresh[q] == 0) *hdr_of(RD(q), e_row2) = v_done[q];
                 rk_sync();   // (ord is the tie replay's scratch as well)
             }
+            KT(44);
             // ---- F. the lanes take their new identity
             const int gsrc = hb | max(src, 0);
             const int g_fc = sm.f_fc[max(src, 0)], g_crow2 = sm.f_crow2[max(src, 0)];
@@ -1156,6 +1187,7 @@ void beam2d_reg_kernel(X2Args a) {
                 sm.f_depth[s] = n_depth; sm.f_alias[s] = rc ? n_alias : -1;
             }
             live = nlive;
+            KT(45);
             // ---- the parent slot of the beam nodes: a beam node, a child of a beam node, the root, or none (frozen)
             nb = nbn; ne = nen;
             {   // (wave-uniform loops: v_readlane)
@@ -1171,6 +1203,7 @@ void beam2d_reg_kernel(X2Args a) {
                 }
             }
             e_ps = n_ps;
+            KT(46);
             // ---- G. a frozen parent that is an element again.  A beam node whose parent had left the table computed its
             // newest values against "absent" (-inf beyond the parent's last time).  When the grandparent enters the beam the
             // parent comes back as one of its children, computes its whole window — times it never had — and the
@@ -1237,10 +1270,12 @@ void beam2d_reg_kernel(X2Args a) {
 #pragma unroll
                 for (int q = 0; q < NR; ++q) {
                     pf_e[q] = 0.0; pf_t[q] = -1;
-                    if (pf0_step == mstep && s < PF0N) {   // ... or with the staging of the new elements' step just before this run
-                        const int r = RD(q);
-                        pf_t[q] = sm.pf0_t[r][s];
-                        if (pf_t[q] >= 0) pf_e[q] = sm.pf0[r][s];
+                    if (pf0_step == mstep) {   // ... or with the staging of the new elements' step just before this run  (wave-uniform)
+                        const int ln = po_lane_here(), sh = (NR == 1) ? (ln & 31) : ln, rh = (NR == 1) ? (ln >> 5) : RD(q);
+                        if (sh < PF0N) {
+                            pf_t[q] = sm.pf0_t[rh][sh];
+                            if (pf_t[q] >= 0) pf_e[q] = sm.pf0[rh][sh];
+                        }
                     }
                 }
                 for (;;) {
@@ -1519,7 +1554,7 @@ void beam2d_reg_kernel(X2Args a) {
     }
 #ifdef PO_REG_TIMING
     if (lane == 0 && a.dbg && slotid == 0)
-        for (int i = 0; i < 40; ++i) a.dbg[i] = tk[i];
+        for (int i = 0; i < 56; ++i) a.dbg[i] = tk[i];
 #endif
     if (COUNT && lane == 0 && a.upd_count) { atomicAdd(a.upd_count, sm.nupd); atomicAdd(a.upd_count + 1, sm.nupd_x); }
     // (everything this wave wrote into the slice leaves this XCD's L2 before another wave — any CU, any XCD — may claim it)
@@ -1585,8 +1620,8 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide
     a.reg_slots = slots;
 #ifdef PO_REG_TIMING
     static long long* dbg = nullptr;
-    if (!dbg) { (void)hipMalloc((void**)&dbg, 40 * sizeof(long long)); }
-    (void)hipMemsetAsync(dbg, 0, 40 * sizeof(long long), stream);
+    if (!dbg) { (void)hipMalloc((void**)&dbg, 56 * sizeof(long long)); }
+    (void)hipMemsetAsync(dbg, 0, 56 * sizeof(long long), stream);
     a.dbg = dbg;
 #endif
     if (wide) {
@@ -1600,7 +1635,7 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide
     }
 #ifdef PO_REG_TIMING
     {
-        long long h[40];
+        long long h[56];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         fprintf(stderr, "[po_reg_timing] pair slot 0, 10 ns ticks\n");
@@ -1610,6 +1645,8 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide
         fprintf(stderr, "   step top + score + prune test %lld, ranking %lld, rebuild %lld, pair setup + label %lld\n", h[6], h[7], h[8], h[9]);
         fprintf(stderr, "   new-element steps handed to the general scan: window order %lld, uneven ends %lld, root's children %lld, fresh without a parent lane %lld, fresh under fresh %lld, more than PS parents %lld\n", h[22], h[23], h[24], h[25], h[26], h[27]);
         fprintf(stderr, "   run loop left for the general scan: window order / last step %lld, a frozen parent's older values %lld; general main scans on a table that is not fresh %lld, uneven %lld, beam not full %lld\n", h[28], h[29], h[30], h[32], h[33]);
+        fprintf(stderr, "   table build by part: A fields %lld, B marks + expansion + row groups %lld, C children %lld, D continuing slots %lld, E leaving headers %lld, F identity moves %lld, parent slots %lld, G rewind + rest %lld (the rest is in the total above)\n", h[40], h[41], h[42], h[43], h[44], h[45], h[46], h[8]);
+        fprintf(stderr, "   row groups handed out: %lld\n", h[47]);
         fprintf(stderr, "   closed-form chains: %lld passes (a staged parent's children on both reads), %lld of them left to the serial chain\n", h[34], h[35]);
         fprintf(stderr, "   nodes entering the beam: %lld, of them expanded before %lld, with their children's row group still theirs %lld\n", h[36], h[37], h[38]);
         fprintf(stderr, "   table builds that ask the arena for a node's children: %lld; window rescans: %lld lanes in %lld calls; bounds made exact in %lld steps\n", h[20], h[21], h[10], h[31]);

@@ -334,6 +334,33 @@ __device__ __forceinline__ double po_wave_max(double x) {
     return po_vmax(po_vmax(rl(0), rl(16)), po_vmax(rl(32), rl(48)));
 }
 
+// "These registers are final HERE."  gfx9 counts a wave's vector loads AND stores on one counter (vmcnt) and they complete in
+// order, so `s_waitcnt vmcnt(0)` in front of the first use of a loaded value also waits for every store the wave has in flight.
+// The compiler places that wait where the value is first used — after the join of a RARE branch that loaded it, that is on the
+// common path too, where nothing was loaded and a full store queue is drained for nothing (po_beam2d_reg.hip's table build: a
+// round trip of ~ 2.5 us per beam change at full load, 11 % of the kernel: round 6).  Called at the end of the rare branch, this
+// makes the branch itself wait: past the join nothing is pending.
+__device__ __forceinline__ void po_settle(int& a, int& b) {
+#ifndef PO_EMU
+    asm volatile("" : "+v"(a), "+v"(b));
+#else
+    (void)a; (void)b;
+#endif
+}
+
+// The lane number as a value the compiler cannot carry from somewhere else: an address built from it is computed where it is
+// used (two or three VALU operations).  Hoisted out of the walk loop instead, such an address is one more kernel-lifetime
+// register — the ones that get SPILLED — and on gfx9 a scratch reload is a vector load: the wait in front of its first use is
+// `s_waitcnt vmcnt(0)`, which drains the wave's store queue (po_settle above).  Used where a spilled LDS address was reloaded
+// once per main step (po_beam2d_reg.hip: sm.pf0).
+__device__ __forceinline__ int po_lane_here() {
+    int l = (int)threadIdx.x;
+#ifndef PO_EMU
+    asm volatile("" : "+v"(l));
+#endif
+    return l & (PO_WAVE - 1);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
 // outstanding global access (s_waitcnt vmcnt(0)); inside a dependent loop that turns each
 // fire-and-forget global store into a full round trip.  Use this one when only LDS data is
