@@ -647,6 +647,8 @@ void beam2d_reg_kernel(X2Args a) {
                 }
             }
             if (__ballot(bad_root) != 0ull) st = PO_E_NOMEM;   // (a time the sums have not reached: cannot happen — beam2d_kernel would take the pair)
+            po_settle(cmx);   // (this scan is the rare path: what it loaded is final before it returns — po_settle)
+            for (int k2 = 0; k2 < K; ++k2) po_settle(self.v[k2]);
             if (has_c && !(mx >= cmx)) { mx = cmx; mt = cmt; }   // (new values, later in time, win ties)
             if (part2) { v_done[q] = we; v_self[q] = self; v_fresh[q] = 0; }
             if (is_main) {
@@ -1040,6 +1042,7 @@ void beam2d_reg_kernel(X2Args a) {
                 po_settle(n_fc, n_crow2);
             }
             rk_sync();
+            KT(49);
             bool isnew = false, need_group = false;
             if (rb) {
                 isnew = n_fc < 0;
@@ -1056,6 +1059,7 @@ void beam2d_reg_kernel(X2Args a) {
                 if (__builtin_expect(next_id > arena_cap, 0)) st = PO_E_NOMEM;   // (the slice's arena is full: beam2d_kernel takes the pair)
                 if (rb && !need_group) { atomicMax(&sm.g_hi0[n_crow2], nce); atomicMax(&sm.g_hi1[n_crow2], nre); }
                 rk_sync();
+                KT(50);
                 const SMask hg = smask_of(need_group);
                 if (hg != 0) {   // (wave-uniform)
                     // Round 6: every row group the step needs in ONE pass.  (Rounds 4 - 5 handed them out one after the other — walk
@@ -1227,6 +1231,7 @@ void beam2d_reg_kernel(X2Args a) {
                             v_self[q] = read_own_all(r, wsn - 1, true);   // (wsn - 1 < v_done: its own)
                             v_done[q] = wsn;
                         }
+                        for (int k2 = 0; k2 < K; ++k2) po_settle(v_self[q].v[k2]);   // (the loads are waited for in THIS branch: po_settle)
                     }
                 }
             }
@@ -1309,12 +1314,29 @@ void beam2d_reg_kernel(X2Args a) {
                         has_c[q] = live && dr > ws;
                         bnd[q] = has_c[q] && child && !(v_mx[q] == PO_NEG_INF || v_mt[q] >= ws);
                         mx[q] = PO_NEG_INF; cmx[q] = PO_NEG_INF; mt[q] = -1; cmt[q] = -1; td[q] = has_c[q] ? v_td[q] : ws; tr[q] = INT_MIN;
-                        pf_val[q] = (pf_t[q] >= 0) ? pf_e[q] : PO_NEG_INF;
-                        bool rsc = false;
-                        if (has_c[q]) {
-                            if (v_mx[q] == PO_NEG_INF || v_mt[q] >= ws || child) { cmx[q] = v_mx[q]; cmt[q] = v_mt[q]; }
-                            else rsc = carried_one(r, ws, cmx[q], cmt[q], td[q], pf_t[q], pf_val[q]);
+                        // (Round 6: every value that comes from the store is waited for INSIDE a wave-uniform branch that is taken only
+                        //  when some lane asked for one — po_settle.  Written as `pf_val = pf_t >= 0 ? pf_e : -inf` and a load in one arm of
+                        //  a per-lane branch, the compiler's s_waitcnt vmcnt(0) sat on the common path behind the joins: one in front of the
+                        //  carried maxima and TWO behind the new times' loop — where it waited for that loop's stores, a full round trip
+                        //  per step.)
+                        pf_val[q] = PO_NEG_INF;
+                        if (__ballot(pf_t[q] >= 0) != 0ull) {   // (a value was requested a step ago)
+                            double pe = pf_e[q];
+                            po_settle(pe);
+                            pf_val[q] = (pf_t[q] >= 0) ? pe : PO_NEG_INF;
                         }
+                        const bool keep = has_c[q] && (v_mx[q] == PO_NEG_INF || v_mt[q] >= ws || child);
+                        const bool gone = has_c[q] && !keep;             // the carried maximum has left the window ...
+                        const bool one = gone && !(td[q] > ws);          // ... of a decaying element: the maximum is its value at ws
+                        const bool rsc = gone && !one;
+                        if (keep) { cmx[q] = v_mx[q]; cmt[q] = v_mt[q]; }
+                        const bool ld = one && ws != pf_t[q];            // ... which was not the one requested
+                        double lv = PO_NEG_INF;
+                        if (__builtin_expect(__ballot(ld) != 0ull, 0)) {
+                            if (ld) { SH_CHK(r, e_row2, ws, true, e_id, 1); lv = read_own(r, ws); }
+                            po_settle(lv);
+                        }
+                        if (one) { cmx[q] = ld ? lv : pf_val[q]; cmt[q] = ws; }
                         rescan_wave(q, rsc, ws, dr, cmx[q], cmt[q], td[q]);
                     }
                     // ---- the new times [dr, we), everybody in lockstep: the parent's previous value comes from its lane
@@ -1391,6 +1413,7 @@ void beam2d_reg_kernel(X2Args a) {
                             double cx = PO_NEG_INF;
                             int ct = -1, td2 = td[q];
                             const bool rs2 = hot[q] && carried_one(r, ws, cx, ct, td2, pf_t[q], pf_val[q]);
+                            po_settle(cx);   // (inside this branch: see the carried part above)
                             rescan_wave(q, rs2, ws, dr, cx, ct, td2);
                             if (hot[q]) {
                                 const bool keep = (nmx[q] >= cx);
@@ -1414,15 +1437,17 @@ void beam2d_reg_kernel(X2Args a) {
                     rec = rec_at(min(mstep, nmain - 1));
                     // the stored value the next step's carried maximum will ask for, if any, requested now: the beam lanes,
                     // and a child whose bound has just had to be made exact (it will be again)
+                    // (not on the step that leaves the run: the ranking and the table build would find a load in flight — po_settle)
+                    const bool leave = __ballot(viol) != 0ull;
 #pragma unroll
                     for (int q = 0; q < NR; ++q) {
                         const int r = RD(q);
                         const int wsn = r ? rec.y : rec.x;
                         pf_t[q] = -1;
-                        if (live && (!child || hot[q]) && v_done[q] > wsn && v_mx[q] != PO_NEG_INF && v_mt[q] < wsn) { pf_t[q] = wsn; pf_e[q] = t2_load0(r, e_row2, wsn); SH_CHK(r, e_row2, wsn, true, e_id, 11); }
+                        if (!leave && live && (!child || hot[q]) && v_done[q] > wsn && v_mx[q] != PO_NEG_INF && v_mt[q] < wsn) { pf_t[q] = wsn; pf_e[q] = t2_load0(r, e_row2, wsn); SH_CHK(r, e_row2, wsn, true, e_id, 11); }
                     }
                     KC(12, 1);
-                    if (__ballot(viol) != 0ull) { run_viol = true; break; }
+                    if (leave) { run_viol = true; break; }
                 }
                 KT(0);
             }
@@ -1646,7 +1671,7 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide
         fprintf(stderr, "   new-element steps handed to the general scan: window order %lld, uneven ends %lld, root's children %lld, fresh without a parent lane %lld, fresh under fresh %lld, more than PS parents %lld\n", h[22], h[23], h[24], h[25], h[26], h[27]);
         fprintf(stderr, "   run loop left for the general scan: window order / last step %lld, a frozen parent's older values %lld; general main scans on a table that is not fresh %lld, uneven %lld, beam not full %lld\n", h[28], h[29], h[30], h[32], h[33]);
         fprintf(stderr, "   table build by part: A fields %lld, B marks + expansion + row groups %lld, C children %lld, D continuing slots %lld, E leaving headers %lld, F identity moves %lld, parent slots %lld, G rewind + rest %lld (the rest is in the total above)\n", h[40], h[41], h[42], h[43], h[44], h[45], h[46], h[8]);
-        fprintf(stderr, "   row groups handed out: %lld\n", h[47]);
+        fprintf(stderr, "   row groups handed out: %lld; B by part: marks + arena look-up %lld, expansion %lld, row groups (in B above)\n", h[47], h[49], h[50]);
         fprintf(stderr, "   closed-form chains: %lld passes (a staged parent's children on both reads), %lld of them left to the serial chain\n", h[34], h[35]);
         fprintf(stderr, "   nodes entering the beam: %lld, of them expanded before %lld, with their children's row group still theirs %lld\n", h[36], h[37], h[38]);
         fprintf(stderr, "   table builds that ask the arena for a node's children: %lld; window rescans: %lld lanes in %lld calls; bounds made exact in %lld steps\n", h[20], h[21], h[10], h[31]);

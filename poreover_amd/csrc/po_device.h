@@ -347,6 +347,13 @@ __device__ __forceinline__ void po_settle(int& a, int& b) {
     (void)a; (void)b;
 #endif
 }
+__device__ __forceinline__ void po_settle(double& a) {
+#ifndef PO_EMU
+    asm volatile("" : "+v"(a));
+#else
+    (void)a;
+#endif
+}
 
 // The lane number as a value the compiler cannot carry from somewhere else: an address built from it is computed where it is
 // used (two or three VALU operations).  Hoisted out of the walk loop instead, such an address is one more kernel-lifetime
