@@ -90,9 +90,17 @@ __device__ __forceinline__ double rg1_readlane_d(double x, int l) {
 }
 template <int N>
 __device__ __forceinline__ double b1_pick(const double* yr, int i) {
+    // (each entry passes through an empty asm first: a select between two LOADS of the row is otherwise folded into one
+    // load from a selected ADDRESS, which pins the row in scratch memory and puts a scratch round trip — on gfx9 a drain of
+    // the wave's store queue as well, vmcnt counts both — on every pick)
     double r = yr[0];
+    asm("" : "+v"(r));
 #pragma unroll
-    for (int c = 1; c < N; ++c) r = (i == c) ? yr[c] : r;
+    for (int c = 1; c < N; ++c) {
+        double v = yr[c];
+        asm("" : "+v"(v));
+        r = (i == c) ? v : r;
+    }
     return r;
 }
 
@@ -198,11 +206,6 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
     int Wc = A;  // beam size entering step 1 (all root children; the first prune is at t = 1)
     __syncthreads();
 
-    // y[t] is loaded one step ahead: a load issued at the top of a step would be waited for right away, and
-    // (vmcnt counts in order) together with every arena store of the previous step
-    double yn[CMAX];
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) yn[c] = (c < C && T > 1 && C != CMAX) ? yr0[(int64_t)C + c] : 0.0;
     // STEADY TABLE (as in beam1d_wave_kernel): a frame that finds the beam exactly as the previous frame left it
     // rebuilds nothing — every slot updates its value in place (all reads, a fence, all
     // writes) from its own previous value and its parent's (kps / kss: left by the last frame that built a table), and the
@@ -216,12 +219,12 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             if (C == CMAX) {   // (the standard alphabets: whole rows of CMAX doubles)
                 b1_sload_row<CMAX>(yr0 + (int64_t)tt * C, yr);
             } else {
+                // (other alphabets: per-lane loads, waited for HERE — a value still in flight at the join with the scalar-load
+                // path would put an s_waitcnt vmcnt(0) on that path too, where it drains the frame's arena stores)
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) yr[c] = yn[c];
-                if (tt + 1 < T) {
+                for (int c = 0; c < CMAX; ++c) yr[c] = (c < C) ? yr0[(int64_t)tt * C + c] : 0.0;
 #pragma unroll
-                    for (int c = 0; c < CMAX; ++c) yn[c] = (c < C) ? yr0[(int64_t)(tt + 1) * C + c] : 0.0;
-                }
+                for (int c = 0; c < CMAX; ++c) asm volatile("" : "+v"(yr[c]));
             }
         };
         load_y(t);
@@ -364,7 +367,10 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_kernel(
             else { for (int k = 0; k < K; ++k) pp[k] = PO_NEG_INF; }
             po_update<MODEL>(sp, pp, b1_pick<CMAX>(yr, last), (MODEL == PO_MODEL_FLIPFLOP) ? b1_pick<CMAX>(yr, last + A) : b1_pick<CMAX>(yr, A), plast == last, false, out, lae);
             int fc = P.fc[s];
-            if (fc == -2) fc = afc[P.id[s]];  // re-entered the beam: the arena remembers
+            if (__ballot(fc == -2) != 0ull) {   // re-entered the beam: the arena remembers (rare; its load is waited for inside
+                if (fc == -2) fc = afc[P.id[s]];   // the branch — at the join the wait would drain the frame's arena stores)
+                po_settle(fc);
+            }
             Q.id[j] = P.id[s]; Q.depth[j] = P.depth[s];
             Q.par[j] = par; Q.gpar[j] = gpar; Q.plast[j] = plast; Q.last[j] = last;
 #pragma unroll
@@ -886,7 +892,10 @@ __global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
 #ifdef PO_B1_COUNT
         if (__ballot(refetch) != 0ull) ++cnt_refetch;
 #endif
-        if (refetch) q_fc = afc[q_id];   // re-entered the beam: the arena remembers
+        if (__ballot(refetch) != 0ull) {   // re-entered the beam: the arena remembers (waited for inside the rare branch: at the
+            if (refetch) q_fc = afc[q_id];   // join the wait would drain the frame's arena stores, vmcnt counting both)
+            po_settle(q_fc);
+        }
         // ---- expansion: A fresh ids per beam node that has never had children, in beam order
         const bool need = rb && (q_fc == -1);
         {

@@ -347,6 +347,13 @@ __device__ __forceinline__ void po_settle(int& a, int& b) {
     (void)a; (void)b;
 #endif
 }
+__device__ __forceinline__ void po_settle(int& a) {
+#ifndef PO_EMU
+    asm volatile("" : "+v"(a));
+#else
+    (void)a;
+#endif
+}
 __device__ __forceinline__ void po_settle(double& a) {
 #ifndef PO_EMU
     asm volatile("" : "+v"(a));
