@@ -48,8 +48,18 @@ constexpr int RK_NY = 32;     // y rows per read resident in LDS
 #define PO_REG_NGL 96
 #endif
 #ifndef PO_REG_PS
-#define PO_REG_PS 4
+#define PO_REG_PS 5   // (round 6, late: 4 -> 5 — at W = 5 every step's parents are staged; 7 % of the steps with new elements had five and
+#endif                //  took the general scan, 19 us each at full load.  The 512 B of LDS come from `tie` sharing the staging buffer's bytes)
+#ifndef PO_REG_PS_MR
+#define PO_REG_PS_MR 3      // ... the merge-repeats model (three values, two of them staged: 1 KB of LDS per parent)
 #endif
+#ifndef PO_REG_PS_FF
+#define PO_REG_PS_FF 3      // ... flip-flop
+#endif
+#ifndef PO_REG_STAGE_NB
+#define PO_REG_STAGE_NB 2   // staged parents whose entries a 32-slot step asks for in ONE memory round trip (the others: one each)
+#endif
+constexpr int RK_NB = PO_REG_STAGE_NB;
 constexpr int RK_FRESH = INT_MIN / 2;
 
 // What the tree model and the lane layout decide (update_prob: PrefixTree.h:518-531 ctc, :690-704 merge repeats, :600-632
@@ -68,7 +78,7 @@ struct RegCfg {
     // (64 slots: ten — the reads go one after the other there, both use ONE staging buffer, and a block's 32 times leave half
     //  the read's 64 lanes free to ask for a second parent: at W = 10 a third of the steps with new elements have five to
     //  ten parents, and all of them went the general way)
-    static constexpr int PS = (NR == 2) ? 10 : ((K == 1) ? PO_REG_PS : 3);
+    static constexpr int PS = (NR == 2) ? 10 : ((K == 1) ? PO_REG_PS : ((MODEL == PO_MODEL_FLIPFLOP) ? PO_REG_PS_FF : PO_REG_PS_MR));
     static constexpr int PF0N = (NR == 1) ? 8 : 16;               // beam slots whose window-start value a new-element step fetches ahead
     // waves per SIMD the register budget is set for (128 / 168 / 256 VGPRs)
 #ifndef PO_REG_WAVES_K1W
@@ -103,13 +113,17 @@ template <int MODEL, int NR, bool SCAN = false>
 struct RegSmem {              // per pair wave
     using Cfg = RegCfg<MODEL, NR>;
     double ybuf[2][RK_NY][Cfg::YC];
-    double pst[(NR == 1) ? 2 : 1][Cfg::PS * RK_NY][Cfg::KP];   // staged values (per read for NR = 1): a block of RK_NY times of every staged parent
+    union {
+        double pst[(NR == 1) ? 2 : 1][Cfg::PS * RK_NY][Cfg::KP];   // staged values (per read for NR = 1): a block of RK_NY times of every staged parent
+        // ... and, in the same bytes (the staged values live inside one new-element step's scan; these between the scans and
+        // the table build): the prune with exact score ties' candidate slots in node-id order (po_stl_prune) and their scores;
+        // `ord` is also the table build's "this old slot continues" mark
+        struct { int ord[Cfg::NS]; double csc[Cfg::NS]; } tie;
+    };
     int g_owner[Cfg::NGL], g_hi0[Cfg::NGL], g_hi1[Cfg::NGL];
     // the table fields only the table build (and the rare general scan) looks at, per element slot — the same for both reads:
     // in LDS they cost no register between two table builds
     int f_fc[Cfg::NS], f_crow2[Cfg::NS], f_par[Cfg::NS], f_gpar[Cfg::NS], f_prow2[Cfg::NS], f_depth[Cfg::NS], f_alias[Cfg::NS];
-    int ord[Cfg::NS];         // prune with exact score ties: candidate slots in node-id order (po_stl_prune)
-    double csc[Cfg::NS];      // ... and their scores
     double rootcum[2];        // the ctc root's alpha (blank prefix sum, PrefixTree.h:509-515) of each read at time rootT: added up as the
     int rootT[2];             // scans pass the times, while children of the root are in the table (the start of a pair)
     double pf0[2][Cfg::PF0N]; // a run's first step: the beam lanes' values at the window start, fetched with the staging of the
@@ -751,10 +765,11 @@ void beam2d_reg_kernel(X2Args a) {
                 const int i = k0 + s, tq = ws - 1 + i;
                 const bool stg = i < n1;
                 // (a staged parent is a continuing beam lane: its stored values end at its v_done on this read)
-                Val e01[2];
-                bool ok01[2] = {false, false};
+                Val e01[RK_NB];
+                bool ok01[RK_NB];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < RK_NB; ++k) {
+                    ok01[k] = false;
                     for (int c = 0; c < K; ++c) e01[k].v[c] = 0.0;
                     if (k < nps) {   // (wave-uniform)
                         const int jk = pj(k);
@@ -770,11 +785,11 @@ void beam2d_reg_kernel(X2Args a) {
                     if (hi > lo && !(lo >= yhi[q] - RK_NY && hi <= yhi[q])) { y_reload(r, lo); yhi[q] = lo + RK_NY; }
                 }
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
+                for (int k = 0; k < RK_NB; ++k)
                     if (k < nps && stg) {
                         for (int c = 0; c < KP; ++c) sm.pst[r][k * RK_NY + s][c] = ok01[k] ? e01[k].v[PC0 + c] : PO_NEG_INF;
                     }
-                for (int k = 2; __builtin_expect(k < nps, 0); ++k) {   // (wave-uniform; three and more parents: rare)
+                for (int k = RK_NB; __builtin_expect(k < nps, 0); ++k) {   // (wave-uniform; three and more parents: rare)
                     const int jk = pj(k);
                     const int prow = __builtin_amdgcn_readlane(e_row2, jk);
                     const int pdone = __shfl(v_done[q], hb | jk);
@@ -1145,11 +1160,11 @@ void beam2d_reg_kernel(X2Args a) {
             // become an element again) finds the answer there.  (A handful of lanes per table build: writing every element's
             // header every time cost 12 GB of 4-byte stores per 10 000-pair launch.)
             {
-                if (lo_half) sm.ord[s] = 0;
+                if (lo_half) sm.tie.ord[s] = 0;
                 rk_sync();
-                if (lo_half && nlive && src >= 0) sm.ord[src] = 1;
+                if (lo_half && nlive && src >= 0) sm.tie.ord[src] = 1;
                 rk_sync();
-                const bool leaving = live && sm.ord[s] == 0;
+                const bool leaving = live && sm.tie.ord[s] == 0;
 #pragma unroll
                 for (int q = 0; q < NR; ++q)
                     if (leaving && v_fresh[q] == 0) *hdr_of(RD(q), e_row2) = v_done[q];
@@ -1535,15 +1550,15 @@ void beam2d_reg_kernel(X2Args a) {
                     const int io = __builtin_amdgcn_readlane(e_id, o);
                     pos += (int)((cm >> o) & (SMask)1) & ((io < e_id) ? 1 : 0);
                 }
-                if (cand && lo_half) { sm.ord[pos] = s; sm.csc[s] = sc; }
+                if (cand && lo_half) { sm.tie.ord[pos] = s; sm.tie.csc[s] = sc; }
                 rk_sync();
                 if (lane == 0) {
-                    const double* cp = sm.csc;
-                    po_stl_prune<WS>(sm.ord, ncand, W, [&](int slot) { return cp[slot]; });
+                    const double* cp = sm.tie.csc;
+                    po_stl_prune<WS>(sm.tie.ord, ncand, W, [&](int slot) { return cp[slot]; });
                 }
                 rk_sync();
 #pragma unroll
-                for (int jx = 0; jx < WS; ++jx) sel[jx] = (jx < nbn) ? sm.ord[jx] : 0;
+                for (int jx = 0; jx < WS; ++jx) sel[jx] = (jx < nbn) ? sm.tie.ord[jx] : 0;
                 rk_sync();
             }
             KT(7);
