@@ -1636,6 +1636,24 @@ void reg_launch_model(const X2Args& a, int slots, hipStream_t stream) {
     else hipLaunchKernelGGL((beam2d_reg_kernel<MODEL, NR, false, false>), grid, block, 0, stream, a);
 }
 }  // namespace
+// PO_REG_TU — poreover_amd/build.py compiles this file TWICE: 1 = the 32-slot kernels and the C entry points, 2 = the 64-slot kernels
+// behind the two functions below (undefined: one translation unit with everything — the tools' and the emulator's build).  Two
+// objects because they are compiled with different scheduler options (build.py: -amdgpu-use-amdgpu-trackers gains 1 % on the 32-slot
+// one-value kernel and loses 1.5 % on the 64-slot one, profiles/r06_ab_compiler_flags.txt) and the option is per translation unit.
+extern "C" __attribute__((visibility("hidden"))) int po_reg_wide_occupancy(int mi);
+extern "C" __attribute__((visibility("hidden"))) void po_reg_wide_launch(const void* x2args, int slots, int model, hipStream_t stream);
+#if !defined(PO_REG_TU) || PO_REG_TU == 2
+extern "C" int po_reg_wide_occupancy(int mi) {
+    return mi == 0 ? reg_occupancy<PO_MODEL_CTC, 2>() : (mi == 1 ? reg_occupancy<PO_MODEL_MERGE, 2>() : reg_occupancy<PO_MODEL_FLIPFLOP, 2>());
+}
+extern "C" void po_reg_wide_launch(const void* x2args, int slots, int model, hipStream_t stream) {
+    const X2Args& a = *(const X2Args*)x2args;
+    if (model == PO_MODEL_CTC) reg_launch_model<PO_MODEL_CTC, 2>(a, slots, stream);
+    else if (model == PO_MODEL_MERGE) reg_launch_model<PO_MODEL_MERGE, 2>(a, slots, stream);
+    else reg_launch_model<PO_MODEL_FLIPFLOP, 2>(a, slots, stream);
+}
+#endif
+#if !defined(PO_REG_TU) || PO_REG_TU == 1
 // wide != 0: the 64-slot layout (7 <= W <= 12)
 extern "C" int po_reg_slots_per_cu(int model, int wide) {
 #ifdef PO_EMU
@@ -1644,7 +1662,7 @@ extern "C" int po_reg_slots_per_cu(int model, int wide) {
     static PoPerDeviceCache<6> per_cu;
     const int mi = model == PO_MODEL_CTC ? 0 : (model == PO_MODEL_MERGE ? 1 : 2);
     return per_cu.get(mi * 2 + (wide ? 1 : 0), [mi, wide] {
-        if (wide) return mi == 0 ? reg_occupancy<PO_MODEL_CTC, 2>() : (mi == 1 ? reg_occupancy<PO_MODEL_MERGE, 2>() : reg_occupancy<PO_MODEL_FLIPFLOP, 2>());
+        if (wide) return po_reg_wide_occupancy(mi);
         return mi == 0 ? reg_occupancy<PO_MODEL_CTC, 1>() : (mi == 1 ? reg_occupancy<PO_MODEL_MERGE, 1>() : reg_occupancy<PO_MODEL_FLIPFLOP, 1>());
     });
 #endif
@@ -1665,9 +1683,7 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide
     a.dbg = dbg;
 #endif
     if (wide) {
-        if (model == PO_MODEL_CTC) reg_launch_model<PO_MODEL_CTC, 2>(a, slots, stream);
-        else if (model == PO_MODEL_MERGE) reg_launch_model<PO_MODEL_MERGE, 2>(a, slots, stream);
-        else reg_launch_model<PO_MODEL_FLIPFLOP, 2>(a, slots, stream);
+        po_reg_wide_launch(&a, slots, model, stream);
     } else {
         if (model == PO_MODEL_CTC) reg_launch_model<PO_MODEL_CTC, 1>(a, slots, stream);
         else if (model == PO_MODEL_MERGE) reg_launch_model<PO_MODEL_MERGE, 1>(a, slots, stream);
@@ -1693,3 +1709,4 @@ extern "C" void po_reg_launch(const void* x2args, int slots, int model, int wide
     }
 #endif
 }
+#endif   // PO_REG_TU: the C entry points

@@ -3,17 +3,20 @@
 -Rpass-analysis=kernel-resource-usage prints, as a table): python3 tools/isa/resource_usage.py > profiles/rNN_kernel_resource_usage.txt"""
 import glob, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SRC = sorted(glob.glob(os.path.join(ROOT, "poreover_amd", "csrc", "*.hip")))
+sys.path.insert(0, os.path.join(ROOT, "poreover_amd"))
+import build as _build   # (the objects of the library and each one's options)
+SRC = sorted(_build.OBJECTS)
 print("# kernel resource usage, hipcc -O3 --offload-arch=gfx950 -S (code-object metadata), the sources of this commit")
 print("# kernel | VGPRs | AGPRs | SGPRs | SGPR spills | VGPR spills | scratch B/lane | LDS B/block | waves/SIMD (512 / VGPRs, at most 8)")
-for src in SRC:
+for oname, sname, extra in SRC:
+    src = os.path.join(ROOT, "poreover_amd", "csrc", sname)
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "x.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
-                        "-S", "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unused-function",
+                        *extra, "-S", "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
     meta = txt[txt.index("amdhsa.kernels:"):] if "amdhsa.kernels:" in txt else ""
-    print("## " + os.path.basename(src))
+    print("## " + oname + ((" (" + sname + " " + " ".join(extra) + ")") if extra else ""))
     for blk in meta.split("  - .agpr_count:")[1:]:
         g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "0"])[1]
         name = g("name")
