@@ -10,12 +10,12 @@ LIB = os.path.join(HERE, "libporeover_hip.so")
 SOURCES = ["po_capi.hip", "po_viterbi.hip", "po_beam1d.hip", "po_beam2d.hip", "po_beam2d_reg.hip", "po_pair.hip", "po_lattice.hip", "po_prefix.hip", "po_ingest.hip", "po_gamma.hip", "po_stream.hip"]
 HEADERS = ["po_device.h", os.path.join("..", "..", "include", "poreover_hip.h")]
 # Per-object compiler options (measured, round 6: profiles/r06_ab_compiler_flags.txt).  -amdgpu-use-amdgpu-trackers (the AMDGPU register-pressure
-# trackers in the machine scheduler) is worth 1 % on the 32-slot pair kernel and 1.5 % on the W <= 12 1-D kernel, costs 1.5 % on the 64-slot pair
-# kernel and 5 % on beam2d_kernel's W = 25 class: po_beam2d_reg.hip is compiled twice (PO_REG_TU: the 32-slot kernels + the C entry points | the
-# 64-slot kernels), each object with what it runs best with.  (object name, source, extra options)
+# trackers in the machine scheduler) is worth 1 % on the 32-slot pair kernel, costs 1.5 % on the 64-slot pair kernel and 5 % on beam2d_kernel's
+# W = 25 class; in po_beam1d.hip it gives beam1d_wave_kernel 1.5 % and takes 4.5 % from beam1d_kernel (W = 25), so that file goes without.
+# po_beam2d_reg.hip is compiled twice (PO_REG_TU: the 32-slot kernels + the C entry points | the 64-slot kernels), each object with what it
+# runs best with.  (object name, source, extra options)
 TRACKERS = ["-mllvm", "-amdgpu-use-amdgpu-trackers"]
-OBJECTS = [(s, s, []) for s in SOURCES if s not in ("po_beam2d_reg.hip", "po_beam1d.hip")] + [
-    ("po_beam1d.hip", "po_beam1d.hip", TRACKERS),
+OBJECTS = [(s, s, []) for s in SOURCES if s != "po_beam2d_reg.hip"] + [
     ("po_beam2d_reg.hip", "po_beam2d_reg.hip", ["-DPO_REG_TU=1"] + TRACKERS),
     ("po_beam2d_reg_wide.hip", "po_beam2d_reg.hip", ["-DPO_REG_TU=2"]),
 ]

@@ -61,6 +61,9 @@ __device__ __forceinline__ char* carve(char*& p, size_t bytes) {
 // One row of y (N doubles at a wave-uniform address) through the SCALAR data cache: y is read-only input, the row
 // of the next frame used to be requested a frame ahead by vector loads — and waiting for those (vmcnt counts in
 // order) also waited for every tree-node store of the frame.  Scalar loads count on lgkmcnt.
+#ifndef PO_B1_WAVES
+#define PO_B1_WAVES 4   // waves per SIMD beam1d_wave_kernel is compiled for
+#endif
 template <int N>
 __device__ __forceinline__ void b1_sload_row(const double* p, double* out) {
     const unsigned long long pv = (unsigned long long)p;
@@ -626,7 +629,7 @@ __device__ __forceinline__ double b1_row0_min(double x) {
 }
 
 template <int MODEL>
-__global__ __launch_bounds__(PO_WAVE) void beam1d_wave_kernel(
+__global__ __launch_bounds__(PO_WAVE, PO_B1_WAVES) void beam1d_wave_kernel(
     const double* __restrict__ y, const int64_t* __restrict__ y_off, int A, uint32_t alphabet, int W,
     int* __restrict__ arena_pl, int* __restrict__ arena_fc, char* __restrict__ seq,
     const int64_t* __restrict__ seq_off, int32_t* __restrict__ seq_len, int32_t* __restrict__ status) {
