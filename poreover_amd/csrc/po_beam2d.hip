@@ -60,15 +60,16 @@ constexpr int B2_YD = 256;   // doubles per read in the y window buffer (51 rows
 // share a CU.  The chains of dependent f64 operations in logaddexp leave a wave idle most of the time, so resident
 // waves are what buys throughput here: 96 doubles of y rows per read (19 rows of 5) and 112 row groups bring the
 // workgroup to 10 096 B (16 per CU) and the kernel from 65k to 85k pairs/s at 10 000 pairs.
-// waves per SIMD the W = 25 class of the one-value model is compiled for (256-thread workgroups: a wave per SIMD each).  Unbounded it took
-// 176 VGPRs — two workgroups per CU; at 168 (no VGPR spill) three fit, LDS included: `row` / `row_col` W = 25, the Python API's defaults,
-// 9.96k -> 13.76k / 11.28k -> 15.97k pairs/s (profiles/r06_ab_w25_occupancy.txt).  The three-value models' W > 6 classes (195 - 206 VGPRs)
-// would spill 12 - 13 registers at 168 and have no timed leg: left unbounded.
+// waves per SIMD the W = 25 classes are compiled for (256-thread workgroups: a wave per SIMD each).  Unbounded the one-value kernel took
+// 176 VGPRs, the three-value ones 204 - 206 — two workgroups per CU; at 168 (no VGPR spill / 12 - 13 spilled registers) three fit, LDS
+// included: `row` / `row_col` W = 25, the Python API's defaults, 9.96k -> 13.76k / 11.28k -> 15.97k pairs/s; Bonito's and the flip-flop
+// model's W = 25 launches + 26 .. 29 % (profiles/r06_ab_w25_occupancy.txt).  The W <= 12 class of the three-value models (128-thread
+// workgroups, 195 - 198 VGPRs unbounded): flip-flop + 5 % at 168, merge repeats - 1 % — the first is bound, the second is not.
 #ifndef PO_B2_W25_WAVES
 #define PO_B2_W25_WAVES 3
 #endif
-#ifndef PO_B2_K3_WAVES
-#define PO_B2_K3_WAVES 1
+#ifndef PO_B2_FF12_WAVES
+#define PO_B2_FF12_WAVES 3
 #endif
 #ifndef B2_YD6
 #define B2_YD6 96
@@ -127,7 +128,7 @@ template <int MODEL, int WMAX, bool RC_ONLY = false>
 // -Rpass-analysis=kernel-resource-usage.  Forcing the bound here makes the allocator's choices 2 % worse today.)
 // (The three-value models sit at 163 - 173 VGPRs in the W <= 6 class: 168 is the step between three waves per SIMD and
 // two, so that bound is explicit too.)
-__global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <= 12) ? 4 : (WMAX <= 6 ? 3 : ((MODEL == PO_MODEL_CTC) ? PO_B2_W25_WAVES : PO_B2_K3_WAVES)))) void beam2d_kernel(B2Args a) {
+__global__ __launch_bounds__(B2_THREADS(WMAX), ((MODEL == PO_MODEL_CTC && WMAX <= 12) ? 4 : (WMAX <= 6 ? 3 : ((MODEL == PO_MODEL_CTC || WMAX > 12) ? PO_B2_W25_WAVES : (MODEL == PO_MODEL_FLIPFLOP ? PO_B2_FF12_WAVES : 1))))) void beam2d_kernel(B2Args a) {
     using SM = B2Smem<MODEL, WMAX>;
     if (a.retry_flag != nullptr && *a.retry_flag == 0) return;   // retry pass and the first pass left nothing over: not one queue round trip
     constexpr int K = SM::K, NCM = SM::NCM, NCP = SM::NCP, nthr = 2 * NCP;
