@@ -206,7 +206,7 @@ __global__ __launch_bounds__(PO_WAVE) void flipflop_dp_kernel(const double* __re
                                                               int8_t* __restrict__ ptr,
                                                               int8_t* __restrict__ path,
                                                               int32_t* __restrict__ status) {
-    __shared__ int8_t chunk[8][512 * FF_S];
+    __shared__ __attribute__((aligned(8))) int8_t chunk[8][512 * FF_S];
     const int lane = po_lane(), g = lane >> 3, j = lane & 7;
     const int r = blockIdx.x * 8 + g;
     const bool live = r < n;
@@ -219,22 +219,52 @@ __global__ __launch_bounds__(PO_WAVE) void flipflop_dp_kernel(const double* __re
     const double* yr = y + r0 * S;
     int8_t* pr = ptr + r0 * FF_S;
     double v = (T > 0 && j < S) ? yr[j] : PO_NEG_INF;
-    for (int t = 1; t < Tmax; ++t) {
-        const bool on = t < T;
-        const double yt = (on && j < S) ? yr[(int64_t)t * S + j] : 0.0;
-        double bv = 0;
-        int bi = 0;
+    // The frames are one dependent chain per read and a launch has little more than one wave per SIMD (8 reads per wave): a row
+    // asked for in the frame that uses it is a memory round trip PER FRAME.  The rows of the next FF_PF frames are requested
+    // while this block's frames are computed — and the block's back-pointers are written at the START of the next block, behind
+    // those requests: gfx9 counts loads and stores on one counter, so the wait for the rows (s_waitcnt vmcnt(0)) also waits for
+    // every store in flight; issued a block ahead of that wait, they have landed by then.
+    constexpr int FF_PF = 16;
+    auto row_at = [&](int t) -> double { return (t < T && j < S) ? yr[(int64_t)t * S + j] : 0.0; };
+    double yq[FF_PF];
+    int bq[FF_PF];      // the previous block's back-pointers (-1: none)
 #pragma unroll
-        for (int i = 0; i < FF_S; ++i) {
-            const double vi = __shfl(v, (g << 3) | i);
-            const double tr = (j < A) ? 1.0 : (((i % A) == (j - A)) ? 1.0 : 0.0);
-            const double cand = tr + vi;
-            if (i < S && (i == 0 || cand > bv)) { bv = cand; bi = i; }
+    for (int i = 0; i < FF_PF; ++i) { yq[i] = row_at(1 + i); bq[i] = -1; }
+    for (int t0 = 1; t0 < Tmax + FF_PF; t0 += FF_PF) {   // (one trip more: the last block's stores)
+        // (this block's rows — requested a block ago — are waited for HERE, before the next requests go out: left to their first
+        //  use, the wait would sit behind those requests and, being vmcnt(0), wait for them too)
+#pragma unroll
+        for (int i = 0; i < FF_PF; ++i) po_settle(yq[i]);
+        double yn[FF_PF];
+#pragma unroll
+        for (int i = 0; i < FF_PF; ++i) yn[i] = row_at(t0 + FF_PF + i);
+#pragma unroll
+        for (int i = 0; i < FF_PF; ++i)
+            if (bq[i] >= 0) pr[(int64_t)(t0 - FF_PF + i) * FF_S + j] = (int8_t)bq[i];
+#pragma unroll
+        for (int f = 0; f < FF_PF; ++f) {
+            const int t = t0 + f;
+            bq[f] = -1;
+            if (t < Tmax) {   // (wave-uniform)
+                const bool on = t < T;
+                const double yt = yq[f];
+                double bv = 0;
+                int bi = 0;
+#pragma unroll
+                for (int i = 0; i < FF_S; ++i) {
+                    const double vi = __shfl(v, (g << 3) | i);
+                    const double tr = (j < A) ? 1.0 : (((i % A) == (j - A)) ? 1.0 : 0.0);
+                    const double cand = tr + vi;
+                    if (i < S && (i == 0 || cand > bv)) { bv = cand; bi = i; }
+                }
+                if (on && j < S) {
+                    bq[f] = bi;
+                    v = yt + bv;
+                }
+            }
         }
-        if (on && j < S) {
-            pr[(int64_t)t * FF_S + j] = (int8_t)bi;
-            v = yt + bv;
-        }
+#pragma unroll
+        for (int i = 0; i < FF_PF; ++i) yq[i] = yn[i];
     }
     // argmax of the final column (first maximum), held by every lane of the group
     double bv = __shfl(v, g << 3);
@@ -250,7 +280,15 @@ __global__ __launch_bounds__(PO_WAVE) void flipflop_dp_kernel(const double* __re
     int cur = best;
     for (int lo = ((Tmax + 511) / 512 - 1) * 512; lo >= 0; lo -= 512) {  // uniform trip count
         const int hi = min(T, lo + 512), len = hi - lo;                  // len <= 0: nothing here
-        for (int i = j; i < len * FF_S; i += 8) chunk[g][i] = pr[(int64_t)lo * FF_S + i];
+        {   // (a frame's eight back-pointers are eight consecutive bytes, 8-byte aligned: one load per frame, not one per byte)
+            const unsigned long long* src = (const unsigned long long*)(pr + (int64_t)lo * FF_S);
+            unsigned long long* dst = (unsigned long long*)&chunk[g][0];
+            if (((unsigned long long)src & 7ull) == 0ull) {
+                for (int f = j; f < len; f += 8) dst[f] = src[f];
+            } else {   // (a workspace that is not 8-byte aligned: byte by byte)
+                for (int i = j; i < len * FF_S; i += 8) chunk[g][i] = pr[(int64_t)lo * FF_S + i];
+            }
+        }
         __syncthreads();
         if (j == 0) {
             for (int t = hi - 1; t >= lo; --t) {
