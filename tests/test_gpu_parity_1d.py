@@ -43,6 +43,20 @@ def test_viterbi_matches_oracle(eng, oracle, kind):
             assert st[i] != 0
 
 
+def test_flipflop_viterbi_block_boundaries(eng, oracle):
+    """flipflop_dp_kernel requests its rows 16 frames ahead and stores a block's back-pointers a block late (round 6): read
+    lengths around the block size and the back-trace's 512-frame chunks, ragged within a wave (8 reads per wave share the loop)"""
+    base = _reads(3, 1100, ff=True, base=7300)
+    lens = [1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 34, 47, 48, 49, 511, 512, 513, 527, 528, 529, 1023, 1024, 1025, 1040, 1041]
+    reads = [base[i % 3][:L] for i, L in enumerate(lens)]
+    seqs, paths, maps, st = eng.viterbi_batch(reads, "flipflop", return_path=True, return_map=True)
+    for i, y in enumerate(reads):
+        s, p = oracle.viterbi_decode(y, "flipflop")
+        assert seqs[i] == s, (lens[i], seqs[i][:20], s[:20])
+        assert np.array_equal(paths[i], p), lens[i]
+        assert st[i] == 0 and np.array_equal(maps[i], oracle.get_sequence_mapping(p, "flipflop")), lens[i]
+
+
 def test_viterbi_golden(eng, golden, golden_inputs):
     y = np.log(golden_inputs["poreover_csv_prob"])
     seqs, paths = eng.viterbi_batch([y], "poreover", return_path=True)
