@@ -58,12 +58,13 @@ __device__ __forceinline__ char* carve(char*& p, size_t bytes) {
 
 }  // namespace
 
+#ifndef PO_B1_WAVES
+#define PO_B1_WAVES 4   // waves per SIMD beam1d_wave_kernel is compiled for (5: 10 000 reads + 5 %, 1 000 reads - 1 .. 2.5 %: profiles/r06_ab_compiler_flags.txt)
+#endif
+
 // One row of y (N doubles at a wave-uniform address) through the SCALAR data cache: y is read-only input, the row
 // of the next frame used to be requested a frame ahead by vector loads — and waiting for those (vmcnt counts in
 // order) also waited for every tree-node store of the frame.  Scalar loads count on lgkmcnt.
-#ifndef PO_B1_WAVES
-#define PO_B1_WAVES 4   // waves per SIMD beam1d_wave_kernel is compiled for
-#endif
 template <int N>
 __device__ __forceinline__ void b1_sload_row(const double* p, double* out) {
     const unsigned long long pv = (unsigned long long)p;

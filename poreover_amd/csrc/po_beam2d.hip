@@ -60,7 +60,8 @@ constexpr int B2_YD = 256;   // doubles per read in the y window buffer (51 rows
 // share a CU.  The chains of dependent f64 operations in logaddexp leave a wave idle most of the time, so resident
 // waves are what buys throughput here: 96 doubles of y rows per read (19 rows of 5) and 112 row groups bring the
 // workgroup to 10 096 B (16 per CU) and the kernel from 65k to 85k pairs/s at 10 000 pairs.
-// waves per SIMD the W = 25 classes are compiled for (256-thread workgroups: a wave per SIMD each).  Unbounded the one-value kernel took
+//
+// Waves per SIMD the W = 25 classes are compiled for (256-thread workgroups: a wave per SIMD each).  Unbounded the one-value kernel took
 // 176 VGPRs, the three-value ones 204 - 206 — two workgroups per CU; at 168 (no VGPR spill / 12 - 13 spilled registers) three fit, LDS
 // included: `row` / `row_col` W = 25, the Python API's defaults, 9.96k -> 13.76k / 11.28k -> 15.97k pairs/s; Bonito's and the flip-flop
 // model's W = 25 launches + 26 .. 29 % (profiles/r06_ab_w25_occupancy.txt).  The W <= 12 class of the three-value models (128-thread
