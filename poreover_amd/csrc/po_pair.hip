@@ -851,12 +851,14 @@ PPGeom pp_geometry(int n, int64_t tr1, int64_t tr2, int64_t mr1, int64_t mr2, in
     g.dp_cap = skew_only ? pp_skew_cells(lmax1, lmax2, NW_BAND) : (size_t)((lmax1 + 1) * width);
     if (g.one_wave && !skew_only) g.dp_cap = std::max(g.dp_cap, pp_skew_cells(lmax1, lmax2, NW_BAND));
     g.aln_cap = (size_t)(lmax1 + lmax2 + 16);
-    {   // the first pass's slices within 2.5 GB (T = 4000: ~ 2 000 workgroups of 1.2 MB, eight per CU — the kernel is 2 ms of a
-        // 10 000-pair step and loses nothing to that — so that a wave's workspace stays a few GB: large allocations are what
-        // a process's first call waits for) and within 1/16 of the board's memory (very long reads: fewer workgroups)
-        static const size_t budget = [] { const char* e = getenv("PO_PP_BUDGET_MB"); return (size_t)(e ? atoi(e) : 2560) << 20; }();
+    {   // the first pass's slices within 5 GB (T = 4000: workgroups of 1.2 MB — all sixteen per CU of a 10 000-pair call; a pipeline
+        // slot's wave of 3 334 pairs: 4 GB — so that a wave's workspace stays a few GB: large allocations are what a process's first
+        // call waits for) and within 1/16 of the board's memory (very long reads: fewer workgroups).  (2.5 GB — eight workgroups
+        // per CU — until late in round 6: the kernel 2.38 instead of 1.96 ms per 10 000 pairs, 1 % of the step;
+        // profiles/r06_ab_align_budget.txt.  The end-to-end figures and the first call of a process do not move.)
+        static const size_t budget = [] { const char* e = getenv("PO_PP_BUDGET_MB"); return (size_t)(e ? atoi(e) : 5120) << 20; }();
         const size_t per_block = sizeof(int) * g.dp_cap + sizeof(int) * 4 * g.row_cap + 2 * g.aln_cap;
-        // (the one-workgroup-per-CU floor applies against the 2.5 GB budget only — a comfort figure; the board's 1/16 is a HARD
+        // (the one-workgroup-per-CU floor applies against that budget only — a comfort figure; the board's 1/16 is a HARD
         //  cap: reads of 4e5 frames make a slice 105 MB, and a floor of 256 of them is 27 GB of workspace: ADVICE round 5)
         const size_t pb = std::max<size_t>(per_block, 1);
         const size_t fit_budget = std::max<size_t>(budget / pb, (size_t)pp_num_cus());
