@@ -34,6 +34,29 @@ def test_header_symbols_all_exported():
     assert lib.po_version() >= 100
 
 
+def test_build_objects_cover_every_source():
+    """poreover_amd/build.py: every HIP source under csrc/ is an object of the library, exactly once — but po_beam2d_reg.hip,
+    which is compiled as two objects (PO_REG_TU = 1: the 32-slot kernels and the C entry points; 2: the 64-slot kernels), so
+    that each gets its own scheduler option; a variant object built without PO_REG_TU holds both (the tools, the emulator)."""
+    import glob
+    from poreover_amd import build
+    on_disk = sorted(os.path.basename(f) for f in glob.glob(os.path.join(os.path.dirname(build.__file__), "csrc", "*.hip")))
+    assert sorted(build.SOURCES) == on_disk
+    by_src = {}
+    for oname, sname, extra in build.OBJECTS:
+        by_src.setdefault(sname, []).append((oname, extra))
+    assert sorted(by_src) == on_disk
+    assert len({o for o, _, _ in build.OBJECTS}) == len(build.OBJECTS)      # (object names are distinct)
+    for sname, objs in by_src.items():
+        if sname == "po_beam2d_reg.hip":
+            tus = sorted(x for _, extra in objs for x in extra if x.startswith("-DPO_REG_TU="))
+            assert tus == ["-DPO_REG_TU=1", "-DPO_REG_TU=2"], objs
+        else:
+            assert len(objs) == 1 and not any(x.startswith("-DPO_REG_TU") for x in objs[0][1]), (sname, objs)
+    src = open(os.path.join(os.path.dirname(build.__file__), "csrc", "po_beam2d_reg.hip")).read()
+    assert "PO_REG_TU == 1" in src and "PO_REG_TU == 2" in src and "po_reg_wide_launch" in src
+
+
 def test_product_never_imports_oracle():
     bad = []
     for root, _, files in os.walk(os.path.join(REPO, "poreover_amd")):
